@@ -1,0 +1,446 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+The reference (``/root/reference``) is a Python/PyTorch repo with no tests of its own, so
+parity is pinned on outputs of the reference run here on CPU.  It needs a few import shims
+(SURVEY.md section 8(c)): ``timm`` and ``torchvision`` are not installed, the ResNet ctor
+``torch.load``s a hard-coded path, the contrastive package calls ``.cuda()`` and reads a
+non-existent checkpoint.  Nothing of the reference is copied: this script imports it,
+feeds it seeded inputs and deterministic weights (tests/golden_util.det_fill) and stores
+inputs/outputs as data.  The fixtures travel; this script's dependency does not.
+
+Usage:  python tools/gen_golden.py [--only NAME]
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import golden_util as gu  # noqa: E402
+
+REF = "/root/reference"
+OUT = gu.GOLDEN_DIR
+warnings.filterwarnings("ignore")
+
+
+# ------------------------------------------------------------------ shims
+def _install_timm():
+    timm = types.ModuleType("timm")
+    models = types.ModuleType("timm.models")
+    layers = types.ModuleType("timm.models.layers")
+
+    class DropPath(nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+            assert p == 0.0
+
+        def forward(self, x):
+            return x
+
+    layers.DropPath = DropPath
+    layers.to_2tuple = lambda v: v if isinstance(v, tuple) else (v, v)
+    layers.trunc_normal_ = lambda t, mean=0.0, std=1.0: nn.init.trunc_normal_(t, mean, std, -2.0, 2.0)
+    timm.models, models.layers = models, layers
+    sys.modules.update({"timm": timm, "timm.models": models, "timm.models.layers": layers})
+
+
+class _TVBlock(nn.Module):
+    """Stand-in for torchvision's BasicBlock (child names conv1,bn1,relu,conv2,bn2,downsample)."""
+
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        idn = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + idn)
+
+
+class _TVResNet18(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = nn.Sequential(_TVBlock(64, 64, 1), _TVBlock(64, 64, 1))
+        self.layer2 = nn.Sequential(_TVBlock(64, 128, 2), _TVBlock(128, 128, 1))
+        self.layer3 = nn.Sequential(_TVBlock(128, 256, 2), _TVBlock(256, 256, 1))
+        self.layer4 = nn.Sequential(_TVBlock(256, 512, 2), _TVBlock(512, 512, 1))
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512, 1000)
+
+
+def _install_torchvision():
+    tv = types.ModuleType("torchvision")
+    models = types.ModuleType("torchvision.models")
+    models.resnet18 = lambda *a, **k: _TVResNet18()
+    models.resnet34 = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
+    tv.models = models
+    sys.modules.update({"torchvision": tv, "torchvision.models": models})
+    real_load = torch.load
+
+    def fake_load(path, *a, **k):
+        if isinstance(path, str) and path.endswith("resnet18-5c106cde.pth"):
+            return _TVResNet18().state_dict()
+        return real_load(path, *a, **k)
+
+    torch.load = fake_load
+
+
+def _purge(prefixes):
+    for name in list(sys.modules):
+        if any(name == p or name.startswith(p + ".") for p in prefixes):
+            del sys.modules[name]
+
+
+def import_seg():
+    """-> modules (swin_512, base18, ASPP, losses) of /root/reference/seg18."""
+    _install_timm()
+    _install_torchvision()
+    _purge(["net", "utils", "contrast", "Ours"])
+    sys.path[:] = [p for p in sys.path if not p.startswith(REF)]
+    sys.path.insert(0, os.path.join(REF, "seg18"))
+    swin = importlib.import_module("net.Ours.swin_512")
+    base = importlib.import_module("net.Ours.base18")
+    aspp = importlib.import_module("net.Ours.ASPP")
+    losses = importlib.import_module("utils.losses")
+    return swin, base, aspp, losses
+
+
+def import_contrast():
+    _install_timm()
+    _install_torchvision()
+    _purge(["net", "utils", "contrast", "Ours"])
+    sys.path[:] = [p for p in sys.path if not p.startswith(REF)]
+    sys.path.insert(0, os.path.join(REF, "pixcontrast_18"))
+    stub = types.ModuleType("contrast.resnet")
+    stub.__all__ = []
+    import contrast  # noqa: F401  (package dir exists in the reference)
+    sys.modules["contrast.resnet"] = stub
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+    nn.SyncBatchNorm.convert_sync_batchnorm = classmethod(lambda cls, m, pg=None: m)
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    pix = importlib.import_module("contrast.models.PixPro_swin_v5")
+    pix.load_model_full = lambda model, path: model
+    return pix
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print(f"  wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def sd_arrays(sd, prefix="sd/"):
+    return {prefix + k: v for k, v in sd.items()}
+
+
+def sd_meta(sd):
+    keys = [k for k in sd if not (k.endswith("attn_mask") or k.endswith("relative_position_index"))]
+    return dict(keys=np.array(keys), shapes=np.array([gu.shape_str(sd[k]) for k in keys]),
+                dtypes=np.array([str(sd[k].dtype).replace("torch.", "") for k in keys]))
+
+
+# ------------------------------------------------------------------ generators
+def gen_index_maps(swin):
+    """a1-a4: the gather order the reference block feeds its attention with (captured live)."""
+    out = {}
+    for tag, (h, w, ws, shift) in {"s1_64x64": (64, 64, 8, 4), "s2_32x32": (32, 32, 4, 2),
+                                   "s1_64x80": (64, 80, 8, 4), "s1_32x56": (32, 56, 8, 4),
+                                   "s1_64x64_noshift": (64, 64, 8, 0), "s2_16x16": (16, 16, 4, 2)}.items():
+        blk = swin.SwinTransformerBlock(4, (h, w), 1, window_size=ws, shift_size=shift)
+        cap = {}
+
+        def spy(x, mask=None, cap=cap):
+            cap["win"] = x.clone()
+            return x
+
+        blk.attn.forward = spy
+        blk.mlp = nn.Identity()
+        blk.norm1 = nn.Identity()
+        blk.norm2 = nn.Identity()
+        b, t = 2, 2
+        ids = torch.arange(b * t * h * w, dtype=torch.float32).reshape(b, t, h * w, 1).repeat(1, 1, 1, 4)
+        y = blk(ids)
+        # shortcut + identity-attention + identity mlp-of-x: y = 2*(x+x)?  Only the capture matters, but
+        # the round trip (reverse + un-roll) must restore token order: y = x + x + mlp(x)=... check below.
+        assert torch.equal(y, ids * 4), "reference gather/scatter round trip is not the identity"
+        out[tag] = cap["win"][..., 0].reshape(-1).to(torch.int32)
+        out[tag + "_cfg"] = np.array([b, t, h, w, ws, shift], dtype=np.int32)
+    # SURVEY 8(a) a4 known-answer test
+    x = torch.arange(2 * 8 * 8, dtype=torch.float32).reshape(2, 8, 8, 1)
+    out["kat_partition"] = swin.window_partition(x, 4).reshape(-1).to(torch.int32)
+    save("index_maps.npz", **out)
+
+
+def gen_tables(swin):
+    out = {}
+    for ws in (8, 4):
+        att = swin.WindowAttention(8, (ws, ws), 1)
+        out[f"rel_index_ws{ws}"] = att.relative_position_index.to(torch.int32)
+    for tag, (h, w, ws, shift) in {"64x64": (64, 64, 8, 4), "32x32": (32, 32, 4, 2), "64x80": (64, 80, 8, 4),
+                                   "32x56": (32, 56, 8, 4), "16x28": (16, 28, 4, 2)}.items():
+        blk = swin.SwinTransformerBlock(4, (h, w), 1, window_size=ws, shift_size=shift)
+        m = blk.attn_mask
+        assert set(torch.unique(m).tolist()) <= {0.0, -100.0}
+        out[f"mask_{tag}"] = (m != 0).to(torch.uint8)
+        out[f"mask_{tag}_cfg"] = np.array([h, w, ws, shift], dtype=np.int32)
+    save("tables.npz", **out)
+
+
+def gen_window_attention(swin):
+    torch.manual_seed(11)
+    c, heads, ws, t, n_w, b = 32, 4, 4, 2, 4, 2
+    att = swin.WindowAttention(c, (ws, ws), heads)
+    gu.det_fill(att.state_dict())
+    blk = swin.SwinTransformerBlock(c, (8, 8), heads, window_size=ws, shift_size=2)
+    mask = blk.attn_mask  # (4,16,16)
+    x = torch.randn(b * n_w, t, ws * ws, c, requires_grad=True)
+    g = torch.randn(b * n_w, t, ws * ws, c)
+    res = {}
+    for tag, m in (("nomask", None), ("mask", mask)):
+        att.zero_grad()
+        if x.grad is not None:
+            x.grad = None
+        y = att(x, m)
+        (y * g).sum().backward()
+        res[f"y_{tag}"] = y
+        res[f"dx_{tag}"] = x.grad.clone()
+        for k, p in att.named_parameters():
+            res[f"d_{tag}/{k}"] = p.grad.clone()
+    save("window_attention.npz", x=x, g=g, mask=mask, cfg=np.array([c, heads, ws, t, n_w, b]),
+         **sd_arrays(att.state_dict()), **res)
+
+
+def gen_swin_block(swin):
+    torch.manual_seed(1234)
+    res = {}
+    x = torch.randn(1, 2, 64, 32)
+    g = torch.randn(1, 2, 64, 32)
+    for tag, shift in (("shift0", 0), ("shift2", 2)):
+        blk = swin.SwinTransformerBlock(32, (8, 8), 4, window_size=4, shift_size=shift)
+        gu.det_fill(blk.state_dict(), salt=shift)
+        xi = x.clone().requires_grad_(True)
+        y = blk(xi)
+        (y * g).sum().backward()
+        res[f"y_{tag}"] = y
+        res[f"dx_{tag}"] = xi.grad
+        res.update(sd_arrays(blk.state_dict(), f"sd_{tag}/"))
+        for k, p in blk.named_parameters():
+            res[f"d_{tag}/{k}"] = p.grad
+    save("swin_block.npz", x=x, g=g, **res)
+
+
+def gen_patch_merging(swin):
+    torch.manual_seed(5)
+    pm = swin.PatchMerging((8, 8), 32)
+    gu.det_fill(pm.state_dict())
+    x = torch.randn(1, 4, 64, 32, requires_grad=True)
+    g = torch.randn(1, 4, 16, 64)
+    y = pm(x)
+    (y * g).sum().backward()
+    save("patch_merging.npz", x=x, g=g, y=y, dx=x.grad, **sd_arrays(pm.state_dict()),
+         **{f"d/{k}": p.grad for k, p in pm.named_parameters()})
+
+
+def gen_swin_layer(swin):
+    torch.manual_seed(6)
+    net = swin.SwinTransformerLayerv5(dim=32, input_resolution=(16, 16), num_heads=4)
+    gu.det_fill(net.state_dict())
+    x = torch.randn(1, 4, 32, 16, 16, requires_grad=True)
+    g1, g2 = torch.randn(1, 4, 32, 16, 16), torch.randn(1, 4, 64, 8, 8)
+    o1, o2 = net(x)
+    ((o1 * g1).sum() + (o2 * g2).sum()).backward()
+    grads = {f"d/{k}": p.grad for k, p in net.named_parameters()}
+    # keep the fixture small: parameter grads as (sum, abs-sum) pairs + two full tensors
+    gsum = {k: torch.stack([v.sum(), v.abs().sum()]) for k, v in grads.items()}
+    save("swin_layer.npz", x=x, g1=g1, g2=g2, o1=o1, o2=o2, dx=x.grad, **sd_meta(net.state_dict()),
+         **{k.replace("d/", "dsum/"): v for k, v in gsum.items()},
+         **{"d/layers.0.0.attn.relative_position_bias_table": grads["d/layers.0.0.attn.relative_position_bias_table"],
+            "d/layers.4.1.attn.qkv.weight": grads["d/layers.4.1.attn.qkv.weight"]})
+
+
+def gen_aspp(aspp_mod):
+    torch.manual_seed(7)
+    net = aspp_mod.ASPP(num_classes=256)
+    gu.det_fill(net.state_dict())
+    x = torch.randn(2, 1024, 8, 8)
+    net.train()
+    y_train = net(x)
+    rm = net.bn_conv_3x3_2.running_mean.clone()
+    net.eval()
+    y_eval = net(x)
+    save("aspp.npz", x=x, y_train=y_train, y_eval=y_eval, rm_after=rm, **sd_meta(net.state_dict()))
+
+
+def _make_tswin(base, swin, nc, res):
+    net = base.TswinPlus(nc)
+    net.swin = swin.SwinTransformerLayerv5(dim=512, input_resolution=res, num_heads=4)
+    return net
+
+
+def gen_tswinplus(swin, base, losses):
+    torch.manual_seed(8)
+    hh = ww = 128
+    net = _make_tswin(base, swin, 12, (hh // 8, ww // 8))
+    gu.det_fill(net.state_dict())
+    x = gu.det_tensor("tswinplus/x", (2, 4, 3, hh, ww))  # regenerated by the tests, not stored
+    labels = torch.randint(0, 12, (2, hh, ww))
+    labels[0, :5, :7] = -1
+    net.train()
+    y_train = net(x)
+    crit = losses.OhemCELoss2D(hh * ww // 16)
+    loss_train = crit(y_train, labels)
+    rm = net.resnet.layer5[1].bn2.running_mean.clone()
+    nbt = net.resnet.resnet[1].num_batches_tracked.clone()
+    net.eval()
+    y_eval = net(x)
+    save("tswinplus.npz", labels=labels.to(torch.int8), y_train_sub=y_train[:, :, ::2, ::2], y_eval_sub=y_eval[:, :, ::2, ::2],
+         y_train_sum=torch.stack([y_train.sum(), y_train.abs().sum()]),
+         y_eval_sum=torch.stack([y_eval.sum(), y_eval.abs().sum()]),
+         loss_train=loss_train, rm_after=rm, nbt_after=nbt, **sd_meta(net.state_dict()))
+
+
+def gen_ohem(losses):
+    torch.manual_seed(9)
+    res = {}
+    logits = torch.randn(2, 12, 32, 32) * 2
+    labels = torch.randint(0, 12, (2, 32, 32))
+    labels[1, 3:9, 4:20] = -1
+    easy = torch.rand(2, 32, 32) < 0.8
+    boost = torch.nn.functional.one_hot(labels.clamp(min=0), 12).permute(0, 3, 1, 2).float() * easy[:, None] * 12.0
+    for tag, n_min, scale in (("thresh_branch", 128, 0.0), ("topk_branch", 1500, 1.0)):
+        lg = (logits.clone() + scale * boost).requires_grad_(True)
+        crit = losses.OhemCELoss2D(n_min)
+        loss = crit(lg, labels)
+        loss.backward()
+        per = torch.nn.functional.cross_entropy(lg, labels, ignore_index=-1, reduction="none").reshape(-1)
+        srt, _ = torch.sort(per, descending=True)
+        took_thresh = bool(srt[n_min] > crit.thresh)
+        res[f"{tag}_logits"] = lg.detach().clone()
+        res[f"{tag}_loss"] = loss.detach()
+        res[f"{tag}_dlogits"] = lg.grad
+        res[f"{tag}_n_min"] = np.array(n_min)
+        res[f"{tag}_scale"] = np.array(scale)
+        res[f"{tag}_took_thresh"] = np.array(took_thresh)
+        res[f"{tag}_count"] = np.array(int((per > crit.thresh).sum()) if took_thresh else n_min)
+    assert bool(res["thresh_branch_took_thresh"]) and not bool(res["topk_branch_took_thresh"])
+    save("ohem.npz", labels=labels, **res)
+
+
+def gen_regression(pix):
+    torch.manual_seed(10)
+    n, c, h, w = 2, 256, 8, 8
+    feats = [torch.nn.functional.normalize(gu.det_tensor(f"regression/f{i}", (n, c, h, w)), dim=1) for i in range(6)]
+    labs = [torch.randint(0, 12, (n, 1, h, w)).float() for _ in range(6)]
+    labs[2][0] = 3.0  # a frame with one class only -> some rows have no negatives for that key
+    q = feats[0].clone().requires_grad_(True)
+    loss = pix.regression_loss(q, *feats[1:], *labs, 12)
+    loss.backward()
+    save("regression_loss.npz", loss=loss.detach(), dq=q.grad, shape=np.array([n, c, h, w]),
+         **{f"l{i}": l for i, l in enumerate(labs)})
+
+
+def gen_consistency(pix):
+    from types import SimpleNamespace
+    torch.manual_seed(12)
+    args = SimpleNamespace(pixpro_p=1.0, pixpro_momentum=0.99, pixpro_clamp_value=0.0, pixpro_transform_layer=1,
+                           pixpro_ins_loss_weight=0.0, pixpro_pos_ratio=0.7, data="endo18", tag="1",
+                           pretrainpth="none", num_instances=2235, batch_size=2, epochs=150, start_epoch=1)
+    hh = ww = 128
+    # the contrastive copy of the swin hard-codes input_resolution (32,56): patch its default for 128x128
+    sw = sys.modules["Ours.swin_tem"] if "Ours.swin_tem" in sys.modules else None
+    net = pix.ConsistencyLoss(args)
+    swin_cls = type(net.pixpro.encoder_2)
+    net.pixpro.encoder_2 = swin_cls(dim=512, input_resolution=(hh // 8, ww // 8), num_heads=4)
+    net.pixpro.encoder_k_2 = swin_cls(dim=512, input_resolution=(hh // 8, ww // 8), num_heads=4)
+    for p in net.pixpro.encoder_k_2.parameters():
+        p.requires_grad = False
+    sd = net.state_dict()
+    gu.det_fill(sd)
+    # key encoders start as copies of the query encoders (PixPro_swin_v5.py:177-208); det_fill broke that,
+    # which is fine and makes the EMA visible, but keep it explicit:
+    ims = [gu.det_tensor(f"consistency/im{i}", (2, 4, 3, hh, ww)) for i in range(6)]
+    masks = [torch.floor(gu.det_tensor(f"consistency/mask{i}", (2, 1, hh // 8, ww // 8), "uniform", 12.0))
+             .clamp(0, 11).repeat_interleave(8, 2).repeat_interleave(8, 3) for i in range(6)]
+    net.train()
+    k0, big_k = net.pixpro.k, net.pixpro.K
+    loss = net(*ims, *masks)
+    loss.backward()
+    sd_after = net.state_dict()
+    probe = ["pixpro.encoder_k_2.layers.0.0.attn.qkv.weight", "pixpro.projector_k.linear2.weight",
+             "pixpro.encoder_k_1.layer5.1.bn2.running_mean", "pixpro.encoder_k_3.conv_3x3_2.weight"]
+    param_keys = [k for k, _ in net.pixpro.named_parameters()]
+    gq = net.pixpro.projector.linear2.weight.grad
+    save("consistency.npz", loss=loss.detach(), k0=np.array(k0), k1=np.array(net.pixpro.k), big_k=np.array(big_k),
+         param_keys=np.array(param_keys), seed=np.array(12), hw=np.array([hh, ww]),
+         d_projector_linear2=gq,
+         **{"probe/" + k: torch.stack([sd_after[k].double().sum(), sd_after[k].double().abs().sum()]) for k in probe},
+         **sd_meta(sd))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+
+    def want(n):
+        return a.only in (None, n)
+
+    swin, base, aspp_mod, losses = import_seg()
+    if want("index_maps"):
+        gen_index_maps(swin)
+    if want("tables"):
+        gen_tables(swin)
+    if want("window_attention"):
+        gen_window_attention(swin)
+    if want("swin_block"):
+        gen_swin_block(swin)
+    if want("patch_merging"):
+        gen_patch_merging(swin)
+    if want("swin_layer"):
+        gen_swin_layer(swin)
+    if want("aspp"):
+        gen_aspp(aspp_mod)
+    if want("ohem"):
+        gen_ohem(losses)
+    if want("tswinplus"):
+        gen_tswinplus(swin, base, losses)
+    if want("regression_loss") or want("consistency"):
+        pix = import_contrast()
+        if want("regression_loss"):
+            gen_regression(pix)
+        if want("consistency"):
+            gen_consistency(pix)
+
+
+if __name__ == "__main__":
+    main()
