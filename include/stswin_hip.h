@@ -1,0 +1,85 @@
+/* libstswin_hip -- C ABI of the MI355X-native STswinCL hot path.
+ *
+ * The reference (YuemingJin/STswinCL) is pure Python: its "operator interface" for this path is the
+ * nn.Module surface; there is no FFI table to mirror.  This header is therefore the
+ * boundary a maintainer binds with ctypes: plain device pointers, sizes and a
+ * hipStream_t, no torch types.  Each entry point names the reference lines it replaces
+ * (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   dtype      0 = bf16 storage (fp32 accumulate), 1 = fp32 storage (exact fp32 MFMA; parity path)
+ *   pointers   device memory on the current HIP device; row pitches (ld*) in ELEMENTS
+ *   row maps   int32, -1 = zero row (padding); NULL = identity
+ *   stream     hipStream_t (pass torch.cuda.current_stream().cuda_stream); kernels are asynchronous
+ *   return     0 on success, negative on error (-hipError_t, or -1xxx for argument errors)
+ *   No entry point allocates, synchronises or keeps state: all workspaces are caller-owned.
+ */
+#ifndef STSWIN_HIP_H
+#define STSWIN_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* gemm_nt epilogue flags */
+#define STSWIN_GF_GELU 1       /* out = gelu_erf(v); C2 (if given) receives v            (swin_512.py:18-19) */
+#define STSWIN_GF_RESID 2      /* v += R[r_rows[m]][n]                                   (swin_512.py:234-235) */
+#define STSWIN_GF_MUL_DGELU 4  /* v *= gelu'(R[..])   (backward of swin_512.py:19) */
+#define STSWIN_GF_OUT_F32 8    /* C is fp32 regardless of dtype */
+#define STSWIN_GF_ACCUM 16     /* C += v (needs OUT_F32) */
+#define STSWIN_GF_RELU 32
+
+int stswin_abi_version(void);
+
+/* ---- a1-a4: roll + window_partition + pair regroup, and its inverse ------------------------------------
+ * swin_512.py:26-38 (window_partition), :57-71 (window_reverse, T-aware), :210-218, :224-231 (roll, regroup).
+ * Tokens are rows of a (B, frames_total, H*W, C) tensor; the pair is frames f0..f0+T-1 of every clip.
+ * win_rowmap writes map[r] = source token of gathered row r (row order (B*nW, T, ws*ws));
+ * win_move copies rows: dir 0 gather (out[r] = in[map[r]]), dir 1 scatter (out[map[r]] = in[r]). Bit-exact. */
+int stswin_win_rowmap(int* map, int B, int T, int H, int W, int ws, int shift, int f0, int frames_total, void* stream);
+int stswin_win_move(int dtype, const void* in, void* out, int B, int T, int H, int W, int C, int ws, int shift,
+                    int f0, int frames_total, int dir, void* stream);
+/* PatchMerging 2x2 gather map, 4 segments in the order (0,0),(1,0),(0,1),(1,1)  (swin_512.py:267-271). */
+int stswin_merge_rowmap(int* map /*[4][frames*H/2*W/2]*/, int frames, int H, int W, void* stream);
+/* 3x3 convolution tap map (padding = dilation), 9 segments ky*3+kx   (ASPP.py:13-20, base18.py:73). */
+int stswin_conv3x3_rowmap(int* map /*[9][frames*H*W]*/, int frames, int H, int W, int dilation, void* stream);
+
+/* ---- segmented gather GEMM: C[c_rows[m]][n] = epi( sum_s A[a_rows[s][m]][0:Kseg] . B[n][s*Kseg:(s+1)*Kseg] )
+ * nn.Linear of swin_512.py:115 (qkv, with the window gather fused via a_rows and the q scaling via
+ * scale/scale_cols, :118), :139 (proj, with window_reverse + un-roll + shortcut fused via c_rows/r_rows, :224-234),
+ * :18-21 (Mlp fc1+GELU, fc2 + residual), :275 (PatchMerging reduction); 1x1 / 3x3 / dilated nn.Conv2d of
+ * ASPP.py:37-50 and base18.py:60-77 as implicit GEMM over NHWC tokens.  Kseg must be a multiple of 64 (bf16) / 32 (f32). */
+int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_rows, const void* B, long ldb, void* C, long ldc,
+                   const int* c_rows, void* C2, long ldc2, const float* bias, const void* R, long ldr,
+                   const int* r_rows, int M, int N, int Kseg, int S, float scale, int scale_cols, int flags, void* stream);
+/* weight gradients: C[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]   (fp32 atomics; splits<=0: auto) */
+int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, const void* Bt, long ldb, const int* bt_rows,
+                   float* C, long ldc, int Mk, int Ni, int Nj, int splits, void* stream);
+/* out[n] += sum_m Y[m][n]  (bias gradients) */
+int stswin_colsum(int dtype, const void* y, long ldy, float* out, int M, int N, void* stream);
+
+/* ---- nn.LayerNorm (swin_512.py:160,166 norm1/norm2; :253,:274 PatchMerging.norm with the 2x2 gather fused:
+ * row r = concat_s x[rows[s][r]][0:Cseg]).  mean/rstd (fp32 [M]) are saved for the backward. */
+int stswin_layernorm_fwd(int dtype, const void* x, long ldx, const int* rows, int S, int Cseg, void* y, long ldy,
+                         const float* gamma, const float* beta, float* mean, float* rstd, int M, float eps, void* stream);
+int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const int* rows, int S, int Cseg,
+                         const float* gamma, const float* mean, const float* rstd, void* dx, long lddx, float* dgamma,
+                         float* dbeta, int M, int accumulate_dx, void* stream);
+
+/* ---- a6: windowed attention core (swin_512.py:117-138).  qkv [nB_*T*N][3C] = q (pre-scaled) | k | v in window
+ * order; biasT [heads][N][N] and maskT [nW][N][N] are the expanded relative-position bias (:122-124) and the
+ * SW-MSA mask (:126-131), both transposed to [key][query]; out [nB_*T*N][C] is the (B_, T*N, heads*d) layout of :136.
+ * bwd: dqkv gets (scale*dS k | dS^T q_s | P^T dO); dbiasT is atomically accumulated. */
+int stswin_win_attn_fwd(int dtype, const void* qkv, long ld, void* out, long ldo, const float* biasT, const float* maskT,
+                        int nB_, int nW, int T_frames, int ws, int heads, int C, void* stream);
+int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, long lddo, void* dqkv, long lddq,
+                        const float* biasT, const float* maskT, float* dbiasT, int nB_, int nW, int T_frames, int ws,
+                        int heads, int C, float scale, void* stream);
+
+/* ---- device self-test of the MFMA / LDS primitives the kernels are built on; writes a report into `out`
+ * (fp32, >= 64 KiB) and returns the number of failed checks (0 = all good). Used by tests only. */
+int stswin_selftest(float* out, int which, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

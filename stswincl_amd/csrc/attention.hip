@@ -1,0 +1,467 @@
+// Temporal window attention core for gfx950: per (window, head) problem of NTOK = T*ws*ws tokens,
+//     S = q_s k^T + bias[(i mod N),(j mod N)] + mask[w][(i mod N),(j mod N)] ; P = softmax(S) ; O = P v
+// (reference swin_512.py:117-138; q arrives pre-scaled from the QKV GEMM epilogue, bias/mask arrive
+// expanded and TRANSPOSED as [.., key n, query n] fp32 so a wave reads them coalesced.)
+//
+// MFMA 32x32x16 bf16 (32x32x2 exact f32).  The scores are computed TRANSPOSED, S^T = K Q^T, so that a
+// lane owns one query column and the softmax reduction over keys is in-lane (+ one exchange with lane^32).
+// Work split: a wave owns 32 queries; a workgroup of 4 waves owns 128/NTOK problems (stage 1: one
+// 128-token problem; stage 2: the 4 heads of one 32-token window).
+//
+// bf16: K and V tiles are staged in LDS by LDS-DMA (swz256 image); Q / dO operands come straight from
+// global as 16-byte row fragments; P (and dS) go through LDS so the second product can read them either
+// row-wise (ds_read_b128) or transposed (ds_read_b64_tr_b16).
+// f32 : fragments are single elements, so K/V/Q/dO are read from global directly; only P/dS use LDS.
+#include "common.h"
+
+struct AttnArgs {
+  const void* qkv; long ld;       // [rows][3C]: q (pre-scaled) | k | v, window-ordered rows
+  void* out; long ldo;            // fwd: O [rows][C] ; bwd: dqkv [rows][3C]
+  const void* dout; long lddo;    // bwd only: dO [rows][C]
+  const float* biasT;             // [heads][N][N]   biasT[h][key n][query n]
+  const float* maskT;             // [nW][N][N] or null
+  float* dbiasT;                  // bwd: [heads][N][N] fp32, atomically accumulated
+  int nB_, nW, heads, C, N;       // nB_ = number of (clip, window) problems = B*nW
+  float scale;                    // bwd: dq = scale * (dS k)
+};
+
+template <int CPR> DEVI int swz_cpr(int row) {
+  constexpr int m = (CPR >= 16 ? 16 : CPR) - 1;
+  return swz256(row) & m;
+}
+template <int ROWB> DEVI int tile_off(int row, int chunk) {   // byte offset of 16-byte chunk `chunk` of row `row`
+  constexpr int CPR = ROWB / 16;
+  return row * ROWB + (((chunk & ~15) | ((chunk ^ swz_cpr<CPR>(row)) & 15)) << 4);
+}
+
+// LDS-DMA a [ROWS][ROWB bytes] tile (rows `row0..` of a row-major global matrix with pitch ld_bytes) using
+// `nwaves` waves (this wave is number `wv` of them).  Destination image: tile_off().
+template <int ROWS, int ROWB>
+DEVI void stage_tile(char* lds, const char* g, long ld_bytes, int wv, int nwaves) {
+  constexpr int CPR = ROWB / 16;
+  constexpr int RPI = (1024 / ROWB) > 0 ? (1024 / ROWB) : 1;       // rows per wave instruction
+  constexpr int IPR = ROWB > 1024 ? ROWB / 1024 : 1;               // instructions per row (rows > 1 KiB)
+  constexpr int NINST = ROWS * ROWB / 1024;
+  const int l = threadIdx.x & 63;
+  for (int ins = wv; ins < NINST; ins += nwaves) {
+    int row, cphys;
+    if constexpr (IPR == 1) { row = ins * RPI + l / CPR; cphys = l % CPR; }
+    else { row = ins / IPR; cphys = (ins % IPR) * 64 + l; }
+    const int csrc = (cphys & ~15) | ((cphys ^ swz_cpr<CPR>(row)) & 15);
+    glds16(g + row * ld_bytes + csrc * 16, lds + ins * 1024);
+  }
+}
+
+// row fragment (k contiguous) of a tile whose rows are the MFMA row/col index: 8 bf16 at k = 16*ks + 8*half
+template <int ROWB> DEVI bf16x8 frag_row(const char* tile, int row, int ks, int half) {
+  return *(const bf16x8*)(tile + tile_off<ROWB>(row, 2 * ks + half));
+}
+// transposed fragment of a tile whose ROWS are the contraction index: operand element (idx = tile col, k)
+template <int ROWB> DEVI bf16x8 frag_tr(const char* tile, int ks, int col_tile) {
+  const int l = threadIdx.x & 63;
+  const int k0 = 16 * ks + 8 * (l >> 5), col0 = 32 * col_tile + 16 * ((l >> 4) & 1);
+  const int lam = l & 15, q = lam >> 2, p = lam & 3;
+  bf16x4 r[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int row = k0 + 4 * e + q, col = col0 + 4 * p;
+    const char* addr = tile + tile_off<ROWB>(row, col >> 3) + ((col & 7) << 1);
+    short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)addr);
+    r[e] = __builtin_bit_cast(bf16x4, t);
+  }
+  return cat4(r[0], r[1]);
+}
+
+DEVI int crow32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }   // C-map row of register r
+
+template <typename T, int NTOK, int HD>
+struct AttnCfg {
+  static constexpr int QW = NTOK / 32;            // waves (query tiles) per problem
+  static constexpr int PPB = 4 / QW;              // problems per workgroup
+  static constexpr int KT = NTOK / 32;            // key tiles
+  static constexpr int DT = HD / 32;              // head-dim tiles
+  static constexpr int RB = HD * sizeof(T);       // K/V/Q/dO tile row bytes
+  static constexpr int PRB = NTOK * sizeof(T);    // P/dS tile row bytes
+  static constexpr int KV_BYTES = TT<T>::IS_BF16 ? NTOK * RB : 0;
+  static constexpr int P_BYTES = NTOK * PRB;      // per problem, all query tiles
+  static constexpr int FWD_LDS = PPB * (2 * KV_BYTES + P_BYTES);
+  static constexpr int BWD_LDS = PPB * (2 * KV_BYTES + 2 * P_BYTES);
+  static_assert(NTOK % 32 == 0 && HD % 32 == 0 && (QW == 1 || QW == 2 || QW == 4), "shape");
+};
+
+// ---- S^T (+bias, +mask) and softmax for this wave's 32 queries: returns normalised P^T in p[KT] -------------
+template <typename T, int NTOK, int HD>
+DEVI void scores_softmax(f32x16 (&p)[NTOK / 32], const AttnArgs& a, const char* Kt, const T* qbase, const T* kbase,
+                         int q0, int head, int widx) {
+  using Cfg = AttnCfg<T, NTOK, HD>;
+  const int l = threadIdx.x & 63, lr = l & 31, half = l >> 5;
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[kt][r] = 0.f;
+  if constexpr (TT<T>::IS_BF16) {
+    bf16x8 qf[HD / 16];
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) qf[ks] = *(const bf16x8*)(qbase + (long)(q0 + lr) * a.ld + 16 * ks + 8 * half);
+#pragma unroll
+    for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks)
+        p[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<Cfg::RB>(Kt, kt * 32 + lr, ks, half), qf[ks], p[kt], 0, 0, 0);
+  } else {
+#pragma unroll 4
+    for (int kk = 0; kk < HD / 2; ++kk) {
+      const float qv = qbase[(long)(q0 + lr) * a.ld + 2 * kk + half];
+#pragma unroll
+      for (int kt = 0; kt < Cfg::KT; ++kt)
+        p[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kbase[(long)(kt * 32 + lr) * a.ld + 2 * kk + half], qv, p[kt], 0, 0, 0);
+    }
+  }
+  // + bias + mask (transposed tables: [key n][query n], lanes contiguous in query)
+  const int N = a.N;
+  const int qn = (q0 + lr) % N;
+  const float* bt = a.biasT + (long)head * N * N + qn;
+  const float* mt = a.maskT ? a.maskT + (long)widx * N * N + qn : nullptr;
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kn = (kt * 32 + crow32(r, half)) % N;
+      float s = p[kt][r] + bt[kn * N];
+      if (mt) s += mt[kn * N];
+      p[kt][r] = s;
+      mx = fmaxf(mx, s);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = TT<T>::IS_BF16 ? __expf(p[kt][r] - mx) : expf(p[kt][r] - mx);
+      p[kt][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[kt][r] *= inv;
+}
+
+// write this wave's X^T registers (lane = query column, regs = keys) into tile[query row][key] (T elements)
+template <typename T, int NTOK>
+DEVI void store_qk_tile(char* tile, const f32x16 (&x)[NTOK / 32], int q0) {
+  constexpr int PRB = NTOK * sizeof(T);
+  const int l = threadIdx.x & 63, lr = l & 31, half = l >> 5;
+#pragma unroll
+  for (int kt = 0; kt < NTOK / 32; ++kt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int key = kt * 32 + 8 * g + 4 * half;      // 4 consecutive keys: registers 4g..4g+3
+      if constexpr (TT<T>::IS_BF16) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (bf16)x[kt][4 * g + e];
+        *(bf16x4*)(tile + tile_off<PRB>(q0 + lr, key >> 3) + ((key & 7) << 1)) = v;
+      } else {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = x[kt][4 * g + e];
+        *(f32x4*)(tile + tile_off<PRB>(q0 + lr, key >> 2)) = v;
+      }
+    }
+}
+template <typename T, int ROWB> DEVI float tile_elem_f32(const char* tile, int row, int col) {   // f32 tiles only
+  return *(const float*)(tile + tile_off<ROWB>(row, col >> 2) + ((col & 3) << 2));
+}
+
+// ====================================================================================================
+template <typename T, int NTOK, int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  using Cfg = AttnCfg<T, NTOK, HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int l = threadIdx.x & 63, lr = l & 31, half = l >> 5, w = wave_id();
+  const int sp = w / Cfg::QW, qt = w % Cfg::QW;
+  const long prob = (long)blockIdx.x * Cfg::PPB + sp;
+  const int b_ = prob / a.heads, head = prob % a.heads;
+  const bool live = b_ < a.nB_;
+  const long rowbase = (long)b_ * NTOK;
+  const T* qbase = (const T*)a.qkv + rowbase * a.ld + head * HD;
+  const T* kbase = qbase + a.C;
+  const T* vbase = qbase + 2 * a.C;
+  char* Kt = smem + sp * (2 * Cfg::KV_BYTES + Cfg::P_BYTES);
+  char* Vt = Kt + Cfg::KV_BYTES;
+  char* Pt = Vt + Cfg::KV_BYTES;
+  const int q0 = qt * 32;
+  if constexpr (TT<T>::IS_BF16) {
+    if (live) {
+      stage_tile<NTOK, Cfg::RB>(Kt, (const char*)kbase, a.ld * sizeof(T), qt, Cfg::QW);
+      stage_tile<NTOK, Cfg::RB>(Vt, (const char*)vbase, a.ld * sizeof(T), qt, Cfg::QW);
+    }
+    wait_vm0();
+    __syncthreads();
+  }
+  if (!live) return;   // (no barrier below is reached by a subset of a PROBLEM's waves only when QW == 1)
+
+  f32x16 p[Cfg::KT];
+  scores_softmax<T, NTOK, HD>(p, a, Kt, qbase, kbase, q0, head, b_ % a.nW);
+  store_qk_tile<T, NTOK>(Pt, p, q0);   // rows q0..q0+31 are private to this wave
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own LDS writes visible to own reads
+
+  f32x16 o[Cfg::DT];
+#pragma unroll
+  for (int dt = 0; dt < Cfg::DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  if constexpr (TT<T>::IS_BF16) {
+#pragma unroll
+    for (int ks = 0; ks < NTOK / 16; ++ks) {
+      const bf16x8 pa = frag_row<Cfg::PRB>(Pt, q0 + lr, ks, half);
+#pragma unroll
+      for (int dt = 0; dt < Cfg::DT; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<Cfg::RB>(Vt, ks, dt), o[dt], 0, 0, 0);
+    }
+  } else {
+#pragma unroll 4
+    for (int kk = 0; kk < NTOK / 2; ++kk) {
+      const float pa = tile_elem_f32<T, Cfg::PRB>(Pt, q0 + lr, 2 * kk + half);
+#pragma unroll
+      for (int dt = 0; dt < Cfg::DT; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, vbase[(long)(2 * kk + half) * a.ld + dt * 32 + lr], o[dt], 0, 0, 0);
+    }
+  }
+  // O[query = crow32(r)][d = 32 dt + lr] -> out[rowbase + q0 + query][head*HD + d]
+  T* ob = (T*)a.out + (rowbase + q0) * a.ldo + head * HD;
+#pragma unroll
+  for (int dt = 0; dt < Cfg::DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ob[(long)crow32(r, half) * a.ldo + dt * 32 + lr] = from_f32<T>(o[dt][r]);
+}
+
+// ====================================================================================================
+// Backward: dq = scale * dS k ; dk = dS^T q_s ; dv = P^T dO ; dbias += fold(dS) ;  dS = P o (dP - rowsum(P o dP)).
+template <typename T, int NTOK, int HD>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
+  using Cfg = AttnCfg<T, NTOK, HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int l = threadIdx.x & 63, lr = l & 31, half = l >> 5, w = wave_id();
+  const int sp = w / Cfg::QW, qt = w % Cfg::QW;
+  const long prob = (long)blockIdx.x * Cfg::PPB + sp;
+  const int b_ = min((int)(prob / a.heads), a.nB_ - 1), head = prob % a.heads;
+  const bool live = prob / a.heads < a.nB_;      // dead problems recompute a live one and skip every store
+  const long rowbase = (long)b_ * NTOK;
+  const T* qbase = (const T*)a.qkv + rowbase * a.ld + head * HD;
+  const T* kbase = qbase + a.C;
+  const T* vbase = qbase + 2 * a.C;
+  const T* dobase = (const T*)a.dout + rowbase * a.lddo + head * HD;
+  char* Kt = smem + sp * (2 * Cfg::KV_BYTES + 2 * Cfg::P_BYTES);
+  char* Vt = Kt + Cfg::KV_BYTES;                 // V, later dO, later Q
+  char* Pt = Vt + Cfg::KV_BYTES;
+  char* St = Pt + Cfg::P_BYTES;                  // dS
+  const int q0 = qt * 32;
+  if constexpr (TT<T>::IS_BF16) {
+    stage_tile<NTOK, Cfg::RB>(Kt, (const char*)kbase, a.ld * sizeof(T), qt, Cfg::QW);
+    stage_tile<NTOK, Cfg::RB>(Vt, (const char*)vbase, a.ld * sizeof(T), qt, Cfg::QW);
+    wait_vm0();
+    __syncthreads();
+  }
+  f32x16 p[Cfg::KT], dp[Cfg::KT];
+  scores_softmax<T, NTOK, HD>(p, a, Kt, qbase, kbase, q0, head, b_ % a.nW);
+  // dP^T = V dO^T
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dp[kt][r] = 0.f;
+  if constexpr (TT<T>::IS_BF16) {
+    bf16x8 df[HD / 16];
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) df[ks] = *(const bf16x8*)(dobase + (long)(q0 + lr) * a.lddo + 16 * ks + 8 * half);
+#pragma unroll
+    for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks)
+        dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<Cfg::RB>(Vt, kt * 32 + lr, ks, half), df[ks], dp[kt], 0, 0, 0);
+  } else {
+#pragma unroll 4
+    for (int kk = 0; kk < HD / 2; ++kk) {
+      const float dv = dobase[(long)(q0 + lr) * a.lddo + 2 * kk + half];
+#pragma unroll
+      for (int kt = 0; kt < Cfg::KT; ++kt)
+        dp[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vbase[(long)(kt * 32 + lr) * a.ld + 2 * kk + half], dv, dp[kt], 0, 0, 0);
+    }
+  }
+  float delta = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) delta += p[kt][r] * dp[kt][r];
+  delta += __shfl_xor(delta, 32);
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dp[kt][r] = p[kt][r] * (dp[kt][r] - delta);     // dp now holds dS^T
+  // relative-position-bias gradient (expanded, transposed table)
+  if (live && a.dbiasT) {
+    const int N = a.N, qn = (q0 + lr) % N;
+    float* db = a.dbiasT + (long)head * N * N + qn;
+#pragma unroll
+    for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) atomicAdd(db + ((kt * 32 + crow32(r, half)) % N) * N, dp[kt][r]);
+  }
+  store_qk_tile<T, NTOK>(Pt, p, q0);
+  store_qk_tile<T, NTOK>(St, dp, q0);
+  __syncthreads();                               // P, dS complete; every wave is done with V
+  T* dqb = (T*)a.out + rowbase * a.ldo + head * HD;
+  T* dkb = dqb + a.C;
+  T* dvb = dqb + 2 * a.C;
+  const int k0 = qt * 32;                        // this wave's KEY tile for dV / dK
+
+  f32x16 acc[Cfg::DT];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int dt = 0; dt < Cfg::DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+  };
+  auto store_acc = [&](T* base, int row0, float mul) {
+    if (!live) return;
+#pragma unroll
+    for (int dt = 0; dt < Cfg::DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        base[(long)(row0 + crow32(r, half)) * a.ldo + dt * 32 + lr] = from_f32<T>(acc[dt][r] * mul);
+  };
+
+  // ---- dV[key][d] = sum_q P[q][key] dO[q][d]
+  if constexpr (TT<T>::IS_BF16) {
+    stage_tile<NTOK, Cfg::RB>(Vt, (const char*)dobase, a.lddo * sizeof(T), qt, Cfg::QW);
+    wait_vm0();
+    __syncthreads();
+  }
+  zero_acc();
+  if constexpr (TT<T>::IS_BF16) {
+#pragma unroll
+    for (int ks = 0; ks < NTOK / 16; ++ks) {
+      const bf16x8 pa = frag_tr<Cfg::PRB>(Pt, ks, qt);
+#pragma unroll
+      for (int dt = 0; dt < Cfg::DT; ++dt)
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<Cfg::RB>(Vt, ks, dt), acc[dt], 0, 0, 0);
+    }
+  } else {
+#pragma unroll 4
+    for (int kk = 0; kk < NTOK / 2; ++kk) {
+      const int qq = 2 * kk + half;
+      const float pa = tile_elem_f32<T, Cfg::PRB>(Pt, qq, k0 + lr);
+#pragma unroll
+      for (int dt = 0; dt < Cfg::DT; ++dt)
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, dobase[(long)qq * a.lddo + dt * 32 + lr], acc[dt], 0, 0, 0);
+    }
+  }
+  store_acc(dvb, k0, 1.0f);
+
+  // ---- dK[key][d] = sum_q dS[q][key] q_s[q][d]
+  if constexpr (TT<T>::IS_BF16) {
+    __syncthreads();                             // all waves finished reading the dO tile
+    stage_tile<NTOK, Cfg::RB>(Vt, (const char*)qbase, a.ld * sizeof(T), qt, Cfg::QW);
+    wait_vm0();
+    __syncthreads();
+  }
+  zero_acc();
+  if constexpr (TT<T>::IS_BF16) {
+#pragma unroll
+    for (int ks = 0; ks < NTOK / 16; ++ks) {
+      const bf16x8 sa = frag_tr<Cfg::PRB>(St, ks, qt);
+#pragma unroll
+      for (int dt = 0; dt < Cfg::DT; ++dt)
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa, frag_tr<Cfg::RB>(Vt, ks, dt), acc[dt], 0, 0, 0);
+    }
+  } else {
+#pragma unroll 4
+    for (int kk = 0; kk < NTOK / 2; ++kk) {
+      const int qq = 2 * kk + half;
+      const float sa = tile_elem_f32<T, Cfg::PRB>(St, qq, k0 + lr);
+#pragma unroll
+      for (int dt = 0; dt < Cfg::DT; ++dt)
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, qbase[(long)qq * a.ld + dt * 32 + lr], acc[dt], 0, 0, 0);
+    }
+  }
+  store_acc(dkb, k0, 1.0f);
+
+  // ---- dQ[q][d] = scale * sum_key dS[q][key] K[key][d]
+  zero_acc();
+  if constexpr (TT<T>::IS_BF16) {
+#pragma unroll
+    for (int ks = 0; ks < NTOK / 16; ++ks) {
+      const bf16x8 sa = frag_row<Cfg::PRB>(St, q0 + lr, ks, half);
+#pragma unroll
+      for (int dt = 0; dt < Cfg::DT; ++dt)
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa, frag_tr<Cfg::RB>(Kt, ks, dt), acc[dt], 0, 0, 0);
+    }
+  } else {
+#pragma unroll 4
+    for (int kk = 0; kk < NTOK / 2; ++kk) {
+      const int key = 2 * kk + half;
+      const float sa = tile_elem_f32<T, Cfg::PRB>(St, q0 + lr, key);
+#pragma unroll
+      for (int dt = 0; dt < Cfg::DT; ++dt)
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, kbase[(long)key * a.ld + dt * 32 + lr], acc[dt], 0, 0, 0);
+    }
+  }
+  store_acc(dqb, q0, a.scale);
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+template <typename T, int NTOK, int HD>
+static int launch_attn(const AttnArgs& a, bool bwd, hipStream_t st) {
+  using Cfg = AttnCfg<T, NTOK, HD>;
+  const long probs = (long)a.nB_ * a.heads;
+  const int grid = (int)((probs + Cfg::PPB - 1) / Cfg::PPB);
+  const int lds = bwd ? Cfg::BWD_LDS : Cfg::FWD_LDS;
+  static_assert(Cfg::BWD_LDS <= 160 * 1024, "LDS budget");
+  const void* fn = bwd ? (const void*)attn_bwd_kernel<T, NTOK, HD> : (const void*)attn_fwd_kernel<T, NTOK, HD>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return -(int)e;
+  if (bwd) hipLaunchKernelGGL((attn_bwd_kernel<T, NTOK, HD>), dim3(grid), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<T, NTOK, HD>), dim3(grid), dim3(256), lds, st, a);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+static int dispatch_attn(const AttnArgs& a, int ntok, int hd, bool bwd, hipStream_t st) {
+#define CASE(NT, D) if (ntok == NT && hd == D) return launch_attn<T, NT, D>(a, bwd, st)
+  CASE(128, 128); CASE(32, 256);      // the reference model (stage 1 / stage 2)
+  CASE(128, 32);  CASE(32, 64);       // reduced-width test configuration (dim 128)
+  CASE(128, 64);  CASE(32, 128);
+  CASE(32, 32);
+#undef CASE
+  return -1201;
+}
+
+static int attn_common(int dtype, AttnArgs& a, int T_frames, int ws, bool bwd, void* stream) {
+  const int ntok = T_frames * ws * ws;
+  if (a.C % a.heads) return -1202;
+  const int hd = a.C / a.heads;
+  a.N = ws * ws;
+  if (a.nW <= 0 || a.nB_ % a.nW) return -1203;
+  return dtype == 0 ? dispatch_attn<bf16>(a, ntok, hd, bwd, (hipStream_t)stream)
+                    : dispatch_attn<float>(a, ntok, hd, bwd, (hipStream_t)stream);
+}
+
+extern "C" int stswin_win_attn_fwd(int dtype, const void* qkv, long ld, void* out, long ldo, const float* biasT,
+                                   const float* maskT, int nB_, int nW, int T_frames, int ws, int heads, int C,
+                                   void* stream) {
+  AttnArgs a{qkv, ld, out, ldo, nullptr, 0, biasT, maskT, nullptr, nB_, nW, heads, C, 0, 1.0f};
+  return attn_common(dtype, a, T_frames, ws, false, stream);
+}
+
+extern "C" int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, long lddo, void* dqkv, long lddq,
+                                   const float* biasT, const float* maskT, float* dbiasT, int nB_, int nW, int T_frames,
+                                   int ws, int heads, int C, float scale, void* stream) {
+  AttnArgs a{qkv, ld, dqkv, lddq, dout, lddo, biasT, maskT, dbiasT, nB_, nW, heads, C, 0, scale};
+  return attn_common(dtype, a, T_frames, ws, true, stream);
+}

@@ -1,0 +1,127 @@
+// Device-side helpers shared by every kernel of libstswin_hip (gfx950 / CDNA4 only).
+//
+// Conventions
+//   * wave = 64 lanes; workgroups are 256 threads (4 waves, one per SIMD) unless stated.
+//   * storage type T is __bf16 (fast path) or float (exact-fp32 parity path); accumulation is fp32.
+//   * MFMA lane maps (cdna_hip_programming.md section 3):
+//       16x16x32 bf16 : A[row l&15][k 8(l>>4)+j]  B[k 8(l>>4)+j][col l&15]  C[row 4(l>>4)+r][col l&15]
+//       32x32x16 bf16 : A[row l&31][k 8(l>>5)+j]  B[k 8(l>>5)+j][col l&31]  C[row (r&3)+8(r>>2)+4(l>>5)][col l&31]
+//       16x16x4  f32  : A[row l&15][k l>>4]       B[k l>>4][col l&15]       C as 16x16
+//       32x32x2  f32  : A[row l&31][k l>>5]       B[k l>>5][col l&31]       C as 32x32
+//   * LDS images are written by LDS-DMA (global_load_lds_dwordx4: destination = wave base + lane*16,
+//     so the XOR swizzle is applied to the per-lane SOURCE address and again on the read).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define DEVI __device__ __forceinline__
+
+// 256 B of zeros in device memory: the source of every padded / out-of-range 16-byte chunk.
+static __device__ uint4 g_stswin_zero[16];  // per-TU copy (no -fgpu-rdc); zero-initialised
+
+DEVI int lane_id() { return threadIdx.x & 63; }
+DEVI int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+// ---- LDS-DMA: 16 B per lane, LDS destination = wave-uniform base + lane*16 -----------------
+DEVI void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+DEVI void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ---- swizzles ---------------------------------------------------------------------------------
+// 128-byte rows (8 chunks of 16 B): chunk ^= row & 7   -> ds_read_b128 fragment reads conflict-free.
+DEVI int swz128(int row) { return row & 7; }
+// 256-byte (or longer) rows: chunk ^= ((row&3)<<2)|((row>>2)&3) on the low 4 chunk bits -> both the
+// row-wise ds_read_b128 and the transposed ds_read_b64_tr_b16 reads are conflict-free (guide T10 (b)).
+DEVI int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// ---- scalar conversions -----------------------------------------------------------------------
+template <typename T> DEVI float to_f32(T v);
+template <> DEVI float to_f32<float>(float v) { return v; }
+template <> DEVI float to_f32<bf16>(bf16 v) { return (float)v; }
+template <typename T> DEVI T from_f32(float v);
+template <> DEVI float from_f32<float>(float v) { return v; }
+template <> DEVI bf16 from_f32<bf16>(float v) { return (bf16)v; }  // v_cvt_pk_bf16_f32, RNE, NaN-safe
+
+DEVI float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+DEVI float dgelu_erf(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+// ---- per-type traits ----------------------------------------------------------------------------
+template <typename T> struct TT;
+template <> struct TT<bf16> {
+  static constexpr int PACK = 8;    // elements per 16-byte chunk
+  static constexpr bool IS_BF16 = true;
+};
+template <> struct TT<float> {
+  static constexpr int PACK = 4;
+  static constexpr bool IS_BF16 = false;
+};
+
+// 8 (bf16) or 4 (f32) consecutive elements <-> 16 bytes
+template <typename T> struct Vec16;
+template <> struct Vec16<bf16> {
+  bf16x8 v;
+  DEVI float get(int i) const { return (float)v[i]; }
+  DEVI void set(int i, float f) { v[i] = (bf16)f; }
+};
+template <> struct Vec16<float> {
+  f32x4 v;
+  DEVI float get(int i) const { return v[i]; }
+  DEVI void set(int i, float f) { v[i] = f; }
+};
+
+// ---- transposed fragment read from an LDS tile whose ROW index is the contraction index -------
+// Returns, for the calling lane, the 4 elements tile[k0 + 0..3][col0 + (lane&15)] of a 16-lane group's
+// 4x16 block (ds_read_b64_tr_b16; EXEC must be full).  `row_bytes` = LDS row pitch, swizzle = swz256.
+DEVI bf16x4 lds_tr4(const char* tile, int row_bytes, int k0, int col0) {
+  const int lam = threadIdx.x & 15;
+  const int q = lam >> 2, p = lam & 3;
+  const int row = k0 + q;
+  const int col = col0 + 4 * p;              // element column; 8 elements per chunk
+  const int chunk = (col >> 3) ^ swz256(row);
+  const char* addr = tile + row * row_bytes + (chunk << 4) + ((col & 7) << 1);
+  short4v r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)addr);
+  return __builtin_bit_cast(bf16x4, r);
+}
+
+DEVI bf16x8 cat4(bf16x4 a, bf16x4 b) {
+  bf16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+
+// ---- XCD-aware, bijective block-id remap: blocks that share an XCD (bid % 8) get contiguous tiles -
+DEVI int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}
+
+DEVI float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+DEVI float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+#define STSWIN_CHECK_LAUNCH()                                  \
+  do {                                                         \
+    hipError_t e__ = hipGetLastError();                        \
+    if (e__ != hipSuccess) return -(int)e__;                   \
+  } while (0)

@@ -1,0 +1,429 @@
+// Segmented gather GEMMs for gfx950 (MFMA 16x16x32 bf16 / exact-f32 16x16x4).
+//
+//   gemm_nt : C[M,N] = epilogue( sum_s A[a_rows[s][m], 0:Kseg] . B[n, s*Kseg:(s+1)*Kseg] )
+//             One template serves:  plain Linear (S=1, no maps);  the fused roll+window-partition+pair-regroup
+//             feeding the QKV projection (a_rows = window gather map, reference swin_512.py:207-218 + :115);
+//             the window_reverse+un-roll+residual behind proj (c_rows/r_rows, swin_512.py:224-234);
+//             patch-merging's 2x2 gather (S=4, swin_512.py:265-272) and every 3x3 / dilated convolution of the
+//             decode head as implicit GEMM (S=9 taps, a_rows = shifted pixel or -1 for padding; ASPP.py:13-20,
+//             base18.py:73).
+//   gemm_tn : C[Ni,Nj] += sum_m At[at_rows[m], i] * Bt[bt_rows[m], j]   (weight gradients; fp32 atomics, split over m)
+//
+// Tile 128x128, 256 threads = 2x2 waves of 64x64, BK = 64 (bf16) / 32 (f32): 128-byte LDS rows, written by
+// LDS-DMA (global_load_lds_dwordx4) with the XOR swizzle on the source address, double buffered, one barrier
+// per K tile.  Epilogue goes through an fp32 LDS image so that stores / residual reads are whole 16-byte
+// row pieces (and so that scatter maps cost nothing).
+#include "common.h"
+
+enum {
+  GF_GELU = 1,       // out = gelu(v); C2 (if any) receives v (pre-activation)
+  GF_RESID = 2,      // v += R[r_rows[m]][n]
+  GF_MUL_DGELU = 4,  // v *= gelu'(R[r_rows[m]][n])           (R = saved pre-activation)
+  GF_OUT_F32 = 8,    // C is float regardless of T
+  GF_ACCUM = 16,     // C += v (only with GF_OUT_F32)
+  GF_RELU = 32,
+};
+
+struct GemmNT {
+  const void* A; long lda; const int* a_rows;
+  const void* B; long ldb;
+  void* C; long ldc; const int* c_rows;
+  void* C2; long ldc2;
+  const float* bias;
+  const void* R; long ldr; const int* r_rows;
+  int M, N, Kseg, S;
+  float scale; int scale_cols;
+  int flags;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
+  constexpr int PACK = TT<T>::PACK;
+  constexpr int BK = 8 * PACK;               // 128-byte rows
+  constexpr int ROWB = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63, w = wave_id();
+  const int wr = w >> 1, wc = w & 1;
+  const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M + 127) >> 7;
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (t / tiles_n) << 7, n0 = (t % tiles_n) << 7;
+
+  const char* zero = (const char*)g_stswin_zero;
+  const int rsub = l >> 3, cphys = l & 7, csrc = cphys ^ rsub;
+  const char* abase[4]; int astep[4];
+  const char* bbase[4]; int bstep[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gn = n0 + (w * 4 + i) * 8 + rsub;
+    if (gn < p.N) { bbase[i] = (const char*)p.B + ((long)gn * p.ldb) * sizeof(T) + csrc * 16; bstep[i] = BK * sizeof(T); }
+    else { bbase[i] = zero + cphys * 16; bstep[i] = 0; }
+  }
+  auto load_a_bases = [&](int seg) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gm = m0 + (w * 4 + i) * 8 + rsub;
+      long row = -1;
+      if (gm < p.M) row = p.a_rows ? (long)p.a_rows[(long)seg * p.M + gm] : (long)gm;
+      if (row >= 0) { abase[i] = (const char*)p.A + (row * p.lda) * sizeof(T) + csrc * 16; astep[i] = BK * sizeof(T); }
+      else { abase[i] = zero + cphys * 16; astep[i] = 0; }
+    }
+  };
+  const int kps = p.Kseg / BK;               // K tiles per segment
+  const int nt = p.S * kps;
+  auto stage = [&](int ktg, int kt, int buf) {
+    char* Ab = smem + buf * 32768;
+    char* Bb = Ab + 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(abase[i] + (long)kt * astep[i], Ab + (w * 4 + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(bbase[i] + (long)ktg * bstep[i], Bb + (w * 4 + i) * 1024);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int seg = 0;
+  load_a_bases(0);
+  stage(0, 0, 0);
+  const int fr = l & 15, fq = l >> 4;
+  for (int ktg = 0; ktg < nt; ++ktg) {
+    wait_vm0();
+    __syncthreads();
+    if (ktg + 1 < nt) {
+      const int nseg = (ktg + 1) / kps;
+      if (nseg != seg) { seg = nseg; load_a_bases(seg); }
+      stage(ktg + 1, (ktg + 1) - nseg * kps, (ktg + 1) & 1);
+    }
+    const char* Ab = smem + (ktg & 1) * 32768;
+    const char* Bb = Ab + 16384;
+    if constexpr (TT<T>::IS_BF16) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wr * 64 + i * 16 + fr;
+          a[i] = *(const bf16x8*)(Ab + row * ROWB + (((kk * 4 + fq) ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = wc * 64 + j * 16 + fr;
+          b[j] = *(const bf16x8*)(Bb + row * ROWB + (((kk * 4 + fq) ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        float a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wr * 64 + i * 16 + fr;
+          a[i] = *(const float*)(Ab + row * ROWB + ((kk ^ (row & 7)) << 4) + fq * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = wc * 64 + j * 16 + fr;
+          b[j] = *(const float*)(Bb + row * ROWB + ((kk ^ (row & 7)) << 4) + fq * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---------------- epilogue: accumulators -> fp32 LDS image -> row-wise 16-byte pieces ----------------
+  __syncthreads();
+  float* ct = (float*)smem;                  // [128][128]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        ct[(wr * 64 + i * 16 + 4 * fq + r) * 128 + wc * 64 + j * 16 + fr] = acc[i][j][r];
+  __syncthreads();
+
+  const int c8 = (tid & 15) * 8;
+  const int gn0 = n0 + c8;
+  if (gn0 >= p.N) return;
+  const int ncols = min(8, p.N - gn0);
+  const bool vec_ok = (ncols == 8);
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = (p.bias && e < ncols) ? p.bias[gn0 + e] : 0.f;
+  for (int pass = 0; pass < 8; ++pass) {
+    const int rr = pass * 16 + (tid >> 4);
+    const int gm = m0 + rr;
+    if (gm >= p.M) break;
+    float v[8];
+    {
+      const f32x4 lo = *(const f32x4*)(ct + rr * 128 + c8);
+      const f32x4 hi = *(const f32x4*)(ct + rr * 128 + c8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] += bv[e];
+      if (gn0 + e < p.scale_cols) v[e] *= p.scale;
+    }
+    const long orow = p.c_rows ? (long)p.c_rows[gm] : (long)gm;
+    if (p.C2) {
+      T* dst = (T*)p.C2 + orow * p.ldc2 + gn0;
+      if (vec_ok && (p.ldc2 % PACK) == 0) {
+#pragma unroll
+        for (int h = 0; h < 8 / PACK; ++h) {
+          Vec16<T> o;
+#pragma unroll
+          for (int e = 0; e < PACK; ++e) o.set(e, v[h * PACK + e]);
+          *(decltype(o.v)*)(dst + h * PACK) = o.v;
+        }
+      } else {
+        for (int e = 0; e < ncols; ++e) dst[e] = from_f32<T>(v[e]);
+      }
+    }
+    if (p.flags & GF_GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+    }
+    if (p.flags & (GF_RESID | GF_MUL_DGELU)) {
+      const long rrow = p.r_rows ? (long)p.r_rows[gm] : (long)gm;
+      const T* src = (const T*)p.R + rrow * p.ldr + gn0;
+      float rv[8];
+      if (vec_ok && (p.ldr % PACK) == 0) {
+#pragma unroll
+        for (int h = 0; h < 8 / PACK; ++h) {
+          Vec16<T> in;
+          in.v = *(const decltype(in.v)*)(src + h * PACK);
+#pragma unroll
+          for (int e = 0; e < PACK; ++e) rv[h * PACK + e] = in.get(e);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rv[e] = (e < ncols) ? to_f32<T>(src[e]) : 0.f;
+      }
+      if (p.flags & GF_RESID) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf(rv[e]);
+      }
+    }
+    if (p.flags & GF_RELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (p.flags & GF_OUT_F32) {
+      float* dst = (float*)p.C + orow * p.ldc + gn0;
+      if (p.flags & GF_ACCUM) {
+        for (int e = 0; e < ncols; ++e) dst[e] += v[e];
+      } else if (vec_ok && (p.ldc % 4) == 0) {
+        *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+        *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+      } else {
+        for (int e = 0; e < ncols; ++e) dst[e] = v[e];
+      }
+    } else {
+      T* dst = (T*)p.C + orow * p.ldc + gn0;
+      if (vec_ok && (p.ldc % PACK) == 0) {
+#pragma unroll
+        for (int h = 0; h < 8 / PACK; ++h) {
+          Vec16<T> o;
+#pragma unroll
+          for (int e = 0; e < PACK; ++e) o.set(e, v[h * PACK + e]);
+          *(decltype(o.v)*)(dst + h * PACK) = o.v;
+        }
+      } else {
+        for (int e = 0; e < ncols; ++e) dst[e] = from_f32<T>(v[e]);
+      }
+    }
+  }
+}
+
+// =====================================================================================================
+// TN: C[i][j] += sum_m At[m][i] * Bt[m][j]      (both operands have the contraction index as their ROW)
+// LDS tiles [BM rows m][128 cols] (bf16: 64 rows x 256 B, f32: 32 rows x 512 B), swz256, read transposed.
+// =====================================================================================================
+struct GemmTN {
+  const void* At; long lda; const int* at_rows;   // rows m (after optional gather) x Ni columns
+  const void* Bt; long ldb; const int* bt_rows;   // rows m x Nj columns
+  float* C; long ldc;                             // [Ni][Nj] fp32, atomically accumulated
+  int Mk, Ni, Nj;
+  int splits;                                     // grid.z
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
+  constexpr int PACK = TT<T>::PACK;
+  constexpr int BM = TT<T>::IS_BF16 ? 64 : 32;      // contraction rows per tile
+  constexpr int ROWB = 128 * sizeof(T);             // 256 / 512
+  constexpr int RPI = 1024 / ROWB;                  // rows per wave-instruction: 4 / 2
+  constexpr int NI = BM / (4 * RPI);                // DMA instructions per wave per operand: 4
+  constexpr int CPR = ROWB / 16;                    // chunks per row: 16 / 32
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63, w = wave_id();
+  const int wr = w >> 1, wc = w & 1;
+  const int tiles_j = (p.Nj + 127) >> 7;
+  const int i0 = (blockIdx.x / tiles_j) << 7, j0 = (blockIdx.x % tiles_j) << 7;
+  // split the contraction range in multiples of BM
+  const int ntile_all = (p.Mk + BM - 1) / BM;
+  const int per = (ntile_all + p.splits - 1) / p.splits;
+  const int t_begin = blockIdx.y * per, t_end = min(ntile_all, t_begin + per);
+  if (t_begin >= t_end) return;
+
+  const char* zero = (const char*)g_stswin_zero;
+  const int rsub = l / CPR, cphys = l % CPR;        // row within the instruction's RPI rows, physical chunk
+  // per-lane row of instruction i: r = (w*NI + i)*RPI + rsub ; source chunk = cphys ^ swz256(r) (low 4 bits)
+  auto src_row = [&](const int* map, int m) -> long {
+    if (m >= p.Mk) return -1;
+    return map ? (long)map[m] : (long)m;
+  };
+  long arow[NI], brow[NI];                          // gathered source rows of the NEXT tile to stage
+  auto fetch_rows = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int m = tile * BM + (w * NI + i) * RPI + rsub;
+      arow[i] = src_row(p.at_rows, m);
+      brow[i] = src_row(p.bt_rows, m);
+    }
+  };
+  auto stage = [&](int buf) {
+    char* Ab = smem + buf * 32768;
+    char* Bb = Ab + 16384;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = (w * NI + i) * RPI + rsub;
+      const int cs = (cphys & ~15) | ((cphys ^ swz256(r)) & 15);
+      const int ci = i0 + cs * PACK, cj = j0 + cs * PACK;
+      const char* sa = (arow[i] >= 0 && ci < p.Ni) ? (const char*)p.At + (arow[i] * p.lda + ci) * sizeof(T) : zero;
+      const char* sb = (brow[i] >= 0 && cj < p.Nj) ? (const char*)p.Bt + (brow[i] * p.ldb + cj) * sizeof(T) : zero;
+      glds16(sa, Ab + (w * NI + i) * 1024);
+      glds16(sb, Bb + (w * NI + i) * 1024);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = l & 15, fq = l >> 4;
+  fetch_rows(t_begin);
+  stage(0);
+  if (t_begin + 1 < t_end) fetch_rows(t_begin + 1);
+  for (int tk = t_begin; tk < t_end; ++tk) {
+    const int buf = (tk - t_begin) & 1;
+    wait_vm0();
+    __syncthreads();
+    if (tk + 1 < t_end) {
+      stage(buf ^ 1);
+      if (tk + 2 < t_end) fetch_rows(tk + 2);
+    }
+    const char* Ab = smem + buf * 32768;
+    const char* Bb = Ab + 16384;
+    if constexpr (TT<T>::IS_BF16) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          a[i] = cat4(lds_tr4(Ab, ROWB, kk * 32 + 8 * fq, wr * 64 + i * 16),
+                      lds_tr4(Ab, ROWB, kk * 32 + 8 * fq + 4, wr * 64 + i * 16));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          b[j] = cat4(lds_tr4(Bb, ROWB, kk * 32 + 8 * fq, wc * 64 + j * 16),
+                      lds_tr4(Bb, ROWB, kk * 32 + 8 * fq + 4, wc * 64 + j * 16));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int row = kk * 4 + fq;
+        float a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int col = wr * 64 + i * 16 + fr;
+          a[i] = *(const float*)(Ab + row * ROWB + ((((col >> 2) & ~15) | (((col >> 2) ^ swz256(row)) & 15)) << 4) + (col & 3) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = wc * 64 + j * 16 + fr;
+          b[j] = *(const float*)(Bb + row * ROWB + ((((col >> 2) & ~15) | (((col >> 2) ^ swz256(row)) & 15)) << 4) + (col & 3) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + wr * 64 + i * 16 + 4 * fq + r;
+        const int gj = j0 + wc * 64 + j * 16 + fr;
+        if (gi < p.Ni && gj < p.Nj) atomicAdd(p.C + (long)gi * p.ldc + gj, acc[i][j][r]);
+      }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static int set_lds_once(const void* fn) {
+  return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+}
+
+extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_rows, const void* B, long ldb,
+                              void* C, long ldc, const int* c_rows, void* C2, long ldc2, const float* bias,
+                              const void* R, long ldr, const int* r_rows, int M, int N, int Kseg, int S,
+                              float scale, int scale_cols, int flags, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  const int bk = dtype == 0 ? 64 : 32;
+  if (Kseg <= 0 || Kseg % bk || S <= 0) return -1001;
+  if ((flags & GF_ACCUM) && !(flags & GF_OUT_F32)) return -1002;
+  GemmNT p{A, lda, a_rows, B, ldb, C, ldc, c_rows, C2, ldc2, bias, R, ldr, r_rows, M, N, Kseg, S, scale, scale_cols, flags};
+  const int nblk = ((M + 127) / 128) * ((N + 127) / 128);
+  static int once = set_lds_once((const void*)gemm_nt_kernel<bf16>) | set_lds_once((const void*)gemm_nt_kernel<float>);
+  (void)once;
+  if (dtype == 0) hipLaunchKernelGGL(gemm_nt_kernel<bf16>, dim3(nblk), dim3(256), 65536, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gemm_nt_kernel<float>, dim3(nblk), dim3(256), 65536, (hipStream_t)stream, p);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, const void* Bt, long ldb,
+                              const int* bt_rows, float* C, long ldc, int Mk, int Ni, int Nj, int splits, void* stream) {
+  if (Mk <= 0 || Ni <= 0 || Nj <= 0) return 0;
+  const int pack = dtype == 0 ? 8 : 4;
+  if (Ni % pack || Nj % pack || lda % pack || ldb % pack) return -1003;
+  const int bm = dtype == 0 ? 64 : 32;
+  const int ntile = (Mk + bm - 1) / bm;
+  if (splits <= 0) {   // fill ~2 waves of the chip
+    const int tiles = ((Ni + 127) / 128) * ((Nj + 127) / 128);
+    splits = (512 + tiles - 1) / tiles;
+  }
+  if (splits > ntile) splits = ntile;
+  GemmTN p{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, splits};
+  dim3 grid(((Ni + 127) / 128) * ((Nj + 127) / 128), splits);
+  static int once = set_lds_once((const void*)gemm_tn_kernel<bf16>) | set_lds_once((const void*)gemm_tn_kernel<float>);
+  (void)once;
+  if (dtype == 0) hipLaunchKernelGGL(gemm_tn_kernel<bf16>, grid, dim3(256), 65536, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 65536, (hipStream_t)stream, p);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,350 @@
+// HBM-bound row kernels: window gather / scatter (bit-exact indexing), row-map builders, LayerNorm, column sums.
+// Every kernel moves whole 16-byte pieces per lane (8 bf16 / 4 f32), one wave per token row.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// Source token of row `r` of the pair-regrouped window layout  (B*nW, T, ws*ws)  <-  (B, T, H*W).
+// Restates swin_512.py:210-218: roll(-s,-s) -> window_partition -> view(B,T,nW,N) -> permute(0,2,1,3).
+// Returned index is into a token list of `frames_total` frames per clip starting at frame `f0`
+// (so a layer that only touches frames 1..2 of a 4-frame clip needs no slice copy).
+// ---------------------------------------------------------------------------------------------------
+DEVI int win_src_token(int r, int T, int H, int W, int ws, int shift, int f0, int frames_total) {
+  const int N = ws * ws, nwx = W / ws, nW = (H / ws) * nwx;
+  const int n = r % N; int q = r / N;
+  const int t = q % T; q /= T;
+  const int wi = q % nW; const int b = q / nW;
+  const int ys = (wi / nwx) * ws + n / ws, xs = (wi % nwx) * ws + n % ws;   // position in the rolled image
+  int y = ys + shift, x = xs + shift;                                        // rolled[i] = orig[(i+s) mod n]
+  if (y >= H) y -= H;
+  if (x >= W) x -= W;
+  return ((b * frames_total + f0 + t) * H + y) * W + x;
+}
+
+__global__ void win_rowmap_kernel(int* map, int rows, int T, int H, int W, int ws, int shift, int f0, int ftot) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) map[r] = win_src_token(r, T, H, W, ws, shift, f0, ftot);
+}
+
+// dir = 0: out[r] = in[src(r)]   (gather: a1+a3+a4)      dir = 1: out[src(r)] = in[r]   (scatter: a2+a3^-1)
+template <typename T>
+__global__ __launch_bounds__(256) void win_move_kernel(const T* in, T* out, int rows, int C, int Tt, int H, int W,
+                                                        int ws, int shift, int f0, int ftot, int dir) {
+  constexpr int PACK = TT<T>::PACK;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int s = win_src_token(r, Tt, H, W, ws, shift, f0, ftot);
+  const long from = dir == 0 ? (long)s : (long)r, to = dir == 0 ? (long)r : (long)s;
+  const uint4* src = (const uint4*)(in + from * C);
+  uint4* dst = (uint4*)(out + to * C);
+  for (int c = threadIdx.x & 63; c < C / PACK; c += 64) dst[c] = src[c];
+}
+
+// Patch-merging 2x2 gather map (swin_512.py:267-271): segment order [(0,0),(1,0),(0,1),(1,1)] = (dy,dx).
+__global__ void merge_rowmap_kernel(int* map, int frames, int H, int W) {
+  const int Ho = H / 2, Wo = W / 2, M = frames * Ho * Wo;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= M) return;
+  const int xo = r % Wo, yo = (r / Wo) % Ho, f = r / (Wo * Ho);
+  const int dy[4] = {0, 1, 0, 1}, dx[4] = {0, 0, 1, 1};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) map[s * M + r] = (f * H + 2 * yo + dy[s]) * W + 2 * xo + dx[s];
+}
+
+// 3x3 (dilated) convolution tap map: segment s = ky*3+kx -> source pixel or -1 (zero padding = dilation).
+__global__ void conv3x3_rowmap_kernel(int* map, int frames, int H, int W, int dil) {
+  const int M = frames * H * W;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= M) return;
+  const int x = r % W, y = (r / W) % H, f = r / (W * H);
+#pragma unroll
+  for (int s = 0; s < 9; ++s) {
+    const int yy = y + (s / 3 - 1) * dil, xx = x + (s % 3 - 1) * dil;
+    map[s * M + r] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (f * H + yy) * W + xx : -1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm over rows that may be the concatenation of S gathered segments (patch merging: S = 4).
+// One wave per row; the row lives in registers (C <= 4096); statistics two-pass in fp32 like torch.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int NP>   // NP = pieces of 16 B per lane
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, long ldx, const int* rows, int S, int Cseg, T* y,
+                                                      long ldy, const float* gamma, const float* beta, float* mean,
+                                                      float* rstd, int M, float eps) {
+  constexpr int PACK = TT<T>::PACK;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+  if (r >= M) return;
+  const int C = S * Cseg;
+  float v[NP][PACK];
+  float sum = 0.f;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int c = (p * 64 + l) * PACK;
+    if (c < C) {
+      const int s = c / Cseg, cc = c - s * Cseg;
+      const long row = rows ? (long)rows[(long)s * M + r] : (long)r;
+      Vec16<T> in;
+      in.v = *(const decltype(in.v)*)(x + row * ldx + cc);
+#pragma unroll
+      for (int e = 0; e < PACK; ++e) { v[p][e] = in.get(e); sum += v[p][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < PACK; ++e) v[p][e] = 0.f;
+    }
+  }
+  const float mu = wave_sum(sum) / C;
+  float sq = 0.f;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int c = (p * 64 + l) * PACK;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < PACK; ++e) { const float d = v[p][e] - mu; sq += d * d; }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(sq) / C + eps);
+  if (l == 0 && mean) { mean[r] = mu; rstd[r] = rs; }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int c = (p * 64 + l) * PACK;
+    if (c < C) {
+      Vec16<T> o;
+#pragma unroll
+      for (int e = 0; e < PACK; ++e) o.set(e, (v[p][e] - mu) * rs * gamma[c + e] + beta[c + e]);
+      *(decltype(o.v)*)(y + (long)r * ldy + c) = o.v;
+    }
+  }
+}
+
+// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma += sum dy*xhat ; dbeta += sum dy.
+// Each wave walks `rows_per_wave` consecutive rows keeping its dgamma/dbeta columns in registers, the block
+// folds its 4 waves through LDS and issues one fp32 atomic per column.
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, const T* x, long ldx, const int* rows,
+                                                      int S, int Cseg, const float* gamma, const float* mean,
+                                                      const float* rstd, T* dx, long lddx, float* dgamma,
+                                                      float* dbeta, int M, int rows_per_wave, int accumulate_dx) {
+  constexpr int PACK = TT<T>::PACK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int C = S * Cseg;
+  float dg[NP][PACK], db[NP][PACK];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int e = 0; e < PACK; ++e) { dg[p][e] = 0.f; db[p][e] = 0.f; }
+  const int r_begin = (blockIdx.x * 4 + w) * rows_per_wave;
+  for (int r = r_begin; r < min(M, r_begin + rows_per_wave); ++r) {
+    const float mu = mean[r], rs = rstd[r];
+    float g[NP][PACK], xh[NP][PACK];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int c = (p * 64 + l) * PACK;
+      if (c < C) {
+        const int s = c / Cseg, cc = c - s * Cseg;
+        const long row = rows ? (long)rows[(long)s * M + r] : (long)r;
+        Vec16<T> xi, di;
+        xi.v = *(const decltype(xi.v)*)(x + row * ldx + cc);
+        di.v = *(const decltype(di.v)*)(dy + (long)r * lddy + c);
+#pragma unroll
+        for (int e = 0; e < PACK; ++e) {
+          const float d = di.get(e);
+          xh[p][e] = (xi.get(e) - mu) * rs;
+          g[p][e] = d * gamma[c + e];
+          s1 += g[p][e];
+          s2 += g[p][e] * xh[p][e];
+          dg[p][e] += d * xh[p][e];
+          db[p][e] += d;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int c = (p * 64 + l) * PACK;
+      if (c < C) {
+        const int s = c / Cseg, cc = c - s * Cseg;
+        const long row = rows ? (long)rows[(long)s * M + r] : (long)r;
+        T* dst = dx + row * lddx + cc;
+        Vec16<T> o;
+        if (accumulate_dx) o.v = *(const decltype(o.v)*)dst;
+#pragma unroll
+        for (int e = 0; e < PACK; ++e) {
+          const float val = rs * (g[p][e] - s1 - xh[p][e] * s2);
+          o.set(e, accumulate_dx ? o.get(e) + val : val);
+        }
+        *(decltype(o.v)*)dst = o.v;
+      }
+    }
+  }
+  // fold the 4 waves: smem[w][C] x 2
+  float* sg = (float*)smem;
+  float* sb = sg + 4 * C;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int c = (p * 64 + l) * PACK;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < PACK; ++e) { sg[w * C + c + e] = dg[p][e]; sb[w * C + c + e] = db[p][e]; }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgamma + c, sg[c] + sg[C + c] + sg[2 * C + c] + sg[3 * C + c]);
+    atomicAdd(dbeta + c, sb[c] + sb[C + c] + sb[2 * C + c] + sb[3 * C + c]);
+  }
+}
+
+// out[n] += sum_m Y[m][n]   (bias gradients).  Block = 256 threads: 32 column-pieces x 8 row lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* y, long ldy, float* out, int M, int N, int rows_per_block) {
+  constexpr int PACK = TT<T>::PACK;
+  __shared__ float part[8][32 * 8];
+  const int cp = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + cp) * PACK;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int r0 = blockIdx.y * rows_per_block;
+  if (c < N) {
+    for (int r = r0 + rl; r < min(M, r0 + rows_per_block); r += 8) {
+      Vec16<T> in;
+      in.v = *(const decltype(in.v)*)(y + (long)r * ldy + c);
+#pragma unroll
+      for (int e = 0; e < PACK; ++e) acc[e] += in.get(e);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[rl][cp * 8 + e] = acc[e];
+  __syncthreads();
+  if (rl == 0 && c < N) {
+#pragma unroll
+    for (int e = 0; e < PACK; ++e) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += part[k][cp * 8 + e];
+      atomicAdd(out + c + e, s);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" int stswin_win_rowmap(int* map, int B, int T, int H, int W, int ws, int shift, int f0, int frames_total,
+                                 void* stream) {
+  if (H % ws || W % ws || shift < 0 || shift >= ws) return -1101;
+  const int rows = B * T * H * W;
+  hipLaunchKernelGGL(win_rowmap_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, map, rows, T, H, W,
+                     ws, shift, f0, frames_total);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_win_move(int dtype, const void* in, void* out, int B, int T, int H, int W, int C, int ws, int shift,
+                               int f0, int frames_total, int dir, void* stream) {
+  if (H % ws || W % ws || shift < 0 || shift >= ws) return -1101;
+  if (C % (dtype == 0 ? 8 : 4)) return -1102;
+  const int rows = B * T * H * W;
+  if (dtype == 0)
+    hipLaunchKernelGGL(win_move_kernel<bf16>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)in,
+                       (bf16*)out, rows, C, T, H, W, ws, shift, f0, frames_total, dir);
+  else
+    hipLaunchKernelGGL(win_move_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)in,
+                       (float*)out, rows, C, T, H, W, ws, shift, f0, frames_total, dir);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_merge_rowmap(int* map, int frames, int H, int W, void* stream) {
+  if ((H | W) & 1) return -1103;
+  const int M = frames * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(merge_rowmap_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, map, frames, H, W);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_conv3x3_rowmap(int* map, int frames, int H, int W, int dilation, void* stream) {
+  const int M = frames * H * W;
+  hipLaunchKernelGGL(conv3x3_rowmap_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, map, frames, H, W,
+                     dilation);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+static int ln_fwd_launch(const void* x, long ldx, const int* rows, int S, int Cseg, void* y, long ldy, const float* g,
+                         const float* b, float* mean, float* rstd, int M, float eps, hipStream_t st) {
+  constexpr int PACK = TT<T>::PACK;
+  const int C = S * Cseg, np = (C / PACK + 63) / 64;
+  dim3 grid((M + 3) / 4), blk(256);
+#define LN_F(NP) hipLaunchKernelGGL((ln_fwd_kernel<T, NP>), grid, blk, 0, st, (const T*)x, ldx, rows, S, Cseg, (T*)y, ldy, g, b, mean, rstd, M, eps)
+  switch (np) {
+    case 1: LN_F(1); break;
+    case 2: LN_F(2); break;
+    case 3: case 4: LN_F(4); break;
+    case 5: case 6: case 7: case 8: LN_F(8); break;
+    default:
+      if (np <= 16) { LN_F(16); break; }
+      return -1104;
+  }
+#undef LN_F
+  return 0;
+}
+
+extern "C" int stswin_layernorm_fwd(int dtype, const void* x, long ldx, const int* rows, int S, int Cseg, void* y,
+                                    long ldy, const float* gamma, const float* beta, float* mean, float* rstd, int M,
+                                    float eps, void* stream) {
+  const int pack = dtype == 0 ? 8 : 4;
+  if (Cseg % pack || ldx % pack || ldy % pack) return -1105;
+  int rc = dtype == 0 ? ln_fwd_launch<bf16>(x, ldx, rows, S, Cseg, y, ldy, gamma, beta, mean, rstd, M, eps, (hipStream_t)stream)
+                      : ln_fwd_launch<float>(x, ldx, rows, S, Cseg, y, ldy, gamma, beta, mean, rstd, M, eps, (hipStream_t)stream);
+  if (rc) return rc;
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+static int ln_bwd_launch(const void* dy, long lddy, const void* x, long ldx, const int* rows, int S, int Cseg,
+                         const float* g, const float* mean, const float* rstd, void* dx, long lddx, float* dg, float* db,
+                         int M, int acc, hipStream_t st) {
+  constexpr int PACK = TT<T>::PACK;
+  const int C = S * Cseg, np = (C / PACK + 63) / 64;
+  const int rpw = 32;
+  dim3 grid((M + 4 * rpw - 1) / (4 * rpw)), blk(256);
+  const size_t lds = (size_t)8 * C * sizeof(float);
+#define LN_B(NP) hipLaunchKernelGGL((ln_bwd_kernel<T, NP>), grid, blk, lds, st, (const T*)dy, lddy, (const T*)x, ldx, rows, S, Cseg, g, mean, rstd, (T*)dx, lddx, dg, db, M, rpw, acc)
+  switch (np) {
+    case 1: LN_B(1); break;
+    case 2: LN_B(2); break;
+    case 3: case 4: LN_B(4); break;
+    case 5: case 6: case 7: case 8: LN_B(8); break;
+    default: return -1104;
+  }
+#undef LN_B
+  return 0;
+}
+
+extern "C" int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const int* rows, int S,
+                                    int Cseg, const float* gamma, const float* mean, const float* rstd, void* dx,
+                                    long lddx, float* dgamma, float* dbeta, int M, int accumulate_dx, void* stream) {
+  const int pack = dtype == 0 ? 8 : 4;
+  if (Cseg % pack || ldx % pack || lddy % pack || lddx % pack) return -1105;
+  if ((long)S * Cseg * 8 * 4 > 65536) return -1106;
+  int rc = dtype == 0 ? ln_bwd_launch<bf16>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, accumulate_dx, (hipStream_t)stream)
+                      : ln_bwd_launch<float>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, accumulate_dx, (hipStream_t)stream);
+  if (rc) return rc;
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_colsum(int dtype, const void* y, long ldy, float* out, int M, int N, void* stream) {
+  const int pack = dtype == 0 ? 8 : 4;
+  if (N % pack || ldy % pack) return -1107;
+  const int rpb = 512;
+  dim3 grid((N / pack + 31) / 32, (M + rpb - 1) / rpb);
+  if (dtype == 0)
+    hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)y, ldy, out, M, N, rpb);
+  else
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, ldy, out, M, N, rpb);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,77 @@
+// Device self-test of the hardware primitives the kernels rely on (MFMA lane maps, ds_read_b64_tr_b16,
+// LDS-DMA placement).  Each case writes raw results to `out`; tests/test_hip_primitives.py checks them against
+// the documented semantics.  Test infrastructure only - never on the product path.
+#include "common.h"
+
+DEVI float ta(int i, int k) { return (float)((i * 3 + k * 5) % 7 - 3); }   // asymmetric small integers (bf16-exact)
+DEVI float tb(int k, int j) { return (float)((k * 2 + j * 7) % 5 - 2); }
+
+__global__ void st_mfma16_bf16(float* out) {
+  const int l = threadIdx.x, fr = l & 15, fq = l >> 4;
+  bf16x8 a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = (bf16)ta(fr, 8 * fq + j); b[j] = (bf16)tb(8 * fq + j, fr); }
+  f32x4 c = {0, 0, 0, 0};
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) out[(4 * fq + r) * 16 + fr] = c[r];
+}
+__global__ void st_mfma32_bf16(float* out) {
+  const int l = threadIdx.x, lr = l & 31, h = l >> 5;
+  bf16x8 a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = (bf16)ta(lr, 8 * h + j); b[j] = (bf16)tb(8 * h + j, lr); }
+  f32x16 c;
+  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + lr] = c[r];
+}
+__global__ void st_mfma16_f32(float* out) {
+  const int l = threadIdx.x, fr = l & 15, fq = l >> 4;
+  f32x4 c = {0, 0, 0, 0};
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(ta(fr, fq), tb(fq, fr), c, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) out[(4 * fq + r) * 16 + fr] = c[r];
+}
+__global__ void st_mfma32_f32(float* out) {
+  const int l = threadIdx.x, lr = l & 31, h = l >> 5;
+  f32x16 c;
+  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(ta(lr, h), tb(h, lr), c, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + lr] = c[r];
+}
+// tile[r][c] = r*16 + c for a [16][16] bf16 tile with 32-byte rows (no swizzle).  16-lane group g reads the
+// 4x16 block of rows 4g..4g+3: lane 4q+p supplies &tile[4g+q][4p]; expectation: lane lam gets tile[4g+e][lam].
+__global__ void st_tr16(float* out) {
+  __shared__ __attribute__((aligned(16))) bf16 tile[16 * 16];
+  const int l = threadIdx.x;
+  for (int i = l; i < 256; i += 64) tile[i] = (bf16)(float)i;
+  __syncthreads();
+  const int g = l >> 4, lam = l & 15, q = lam >> 2, p = lam & 3;
+  const bf16* addr = tile + (4 * g + q) * 16 + 4 * p;
+  short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)addr);
+  bf16x4 v = __builtin_bit_cast(bf16x4, t);
+  for (int e = 0; e < 4; ++e) out[l * 4 + e] = (float)v[e];
+}
+// LDS-DMA: lane l sources 16 bytes from src + perm(l)*16 ; expectation: LDS byte offset l*16 holds them.
+__global__ void st_glds(float* out, const float* src) {
+  __shared__ __attribute__((aligned(16))) float buf[2 * 256];
+  const int l = threadIdx.x & 63, w = wave_id();
+  glds16(src + ((l * 7 + 3) % 64) * 4 + w * 256, (char*)buf + w * 1024);
+  wait_vm0();
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += 128) out[i] = buf[i];
+}
+
+extern "C" int stswin_abi_version(void) { return 1; }
+
+extern "C" int stswin_selftest(float* out, int which, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  switch (which) {
+    case 0: hipLaunchKernelGGL(st_mfma16_bf16, dim3(1), dim3(64), 0, st, out); break;
+    case 1: hipLaunchKernelGGL(st_mfma32_bf16, dim3(1), dim3(64), 0, st, out); break;
+    case 2: hipLaunchKernelGGL(st_mfma16_f32, dim3(1), dim3(64), 0, st, out); break;
+    case 3: hipLaunchKernelGGL(st_mfma32_f32, dim3(1), dim3(64), 0, st, out); break;
+    case 4: hipLaunchKernelGGL(st_tr16, dim3(1), dim3(64), 0, st, out); break;
+    case 5: hipLaunchKernelGGL(st_glds, dim3(1), dim3(128), 0, st, out + 512, out); break;  /* src = out[0:512] */
+    default: return -1301;
+  }
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,204 @@
+"""ctypes binding of libstswin_hip.so (the C ABI declared in include/stswin_hip.h).
+
+There is NO fallback: every wrapper raises if the library is missing or a kernel reports an error, and
+every wrapper demands CUDA (ROCm) tensors.  PyTorch is used only for device memory and the stream handle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Optional
+
+import torch
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_ROOT, "stswincl_amd", "lib", "libstswin_hip.so")
+HEADER_PATH = os.path.join(_ROOT, "include", "stswin_hip.h")
+_lib: Optional[ctypes.CDLL] = None
+
+GF_GELU, GF_RESID, GF_MUL_DGELU, GF_OUT_F32, GF_ACCUM, GF_RELU = 1, 2, 4, 8, 16, 32
+
+_c_int, _c_long, _c_float, _c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+
+
+class StswinHipError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Every entry point include/stswin_hip.h declares."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(stswin_\w+)\s*\(", text)))
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the library and check that it exports the whole declared ABI (works without a GPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StswinHipError(f"{LIB_PATH} not found: run `python __graft_entry__.py` (build()) first; "
+                             "stswincl_amd has no CPU or eager fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    if missing:
+        raise StswinHipError(f"libstswin_hip.so lacks declared symbols: {missing}")
+    for s in declared_symbols():
+        getattr(lib, s).restype = _c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise StswinHipError(f"{what} failed with code {rc}")
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return 0
+    if t.dtype == torch.float32:
+        return 1
+    raise StswinHipError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return _c_void_p(0)
+    if not t.is_cuda:
+        raise StswinHipError("stswincl_amd ops need tensors on the GPU (no CPU path exists)")
+    return _c_void_p(t.data_ptr())
+
+
+def _stream():
+    return _c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D view"
+    return t.stride(0)
+
+
+# ----------------------------------------------------------------------------------------------- row maps
+def win_rowmap(B, T, H, W, ws, shift, f0=0, frames_total=None, device="cuda") -> torch.Tensor:
+    frames_total = T if frames_total is None else frames_total
+    m = torch.empty(B * T * H * W, dtype=torch.int32, device=device)
+    _check(load().stswin_win_rowmap(_p(m), B, T, H, W, ws, shift, f0, frames_total, _stream()), "win_rowmap")
+    return m
+
+
+def win_move(x: torch.Tensor, B, T, H, W, ws, shift, direction: int, f0=0, frames_total=None) -> torch.Tensor:
+    """direction 0: (B,Ftot,H*W,C) tokens -> (B*nW*T*N, C) window rows; 1: the inverse (into zeros)."""
+    frames_total = T if frames_total is None else frames_total
+    C = x.shape[-1]
+    x = x.contiguous()
+    if direction == 0:
+        out = torch.empty(B * T * H * W, C, dtype=x.dtype, device=x.device)
+    else:
+        out = torch.zeros(B * frames_total * H * W, C, dtype=x.dtype, device=x.device)
+    _check(load().stswin_win_move(_dt(x), _p(x), _p(out), B, T, H, W, C, ws, shift, f0, frames_total, direction,
+                                  _stream()), "win_move")
+    return out
+
+
+def merge_rowmap(frames, H, W, device="cuda") -> torch.Tensor:
+    m = torch.empty(4, frames * (H // 2) * (W // 2), dtype=torch.int32, device=device)
+    _check(load().stswin_merge_rowmap(_p(m), frames, H, W, _stream()), "merge_rowmap")
+    return m
+
+
+def conv3x3_rowmap(frames, H, W, dilation, device="cuda") -> torch.Tensor:
+    m = torch.empty(9, frames * H * W, dtype=torch.int32, device=device)
+    _check(load().stswin_conv3x3_rowmap(_p(m), frames, H, W, dilation, _stream()), "conv3x3_rowmap")
+    return m
+
+
+# ----------------------------------------------------------------------------------------------- GEMMs
+def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_rows=None, c_rows=None, bias=None,
+            resid=None, r_rows=None, out2=None, S: int = 1, scale: float = 1.0, scale_cols: int = 0, flags: int = 0):
+    """out[c_rows[m]] = epi(sum_s A[a_rows[s][m], :Kseg] @ Bw[:, s*Kseg:(s+1)*Kseg].T); see include/stswin_hip.h."""
+    N, Ktot = Bw.shape
+    assert Ktot % S == 0
+    Kseg = Ktot // S
+    assert A.dtype == Bw.dtype and A.shape[1] >= Kseg
+    if not (flags & GF_OUT_F32):
+        assert out.dtype == A.dtype
+    else:
+        assert out.dtype == torch.float32
+    rc = load().stswin_gemm_nt(
+        _dt(A), _p(A), _c_long(_ld(A)), _p(a_rows), _p(Bw), _c_long(_ld(Bw)), _p(out), _c_long(_ld(out)), _p(c_rows),
+        _p(out2), _c_long(_ld(out2) if out2 is not None else 0), _p(bias), _p(resid),
+        _c_long(_ld(resid) if resid is not None else 0), _p(r_rows), M, N, Kseg, S, _c_float(scale), scale_cols, flags,
+        _stream())
+    _check(rc, "gemm_nt")
+    return out
+
+
+def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: int, at_rows=None, bt_rows=None,
+            splits: int = 0):
+    """out_f32[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]  (fp32, atomically accumulated)."""
+    Ni, Nj = out_f32.shape
+    assert out_f32.dtype == torch.float32 and At.dtype == Bt.dtype
+    rc = load().stswin_gemm_tn(_dt(At), _p(At), _c_long(_ld(At)), _p(at_rows), _p(Bt), _c_long(_ld(Bt)), _p(bt_rows),
+                               _p(out_f32), _c_long(_ld(out_f32)), Mk, Ni, Nj, splits, _stream())
+    _check(rc, "gemm_tn")
+    return out_f32
+
+
+def colsum(y: torch.Tensor, out_f32: torch.Tensor, M: Optional[int] = None):
+    M = y.shape[0] if M is None else M
+    _check(load().stswin_colsum(_dt(y), _p(y), _c_long(_ld(y)), _p(out_f32), M, y.shape[1], _stream()), "colsum")
+    return out_f32
+
+
+# ----------------------------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x, gamma, beta, *, M, rows=None, S=1, Cseg=None, eps=1e-5, save_stats=True):
+    Cseg = x.shape[1] if Cseg is None else Cseg
+    y = torch.empty(M, S * Cseg, dtype=x.dtype, device=x.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    rc = load().stswin_layernorm_fwd(_dt(x), _p(x), _c_long(_ld(x)), _p(rows), S, Cseg, _p(y), _c_long(_ld(y)),
+                                     _p(gamma), _p(beta), _p(mean), _p(rstd), M, _c_float(eps), _stream())
+    _check(rc, "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, *, M, rows=None, S=1, Cseg=None, dx=None, accumulate=False):
+    Cseg = x.shape[1] if Cseg is None else Cseg
+    if dx is None:
+        dx = torch.empty_like(x)
+        accumulate = False
+    rc = load().stswin_layernorm_bwd(_dt(x), _p(dy), _c_long(_ld(dy)), _p(x), _c_long(_ld(x)), _p(rows), S, Cseg,
+                                     _p(gamma), _p(mean), _p(rstd), _p(dx), _c_long(_ld(dx)), _p(dgamma), _p(dbeta), M,
+                                     1 if accumulate else 0, _stream())
+    _check(rc, "layernorm_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def win_attn_fwd(qkv, biasT, maskT, *, nB_, nW, T, ws, heads, C):
+    out = torch.empty(qkv.shape[0], C, dtype=qkv.dtype, device=qkv.device)
+    rc = load().stswin_win_attn_fwd(_dt(qkv), _p(qkv), _c_long(_ld(qkv)), _p(out), _c_long(_ld(out)), _p(biasT),
+                                    _p(maskT), nB_, nW, T, ws, heads, C, _stream())
+    _check(rc, "win_attn_fwd")
+    return out
+
+
+def win_attn_bwd(qkv, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, scale):
+    dqkv = torch.empty_like(qkv)
+    rc = load().stswin_win_attn_bwd(_dt(qkv), _p(qkv), _c_long(_ld(qkv)), _p(dout), _c_long(_ld(dout)), _p(dqkv),
+                                    _c_long(_ld(dqkv)), _p(biasT), _p(maskT), _p(dbiasT), nB_, nW, T, ws, heads, C,
+                                    _c_float(scale), _stream())
+    _check(rc, "win_attn_bwd")
+    return dqkv
+
+
+def selftest(which: int) -> torch.Tensor:
+    out = torch.zeros(16384, dtype=torch.float32, device="cuda")
+    if which == 5:
+        out[:512] = torch.arange(512, dtype=torch.float32, device="cuda")
+    _check(load().stswin_selftest(_p(out), which, _stream()), "selftest")
+    torch.cuda.synchronize()
+    return out.cpu()

@@ -1,0 +1,59 @@
+"""a6 attention core: HIP forward/backward vs the CPU oracle's formulation (swin_512.py:117-138)."""
+import pytest
+import torch
+
+from oracle import stswin_oracle as O
+from stswincl_amd import hip
+
+pytestmark = pytest.mark.gpu
+DT = [torch.float32, torch.bfloat16]
+
+
+def _ref(qkv, bias, mask, nB_, nW, T, N, heads, C):
+    """qkv (rows, 3C) with q pre-scaled -> out (rows, C) by the reference formulation (fp32, CPU)."""
+    d = C // heads
+    x = qkv.reshape(nB_, T * N, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = x[0], x[1], x[2]
+    attn = q @ k.transpose(-2, -1) + bias.repeat(1, T, T).unsqueeze(0)
+    if mask is not None:
+        attn = attn.reshape(nB_ // nW, nW, heads, T * N, T * N) + mask.repeat(1, T, T)[None, :, None]
+        attn = attn.reshape(-1, heads, T * N, T * N)
+    return (attn.softmax(-1) @ v).transpose(1, 2).reshape(nB_ * T * N, C)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("ws,C,heads,masked", [(8, 512, 4, True), (4, 1024, 4, True), (8, 128, 4, False),
+                                               (4, 256, 4, True), (4, 128, 4, False), (8, 256, 4, True)])
+def test_attention_fwd_bwd(dtype, ws, C, heads, masked):
+    torch.manual_seed(ws * C)
+    T, N, nW, B = 2, ws * ws, 4, 2
+    nB_ = B * nW
+    rows = nB_ * T * N
+    qkv = (torch.randn(rows, 3 * C) * 0.5).to(dtype)
+    qkv[:, :C] *= (C // heads) ** -0.5
+    bias = torch.randn(heads, N, N) * 0.5
+    mask = None
+    if masked:
+        mask = O.shift_attn_mask(2 * ws, 2 * ws, ws, ws // 2)  # (4, N, N) in {0,-100}
+    dout = torch.randn(rows, C).to(dtype)
+    qr = qkv.float().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    ref = _ref(qr, br, mask, nB_, nW, T, N, heads, C)
+    (ref * dout.float()).sum().backward()
+
+    biasT = bias.transpose(1, 2).contiguous().cuda()
+    maskT = mask.transpose(1, 2).contiguous().cuda() if masked else None
+    out = hip.win_attn_fwd(qkv.cuda(), biasT, maskT, nB_=nB_, nW=nW, T=T, ws=ws, heads=heads, C=C)
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    err = float((out.float().cpu() - ref.detach()).abs().max())
+    assert err <= tol * float(ref.abs().max()), f"fwd err {err}"
+
+    dbT = torch.zeros(heads, N, N, device="cuda")
+    dqkv = hip.win_attn_bwd(qkv.cuda(), dout.cuda(), biasT, maskT, dbT, nB_=nB_, nW=nW, T=T, ws=ws, heads=heads, C=C,
+                            scale=1.0)
+    g = qr.grad
+    for name, sl in (("dq", slice(0, C)), ("dk", slice(C, 2 * C)), ("dv", slice(2 * C, 3 * C))):
+        e = float((dqkv[:, sl].float().cpu() - g[:, sl]).abs().max())
+        assert e <= 2 * tol * float(g[:, sl].abs().max()), f"{name} err {e} scale {float(g[:, sl].abs().max())}"
+    e = float((dbT.transpose(1, 2).cpu() - br.grad).abs().max())
+    assert e <= 2 * tol * float(br.grad.abs().max()), f"dbias err {e}"

@@ -1,0 +1,117 @@
+"""Segmented gather GEMMs (NT with fused epilogues, TN for weight gradients): HIP vs fp32 torch on the CPU.
+
+Tolerances: fp32 path (exact-f32 MFMA) 1e-5 relative; bf16 path compared with an fp32 reference evaluated on
+the SAME bf16-rounded operands: 3e-3 relative to the output scale before the final bf16 rounding (+ 1 bf16 ulp)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from stswincl_amd import hip
+
+pytestmark = pytest.mark.gpu
+DT = [torch.float32, torch.bfloat16]
+
+
+def _close(got, exp, dtype, what=""):
+    got, exp = got.float().cpu(), exp.float()
+    scale = float(exp.abs().max()) + 1e-6
+    err = float((got - exp).abs().max())
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} at {int((got - exp).abs().argmax())}"
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 512), (200, 136, 128), (37, 48, 192), (130, 12, 256),
+                                   (1024, 1536, 512)])
+def test_gemm_nt_plain_and_bias(dtype, m, n, k):
+    torch.manual_seed(m + n + k)
+    a = torch.randn(m, k).to(dtype)
+    w = (torch.randn(n, k) / k ** 0.5).to(dtype)
+    bias = torch.randn(n)
+    out = torch.full((m, n), float("nan"), dtype=dtype, device="cuda")
+    hip.gemm_nt(a.cuda(), w.cuda(), out, M=m, bias=bias.cuda())
+    _close(out, F.linear(a.float(), w.float(), bias), dtype, "bias")
+    out32 = torch.zeros(m, n, device="cuda")
+    hip.gemm_nt(a.cuda(), w.cuda(), out32, M=m, flags=hip.GF_OUT_F32)
+    hip.gemm_nt(a.cuda(), w.cuda(), out32, M=m, flags=hip.GF_OUT_F32 | hip.GF_ACCUM)
+    _close(out32, 2 * F.linear(a.float(), w.float()), dtype, "f32 accumulate")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_nt_epilogues(dtype):
+    torch.manual_seed(5)
+    m, n, k = 300, 256, 128
+    a = torch.randn(m, k).to(dtype)
+    w = (torch.randn(n, k) / k ** 0.5).to(dtype)
+    bias = torch.randn(n)
+    r = torch.randn(m, n).to(dtype)
+    ac, wc, rc, bc = a.cuda(), w.cuda(), r.cuda(), bias.cuda()
+    lin = F.linear(a.float(), w.float(), bias)
+    # GELU with the pre-activation as second output (Mlp.fc1 + act, swin_512.py:18-19)
+    out = torch.empty(m, n, dtype=dtype, device="cuda")
+    pre = torch.empty(m, n, dtype=dtype, device="cuda")
+    hip.gemm_nt(ac, wc, out, M=m, bias=bc, out2=pre, flags=hip.GF_GELU)
+    _close(pre, lin, dtype, "pre-activation")
+    _close(out, F.gelu(lin), dtype, "gelu")
+    # residual (fc2 + shortcut)
+    hip.gemm_nt(ac, wc, out, M=m, bias=bc, resid=rc, flags=hip.GF_RESID)
+    _close(out, lin + r.float(), dtype, "resid")
+    # gelu' multiply (backward of fc1's activation)
+    hip.gemm_nt(ac, wc, out, M=m, resid=rc, flags=hip.GF_MUL_DGELU)
+    x = r.float().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    _close(out, F.linear(a.float(), w.float()) * x.grad, dtype, "dgelu")
+    # q scaling of the first columns (swin_512.py:118) + relu
+    hip.gemm_nt(ac, wc, out, M=m, bias=bc, scale=0.25, scale_cols=96)
+    exp = lin.clone()
+    exp[:, :96] *= 0.25
+    _close(out, exp, dtype, "scale_cols")
+    hip.gemm_nt(ac, wc, out, M=m, bias=bc, flags=hip.GF_RELU)
+    _close(out, F.relu(lin), dtype, "relu")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_nt_gather_scatter_segments(dtype):
+    torch.manual_seed(6)
+    rows_src, k, n, m = 500, 64, 136, 333
+    a = torch.randn(rows_src, k).to(dtype)
+    s = 3
+    w = (torch.randn(n, s * k) / (s * k) ** 0.5).to(dtype)
+    amap = torch.randint(-1, rows_src, (s, m), dtype=torch.int32)
+    amap[:, 5] = -1
+    cmap = torch.randperm(400)[:m].to(torch.int32)
+    r = torch.randn(400, n).to(dtype)
+    out = torch.zeros(400, n, dtype=dtype, device="cuda")
+    hip.gemm_nt(a.cuda(), w.cuda(), out, M=m, a_rows=amap.cuda(), c_rows=cmap.cuda(), resid=r.cuda(),
+                r_rows=cmap.cuda(), S=s, flags=hip.GF_RESID)
+    af = a.float()
+    gathered = torch.cat([torch.where((amap[i] >= 0)[:, None], af[amap[i].clamp(min=0).long()], torch.zeros(m, k))
+                          for i in range(s)], 1)
+    exp = torch.zeros(400, n)
+    exp[cmap.long()] = gathered @ w.float().t() + r.float()[cmap.long()]
+    _close(out, exp, dtype, "gather/scatter/segments")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("mk,ni,nj,splits", [(64, 128, 128, 1), (1000, 136, 264, 0), (4096, 512, 1536, 0), (33, 48, 64, 4)])
+def test_gemm_tn(dtype, mk, ni, nj, splits):
+    torch.manual_seed(mk)
+    at = torch.randn(mk, ni).to(dtype)
+    bt = (torch.randn(mk, nj) / mk ** 0.5).to(dtype)
+    out = torch.ones(ni, nj, device="cuda")
+    hip.gemm_tn(at.cuda(), bt.cuda(), out, Mk=mk, splits=splits)
+    _close(out, 1 + at.float().t() @ bt.float(), torch.float32 if dtype == torch.float32 else dtype, "tn")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_tn_row_maps(dtype):
+    torch.manual_seed(8)
+    mk, ni, nj = 777, 64, 128
+    at = torch.randn(900, ni).to(dtype)
+    bt = torch.randn(900, nj).to(dtype) / 30
+    am = torch.randint(0, 900, (mk,), dtype=torch.int32)
+    bm = torch.randint(-1, 900, (mk,), dtype=torch.int32)
+    out = torch.zeros(ni, nj, device="cuda")
+    hip.gemm_tn(at.cuda(), bt.cuda(), out, Mk=mk, at_rows=am.cuda(), bt_rows=bm.cuda())
+    bsel = torch.where((bm >= 0)[:, None], bt.float()[bm.clamp(min=0).long()], torch.zeros(mk, nj))
+    _close(out, at.float()[am.long()].t() @ bsel, dtype, "tn maps")

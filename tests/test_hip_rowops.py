@@ -1,0 +1,111 @@
+"""a1-a4 indexing (bit-exact), LayerNorm, column sums: HIP vs the CPU oracle / golden vectors."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_util as gu
+from oracle import stswin_oracle as O
+from stswincl_amd import hip
+
+pytestmark = pytest.mark.gpu
+DT = [torch.float32, torch.bfloat16]
+
+
+@pytest.mark.parametrize("tag", ["s1_64x64", "s2_32x32", "s1_64x80", "s1_32x56", "s1_64x64_noshift", "s2_16x16"])
+def test_win_rowmap_matches_reference_golden(tag):
+    g = gu.load("index_maps.npz")
+    b, t, h, w, ws, shift = [int(v) for v in g[tag + "_cfg"]]
+    m = hip.win_rowmap(b, t, h, w, ws, shift).cpu().numpy()
+    assert np.array_equal(m, g[tag])
+
+
+def test_win_rowmap_frame_window_of_a_4_frame_clip():
+    b, h, w, ws, shift = 2, 16, 16, 4, 2
+    m = hip.win_rowmap(b, 2, h, w, ws, shift, f0=1, frames_total=4).cpu().numpy()
+    ids = torch.arange(b * 4 * h * w).reshape(b, 4, h * w, 1)
+    exp = O.pair_window_gather(ids[:, 1:3], h, w, ws, shift).reshape(-1).numpy()
+    assert np.array_equal(m, exp)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cfg", [(2, 2, 16, 16, 4, 2, 64), (1, 2, 64, 64, 8, 4, 32), (2, 2, 32, 56, 8, 4, 16),
+                                 (1, 2, 8, 8, 8, 0, 64), (4, 2, 64, 64, 8, 4, 512)])
+def test_win_gather_scatter_bit_exact(dtype, cfg):
+    b, t, h, w, ws, shift, c = cfg
+    torch.manual_seed(0)
+    x = torch.randn(b, t, h * w, c).to(dtype)
+    exp = O.pair_window_gather(x.float(), h, w, ws, shift).reshape(-1, c)
+    got = hip.win_move(x.cuda(), b, t, h, w, ws, shift, 0)
+    assert torch.equal(got.float().cpu(), exp)
+    back = hip.win_move(got, b, t, h, w, ws, shift, 1)
+    assert torch.equal(back.cpu().reshape(b, t, h * w, c), x)
+    exp_back = O.pair_window_scatter(exp.reshape(-1, t, ws * ws, c), h, w, ws, shift)
+    assert torch.equal(back.float().cpu().reshape(b, t, h * w, c), exp_back)
+
+
+def test_merge_and_conv_rowmaps():
+    frames, h, w = 3, 8, 12
+    m = hip.merge_rowmap(frames, h, w).cpu()
+    ids = torch.arange(frames * h * w, dtype=torch.float32).reshape(1, frames, h * w, 1)
+    exp = O.patch_merge_gather(ids, h, w).reshape(-1, 4).t().contiguous().to(torch.int32)
+    assert torch.equal(m, exp)
+    for dil in (1, 2, 6):
+        cm = hip.conv3x3_rowmap(frames, h, w, dil).cpu()
+        img = (torch.arange(frames * h * w, dtype=torch.float32) + 1).reshape(frames, 1, h, w)
+        cols = F.unfold(img, 3, dilation=dil, padding=dil).reshape(frames, 9, h * w)  # 0 where padded
+        exp = (cols.permute(1, 0, 2).reshape(9, -1) - 1).to(torch.int32)
+        assert torch.equal(cm, exp), dil
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("m,c", [(37, 512), (64, 1024), (9, 2048), (130, 128), (5, 64)])
+def test_layernorm_fwd_bwd(dtype, m, c):
+    torch.manual_seed(1)
+    x = (torch.randn(m, c) * 2 + 0.5).to(dtype)
+    g = 1 + 0.1 * torch.randn(c)
+    b = 0.1 * torch.randn(c)
+    dy = torch.randn(m, c).to(dtype)
+    xr = x.float().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (c,), gr, br)
+    (yr * dy.float()).sum().backward()
+    y, mean, rstd = hip.layernorm_fwd(x.cuda(), g.cuda(), b.cuda(), M=m)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert torch.allclose(y.float().cpu(), yr.detach(), atol=tol * 4, rtol=tol)
+    dg = torch.zeros(c, device="cuda")
+    db = torch.zeros(c, device="cuda")
+    dx = hip.layernorm_bwd(dy.cuda(), x.cuda(), g.cuda(), mean, rstd, dg, db, M=m)
+    assert torch.allclose(dx.float().cpu(), xr.grad, atol=tol * 8, rtol=tol * 2)
+    assert torch.allclose(dg.cpu(), gr.grad, atol=2e-4 * m if dtype == torch.float32 else 0.05 * m ** 0.5, rtol=1e-3)
+    assert torch.allclose(db.cpu(), br.grad, atol=2e-4 * m if dtype == torch.float32 else 0.05 * m ** 0.5, rtol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_layernorm_with_patch_merge_gather(dtype):
+    torch.manual_seed(2)
+    frames, h, w, c = 4, 8, 8, 64
+    x = torch.randn(1, frames, h * w, c).to(dtype)
+    g, b = 1 + 0.1 * torch.randn(4 * c), 0.1 * torch.randn(4 * c)
+    rows = hip.merge_rowmap(frames, h, w)
+    mm = frames * h * w // 4
+    y, mean, rstd = hip.layernorm_fwd(x.reshape(-1, c).cuda(), g.cuda(), b.cuda(), M=mm, rows=rows, S=4, Cseg=c)
+    xr = x.float().requires_grad_(True)
+    exp = F.layer_norm(O.patch_merge_gather(xr, h, w).reshape(mm, 4 * c), (4 * c,), g, b)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert torch.allclose(y.float().cpu(), exp.detach(), atol=4 * tol, rtol=tol)
+    dy = torch.randn(mm, 4 * c).to(dtype)
+    (exp * dy.float()).sum().backward()
+    dg, db = torch.zeros(4 * c, device="cuda"), torch.zeros(4 * c, device="cuda")
+    dx = torch.zeros(frames * h * w, c, dtype=dtype, device="cuda")
+    hip.layernorm_bwd(dy.cuda(), x.reshape(-1, c).cuda(), g.cuda(), mean, rstd, dg, db, M=mm, rows=rows, S=4, Cseg=c, dx=dx)
+    assert torch.allclose(dx.float().cpu().reshape(xr.shape), xr.grad, atol=8 * tol, rtol=2 * tol)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_colsum(dtype):
+    torch.manual_seed(3)
+    y = torch.randn(1000, 264).to(dtype)
+    out = torch.zeros(264, device="cuda")
+    hip.colsum(y.cuda(), out)
+    assert torch.allclose(out.cpu(), y.float().sum(0), atol=1e-3, rtol=1e-4)
