@@ -1,0 +1,319 @@
+"""Autograd Functions of the Swin hot path, built only from libstswin_hip kernels (stswincl_amd.hip).
+
+Forward and backward are both hand-scheduled sequences of HIP launches on the caller's current stream; torch
+supplies memory, the tiny (heads x N x N) bias-table gather and nothing else.  No CPU or eager fallback.
+
+Compute dtype: bf16 storage / fp32 accumulate when the input is bf16 or autocast is on (fast path), fp32
+storage / exact fp32 MFMA when the input is fp32 outside autocast (parity path).  Parameters stay fp32 (the
+reference's state-dict); a bf16 (and transposed) copy is cached per parameter version.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import hip
+
+_ROWMAPS: Dict[tuple, torch.Tensor] = {}
+_WCACHE: Dict[tuple, tuple] = {}
+
+
+def compute_dtype(x: torch.Tensor) -> torch.dtype:
+    if x.dtype == torch.bfloat16 or x.dtype == torch.float16:
+        return torch.bfloat16
+    if torch.is_autocast_enabled():
+        return torch.bfloat16
+    return torch.float32
+
+
+def window_rowmap(B, T, H, W, ws, shift, device) -> torch.Tensor:
+    key = ("win", B, T, H, W, ws, shift, str(device))
+    m = _ROWMAPS.get(key)
+    if m is None:
+        m = hip.win_rowmap(B, T, H, W, ws, shift, device=device)
+        _ROWMAPS[key] = m
+    return m
+
+
+def merge_rowmap(frames, H, W, device) -> torch.Tensor:
+    key = ("merge", frames, H, W, str(device))
+    m = _ROWMAPS.get(key)
+    if m is None:
+        m = hip.merge_rowmap(frames, H, W, device=device)
+        _ROWMAPS[key] = m
+    return m
+
+
+def conv_rowmap(frames, H, W, dil, device) -> torch.Tensor:
+    key = ("conv", frames, H, W, dil, str(device))
+    m = _ROWMAPS.get(key)
+    if m is None:
+        m = hip.conv3x3_rowmap(frames, H, W, dil, device=device)
+        _ROWMAPS[key] = m
+    return m
+
+
+def wcast(p: torch.Tensor, dtype: torch.dtype, transpose: bool = False) -> torch.Tensor:
+    """Compute-dtype (optionally transposed) contiguous copy of a parameter, cached until the parameter changes."""
+    key = (id(p), dtype, transpose)
+    hit = _WCACHE.get(key)
+    stamp = (p._version, p.data_ptr(), tuple(p.shape), p.device)
+    if hit is not None and hit[0]() is p and hit[1] == stamp:
+        return hit[2]
+    w = p.detach()
+    if transpose:
+        w = w.t()
+    w = w.to(dtype).contiguous()
+    if len(_WCACHE) > 4096:          # drop entries whose parameter died (ids get recycled)
+        for k in [k for k, v in _WCACHE.items() if v[0]() is None]:
+            del _WCACHE[k]
+    _WCACHE[key] = (weakref.ref(p), stamp, w)
+    return w
+
+
+def clear_caches() -> None:
+    _ROWMAPS.clear()
+    _WCACHE.clear()
+
+
+def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if p is None else p.detach().float().contiguous()
+
+
+def expand_bias_T(table: torch.Tensor, index: torch.Tensor, N: int, heads: int) -> torch.Tensor:
+    """relative_position_bias_table[index] (swin_512.py:122-124) as [heads][key][query] fp32."""
+    b = table.detach().float()[index.reshape(-1).long()].reshape(N, N, heads)  # [query i][key j][h]
+    return b.permute(2, 1, 0).contiguous()
+
+
+class SwinBlockFn(torch.autograd.Function):
+    """One SwinTransformerBlock on a frame pair: (Bp, 2, L, C) -> (Bp, 2, L, C)   (swin_512.py:196-237)."""
+
+    @staticmethod
+    def forward(ctx, x, qkv_w, qkv_b, table, proj_w, proj_b, n1_w, n1_b, n2_w, n2_b, fc1_w, fc1_b, fc2_w, fc2_b,
+                index, attn_mask, geom):
+        H, W, ws, shift, heads = geom
+        dt = compute_dtype(x)
+        Bp, T, L, C = x.shape
+        assert T == 2 and L == H * W, "input feature has wrong size"
+        M, N, d = Bp * T * L, ws * ws, C // heads
+        nW = (H // ws) * (W // ws)
+        X2 = x.detach().to(dt).contiguous().view(M, C)
+        dev = x.device
+        rmap = window_rowmap(Bp, T, H, W, ws, shift, dev)
+        scale = d ** -0.5
+        qkv = torch.empty(M, 3 * C, dtype=dt, device=dev)
+        hip.gemm_nt(X2, wcast(qkv_w, dt), qkv, M=M, a_rows=rmap, bias=_f32(qkv_b), scale=scale, scale_cols=C)
+        biasT = expand_bias_T(table, index, N, heads)
+        maskT = attn_mask.detach().float().transpose(1, 2).contiguous() if (shift > 0 and attn_mask is not None) else None
+        o = hip.win_attn_fwd(qkv, biasT, maskT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads, C=C)
+        x1 = torch.empty(M, C, dtype=dt, device=dev)
+        hip.gemm_nt(o, wcast(proj_w, dt), x1, M=M, c_rows=rmap, bias=_f32(proj_b), resid=X2, r_rows=rmap,
+                    flags=hip.GF_RESID)
+        n2, mean2, rstd2 = hip.layernorm_fwd(x1, _f32(n2_w), _f32(n2_b), M=M)
+        h = torch.empty(M, fc1_w.shape[0], dtype=dt, device=dev)
+        h_pre = torch.empty_like(h)
+        hip.gemm_nt(n2, wcast(fc1_w, dt), h, M=M, bias=_f32(fc1_b), out2=h_pre, flags=hip.GF_GELU)
+        y2 = torch.empty(M, C, dtype=dt, device=dev)
+        hip.gemm_nt(h, wcast(fc2_w, dt), y2, M=M, bias=_f32(fc2_b), resid=x1, flags=hip.GF_RESID)
+        out, mean1, rstd1 = hip.layernorm_fwd(y2, _f32(n1_w), _f32(n1_b), M=M)
+        ctx.geom = geom
+        ctx.dt = dt
+        ctx.in_dtype = x.dtype
+        ctx.save_for_backward(X2, rmap, qkv, biasT, maskT, o, x1, mean2, rstd2, n2, h_pre, h, y2, mean1, rstd1,
+                              qkv_w, proj_w, n1_w, n2_w, fc1_w, fc2_w, index)
+        return out.view(Bp, T, L, C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (X2, rmap, qkv, biasT, maskT, o, x1, mean2, rstd2, n2, h_pre, h, y2, mean1, rstd1,
+         qkv_w, proj_w, n1_w, n2_w, fc1_w, fc2_w, index) = ctx.saved_tensors
+        H, W, ws, shift, heads = ctx.geom
+        dt = ctx.dt
+        M, C = X2.shape
+        N, d = ws * ws, C // heads
+        nW = (H // ws) * (W // ws)
+        dev = X2.device
+        hid = fc1_w.shape[0]
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        g = dout.detach().to(dt).contiguous().view(M, C)
+        # norm1
+        dn1_w, dn1_b = z(C), z(C)
+        dy2 = hip.layernorm_bwd(g, y2, _f32(n1_w), mean1, rstd1, dn1_w, dn1_b, M=M)
+        # fc2 (+ GELU')
+        dfc2_w, dfc2_b = z(C, hid), z(C)
+        hip.gemm_tn(dy2, h, dfc2_w, Mk=M)
+        hip.colsum(dy2, dfc2_b)
+        dh_pre = torch.empty(M, hid, dtype=dt, device=dev)
+        hip.gemm_nt(dy2, wcast(fc2_w, dt, True), dh_pre, M=M, resid=h_pre, flags=hip.GF_MUL_DGELU)
+        # fc1
+        dfc1_w, dfc1_b = z(hid, C), z(hid)
+        hip.gemm_tn(dh_pre, n2, dfc1_w, Mk=M)
+        hip.colsum(dh_pre, dfc1_b)
+        dn2 = torch.empty(M, C, dtype=dt, device=dev)
+        hip.gemm_nt(dh_pre, wcast(fc1_w, dt, True), dn2, M=M)
+        del dh_pre
+        # norm2 ; dx1 = dy2 + LN'(dn2)   (accumulated in place into dy2)
+        dn2_w, dn2_b = z(C), z(C)
+        dx1 = hip.layernorm_bwd(dn2, x1, _f32(n2_w), mean2, rstd2, dn2_w, dn2_b, M=M, dx=dy2, accumulate=True)
+        # proj (window order on the attention side)
+        dproj_w, dproj_b = z(C, C), z(C)
+        hip.gemm_tn(dx1, o, dproj_w, Mk=M, at_rows=rmap)
+        hip.colsum(dx1, dproj_b)
+        do = dn2  # reuse
+        hip.gemm_nt(dx1, wcast(proj_w, dt, True), do, M=M, a_rows=rmap)
+        # attention core
+        dbiasT = z(heads, N, N)
+        dqkv = hip.win_attn_bwd(qkv, do, biasT, maskT, dbiasT, nB_=(M // (2 * N)), nW=nW, T=2, ws=ws, heads=heads,
+                                C=C, scale=d ** -0.5)
+        dtable = z((2 * ws - 1) * (2 * ws - 1), heads)
+        dtable.index_add_(0, index.reshape(-1).long(), dbiasT.permute(2, 1, 0).reshape(N * N, heads))
+        # qkv
+        dqkv_w, dqkv_b = z(3 * C, C), z(3 * C)
+        hip.gemm_tn(dqkv, X2, dqkv_w, Mk=M, bt_rows=rmap)
+        hip.colsum(dqkv, dqkv_b)
+        dx = torch.empty(M, C, dtype=dt, device=dev)
+        hip.gemm_nt(dqkv, wcast(qkv_w, dt, True), dx, M=M, c_rows=rmap, resid=dx1, r_rows=rmap, flags=hip.GF_RESID)
+        Bp = M // (2 * H * W)
+        return (dx.view(Bp, 2, H * W, C).to(ctx.in_dtype), dqkv_w, dqkv_b, dtable, dproj_w, dproj_b, dn1_w, dn1_b,
+                dn2_w, dn2_b, dfc1_w, dfc1_b, dfc2_w, dfc2_b, None, None, None)
+
+
+class PatchMergeFn(torch.autograd.Function):
+    """PatchMerging: 2x2 gather + LayerNorm(4C) + Linear(4C->2C, no bias)   (swin_512.py:255-277)."""
+
+    @staticmethod
+    def forward(ctx, x, norm_w, norm_b, red_w, res):
+        H, W = res
+        dt = compute_dtype(x)
+        B, T, L, C = x.shape
+        assert T == 4, "wrong time dimension"
+        assert L == H * W, "input feature has wrong size"
+        assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."
+        frames = B * T
+        M4 = frames * (H // 2) * (W // 2)
+        X2 = x.detach().to(dt).contiguous().view(frames * L, C)
+        rows = merge_rowmap(frames, H, W, x.device)
+        n, mean, rstd = hip.layernorm_fwd(X2, _f32(norm_w), _f32(norm_b), M=M4, rows=rows, S=4, Cseg=C)
+        y = torch.empty(M4, 2 * C, dtype=dt, device=x.device)
+        hip.gemm_nt(n, wcast(red_w, dt), y, M=M4)
+        ctx.res, ctx.dt, ctx.in_dtype, ctx.shape = res, dt, x.dtype, (B, T, L, C)
+        ctx.save_for_backward(X2, rows, n, mean, rstd, norm_w, red_w)
+        return y.view(B, T, L // 4, 2 * C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        X2, rows, n, mean, rstd, norm_w, red_w = ctx.saved_tensors
+        B, T, L, C = ctx.shape
+        dt = ctx.dt
+        M4 = n.shape[0]
+        dev = X2.device
+        g = dy.detach().to(dt).contiguous().view(M4, 2 * C)
+        dred = torch.zeros(2 * C, 4 * C, dtype=torch.float32, device=dev)
+        hip.gemm_tn(g, n, dred, Mk=M4)
+        dn = torch.empty(M4, 4 * C, dtype=dt, device=dev)
+        hip.gemm_nt(g, wcast(red_w, dt, True), dn, M=M4)
+        dg = torch.zeros(4 * C, dtype=torch.float32, device=dev)
+        db = torch.zeros(4 * C, dtype=torch.float32, device=dev)
+        dx = torch.empty_like(X2)
+        hip.layernorm_bwd(dn, X2, _f32(norm_w), mean, rstd, dg, db, M=M4, rows=rows, S=4, Cseg=C, dx=dx)
+        return dx.view(B, T, L, C).to(ctx.in_dtype), dg, db, dred, None
+
+
+class WindowAttentionFn(torch.autograd.Function):
+    """WindowAttention.forward on already-partitioned windows (B_, T, N, C)   (swin_512.py:109-141)."""
+
+    @staticmethod
+    def forward(ctx, x, qkv_w, qkv_b, table, proj_w, proj_b, index, mask, ws, heads):
+        dt = compute_dtype(x)
+        B_, T, N, C = x.shape
+        M, d = B_ * T * N, C // heads
+        nW = mask.shape[0] if mask is not None else 1
+        X2 = x.detach().to(dt).contiguous().view(M, C)
+        qkv = torch.empty(M, 3 * C, dtype=dt, device=x.device)
+        hip.gemm_nt(X2, wcast(qkv_w, dt), qkv, M=M, bias=_f32(qkv_b), scale=d ** -0.5, scale_cols=C)
+        biasT = expand_bias_T(table, index, N, heads)
+        maskT = mask.detach().float().transpose(1, 2).contiguous() if mask is not None else None
+        o = hip.win_attn_fwd(qkv, biasT, maskT, nB_=B_, nW=nW, T=T, ws=ws, heads=heads, C=C)
+        y = torch.empty(M, C, dtype=dt, device=x.device)
+        hip.gemm_nt(o, wcast(proj_w, dt), y, M=M, bias=_f32(proj_b))
+        ctx.cfg = (ws, heads, nW, T)
+        ctx.dt, ctx.in_dtype = dt, x.dtype
+        ctx.save_for_backward(X2, qkv, biasT, maskT, o, qkv_w, proj_w, index)
+        return y.view(B_, T, N, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        X2, qkv, biasT, maskT, o, qkv_w, proj_w, index = ctx.saved_tensors
+        ws, heads, nW, T = ctx.cfg
+        dt = ctx.dt
+        M, C = X2.shape
+        N, d = ws * ws, C // heads
+        dev = X2.device
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        g = dy.detach().to(dt).contiguous().view(M, C)
+        dproj_w, dproj_b = z(C, C), z(C)
+        hip.gemm_tn(g, o, dproj_w, Mk=M)
+        hip.colsum(g, dproj_b)
+        do = torch.empty(M, C, dtype=dt, device=dev)
+        hip.gemm_nt(g, wcast(proj_w, dt, True), do, M=M)
+        dbiasT = z(heads, N, N)
+        dqkv = hip.win_attn_bwd(qkv, do, biasT, maskT, dbiasT, nB_=M // (T * N), nW=nW, T=T, ws=ws, heads=heads, C=C,
+                                scale=d ** -0.5)
+        dtable = z((2 * ws - 1) * (2 * ws - 1), heads)
+        dtable.index_add_(0, index.reshape(-1).long(), dbiasT.permute(2, 1, 0).reshape(N * N, heads))
+        dqkv_w, dqkv_b = z(3 * C, C), z(3 * C)
+        hip.gemm_tn(dqkv, X2, dqkv_w, Mk=M)
+        hip.colsum(dqkv, dqkv_b)
+        dx = torch.empty(M, C, dtype=dt, device=dev)
+        hip.gemm_nt(dqkv, wcast(qkv_w, dt, True), dx, M=M)
+        return (dx.view(M // (T * N), T, N, C).to(ctx.in_dtype), dqkv_w, dqkv_b, dtable, dproj_w, dproj_b,
+                None, None, None, None)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) over the last dim via the MFMA GEMM (Mlp.fc1 / fc2, 1x1 convs on NHWC tokens)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        dt = compute_dtype(x)
+        K = x.shape[-1]
+        X2 = x.detach().to(dt).contiguous().view(-1, K)
+        M = X2.shape[0]
+        y = torch.empty(M, w.shape[0], dtype=dt, device=x.device)
+        pre = torch.empty_like(y) if act == "gelu" else None
+        flags = hip.GF_GELU if act == "gelu" else (hip.GF_RELU if act == "relu" else 0)
+        hip.gemm_nt(X2, wcast(w, dt), y, M=M, bias=_f32(b), out2=pre, flags=flags)
+        ctx.act, ctx.dt, ctx.in_dtype, ctx.has_b = act, dt, x.dtype, b is not None
+        ctx.save_for_backward(X2, w, pre if act == "gelu" else (y if act == "relu" else None))
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        X2, w, aux = ctx.saved_tensors
+        dt = ctx.dt
+        M, K = X2.shape
+        Nn = w.shape[0]
+        g = dy.detach().to(dt).contiguous().view(M, Nn)
+        if ctx.act == "relu":
+            g = g * (aux > 0).to(dt)
+        dx = torch.empty(M, K, dtype=dt, device=X2.device)
+        if ctx.act == "gelu":
+            # dpre = dy * gelu'(pre): needs an elementwise pass; fold it into the dgrad GEMM of an identity is not
+            # possible, so compute it with the GEMM epilogue on the weight-gradient path instead
+            dpre = (g.float() * _dgelu(aux.float())).to(dt)
+            g = dpre
+        dw = torch.zeros(Nn, K, dtype=torch.float32, device=X2.device)
+        hip.gemm_tn(g, X2, dw, Mk=M)
+        db = None
+        if ctx.has_b:
+            db = torch.zeros(Nn, dtype=torch.float32, device=X2.device)
+            hip.colsum(g, db)
+        hip.gemm_nt(g, wcast(w, dt, True), dx, M=M)
+        return dx.view(*dy.shape[:-1], K).to(ctx.in_dtype), dw, db, None
+
+
+def _dgelu(x: torch.Tensor) -> torch.Tensor:
+    return 0.5 * (1 + torch.erf(x * 0.7071067811865476)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327

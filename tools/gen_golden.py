@@ -287,6 +287,25 @@ def gen_swin_layer(swin):
             "d/layers.4.1.attn.qkv.weight": grads["d/layers.4.1.attn.qkv.weight"]})
 
 
+def gen_swin_layer_d128(swin):
+    """Same as gen_swin_layer at a width the MFMA kernels accept (dim 128 -> head dims 32 / 64)."""
+    net = swin.SwinTransformerLayerv5(dim=128, input_resolution=(16, 16), num_heads=4)
+    gu.det_fill(net.state_dict())
+    x = gu.det_tensor("swin_layer_d128/x", (1, 4, 128, 16, 16)).requires_grad_(True)
+    g1 = gu.det_tensor("swin_layer_d128/g1", (1, 4, 128, 16, 16))
+    g2 = gu.det_tensor("swin_layer_d128/g2", (1, 4, 256, 8, 8))
+    o1, o2 = net(x)
+    ((o1 * g1).sum() + (o2 * g2).sum()).backward()
+    grads = {k: p.grad for k, p in net.named_parameters()}
+    full = ["layers.0.0.attn.relative_position_bias_table", "layers.1.1.attn.relative_position_bias_table",
+            "layers.4.1.attn.relative_position_bias_table", "layers.2.0.norm1.weight", "layers.5.1.mlp.fc2.bias",
+            "downsample.norm.weight", "layers.3.0.attn.qkv.bias"]
+    save("swin_layer_d128.npz", o1=o1, o2=o2, dx=x.grad, **sd_meta(net.state_dict()),
+         **{"dsum/" + k: torch.stack([v.double().sum(), v.double().abs().sum(), (v.double() ** 2).sum()]).float()
+            for k, v in grads.items()},
+         **{"d/" + k: grads[k] for k in full})
+
+
 def gen_aspp(aspp_mod):
     torch.manual_seed(7)
     net = aspp_mod.ASPP(num_classes=256)
@@ -428,6 +447,8 @@ def main():
         gen_patch_merging(swin)
     if want("swin_layer"):
         gen_swin_layer(swin)
+    if want("swin_layer_d128"):
+        gen_swin_layer_d128(swin)
     if want("aspp"):
         gen_aspp(aspp_mod)
     if want("ohem"):
