@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the STswinCL segmentation training step (fwd + bwd + Adam) on MI355X.
+
+Workload = BASELINE.json configs[1], as far as the reference can run it: TswinPlus(12),
+B = 4 clips/GPU of T = 4 frames (the reference asserts T == 4), 3x512x512, bf16 compute / fp32 master weights,
+OHEM cross-entropy (n_min = 512*512/16), Adam lr 1e-4 (seg18/train_swin.py:122), synthetic frames and labels
+resident in HBM, random-init weights.  One step = model fwd + loss + bwd (+ gradient all-reduce) + optimizer.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, live HIP
+events) and `cpu_baseline` (the CPU oracle timed on this host, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="clips per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=512)
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(size: int):
+    """The oracle (a port of the reference graph) doing the same training step on the host cores: one bounded
+    sample = 1 step of B = 2 clips (B = 1 cannot train: ASPP's BatchNorm on a 1x1 map), fp32, all host threads."""
+    from oracle import stswin_oracle as O
+    from stswincl_amd.net.Ours.base18 import TswinPlus
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = TswinPlus(12, (size // 8, size // 8))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    params = {k: sd[k].requires_grad_(True) for k, _ in model.named_parameters()}
+    del model
+    opt = torch.optim.Adam(list(params.values()), 1e-4)
+    x = torch.randn(2, 4, 3, size, size)
+    y = torch.randint(0, 12, (2, size, size))
+    t0 = time.perf_counter()
+    logits = O.tswin_plus(x, sd, True)
+    loss = O.ohem_ce(logits, y, size * size // 16)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    return {"value": 2 * 4 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 fwd+bwd+Adam step, B=2 clips x 4 frames, {size}x{size}, fp32, {dt:.1f} s, "
+                      f"torch threads={torch.get_num_threads()}"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as ge
+    if rank == 0 and not os.path.exists(ge.LIB):
+        ge.build(verbose=False)
+    if world > 1:
+        dist.barrier()
+    from stswincl_amd import hip
+    from stswincl_amd.dp import GradBucketReducer
+    from stswincl_amd.net.Ours.base18 import TswinPlus
+    from stswincl_amd.utils.losses import OhemCELoss2D
+    hip.load()
+
+    S, B = a.size, a.batch
+    torch.manual_seed(0)
+    model = TswinPlus(12, (S // 8, S // 8)).to(dev).to(memory_format=torch.channels_last)
+    model.train()
+    if world > 1:   # identical initial weights on every rank
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+    opt = torch.optim.Adam(model.parameters(), 1e-4)
+    crit = OhemCELoss2D(S * S // 16)
+    reducer = GradBucketReducer(model.parameters(), bucket_mb=64.0) if world > 1 else None
+    torch.manual_seed(1234 + rank)            # each rank owns different clips (weak scaling)
+    x = torch.randn(B, 4, 3, S, S, device=dev)
+    y = torch.randint(0, 12, (B, S, S), device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(x)
+            loss = crit(out, y)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not a.no_profile and rank == 0:
+        hip.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = hip.profile_end() if (not a.no_profile and rank == 0) else {}
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        frames = world * B * 4 * a.steps
+        res = {
+            "metric": "input frames/s, TswinPlus fwd+bwd+Adam, 4-frame 512x512 clips", "value": frames / dt,
+            "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: TswinPlus(12) seg train step, {B} clips/GPU x T=4 frames "
+                                   f"x 3x{S}x{S}, swin res ({S // 8},{S // 8}), OHEM-CE, Adam; T=4 because the reference "
+                                   f"asserts it (swin_512.py:313)",
+                       "clips_per_gpu": B, "frames_per_clip": 4, "parallelism": f"dp{world}",
+                       "loss": float(loss)},
+        }
+        if prof:
+            k = max(prof, key=lambda n: prof[n]["ms_total"])
+            p = prof[k]
+            tf = p["work"] / (p["ms_total"] * 1e-3) / 1e12
+            res["roofline"] = {"kernel": k, "bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / PEAK_BF16_TFLOPS, "traffic": None, "launches_per_step": p["launches"] / a.steps,
+                               "avg_launch_ms": p["ms_avg"], "ms_per_step": p["ms_total"] / a.steps,
+                               "other_kernels": {n: {"ms_per_step": v["ms_total"] / a.steps,
+                                                     "tflops": v["work"] / (v["ms_total"] * 1e-3) / 1e12}
+                                                 for n, v in prof.items() if n != k}}
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.cpu_size)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

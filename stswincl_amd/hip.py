@@ -81,6 +81,47 @@ def _ld(t: torch.Tensor) -> int:
     return t.stride(0)
 
 
+# ----------------------------------------------------------------------------------------------- live profiling
+# bench.py brackets every launch of the dominant kernels with HIP events recorded on the launch stream (torch's
+# current stream IS the stream the kernels are launched on) and reads them back after the timed region.
+_PROFILE = None
+
+
+def profile_begin():
+    global _PROFILE
+    _PROFILE = {}
+
+
+def profile_end():
+    """-> {kernel: dict(launches, ms_total, ms_avg, work)} where work = algorithmic flops (or bytes) summed."""
+    global _PROFILE
+    prof, _PROFILE = _PROFILE, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, recs in (prof or {}).items():
+        ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+        out[name] = dict(launches=len(recs), ms_total=ms, ms_avg=ms / max(len(recs), 1), work=sum(w for _, _, w in recs))
+    return out
+
+
+class _Span:
+    def __init__(self, name, work):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _PROFILE is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _PROFILE.setdefault(self.name, []).append((self.a, b, self.work))
+        return False
+
+
 # ----------------------------------------------------------------------------------------------- row maps
 def win_rowmap(B, T, H, W, ws, shift, f0=0, frames_total=None, device="cuda") -> torch.Tensor:
     frames_total = T if frames_total is None else frames_total
@@ -127,11 +168,12 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
         assert out.dtype == A.dtype
     else:
         assert out.dtype == torch.float32
-    rc = load().stswin_gemm_nt(
-        _dt(A), _p(A), _c_long(_ld(A)), _p(a_rows), _p(Bw), _c_long(_ld(Bw)), _p(out), _c_long(_ld(out)), _p(c_rows),
-        _p(out2), _c_long(_ld(out2) if out2 is not None else 0), _p(bias), _p(resid),
-        _c_long(_ld(resid) if resid is not None else 0), _p(r_rows), M, N, Kseg, S, _c_float(scale), scale_cols, flags,
-        _stream())
+    with _Span("gemm_nt_bf16" if A.dtype == torch.bfloat16 else "gemm_nt_f32", 2.0 * M * N * Ktot):
+        rc = load().stswin_gemm_nt(
+            _dt(A), _p(A), _c_long(_ld(A)), _p(a_rows), _p(Bw), _c_long(_ld(Bw)), _p(out), _c_long(_ld(out)),
+            _p(c_rows), _p(out2), _c_long(_ld(out2) if out2 is not None else 0), _p(bias), _p(resid),
+            _c_long(_ld(resid) if resid is not None else 0), _p(r_rows), M, N, Kseg, S, _c_float(scale), scale_cols,
+            flags, _stream())
     _check(rc, "gemm_nt")
     return out
 
@@ -141,8 +183,9 @@ def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: in
     """out_f32[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]  (fp32, atomically accumulated)."""
     Ni, Nj = out_f32.shape
     assert out_f32.dtype == torch.float32 and At.dtype == Bt.dtype
-    rc = load().stswin_gemm_tn(_dt(At), _p(At), _c_long(_ld(At)), _p(at_rows), _p(Bt), _c_long(_ld(Bt)), _p(bt_rows),
-                               _p(out_f32), _c_long(_ld(out_f32)), Mk, Ni, Nj, splits, _stream())
+    with _Span("gemm_tn_bf16" if At.dtype == torch.bfloat16 else "gemm_tn_f32", 2.0 * Mk * Ni * Nj):
+        rc = load().stswin_gemm_tn(_dt(At), _p(At), _c_long(_ld(At)), _p(at_rows), _p(Bt), _c_long(_ld(Bt)),
+                                   _p(bt_rows), _p(out_f32), _c_long(_ld(out_f32)), Mk, Ni, Nj, splits, _stream())
     _check(rc, "gemm_tn")
     return out_f32
 

@@ -1,0 +1,66 @@
+"""Whole-model parity: TswinPlus logits / OHEM loss vs the reference-generated golden (fp32 path, 1e-3 relative per
+BASELINE.json north_star) and the bf16 path at its documented tolerance."""
+import pytest
+import torch
+
+import golden_util as gu
+from stswincl_amd.net.Ours.base18 import TswinPlus
+from stswincl_amd.utils.losses import OhemCELoss2D
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).double()
+    return float((a - b).norm() / b.norm())
+
+
+def _model():
+    g = gu.load("tswinplus.npz")
+    m = TswinPlus(12, (16, 16))
+    sd = gu.det_fill(gu.skeleton_sd(g["keys"], g["shapes"], g["dtypes"]))
+    r = m.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys and all(k.endswith(("attn_mask", "relative_position_index")) for k in r.missing_keys)
+    return g, m.cuda()
+
+
+def test_tswinplus_fp32_matches_reference():
+    g, m = _model()
+    x = gu.det_tensor("tswinplus/x", (2, 4, 3, 128, 128)).cuda()
+    labels = torch.from_numpy(g["labels"]).long().cuda()
+    m.train()
+    y = m(x)
+    assert rel(y[:, :, ::2, ::2], g["y_train_sub"]) < 1e-3
+    loss = OhemCELoss2D(128 * 128 // 16)(y, labels)
+    assert abs(float(loss) - float(g["loss_train"])) < 1e-3 * float(g["loss_train"])
+    assert rel(m.resnet.layer5[1].bn2.running_mean, g["rm_after"]) < 1e-3
+    assert int(m.resnet.resnet[1].num_batches_tracked) == 4
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    m.eval()
+    with torch.no_grad():
+        assert rel(m(x)[:, :, ::2, ::2], g["y_eval_sub"]) < 1e-3
+
+
+def test_tswinplus_bf16_autocast():
+    g, m = _model()
+    x = gu.det_tensor("tswinplus/x", (2, 4, 3, 128, 128)).cuda()
+    labels = torch.from_numpy(g["labels"]).long().cuda()
+    m.train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(x)
+        loss = OhemCELoss2D(128 * 128 // 16)(y, labels)
+    assert rel(y.float()[:, :, ::2, ::2], g["y_train_sub"]) < 6e-2
+    assert abs(float(loss) - float(g["loss_train"])) < 3e-2 * float(g["loss_train"])
+    loss.backward()
+
+
+@pytest.mark.parametrize("tag", ["thresh_branch", "topk_branch"])
+def test_ohem_matches_reference(tag):
+    g = gu.load("ohem.npz")
+    lg = torch.from_numpy(g[f"{tag}_logits"]).cuda().requires_grad_(True)
+    labels = torch.from_numpy(g["labels"]).long().cuda()
+    loss = OhemCELoss2D(int(g[f"{tag}_n_min"]))(lg, labels)
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-5 * abs(float(g[f"{tag}_loss"]))
+    loss.backward()
+    assert rel(lg.grad, g[f"{tag}_dlogits"]) < 1e-4
