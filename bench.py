@@ -41,31 +41,51 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(size: int):
-    """The oracle (a port of the reference graph) doing the same training step on the host cores: one bounded
-    sample = 1 step of B = 2 clips (B = 1 cannot train: ASPP's BatchNorm on a 1x1 map), fp32, all host threads."""
+def cpu_baseline(size: int, budget_s: float = 25.0):
+    """The oracle (a port of the reference graph) doing the same training step on the host cores.
+
+    Bounded sample: one fwd+bwd+Adam step of B = 2 clips (B = 1 cannot train: ASPP's BatchNorm on a 1x1 map) in fp32.
+    A 128x128 calibration step predicts the cost of the full-resolution step (work scales with pixels); if that would
+    exceed the budget the largest of {size, size/2, size/4} that fits is timed and the rate is scaled by the pixel
+    ratio (stated in `sample`).  Threads are capped at 32: oversubscribing a shared 256-thread host made the same
+    step 20x slower."""
     from oracle import stswin_oracle as O
     from stswincl_amd.net.Ours.base18 import TswinPlus
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    model = TswinPlus(12, (size // 8, size // 8))
-    sd = {k: v.clone() for k, v in model.state_dict().items()}
-    params = {k: sd[k].requires_grad_(True) for k, _ in model.named_parameters()}
-    del model
-    opt = torch.optim.Adam(list(params.values()), 1e-4)
-    x = torch.randn(2, 4, 3, size, size)
-    y = torch.randint(0, 12, (2, size, size))
-    t0 = time.perf_counter()
-    logits = O.tswin_plus(x, sd, True)
-    loss = O.ohem_ce(logits, y, size * size // 16)
-    opt.zero_grad()
-    loss.backward()
-    opt.step()
-    dt = time.perf_counter() - t0
-    return {"value": 2 * 4 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 fwd+bwd+Adam step, B=2 clips x 4 frames, {size}x{size}, fp32, {dt:.1f} s, "
-                      f"torch threads={torch.get_num_threads()}"}
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(32, avail))
+    torch.set_num_threads(threads)
+
+    def one_step(sz):
+        torch.manual_seed(0)
+        model = TswinPlus(12, (sz // 8, sz // 8))
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        params = {k: sd[k].requires_grad_(True) for k, _ in model.named_parameters()}
+        del model
+        opt = torch.optim.Adam(list(params.values()), 1e-4)
+        x = torch.randn(2, 4, 3, sz, sz)
+        y = torch.randint(0, 12, (2, sz, sz))
+        t0 = time.perf_counter()
+        logits = O.tswin_plus(x, sd, True)
+        loss = O.ohem_ce(logits, y, sz * sz // 16)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return time.perf_counter() - t0
+
+    one_step(64)                       # thread-pool / allocator warm-up
+    t_cal = one_step(128)
+    sz = size
+    while sz > 128 and t_cal * (sz / 128.0) ** 2 > budget_s:
+        sz //= 2
+    dt = t_cal if sz == 128 else one_step(sz)
+    scale = (sz / float(size)) ** 2    # pixel-count ratio: a smaller frame is proportionally less work
+    return {"value": 2 * 4 / dt * scale, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"1 fwd+bwd+Adam step of the CPU oracle, B=2 clips x 4 frames at {sz}x{sz} fp32 took {dt:.1f} s on "
+                      f"{threads} threads ({avail} visible); rate scaled by ({sz}/{size})^2 to {size}x{size} frames; "
+                      f"calibration step at 128x128: {t_cal:.1f} s"}
 
 
 def main():

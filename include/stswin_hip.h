@@ -75,6 +75,41 @@ int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, l
                         const float* biasT, const float* maskT, float* dbiasT, int nB_, int nW, int T_frames, int ws,
                         int heads, int C, float scale, void* stream);
 
+/* ---- decode head on NHWC token matrices [M = frames*H*W][C]  (ASPP.py:33-52, base18.py:60-106) ---------------
+ * Grouped BatchNorm2d: rows are `groups` equal groups with separate batch statistics (1 for the head; the number of
+ * frames when the per-frame ResNet calls of base18.py:86-89 are batched).  colstats accumulates pivot-shifted sums
+ * (sumsq may be NULL: plain grouped column sums = adaptive_avg_pool numerator, ASPP.py:43); bn_finalize turns them
+ * into mean / rstd and applies nn.BatchNorm2d's running-stat update group by group; bn_apply fuses affine +
+ * residual + ReLU (resnet.py:42-51); bn_bwd = the two-pass backward (s1/s2 fp32 [groups][C], zeroed by the caller). */
+int stswin_colstats(int dtype, const void* x, long ldx, float* sum, float* sumsq, int M, int C, int groups, void* stream);
+int stswin_bn_finalize(int dtype, const void* x, long ldx, const float* sum, const float* sumsq, float* mean, float* rstd,
+                       float* running_mean, float* running_var, int M, int C, int groups, float eps, float momentum,
+                       void* stream);
+int stswin_bn_apply(int dtype, const void* x, long ldx, const float* mean, const float* rstd, const float* gamma,
+                    const float* beta, const void* resid, long ldr, void* y, long ldy, int M, int C, int groups, int relu,
+                    void* stream);
+int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const void* y, long ldy, const float* mean,
+                  const float* rstd, const float* gamma, float* s1, float* s2, void* dx, long lddx, void* dresid, long lddr,
+                  int M, int C, int groups, int relu, int training, void* stream);
+/* out[r][c] (+)= v[r / (M/groups)][c] * scale : image-pool broadcast (ASPP.py:46) and avg-pool backward */
+int stswin_rows_broadcast(int dtype, const float* v, void* out, long ldo, int M, int C, int groups, float scale,
+                          int accumulate, void* stream);
+/* bilinear, align_corners=False (base18.py:102-103): forward in[F][h][w][C] -> out[F][H][W][C]; backward: in = d(out),
+ * out = d(in) (gather form, no atomics) */
+int stswin_bilinear(int dtype, const void* in, long ldi, void* out, long ldo, int frames, int h, int w, int H, int W, int C,
+                    int backward, void* stream);
+/* final interpolate of base18.py:106: tokens [F][h][w][nc] <-> NCHW logits [F][nc][H][W] */
+int stswin_logits_upsample(int dtype, const void* tokens, long ldt, void* nchw, int frames, int h, int w, int H, int W,
+                           int nc, int backward, void* stream);
+
+/* ---- a15: OHEM cross entropy (seg18/utils/losses.py:32-40).  ce_fwd: per-pixel CE (ignore_index -> 0) and
+ * stats[0] = #(loss > thresh), stats[1] = sum of those.  ce_bwd: dlogits = gscale[0] * sel[1] * (softmax - onehot) for
+ * pixels with loss > sel[0] (>= when sel[2] != 0); sel/gscale live on the device, so no host sync is needed. */
+int stswin_ce_fwd(int dtype, const void* logits, const long* labels, float* loss, float* stats, int frames, long HW, int nc,
+                  int ignore_index, float thresh, void* stream);
+int stswin_ce_bwd(int dtype, const void* logits, const long* labels, const float* loss, const float* sel,
+                  const float* gscale, void* dlogits, int frames, long HW, int nc, int ignore_index, void* stream);
+
 /* ---- device self-test of the MFMA / LDS primitives the kernels are built on; writes a report into `out`
  * (fp32, >= 64 KiB) and returns the number of failed checks (0 = all good). Used by tests only. */
 int stswin_selftest(float* out, int which, void* stream);

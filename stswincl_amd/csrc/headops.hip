@@ -1,0 +1,521 @@
+// Decode-head and loss kernels on NHWC "token" matrices [M = frames*H*W rows][C channels] (HBM-bound work;
+// 16-byte pieces per lane everywhere).  BatchNorm is grouped: the M rows are G equal groups with separate batch
+// statistics (G = 1 for the head; G = frames lets the per-frame ResNet calls of base18.py:86-89 be batched without
+// changing the per-frame statistics the reference computes).
+#include "common.h"
+
+// ----------------------------------------------------------------------------------------- column statistics
+// sum[g][c] += sum_rows (x - pivot), sumsq[g][c] += sum_rows (x - pivot)^2, pivot = x[first row of group][c]
+// (shifted sums keep E[x^2]-E[x]^2 well conditioned).  Block = 32 column pieces x 8 row lanes.
+template <typename T, bool SQ>
+__global__ __launch_bounds__(256) void colstats_kernel(const T* x, long ldx, float* sum, float* sumsq, int C, int group_rows,
+                                                        int chunks_per_group, int rows_per_chunk) {
+  constexpr int PACK = TT<T>::PACK;
+  __shared__ float part[2][8][32 * 8];
+  const int cp = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + cp) * PACK;
+  const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
+  const long gr0 = (long)g * group_rows;
+  float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < C) {
+    if (SQ) {
+      Vec16<T> p0;
+      p0.v = *(const decltype(p0.v)*)(x + gr0 * ldx + c);
+#pragma unroll
+      for (int e = 0; e < PACK; ++e) pv[e] = p0.get(e);
+    }
+    const int r_end = min(group_rows, (ch + 1) * rows_per_chunk);
+    for (int r = ch * rows_per_chunk + rl; r < r_end; r += 8) {
+      Vec16<T> in;
+      in.v = *(const decltype(in.v)*)(x + (gr0 + r) * ldx + c);
+#pragma unroll
+      for (int e = 0; e < PACK; ++e) {
+        const float d = in.get(e) - pv[e];
+        a1[e] += d;
+        if (SQ) a2[e] += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { part[0][rl][cp * 8 + e] = a1[e]; part[1][rl][cp * 8 + e] = a2[e]; }
+  __syncthreads();
+  if (rl == 0 && c < C) {
+#pragma unroll
+    for (int e = 0; e < PACK; ++e) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s1 += part[0][k][cp * 8 + e]; s2 += part[1][k][cp * 8 + e]; }
+      atomicAdd(sum + (long)g * C + c + e, s1);
+      if (SQ) atomicAdd(sumsq + (long)g * C + c + e, s2);
+    }
+  }
+}
+
+// mean/rstd per (group, channel) from the shifted sums; running-stat update group by group in order
+// (nn.BatchNorm2d momentum semantics: running = (1-m) running + m stat, unbiased variance).
+template <typename T>
+__global__ void bn_finalize_kernel(const T* x, long ldx, const float* sum, const float* sumsq, float* mean, float* rstd,
+                                   float* running_mean, float* running_var, int C, int G, int group_rows, float eps,
+                                   float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+  for (int g = 0; g < G; ++g) {
+    const float pivot = to_f32<T>(x[(long)g * group_rows * ldx + c]);
+    const float ms = sum[(long)g * C + c] / group_rows;
+    const float var = fmaxf(sumsq[(long)g * C + c] / group_rows - ms * ms, 0.f);
+    mean[(long)g * C + c] = pivot + ms;
+    rstd[(long)g * C + c] = rsqrtf(var + eps);
+    rm = (1.f - momentum) * rm + momentum * (pivot + ms);
+    rv = (1.f - momentum) * rv + momentum * var * ((float)group_rows / (float)max(group_rows - 1, 1));
+  }
+  if (running_mean) { running_mean[c] = rm; running_var[c] = rv; }
+}
+
+// y = act( (x-mean)*rstd*gamma + beta [+ resid] )
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, long ldx, const float* mean, const float* rstd,
+                                                        const float* gamma, const float* beta, const T* resid, long ldr,
+                                                        T* y, long ldy, int M, int C, int group_rows, int relu) {
+  constexpr int PACK = TT<T>::PACK;
+  const int ppr = C / PACK;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)M * ppr) return;
+  const int r = idx / ppr, c = (idx % ppr) * PACK;
+  const int g = r / group_rows;
+  Vec16<T> in, rs, o;
+  in.v = *(const decltype(in.v)*)(x + (long)r * ldx + c);
+  if (resid) rs.v = *(const decltype(rs.v)*)(resid + (long)r * ldr + c);
+#pragma unroll
+  for (int e = 0; e < PACK; ++e) {
+    float v = (in.get(e) - mean[(long)g * C + c + e]) * rstd[(long)g * C + c + e] * gamma[c + e] + beta[c + e];
+    if (resid) v += rs.get(e);
+    if (relu) v = fmaxf(v, 0.f);
+    o.set(e, v);
+  }
+  *(decltype(o.v)*)(y + (long)r * ldy + c) = o.v;
+}
+
+// pass 1 of the backward: s1[g][c] = sum dyr, s2[g][c] = sum dyr*xhat, dyr = dy * (y > 0 if relu)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, long lddy, const T* x, long ldx, const T* y, long ldy,
+                                                             const float* mean, const float* rstd, float* s1, float* s2,
+                                                             int C, int group_rows, int chunks_per_group, int rows_per_chunk,
+                                                             int relu) {
+  constexpr int PACK = TT<T>::PACK;
+  __shared__ float part[2][8][32 * 8];
+  const int cp = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + cp) * PACK;
+  const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
+  const long gr0 = (long)g * group_rows;
+  float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < C) {
+    float mu[8], rs[8];
+#pragma unroll
+    for (int e = 0; e < PACK; ++e) { mu[e] = mean[(long)g * C + c + e]; rs[e] = rstd[(long)g * C + c + e]; }
+    const int r_end = min(group_rows, (ch + 1) * rows_per_chunk);
+    for (int r = ch * rows_per_chunk + rl; r < r_end; r += 8) {
+      Vec16<T> d, xi, yo;
+      d.v = *(const decltype(d.v)*)(dy + (gr0 + r) * lddy + c);
+      xi.v = *(const decltype(xi.v)*)(x + (gr0 + r) * ldx + c);
+      if (relu) yo.v = *(const decltype(yo.v)*)(y + (gr0 + r) * ldy + c);
+#pragma unroll
+      for (int e = 0; e < PACK; ++e) {
+        float dv = d.get(e);
+        if (relu && !(yo.get(e) > 0.f)) dv = 0.f;
+        a1[e] += dv;
+        a2[e] += dv * (xi.get(e) - mu[e]) * rs[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { part[0][rl][cp * 8 + e] = a1[e]; part[1][rl][cp * 8 + e] = a2[e]; }
+  __syncthreads();
+  if (rl == 0 && c < C) {
+#pragma unroll
+    for (int e = 0; e < PACK; ++e) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { t1 += part[0][k][cp * 8 + e]; t2 += part[1][k][cp * 8 + e]; }
+      atomicAdd(s1 + (long)g * C + c + e, t1);
+      atomicAdd(s2 + (long)g * C + c + e, t2);
+    }
+  }
+}
+
+// pass 2: dx = gamma*rstd*(dyr - [training] (s1 + xhat*s2)/n) ; dresid = dyr (optional)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* dy, long lddy, const T* x, long ldx, const T* y, long ldy,
+                                                         const float* mean, const float* rstd, const float* gamma,
+                                                         const float* s1, const float* s2, T* dx, long lddx, T* dres,
+                                                         long lddr, int M, int C, int group_rows, int relu, int training) {
+  constexpr int PACK = TT<T>::PACK;
+  const int ppr = C / PACK;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)M * ppr) return;
+  const int r = idx / ppr, c = (idx % ppr) * PACK;
+  const int g = r / group_rows;
+  const float inv_n = 1.0f / group_rows;
+  Vec16<T> d, xi, yo, o, od;
+  d.v = *(const decltype(d.v)*)(dy + (long)r * lddy + c);
+  xi.v = *(const decltype(xi.v)*)(x + (long)r * ldx + c);
+  if (relu) yo.v = *(const decltype(yo.v)*)(y + (long)r * ldy + c);
+#pragma unroll
+  for (int e = 0; e < PACK; ++e) {
+    float dv = d.get(e);
+    if (relu && !(yo.get(e) > 0.f)) dv = 0.f;
+    const long gc = (long)g * C + c + e;
+    const float xh = (xi.get(e) - mean[gc]) * rstd[gc];
+    float v = dv;
+    if (training) v -= (s1[gc] + xh * s2[gc]) * inv_n;
+    o.set(e, v * gamma[c + e] * rstd[gc]);
+    od.set(e, dv);
+  }
+  *(decltype(o.v)*)(dx + (long)r * lddx + c) = o.v;
+  if (dres) *(decltype(od.v)*)(dres + (long)r * lddr + c) = od.v;
+}
+
+// out[r][c] (+)= v[r / group_rows][c] * scale      (image-pool broadcast and adaptive-avg-pool backward)
+template <typename T>
+__global__ __launch_bounds__(256) void rows_broadcast_kernel(const float* v, T* out, long ldo, int M, int C, int group_rows,
+                                                              float scale, int accumulate) {
+  constexpr int PACK = TT<T>::PACK;
+  const int ppr = C / PACK;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)M * ppr) return;
+  const int r = idx / ppr, c = (idx % ppr) * PACK;
+  const float* src = v + (long)(r / group_rows) * C + c;
+  T* dst = out + (long)r * ldo + c;
+  Vec16<T> o;
+  if (accumulate) o.v = *(const decltype(o.v)*)dst;
+#pragma unroll
+  for (int e = 0; e < PACK; ++e) o.set(e, (accumulate ? o.get(e) : 0.f) + src[e] * scale);
+  *(decltype(o.v)*)dst = o.v;
+}
+
+// ----------------------------------------------------------------------------------------- bilinear (align_corners=False)
+DEVI void bil_src(int dst, float scale, int n_in, int& i0, int& i1, float& w1) {
+  float s = ((float)dst + 0.5f) * scale - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > n_in - 1) i0 = n_in - 1;
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  w1 = s - (float)i0;
+}
+
+// NHWC tokens [F][h][w][C] -> [F][H][W][C]  (F.interpolate / F.upsample bilinear of base18.py:102-103)
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* in, long ldi, T* out, long ldo, int F, int h, int w,
+                                                            int H, int W, int C) {
+  constexpr int PACK = TT<T>::PACK;
+  const int ppr = C / PACK;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)F * H * W * ppr) return;
+  const int c = (idx % ppr) * PACK;
+  const long px = idx / ppr;
+  const int x = px % W, y = (px / W) % H, f = px / ((long)W * H);
+  int y0, y1, x0, x1; float wy, wx;
+  bil_src(y, (float)h / H, h, y0, y1, wy);
+  bil_src(x, (float)w / W, w, x0, x1, wx);
+  const T* b = in + ((long)f * h * w) * ldi + c;
+  Vec16<T> p00, p01, p10, p11, o;
+  p00.v = *(const decltype(o.v)*)(b + ((long)y0 * w + x0) * ldi);
+  p01.v = *(const decltype(o.v)*)(b + ((long)y0 * w + x1) * ldi);
+  p10.v = *(const decltype(o.v)*)(b + ((long)y1 * w + x0) * ldi);
+  p11.v = *(const decltype(o.v)*)(b + ((long)y1 * w + x1) * ldi);
+#pragma unroll
+  for (int e = 0; e < PACK; ++e)
+    o.set(e, (1.f - wy) * ((1.f - wx) * p00.get(e) + wx * p01.get(e)) + wy * ((1.f - wx) * p10.get(e) + wx * p11.get(e)));
+  *(decltype(o.v)*)(out + px * ldo + c) = o.v;
+}
+
+// gather-form backward: din[f][yi][xi][c] = sum over the output pixels that read (yi, xi)
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* dout, long ldo, T* din, long ldi, int F, int h, int w,
+                                                            int H, int W, int C) {
+  constexpr int PACK = TT<T>::PACK;
+  const int ppr = C / PACK;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)F * h * w * ppr) return;
+  const int c = (idx % ppr) * PACK;
+  const long px = idx / ppr;
+  const int xi = px % w, yi = (px / w) % h, f = px / ((long)w * h);
+  const float sy = (float)h / H, sx = (float)w / W;
+  const int ylo = max(0, (int)floorf(((float)yi - 0.5f) / sy - 0.5f) - 1), yhi = min(H - 1, (int)ceilf(((float)yi + 1.5f) / sy - 0.5f) + 1);
+  const int xlo = max(0, (int)floorf(((float)xi - 0.5f) / sx - 0.5f) - 1), xhi = min(W - 1, (int)ceilf(((float)xi + 1.5f) / sx - 0.5f) + 1);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int y = ylo; y <= yhi; ++y) {
+    int y0, y1; float wy;
+    bil_src(y, sy, h, y0, y1, wy);
+    const float cy = (y0 == yi ? 1.f - wy : 0.f) + (y1 == yi ? wy : 0.f);
+    if (cy == 0.f) continue;
+    for (int x = xlo; x <= xhi; ++x) {
+      int x0, x1; float wx;
+      bil_src(x, sx, w, x0, x1, wx);
+      const float cx = (x0 == xi ? 1.f - wx : 0.f) + (x1 == xi ? wx : 0.f);
+      if (cx == 0.f) continue;
+      Vec16<T> d;
+      d.v = *(const decltype(d.v)*)(dout + (((long)f * H + y) * W + x) * ldo + c);
+#pragma unroll
+      for (int e = 0; e < PACK; ++e) acc[e] += cy * cx * d.get(e);
+    }
+  }
+  Vec16<T> o;
+#pragma unroll
+  for (int e = 0; e < PACK; ++e) o.set(e, acc[e]);
+  *(decltype(o.v)*)(din + px * ldi + c) = o.v;
+}
+
+// tokens [F][h][w][nc] (pitch ldi) -> NCHW logits [F][nc][H][W]  (nn.functional.interpolate of base18.py:106)
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void logits_up_fwd_kernel(const T* in, long ldi, TO* out, int F, int h, int w, int H, int W,
+                                                             int nc) {
+  const long px = (long)blockIdx.x * 256 + threadIdx.x;
+  if (px >= (long)F * H * W) return;
+  const int x = px % W, y = (px / W) % H, f = px / ((long)W * H);
+  int y0, y1, x0, x1; float wy, wx;
+  bil_src(y, (float)h / H, h, y0, y1, wy);
+  bil_src(x, (float)w / W, w, x0, x1, wx);
+  const T* b = in + ((long)f * h * w) * ldi;
+  const T* p00 = b + ((long)y0 * w + x0) * ldi; const T* p01 = b + ((long)y0 * w + x1) * ldi;
+  const T* p10 = b + ((long)y1 * w + x0) * ldi; const T* p11 = b + ((long)y1 * w + x1) * ldi;
+  for (int c = 0; c < nc; ++c) {
+    const float v = (1.f - wy) * ((1.f - wx) * to_f32<T>(p00[c]) + wx * to_f32<T>(p01[c])) +
+                    wy * ((1.f - wx) * to_f32<T>(p10[c]) + wx * to_f32<T>(p11[c]));
+    out[(((long)f * nc + c) * H + y) * W + x] = from_f32<TO>(v);
+  }
+}
+
+// backward, separable gather: dtok[f][yi][xi][c] = sum_y cy(yi,y) sum_x cx(xi,x) dlogits[f][c][y][x]
+// one thread per (f, yi, xi, c); nc is small so the tensor is tiny and L2-resident.
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void logits_up_bwd_kernel(const TO* dout, T* din, long ldi, int F, int h, int w, int H, int W,
+                                                             int nc) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)F * h * w * nc) return;
+  const int c = idx % nc;
+  const long px = idx / nc;
+  const int xi = px % w, yi = (px / w) % h, f = px / ((long)w * h);
+  const float sy = (float)h / H, sx = (float)w / W;
+  const int ylo = max(0, (int)floorf(((float)yi - 0.5f) / sy - 0.5f) - 1), yhi = min(H - 1, (int)ceilf(((float)yi + 1.5f) / sy - 0.5f) + 1);
+  const int xlo = max(0, (int)floorf(((float)xi - 0.5f) / sx - 0.5f) - 1), xhi = min(W - 1, (int)ceilf(((float)xi + 1.5f) / sx - 0.5f) + 1);
+  const TO* plane = dout + ((long)f * nc + c) * H * W;
+  float acc = 0.f;
+  for (int y = ylo; y <= yhi; ++y) {
+    int y0, y1; float wy;
+    bil_src(y, sy, h, y0, y1, wy);
+    const float cy = (y0 == yi ? 1.f - wy : 0.f) + (y1 == yi ? wy : 0.f);
+    if (cy == 0.f) continue;
+    float row = 0.f;
+    for (int x = xlo; x <= xhi; ++x) {
+      int x0, x1; float wx;
+      bil_src(x, sx, w, x0, x1, wx);
+      const float cx = (x0 == xi ? 1.f - wx : 0.f) + (x1 == xi ? wx : 0.f);
+      if (cx != 0.f) row += cx * to_f32<TO>(plane[(long)y * W + x]);
+    }
+    acc += cy * row;
+  }
+  din[px * ldi + c] = from_f32<T>(acc);
+}
+
+// ----------------------------------------------------------------------------------------- OHEM cross entropy
+// per-pixel CE (ignore_index -> 0) + the two scalars the OHEM rule needs: stats[0] = #(loss > thresh),
+// stats[1] = sum of those losses.   losses.py:32-34.
+template <typename TL>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const TL* logits, const long* labels, float* loss, float* stats, int F,
+                                                      long HW, int nc, int ignore_index, float thresh) {
+  const long px = (long)blockIdx.x * 256 + threadIdx.x;
+  float l = 0.f;
+  const bool ok = px < (long)F * HW;
+  if (ok) {
+    const long f = px / HW, p = px % HW;
+    const long lab = labels[px];
+    if (lab != ignore_index) {
+      const TL* b = logits + f * nc * HW + p;
+      float mx = -3.0e38f;
+      for (int c = 0; c < nc; ++c) mx = fmaxf(mx, to_f32<TL>(b[(long)c * HW]));
+      float s = 0.f;
+      for (int c = 0; c < nc; ++c) s += expf(to_f32<TL>(b[(long)c * HW]) - mx);
+      l = mx + logf(s) - to_f32<TL>(b[lab * HW]);
+    }
+    loss[px] = l;
+  }
+  const bool hard = ok && l > thresh;
+  float cnt = wave_sum(hard ? 1.f : 0.f), sm = wave_sum(hard ? l : 0.f);
+  __shared__ float red[2][4];
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = cnt; red[1][threadIdx.x >> 6] = sm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(stats + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(stats + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+// dlogits = g * w(px) * (softmax - onehot),  w = sel[1] if loss(px) `>`/`>=` sel[0] else 0   (sel on device: no host sync)
+template <typename TL>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const TL* logits, const long* labels, const float* loss, const float* sel,
+                                                      const float* gscale, TL* dlogits, int F, long HW, int nc,
+                                                      int ignore_index) {
+  const long px = (long)blockIdx.x * 256 + threadIdx.x;
+  if (px >= (long)F * HW) return;
+  const long f = px / HW, p = px % HW;
+  const long lab = labels[px];
+  const float l = loss[px];
+  const bool take = sel[2] != 0.f ? (l >= sel[0]) : (l > sel[0]);
+  const float wgt = (take && lab != ignore_index) ? sel[1] * gscale[0] : 0.f;
+  const TL* b = logits + f * nc * HW + p;
+  TL* d = dlogits + f * nc * HW + p;
+  if (wgt == 0.f) {
+    for (int c = 0; c < nc; ++c) d[(long)c * HW] = from_f32<TL>(0.f);
+    return;
+  }
+  float mx = -3.0e38f;
+  for (int c = 0; c < nc; ++c) mx = fmaxf(mx, to_f32<TL>(b[(long)c * HW]));
+  float s = 0.f;
+  for (int c = 0; c < nc; ++c) s += expf(to_f32<TL>(b[(long)c * HW]) - mx);
+  const float inv = 1.f / s;
+  for (int c = 0; c < nc; ++c) {
+    const float pr = expf(to_f32<TL>(b[(long)c * HW]) - mx) * inv;
+    d[(long)c * HW] = from_f32<TL>(wgt * (pr - (c == lab ? 1.f : 0.f)));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+#define PACK_OF(dt) ((dt) == 0 ? 8 : 4)
+#define DISPATCH_T(dt, CALL_BF16, CALL_F32) do { if ((dt) == 0) { CALL_BF16; } else { CALL_F32; } } while (0)
+
+extern "C" int stswin_colstats(int dtype, const void* x, long ldx, float* sum, float* sumsq, int M, int C, int groups,
+                               void* stream) {
+  if (C % PACK_OF(dtype) || ldx % PACK_OF(dtype) || groups <= 0 || M % groups) return -1401;
+  const int gr = M / groups, rpc = 256, cpg = (gr + rpc - 1) / rpc;
+  dim3 grid((C / PACK_OF(dtype) + 31) / 32, groups * cpg);
+  hipStream_t st = (hipStream_t)stream;
+  if (sumsq)
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colstats_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)x, ldx, sum, sumsq, C, gr, cpg, rpc),
+               hipLaunchKernelGGL((colstats_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, ldx, sum, sumsq, C, gr, cpg, rpc));
+  else
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colstats_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)x, ldx, sum, sumsq, C, gr, cpg, rpc),
+               hipLaunchKernelGGL((colstats_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, ldx, sum, sumsq, C, gr, cpg, rpc));
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_bn_finalize(int dtype, const void* x, long ldx, const float* sum, const float* sumsq, float* mean,
+                                  float* rstd, float* running_mean, float* running_var, int M, int C, int groups, float eps,
+                                  float momentum, void* stream) {
+  if (groups <= 0 || M % groups) return -1401;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((C + 255) / 256);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_finalize_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, ldx, sum, sumsq, mean, rstd, running_mean, running_var, C, groups, M / groups, eps, momentum),
+             hipLaunchKernelGGL(bn_finalize_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, sum, sumsq, mean, rstd, running_mean, running_var, C, groups, M / groups, eps, momentum));
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_bn_apply(int dtype, const void* x, long ldx, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, const void* resid, long ldr, void* y, long ldy, int M, int C, int groups,
+                               int relu, void* stream) {
+  const int pk = PACK_OF(dtype);
+  if (C % pk || ldx % pk || ldy % pk || (resid && ldr % pk) || groups <= 0 || M % groups) return -1402;
+  const long n = (long)M * (C / pk);
+  dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, ldx, mean, rstd, gamma, beta, (const bf16*)resid, ldr, (bf16*)y, ldy, M, C, M / groups, relu),
+             hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, mean, rstd, gamma, beta, (const float*)resid, ldr, (float*)y, ldy, M, C, M / groups, relu));
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const void* y, long ldy,
+                             const float* mean, const float* rstd, const float* gamma, float* s1, float* s2, void* dx,
+                             long lddx, void* dresid, long lddr, int M, int C, int groups, int relu, int training,
+                             void* stream) {
+  const int pk = PACK_OF(dtype);
+  if (C % pk || ldx % pk || lddy % pk || lddx % pk || (relu && ldy % pk) || groups <= 0 || M % groups) return -1403;
+  const int gr = M / groups, rpc = 256, cpg = (gr + rpc - 1) / rpc;
+  dim3 g1((C / pk + 31) / 32, groups * cpg);
+  const long n = (long)M * (C / pk);
+  dim3 g2((unsigned)((n + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu),
+             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16>, g2, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, gamma, s1, s2, (bf16*)dx, lddx, (bf16*)dresid, lddr, M, C, gr, relu, training),
+             hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, gamma, s1, s2, (float*)dx, lddx, (float*)dresid, lddr, M, C, gr, relu, training));
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_rows_broadcast(int dtype, const float* v, void* out, long ldo, int M, int C, int groups, float scale,
+                                     int accumulate, void* stream) {
+  const int pk = PACK_OF(dtype);
+  if (C % pk || ldo % pk || groups <= 0 || M % groups) return -1404;
+  const long n = (long)M * (C / pk);
+  dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(rows_broadcast_kernel<bf16>, grid, dim3(256), 0, st, v, (bf16*)out, ldo, M, C, M / groups, scale, accumulate),
+             hipLaunchKernelGGL(rows_broadcast_kernel<float>, grid, dim3(256), 0, st, v, (float*)out, ldo, M, C, M / groups, scale, accumulate));
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_bilinear(int dtype, const void* in, long ldi, void* out, long ldo, int frames, int h, int w, int H, int W,
+                               int C, int backward, void* stream) {
+  /* forward: in [F][h][w][C] -> out [F][H][W][C];  backward: `in` = d(out) [F][H][W][C] (pitch ldi), `out` = d(in) (pitch ldo) */
+  const int pk = PACK_OF(dtype);
+  if (C % pk || ldi % pk || ldo % pk) return -1405;
+  hipStream_t st = (hipStream_t)stream;
+  if (!backward) {
+    const long n = (long)frames * H * W * (C / pk);
+    dim3 grid((unsigned)((n + 255) / 256));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)in, ldi, (bf16*)out, ldo, frames, h, w, H, W, C),
+               hipLaunchKernelGGL(bilinear_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)in, ldi, (float*)out, ldo, frames, h, w, H, W, C));
+  } else {
+    const long n = (long)frames * h * w * (C / pk);
+    dim3 grid((unsigned)((n + 255) / 256));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_bwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)in, ldi, (bf16*)out, ldo, frames, h, w, H, W, C),
+               hipLaunchKernelGGL(bilinear_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)in, ldi, (float*)out, ldo, frames, h, w, H, W, C));
+  }
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_logits_upsample(int dtype, const void* tokens, long ldt, void* nchw, int frames, int h, int w, int H,
+                                      int W, int nc, int backward, void* stream) {
+  /* forward: tokens [F][h][w][nc] -> nchw [F][nc][H][W] (same dtype); backward: nchw = dlogits -> tokens = d(tokens) */
+  hipStream_t st = (hipStream_t)stream;
+  if (!backward) {
+    const long n = (long)frames * H * W;
+    dim3 grid((unsigned)((n + 255) / 256));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((logits_up_fwd_kernel<bf16, bf16>), grid, dim3(256), 0, st, (const bf16*)tokens, ldt, (bf16*)nchw, frames, h, w, H, W, nc),
+               hipLaunchKernelGGL((logits_up_fwd_kernel<float, float>), grid, dim3(256), 0, st, (const float*)tokens, ldt, (float*)nchw, frames, h, w, H, W, nc));
+  } else {
+    const long n = (long)frames * h * w * nc;
+    dim3 grid((unsigned)((n + 255) / 256));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((logits_up_bwd_kernel<bf16, bf16>), grid, dim3(256), 0, st, (const bf16*)nchw, (bf16*)tokens, ldt, frames, h, w, H, W, nc),
+               hipLaunchKernelGGL((logits_up_bwd_kernel<float, float>), grid, dim3(256), 0, st, (const float*)nchw, (float*)tokens, ldt, frames, h, w, H, W, nc));
+  }
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_ce_fwd(int dtype, const void* logits, const long* labels, float* loss, float* stats, int frames, long HW,
+                             int nc, int ignore_index, float thresh, void* stream) {
+  const long n = (long)frames * HW;
+  dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(ce_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)logits, labels, loss, stats, frames, HW, nc, ignore_index, thresh),
+             hipLaunchKernelGGL(ce_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, labels, loss, stats, frames, HW, nc, ignore_index, thresh));
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_ce_bwd(int dtype, const void* logits, const long* labels, const float* loss, const float* sel,
+                             const float* gscale, void* dlogits, int frames, long HW, int nc, int ignore_index, void* stream) {
+  const long n = (long)frames * HW;
+  dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(ce_bwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)logits, labels, loss, sel, gscale, (bf16*)dlogits, frames, HW, nc, ignore_index),
+             hipLaunchKernelGGL(ce_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, labels, loss, sel, gscale, (float*)dlogits, frames, HW, nc, ignore_index));
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}

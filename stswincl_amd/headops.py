@@ -1,0 +1,331 @@
+"""Autograd Functions for the decode head / loss on NHWC token matrices, built from libstswin_hip kernels.
+
+A feature map (F, C, H, W) is handled as a token matrix [M = F*H*W][Cp] (Cp = C padded to the GEMM's K granule where
+needed).  Convolutions are the segmented gather GEMM (S = k*k taps), BatchNorm / bilinear / pooling are the HBM-bound
+kernels of csrc/headops.hip.  `Layout` describes where logical channels sit inside a padded token matrix.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import hip
+from .ops import compute_dtype, conv_rowmap, _f32
+
+KGRAN = 64  # channel padding granule (bf16 GEMM K tile; also valid for the f32 path)
+
+
+class Layout:
+    """segments (logical_start, length, padded_start); width = padded channel count."""
+
+    def __init__(self, segs: Sequence[Tuple[int, int, int]], width: int):
+        self.segs, self.width = list(segs), width
+        self.logical = sum(s[1] for s in self.segs)
+
+    @staticmethod
+    def dense(c: int) -> "Layout":
+        w = (c + KGRAN - 1) // KGRAN * KGRAN
+        return Layout([(0, c, 0)], w)
+
+    @staticmethod
+    def concat(parts: Sequence["Layout"]) -> "Layout":
+        segs, lo, po = [], 0, 0
+        for p in parts:
+            segs += [(lo + a, n, po + b) for a, n, b in p.segs]
+            lo += p.logical
+            po += p.width
+        return Layout(segs, po)
+
+    @property
+    def is_identity(self) -> bool:
+        return len(self.segs) == 1 and self.segs[0] == (0, self.width, 0)
+
+    def pad_vec(self, v: torch.Tensor, fill: float = 0.0) -> torch.Tensor:
+        if self.is_identity:
+            return v.detach().float().contiguous()
+        out = torch.full((self.width,), fill, dtype=torch.float32, device=v.device)
+        for a, n, b in self.segs:
+            out[b:b + n] = v.detach()[a:a + n]
+        return out
+
+    def unpad_vec(self, v: torch.Tensor) -> torch.Tensor:
+        if self.is_identity:
+            return v
+        return torch.cat([v[..., b:b + n] for a, n, b in self.segs], dim=-1)
+
+    def key(self):
+        return (tuple(self.segs), self.width)
+
+
+_CW: dict = {}
+
+
+def _conv_mats(w: torch.Tensor, dt, lin: Layout, lout: Layout, dgrad: bool) -> torch.Tensor:
+    """(Cout,Cin,k,k) -> GEMM B matrix.  fwd: [Cout_p][S*Cin_p] (tap-major); dgrad: [Cin_p][S*Cout_p] with taps mirrored."""
+    key = (id(w), dt, lin.key(), lout.key(), dgrad)
+    stamp = (w._version, w.data_ptr(), tuple(w.shape))
+    hit = _CW.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == stamp:
+        return hit[2]
+    co, ci, k, _ = w.shape
+    S = k * k
+    wt = w.detach().float().reshape(co, ci, S)
+    full = torch.zeros(lout.width, S, lin.width, dtype=torch.float32, device=w.device)   # [co_p][s][ci_p]
+    for oa, on, ob in lout.segs:
+        for ia, in_, ib in lin.segs:
+            full[ob:ob + on, :, ib:ib + in_] = wt[oa:oa + on, ia:ia + in_, :].permute(0, 2, 1)
+    if dgrad:
+        m = full.flip(1).permute(2, 1, 0).reshape(lin.width, S * lout.width)
+    else:
+        m = full.reshape(lout.width, S * lin.width)
+    m = m.to(dt).contiguous()
+    if len(_CW) > 2048:
+        for kk in [kk for kk, v in _CW.items() if v[0]() is None]:
+            del _CW[kk]
+    _CW[key] = (weakref.ref(w), stamp, m)
+    return m
+
+
+class ConvTokFn(torch.autograd.Function):
+    """k x k (k in {1,3}) stride-1 'same' convolution with dilation over NHWC tokens, as segmented gather GEMM.
+    ASPP.py:13-31 / base18.py:60-77 / PixPro_swin_v5.py:24-26."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, geom, lin, lout):
+        frames, H, W, dil = geom
+        dt = compute_dtype(x)
+        M = frames * H * W
+        k = weight.shape[-1]
+        S = k * k
+        X = x.detach().to(dt)
+        assert X.shape == (M, lin.width) and X.stride(1) == 1
+        rows = conv_rowmap(frames, H, W, dil, x.device) if k == 3 else None
+        y = torch.empty(M, lout.width, dtype=dt, device=x.device)
+        hip.gemm_nt(X, _conv_mats(weight, dt, lin, lout, False), y, M=M, a_rows=rows, S=S,
+                    bias=lout.pad_vec(bias) if bias is not None else None)
+        ctx.geom, ctx.lin, ctx.lout, ctx.dt, ctx.in_dtype, ctx.has_bias = geom, lin, lout, dt, x.dtype, bias is not None
+        ctx.save_for_backward(X, weight, rows)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        X, weight, rows = ctx.saved_tensors
+        frames, H, W, dil = ctx.geom
+        lin, lout, dt = ctx.lin, ctx.lout, ctx.dt
+        M = X.shape[0]
+        co, ci, k, _ = weight.shape
+        S = k * k
+        g = dy.detach().to(dt).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, lin.width, dtype=dt, device=X.device)
+            hip.gemm_nt(g, _conv_mats(weight, dt, lin, lout, True), dx, M=M, a_rows=rows, S=S)
+            dx = dx.to(ctx.in_dtype)
+        dwp = torch.zeros(lout.width, S, lin.width, dtype=torch.float32, device=X.device)
+        flat = dwp.view(lout.width, S * lin.width)
+        for s in range(S):
+            hip.gemm_tn(g, X, flat[:, s * lin.width:(s + 1) * lin.width], Mk=M,
+                        bt_rows=rows[s] if rows is not None else None)
+        dw = torch.zeros(co, ci, S, dtype=torch.float32, device=X.device)
+        for oa, on, ob in lout.segs:
+            for ia, in_, ib in lin.segs:
+                dw[oa:oa + on, ia:ia + in_, :] = dwp[ob:ob + on, :, ib:ib + in_].permute(0, 2, 1)
+        db = None
+        if ctx.has_bias:
+            dbp = torch.zeros(lout.width, dtype=torch.float32, device=X.device)
+            hip.colsum(g, dbp)
+            db = lout.unpad_vec(dbp)
+        return dx, dw.view(co, ci, k, k), db, None, None, None
+
+
+class BNTokFn(torch.autograd.Function):
+    """nn.BatchNorm2d (+ residual add + ReLU) on tokens with `groups` independent statistic groups."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, relu, resid, groups, lay, eps, momentum):
+        dt = compute_dtype(x)
+        X = x.detach().to(dt)
+        M, Cp = X.shape
+        assert Cp == lay.width
+        gp, bp = lay.pad_vec(gamma), lay.pad_vec(beta)
+        if training:
+            s, ss = hip.colstats(X, groups=groups)
+            if lay.is_identity:
+                mean, rstd = hip.bn_finalize(X, s, ss, running_mean, running_var, groups, eps, momentum)
+            else:
+                rm, rv = lay.pad_vec(running_mean), lay.pad_vec(running_var, 1.0)
+                mean, rstd = hip.bn_finalize(X, s, ss, rm, rv, groups, eps, momentum)
+                running_mean.copy_(lay.unpad_vec(rm))
+                running_var.copy_(lay.unpad_vec(rv))
+        else:
+            mean = lay.pad_vec(running_mean).view(1, Cp).expand(groups, Cp).contiguous()
+            rstd = torch.rsqrt(lay.pad_vec(running_var, 1.0) + eps).view(1, Cp).expand(groups, Cp).contiguous()
+        y = torch.empty(M, Cp, dtype=dt, device=x.device)
+        R = resid.detach().to(dt) if resid is not None else None
+        hip.bn_apply(X, mean, rstd, gp, bp, y, resid=R, groups=groups, relu=relu)
+        ctx.cfg = (training, relu, groups, lay, dt, x.dtype, resid is not None)
+        ctx.save_for_backward(X, y, mean, rstd, gp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        X, y, mean, rstd, gp = ctx.saved_tensors
+        training, relu, groups, lay, dt, in_dtype, has_res = ctx.cfg
+        g = dy.detach().to(dt).contiguous()
+        dx = torch.empty_like(X)
+        dres = torch.empty_like(X) if has_res else None
+        s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training)
+        dgamma = lay.unpad_vec(s2.sum(0))
+        dbeta = lay.unpad_vec(s1.sum(0))
+        return (dx.to(in_dtype), dgamma, dbeta, None, None, None, None, dres.to(in_dtype) if has_res else None,
+                None, None, None, None)
+
+
+def batchnorm_tokens(x, bn: torch.nn.BatchNorm2d, relu=True, resid=None, groups=1, lay: Optional[Layout] = None):
+    lay = lay or Layout.dense(bn.num_features)
+    training = bn.training or bn.running_mean is None
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += groups
+    return BNTokFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, relu, resid, groups, lay,
+                         bn.eps, bn.momentum if bn.momentum is not None else 0.1)
+
+
+class BilinearTokFn(torch.autograd.Function):
+    """F.interpolate(mode='bilinear', align_corners=False) on tokens: [F*h*w][C] -> [F*H*W][C]."""
+
+    @staticmethod
+    def forward(ctx, x, geom):
+        frames, h, w, H, W = geom
+        dt = compute_dtype(x)
+        X = x.detach().to(dt).contiguous()
+        y = torch.empty(frames * H * W, X.shape[1], dtype=dt, device=x.device)
+        hip.bilinear(X, y, frames, h, w, H, W)
+        ctx.geom, ctx.dt, ctx.in_dtype = geom, dt, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        frames, h, w, H, W = ctx.geom
+        g = dy.detach().to(ctx.dt).contiguous()
+        dx = torch.empty(frames * h * w, g.shape[1], dtype=ctx.dt, device=g.device)
+        hip.bilinear(g, dx, frames, h, w, H, W, backward=True)
+        return dx.to(ctx.in_dtype), None
+
+
+class AvgPoolTokFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d(1) on tokens: [F*HW][C] -> [F][C]   (ASPP.py:43)."""
+
+    @staticmethod
+    def forward(ctx, x, frames):
+        dt = compute_dtype(x)
+        X = x.detach().to(dt).contiguous()
+        s, _ = hip.colstats(X, groups=frames, squares=False)
+        ctx.cfg = (frames, X.shape[0], dt, x.dtype)
+        return (s / (X.shape[0] // frames)).to(dt)
+
+    @staticmethod
+    def backward(ctx, dy):
+        frames, M, dt, in_dtype = ctx.cfg
+        dx = torch.empty(M, dy.shape[1], dtype=dt, device=dy.device)
+        hip.rows_broadcast(dy.detach().float().contiguous(), dx, frames, scale=float(frames) / M)
+        return dx.to(in_dtype), None
+
+
+class BroadcastTokFn(torch.autograd.Function):
+    """bilinear upsample of a 1x1 map = broadcast: [F][C] -> [F*HW][C]   (ASPP.py:46)."""
+
+    @staticmethod
+    def forward(ctx, v, rows_per_frame):
+        dt = compute_dtype(v)
+        frames, C = v.shape
+        y = torch.empty(frames * rows_per_frame, C, dtype=dt, device=v.device)
+        hip.rows_broadcast(v.detach().float().contiguous(), y, frames)
+        ctx.cfg = (frames, dt, v.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        frames, dt, in_dtype = ctx.cfg
+        s, _ = hip.colstats(dy.detach().to(dt).contiguous(), groups=frames, squares=False)
+        return s.to(in_dtype), None
+
+
+class LogitsUpFn(torch.autograd.Function):
+    """nn.functional.interpolate(output, (H, W), mode='bilinear') of base18.py:106: tokens -> NCHW logits."""
+
+    @staticmethod
+    def forward(ctx, tok, geom):
+        frames, h, w, H, W, nc = geom
+        dt = compute_dtype(tok)
+        X = tok.detach().to(dt).contiguous()
+        out = torch.empty(frames, nc, H, W, dtype=dt, device=tok.device)
+        hip.logits_upsample(X, out, frames, h, w, H, W, nc)
+        ctx.geom, ctx.dt, ctx.in_dtype, ctx.width = geom, dt, tok.dtype, X.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        frames, h, w, H, W, nc = ctx.geom
+        g = dout.detach().to(ctx.dt).contiguous()
+        dtok = torch.zeros(frames * h * w, ctx.width, dtype=ctx.dt, device=g.device)
+        hip.logits_upsample(dtok, g, frames, h, w, H, W, nc, backward=True)
+        return dtok.to(ctx.in_dtype), None
+
+
+class OhemCEFn(torch.autograd.Function):
+    """OhemCELoss2D (seg18/utils/losses.py:32-40) without the full sort and without a host sync:
+    n_hard = #(loss > thresh); if n_hard > n_min: mean of those, else mean of the n_min largest."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, n_min, thresh, ignore_index):
+        lg = logits.detach()
+        if lg.dtype not in (torch.float32, torch.bfloat16):
+            lg = lg.float()
+        lg = lg.contiguous()
+        lab = labels.contiguous()
+        loss, stats = hip.ce_fwd(lg, lab, ignore_index, thresh)
+        n_hard, s_hard = stats[0], stats[1]
+        use_thresh = n_hard > n_min
+        top = torch.topk(loss, n_min, sorted=False)[0]
+        kth = top.min()
+        value = torch.where(use_thresh, s_hard / n_hard.clamp(min=1.0), top.mean())
+        sel = torch.stack([torch.where(use_thresh, torch.full_like(kth, thresh), kth),
+                           torch.where(use_thresh, 1.0 / n_hard.clamp(min=1.0), torch.full_like(kth, 1.0 / n_min)),
+                           torch.where(use_thresh, torch.zeros_like(kth), torch.ones_like(kth))]).float().contiguous()
+        ctx.ignore_index, ctx.in_dtype = ignore_index, logits.dtype
+        ctx.save_for_backward(lg, lab, loss, sel)
+        return value
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, lab, loss, sel = ctx.saved_tensors
+        d = hip.ce_bwd(lg, lab, loss, sel, g.detach().float().reshape(1).contiguous(), ctx.ignore_index)
+        return d.to(ctx.in_dtype), None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------- helpers
+def to_tokens(x: torch.Tensor) -> torch.Tensor:
+    """(F, C, H, W) logical -> [F*H*W][C] (free when x is channels-last)."""
+    f, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(f * h * w, c)
+
+
+def from_tokens(t: torch.Tensor, f: int, h: int, w: int) -> torch.Tensor:
+    """[F*H*W][C] -> logical (F, C, H, W) view with channels-last strides (no copy)."""
+    return t.view(f, h, w, t.shape[1]).permute(0, 3, 1, 2)
+
+
+def pad_cols(t: torch.Tensor, width: int) -> torch.Tensor:
+    if t.shape[1] == width:
+        return t
+    return torch.cat([t, t.new_zeros(t.shape[0], width - t.shape[1])], dim=1)
+
+
+def conv_bn_relu(x_tok, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, lin=None, lout=None, relu=True, groups=1):
+    frames, H, W = geom
+    lin = lin or Layout.dense(conv.in_channels)
+    lout = lout or Layout.dense(conv.out_channels)
+    y = ConvTokFn.apply(x_tok, conv.weight, conv.bias, (frames, H, W, conv.dilation[0]), lin, lout)
+    return batchnorm_tokens(y, bn, relu=relu, groups=groups, lay=lout)

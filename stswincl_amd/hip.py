@@ -238,6 +238,86 @@ def win_attn_bwd(qkv, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, s
     return dqkv
 
 
+# ----------------------------------------------------------------------------------------------- head ops
+def colstats(x, groups=1, squares=True, M=None):
+    M = x.shape[0] if M is None else M
+    C = x.shape[1]
+    s = torch.zeros(groups, C, dtype=torch.float32, device=x.device)
+    ss = torch.zeros(groups, C, dtype=torch.float32, device=x.device) if squares else None
+    _check(load().stswin_colstats(_dt(x), _p(x), _c_long(_ld(x)), _p(s), _p(ss), M, C, groups, _stream()), "colstats")
+    return s, ss
+
+
+def bn_finalize(x, s, ss, running_mean, running_var, groups=1, eps=1e-5, momentum=0.1, M=None):
+    M = x.shape[0] if M is None else M
+    C = x.shape[1]
+    mean = torch.empty(groups, C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(groups, C, dtype=torch.float32, device=x.device)
+    _check(load().stswin_bn_finalize(_dt(x), _p(x), _c_long(_ld(x)), _p(s), _p(ss), _p(mean), _p(rstd), _p(running_mean),
+                                     _p(running_var), M, C, groups, _c_float(eps), _c_float(momentum), _stream()),
+           "bn_finalize")
+    return mean, rstd
+
+
+def bn_apply(x, mean, rstd, gamma, beta, out, resid=None, groups=1, relu=True, M=None):
+    M = x.shape[0] if M is None else M
+    _check(load().stswin_bn_apply(_dt(x), _p(x), _c_long(_ld(x)), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(resid),
+                                  _c_long(_ld(resid) if resid is not None else 0), _p(out), _c_long(_ld(out)), M,
+                                  x.shape[1], groups, 1 if relu else 0, _stream()), "bn_apply")
+    return out
+
+
+def bn_bwd(dy, x, y, mean, rstd, gamma, dx, dresid=None, groups=1, relu=True, training=True, M=None):
+    M = x.shape[0] if M is None else M
+    C = x.shape[1]
+    s1 = torch.zeros(groups, C, dtype=torch.float32, device=x.device)
+    s2 = torch.zeros(groups, C, dtype=torch.float32, device=x.device)
+    _check(load().stswin_bn_bwd(_dt(x), _p(dy), _c_long(_ld(dy)), _p(x), _c_long(_ld(x)), _p(y),
+                                _c_long(_ld(y) if y is not None else 0), _p(mean), _p(rstd), _p(gamma), _p(s1), _p(s2),
+                                _p(dx), _c_long(_ld(dx)), _p(dresid), _c_long(_ld(dresid) if dresid is not None else 0), M, C,
+                                groups, 1 if relu else 0, 1 if training else 0, _stream()), "bn_bwd")
+    return s1, s2
+
+
+def rows_broadcast(v, out, groups, scale=1.0, accumulate=False, M=None):
+    M = out.shape[0] if M is None else M
+    _check(load().stswin_rows_broadcast(_dt(out), _p(v), _p(out), _c_long(_ld(out)), M, v.shape[1], groups,
+                                        _c_float(scale), 1 if accumulate else 0, _stream()), "rows_broadcast")
+    return out
+
+
+def bilinear(src, dst, frames, h, w, H, W, backward=False):
+    """forward: src [F*h*w][C] -> dst [F*H*W][C]; backward: src = d(out) [F*H*W][C] -> dst = d(in) [F*h*w][C]."""
+    C = dst.shape[1]
+    _check(load().stswin_bilinear(_dt(src), _p(src), _c_long(_ld(src)), _p(dst), _c_long(_ld(dst)), frames, h, w, H, W, C,
+                                  1 if backward else 0, _stream()), "bilinear")
+    return dst
+
+
+def logits_upsample(tokens, nchw, frames, h, w, H, W, nc, backward=False):
+    _check(load().stswin_logits_upsample(_dt(tokens), _p(tokens), _c_long(_ld(tokens)), _p(nchw), frames, h, w, H, W, nc,
+                                         1 if backward else 0, _stream()), "logits_upsample")
+
+
+def ce_fwd(logits, labels, ignore_index, thresh):
+    F_, nc = logits.shape[:2]
+    HW = logits[0, 0].numel()
+    loss = torch.empty(F_ * HW, dtype=torch.float32, device=logits.device)
+    stats = torch.zeros(2, dtype=torch.float32, device=logits.device)
+    _check(load().stswin_ce_fwd(_dt(logits), _p(logits), _p(labels), _p(loss), _p(stats), F_, _c_long(HW), nc, ignore_index,
+                                _c_float(thresh), _stream()), "ce_fwd")
+    return loss, stats
+
+
+def ce_bwd(logits, labels, loss, sel, gscale, ignore_index):
+    F_, nc = logits.shape[:2]
+    HW = logits[0, 0].numel()
+    d = torch.empty_like(logits)
+    _check(load().stswin_ce_bwd(_dt(logits), _p(logits), _p(labels), _p(loss), _p(sel), _p(gscale), _p(d), F_, _c_long(HW),
+                                nc, ignore_index, _stream()), "ce_bwd")
+    return d
+
+
 def selftest(which: int) -> torch.Tensor:
     out = torch.zeros(16384, dtype=torch.float32, device="cuda")
     if which == 5:

@@ -1,13 +1,14 @@
-"""Drop-in for ``net.Ours.ASPP`` (seg18/net/Ours/ASPP.py:7-52; ``ASPPv5`` of the contrastive package is identical).
-
-Round-1 status: library convolutions (MIOpen, channels-last bf16); the segmented gather GEMM of
-libstswin_hip already implements dilated 3x3 as implicit GEMM (tests/test_hip_head.py) and replaces these next.
+"""MI355X-native drop-in for ``net.Ours.ASPP`` (seg18/net/Ours/ASPP.py:7-52; ``ASPPv5`` of the contrastive package is
+the same module).  Same parameter names / shapes; forward runs on NHWC tokens with libstswin_hip kernels:
+every convolution (1x1 and the three dilated 3x3) is the segmented gather GEMM, BatchNorm+ReLU, the image-pool
+average / broadcast are HBM-bound HIP kernels.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
+
+from ... import headops as H
 
 
 class ASPP(nn.Module):
@@ -28,19 +29,30 @@ class ASPP(nn.Module):
         self.conv_1x1_3 = nn.Conv2d(nc // 2 * 5, nc // 2, kernel_size=1)
         self.bn_conv_1x1_3 = nn.BatchNorm2d(nc // 2)
         self.conv_1x1_4 = nn.Conv2d(nc // 2, num_classes, kernel_size=1)
+        self.num_classes = num_classes
+
+    def forward_tokens(self, x, geom):
+        """x [F*h*w][1024] -> [F*h*w][pad64(num_classes)]  (ASPP.py:33-52)."""
+        f, h, w = geom
+        if self.training and f == 1:   # the reference's BatchNorm2d refuses a (1, C, 1, 1) map in train mode (ASPP.py:44-45)
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([1, 512, 1, 1])")
+        o1 = H.conv_bn_relu(x, self.conv_1x1_1, self.bn_conv_1x1_1, geom)
+        o2 = H.conv_bn_relu(x, self.conv_3x3_1, self.bn_conv_3x3_1, geom)
+        o3 = H.conv_bn_relu(x, self.conv_3x3_2, self.bn_conv_3x3_2, geom)
+        o4 = H.conv_bn_relu(x, self.conv_3x3_3, self.bn_conv_3x3_3, geom)
+        img = H.AvgPoolTokFn.apply(x, f)
+        img = H.conv_bn_relu(img, self.conv_1x1_2, self.bn_conv_1x1_2, (f, 1, 1))
+        img = H.BroadcastTokFn.apply(img, h * w)
+        cat = torch.cat([o1, o2, o3, o4, img.to(o1.dtype)], dim=1)
+        out = H.conv_bn_relu(cat, self.conv_1x1_3, self.bn_conv_1x1_3, geom)
+        c4 = self.conv_1x1_4
+        return H.ConvTokFn.apply(out, c4.weight, c4.bias, (f, h, w, 1), H.Layout.dense(c4.in_channels),
+                                 H.Layout.dense(c4.out_channels))
 
     def forward(self, feature_map):
-        h, w = feature_map.shape[2:]
-        o1 = F.relu(self.bn_conv_1x1_1(self.conv_1x1_1(feature_map)))
-        o2 = F.relu(self.bn_conv_3x3_1(self.conv_3x3_1(feature_map)))
-        o3 = F.relu(self.bn_conv_3x3_2(self.conv_3x3_2(feature_map)))
-        o4 = F.relu(self.bn_conv_3x3_3(self.conv_3x3_3(feature_map)))
-        img = self.avg_pool(feature_map)
-        img = F.relu(self.bn_conv_1x1_2(self.conv_1x1_2(img)))
-        img = F.interpolate(img, size=(h, w), mode="bilinear", align_corners=False)
-        out = torch.cat([o1, o2, o3, o4, img], 1)
-        out = F.relu(self.bn_conv_1x1_3(self.conv_1x1_3(out)))
-        return self.conv_1x1_4(out)
+        f, c, h, w = feature_map.shape
+        out = self.forward_tokens(H.to_tokens(feature_map), (f, h, w))
+        return H.from_tokens(out, f, h, w)[:, :self.num_classes]
 
 
 ASPPv5 = ASPP

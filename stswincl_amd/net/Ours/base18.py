@@ -1,18 +1,49 @@
-"""Drop-in for ``net.Ours.base18`` (seg18/net/Ours/base18.py:52-108): the TswinPlus segmentation model.
+"""MI355X-native drop-in for ``net.Ours.base18`` (seg18/net/Ours/base18.py:52-108): the TswinPlus model.
 
 ``TswinPlus(num_classes)`` keeps the reference signature, attribute names (.swin .resnet .aspp .project1-3
-.classifier) and state-dict keys; ``input_resolution`` (feature-map size H/8 x W/8) is an optional extra because
-the reference hard-codes 64x80.  forward: (B,4,3,H,W) -> logits (B,num_classes,H,W).
+.classifier) and state-dict keys; ``input_resolution`` (feature-map size H/8 x W/8) is an optional extra because the
+reference hard-codes 64x80.  forward: (B,4,3,H,W) -> logits (B,num_classes,H,W).
+
+Everything after the ResNet feeder runs on NHWC tokens through libstswin_hip: temporal Swin, ASPP, the three 1x1
+projections (+BN+ReLU), bilinear x2, the 400-channel concat (kept as a 448-wide padded token matrix), the 3x3
+classifier (implicit GEMM) and the final bilinear-to-NCHW upsample.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
+from ... import headops as H
 from .ASPP import ASPP
 from .resnet import ResNet18_OS8
 from .swin_512 import SwinTransformerLayerv5
+
+L48 = H.Layout.dense(48)
+LCAT = H.Layout.concat([L48, L48, L48, H.Layout.dense(256)])   # logical 400 channels inside 448 columns
+
+
+def decode_tokens(resnet, swin, aspp, proj1, proj2, proj3, x):
+    """Frames (B,4,3,Hi,Wi) -> 400-channel decode feature as a padded token matrix [B*h*w][448] (base18.py:80-105 up to
+    the concat; PixPro_swin_v5.py:302-327 is the same pipeline).  The ResNet runs once per frame so that train-mode
+    BatchNorm statistics stay per frame (base18.py:86-89)."""
+    b, t = x.shape[:2]
+    seq = [resnet(x[:, i].contiguous(memory_format=torch.channels_last)) for i in range(t)]
+    h, w = seq[0].shape[2:]
+    c = seq[0].shape[1]
+    toks = [H.to_tokens(s) for s in seq]
+    tem = torch.stack([tk.view(b, h * w, c) for tk in toks], dim=1)          # (B, 4, L, C) tokens
+    t1_all, t2_all = swin.forward_tokens(tem)
+    h2, w2 = h // 2, w // 2
+    t1 = t1_all[:, -1].reshape(b * h * w, c)
+    t2 = t2_all[:, -1].reshape(b * h2 * w2, 2 * c)
+    a = aspp.forward_tokens(t2, (b, h2, w2))
+    p1 = H.conv_bn_relu(toks[-1], proj1[0], proj1[1], (b, h, w), lout=L48)
+    p2 = H.conv_bn_relu(t1, proj2[0], proj2[1], (b, h, w), lout=L48)
+    p3 = H.conv_bn_relu(t2, proj3[0], proj3[1], (b, h2, w2), lout=L48)
+    p3 = H.BilinearTokFn.apply(p3, (b, h2, w2, h, w))
+    a = H.BilinearTokFn.apply(a, (b, h2, w2, h, w))
+    dt = a.dtype
+    return torch.cat([p1.to(dt), p2.to(dt), p3.to(dt), a], dim=1), (b, h, w)
 
 
 class TswinPlus(nn.Module):
@@ -26,26 +57,12 @@ class TswinPlus(nn.Module):
         self.project3 = nn.Sequential(nn.Conv2d(1024, 48, 1, bias=False), nn.BatchNorm2d(48), nn.ReLU(inplace=True))
         self.classifier = nn.Sequential(nn.Conv2d(400, 256, 3, padding=1, bias=False), nn.BatchNorm2d(256),
                                         nn.ReLU(inplace=True), nn.Conv2d(256, num_classes, 1))
-
-    def features(self, x):
-        """Frames -> the 400-channel decode feature at (H/8, W/8) (base18.py:80-105 up to the concat).
-        The ResNet runs once per frame so that train-mode BatchNorm statistics stay per frame (:86-89)."""
-        b, t = x.shape[:2]
-        x = x.contiguous(memory_format=torch.channels_last_3d) if False else x
-        seq = [self.resnet(x[:, i].contiguous(memory_format=torch.channels_last)) for i in range(t)]
-        tem = torch.stack(seq, dim=1)
-        res_output = seq[-1]
-        tem1, tem2 = self.swin(tem)
-        t1, t2 = tem1[:, -1], tem2[:, -1]
-        aspp_output = self.aspp(t2)
-        p1 = self.project1(res_output)
-        p2 = self.project2(t1)
-        p3 = self.project3(t2)
-        p3 = F.interpolate(p3, size=p1.shape[2:], mode="bilinear", align_corners=False)
-        aspp_output = F.interpolate(aspp_output, size=p1.shape[2:], mode="bilinear", align_corners=False)
-        return torch.cat([p1, p2.to(p1.dtype), p3.to(p1.dtype), aspp_output.to(p1.dtype)], dim=1)
+        self.num_classes = num_classes
 
     def forward(self, x):
-        h, w = x.shape[3:]
-        out = self.classifier(self.features(x))
-        return F.interpolate(out, (h, w), mode="bilinear", align_corners=False)
+        hi, wi = x.shape[3:]
+        cat, (b, h, w) = decode_tokens(self.resnet, self.swin, self.aspp, self.project1, self.project2, self.project3, x)
+        y = H.conv_bn_relu(cat, self.classifier[0], self.classifier[1], (b, h, w), lin=LCAT)
+        c3 = self.classifier[3]
+        y = H.ConvTokFn.apply(y, c3.weight, c3.bias, (b, h, w, 1), H.Layout.dense(256), H.Layout.dense(self.num_classes))
+        return H.LogitsUpFn.apply(y, (b, h, w, hi, wi, self.num_classes))

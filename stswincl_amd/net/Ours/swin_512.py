@@ -188,16 +188,23 @@ class SwinTransformerLayerv5(nn.Module):
         mid = layer(x_v[:, p].contiguous())
         return torch.cat([x_v[:, :p.start], mid.to(x_v.dtype), x_v[:, p.stop:]], dim=1)
 
-    def forward(self, x_v):
-        B, T, C, H, W = x_v.shape
+    def forward_tokens(self, x):
+        """(B, 4, L, C) tokens -> ((B, 4, L, C), (B, 4, L/4, 2C)) tokens."""
+        B, T, L, C = x.shape
         assert T == 4, "input feature has wrong size"
-        dt = ops.compute_dtype(x_v)
-        x = x_v.permute(0, 1, 3, 4, 2).to(dt).contiguous().view(B, T, H * W, C)
+        x = x.to(ops.compute_dtype(x))
         for i in range(3):
             x = self._single_layer_forward(x, self.pairs[i], i)
-        out1 = x.view(B, T, H, W, C).permute(0, 1, 4, 2, 3)
+        out1 = x
         x = self.downsample(x)
         for i in range(3):
             x = self._single_layer_forward(x, self.pairs[i], 3 + i)
-        out2 = x.view(B, T, H // 2, W // 2, 2 * C).permute(0, 1, 4, 2, 3)
-        return out1, out2
+        return out1, x
+
+    def forward(self, x_v):
+        B, T, C, H, W = x_v.shape
+        assert T == 4, "input feature has wrong size"
+        x = x_v.permute(0, 1, 3, 4, 2).contiguous().view(B, T, H * W, C)
+        o1, o2 = self.forward_tokens(x)
+        return (o1.view(B, T, H, W, C).permute(0, 1, 4, 2, 3),
+                o2.view(B, T, H // 2, W // 2, 2 * C).permute(0, 1, 4, 2, 3))

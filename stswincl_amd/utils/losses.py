@@ -1,16 +1,17 @@
-"""Drop-in for ``utils.losses.OhemCELoss2D`` (seg18/utils/losses.py:16-40).
+"""MI355X-native drop-in for ``utils.losses.OhemCELoss2D`` (seg18/utils/losses.py:16-40).
 
-The reference sorts all B*H*W per-pixel losses and then branches on ``loss[n_min] > thresh`` (a host sync).
-Here the same selected set is found without the full sort: count(loss > thresh) decides the branch; the
-top-n_min branch uses torch.topk.  Ties at the boundary have equal values, so the mean is identical.
+The reference sorts all B*H*W per-pixel losses and then branches on ``loss[n_min] > thresh`` (a host sync).  Here a HIP
+kernel computes the per-pixel CE together with count / sum of the losses above the threshold, the branch is resolved
+on the device (no sync), and only the rarely-taken top-n_min branch uses a selection.  Same value; ties at the
+selection boundary have equal losses so the mean is identical.
 """
 from __future__ import annotations
 
 import math
 
-import torch
 import torch.nn as nn
-import torch.nn.functional as F
+
+from ..headops import OhemCEFn
 
 
 class OhemCELoss2D(nn.CrossEntropyLoss):
@@ -24,10 +25,4 @@ class OhemCELoss2D(nn.CrossEntropyLoss):
         return self.OhemCELoss(pred, target)
 
     def OhemCELoss(self, logits, labels):
-        loss = F.cross_entropy(logits.float(), labels, ignore_index=self.ignore_index, reduction="none").view(-1)
-        hard = loss > self.thresh
-        n_hard = hard.sum()
-        # loss_sorted[n_min] > thresh  <=>  more than n_min elements exceed thresh
-        if int(n_hard) > self.n_min:
-            return (loss * hard).sum() / n_hard
-        return torch.topk(loss, self.n_min, sorted=False)[0].mean()
+        return OhemCEFn.apply(logits, labels, self.n_min, self.thresh, self.ignore_index)

@@ -1,0 +1,161 @@
+"""Decode-head kernels (conv as gather GEMM, grouped BatchNorm, bilinear, pooling, logits upsample, OHEM-CE) and the
+ASPP module: HIP vs torch fp32 on the CPU / the reference golden.  fp32 path 1e-3 (typically 1e-5), bf16 path 3e-2."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import golden_util as gu
+from stswincl_amd import headops as H
+from stswincl_amd.net.Ours.ASPP import ASPP
+
+pytestmark = pytest.mark.gpu
+MODES = [("fp32", 1e-3), ("bf16", 3e-2)]
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def ac(mode):
+    return torch.autocast("cuda", dtype=torch.bfloat16, enabled=(mode == "bf16"))
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+@pytest.mark.parametrize("cin,cout,k,dil,bias", [(128, 64, 3, 1, False), (64, 128, 3, 6, True), (128, 48, 1, 1, False),
+                                                 (400, 64, 3, 1, False), (64, 12, 1, 1, True)])
+def test_conv_tokens_fwd_bwd(mode, tol, cin, cout, k, dil, bias):
+    torch.manual_seed(cin + cout)
+    f, h, w = 2, 12, 10
+    conv = nn.Conv2d(cin, cout, k, padding=dil if k == 3 else 0, dilation=dil, bias=bias)
+    x = torch.randn(f, cin, h, w, requires_grad=True)
+    g = torch.randn(f, cout, h, w)
+    y = conv(x)
+    (y * g).sum().backward()
+    lin, lout = H.Layout.dense(cin), H.Layout.dense(cout)
+    convg = nn.Conv2d(cin, cout, k, padding=dil if k == 3 else 0, dilation=dil, bias=bias).cuda()
+    convg.load_state_dict(conv.state_dict())
+    xt = H.pad_cols(H.to_tokens(x.detach().cuda()), lin.width).requires_grad_(True)
+    with ac(mode):
+        yt = H.ConvTokFn.apply(xt, convg.weight, convg.bias, (f, h, w, dil), lin, lout)
+    yl = H.from_tokens(yt, f, h, w)[:, :cout]
+    assert rel(yl, y) < tol
+    if lout.width > cout:
+        assert float(yt[:, cout:].abs().max()) == 0.0
+    gt = H.pad_cols(H.to_tokens(g.cuda()), lout.width)
+    (yt.float() * gt).sum().backward()
+    assert rel(H.from_tokens(xt.grad, f, h, w)[:, :cin], x.grad) < 2 * tol
+    assert rel(convg.weight.grad, conv.weight.grad) < 2 * tol
+    if bias:
+        assert rel(convg.bias.grad, conv.bias.grad) < 2 * tol
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+@pytest.mark.parametrize("groups,relu,res,training", [(1, True, False, True), (4, True, True, True), (1, False, False, True),
+                                                      (1, True, False, False)])
+def test_batchnorm_tokens(mode, tol, groups, relu, res, training):
+    torch.manual_seed(groups)
+    f, c, h, w = 4, 64, 6, 5
+    bn = nn.BatchNorm2d(c)
+    bn.weight.data = 1 + 0.2 * torch.randn(c)
+    bn.bias.data = 0.2 * torch.randn(c)
+    bn.running_mean.data = 0.1 * torch.randn(c)
+    bn.running_var.data = 0.5 + torch.rand(c)
+    bng = nn.BatchNorm2d(c).cuda()
+    bng.load_state_dict(bn.state_dict())
+    bn.train(training)
+    bng.train(training)
+    x = (torch.randn(f, c, h, w) * 2 + 3).requires_grad_(True)
+    r = torch.randn(f, c, h, w, requires_grad=True)
+    g = torch.randn(f, c, h, w)
+    if groups == 1:
+        y = bn(x)
+    else:   # one BN call per frame, sequentially (base18.py:86-89)
+        y = torch.cat([bn(x[i:i + 1]) for i in range(f)], 0)
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    (y * g).sum().backward()
+    xt = H.to_tokens(x.detach().cuda()).contiguous().requires_grad_(True)
+    rt = H.to_tokens(r.detach().cuda()).contiguous().requires_grad_(True) if res else None
+    with ac(mode):
+        yt = H.batchnorm_tokens(xt, bng, relu=relu, resid=rt, groups=groups)
+    assert rel(H.from_tokens(yt, f, h, w), y) < tol
+    (yt.float() * H.to_tokens(g.cuda())).sum().backward()
+    assert rel(H.from_tokens(xt.grad, f, h, w), x.grad) < 3 * tol
+    assert rel(bng.weight.grad, bn.weight.grad) < 3 * tol and rel(bng.bias.grad, bn.bias.grad) < 3 * tol
+    if res:
+        assert rel(H.from_tokens(rt.grad, f, h, w), r.grad) < 3 * tol
+    if training:
+        assert rel(bng.running_mean, bn.running_mean) < tol and rel(bng.running_var, bn.running_var) < tol
+        assert int(bng.num_batches_tracked) == int(bn.num_batches_tracked)
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+@pytest.mark.parametrize("h,w,H_,W_", [(8, 8, 16, 16), (6, 10, 12, 20), (4, 4, 32, 32), (5, 7, 13, 9)])
+def test_bilinear_tokens(mode, tol, h, w, H_, W_):
+    torch.manual_seed(h * w)
+    f, c = 2, 64
+    x = torch.randn(f, c, h, w, requires_grad=True)
+    g = torch.randn(f, c, H_, W_)
+    y = F.interpolate(x, size=(H_, W_), mode="bilinear", align_corners=False)
+    (y * g).sum().backward()
+    xt = H.to_tokens(x.detach().cuda()).contiguous().requires_grad_(True)
+    with ac(mode):
+        yt = H.BilinearTokFn.apply(xt, (f, h, w, H_, W_))
+    assert rel(H.from_tokens(yt, f, H_, W_), y) < tol
+    (yt.float() * H.to_tokens(g.cuda())).sum().backward()
+    assert rel(H.from_tokens(xt.grad, f, h, w), x.grad) < 2 * tol
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+def test_pool_broadcast_logits_up(mode, tol):
+    torch.manual_seed(9)
+    f, c, h, w = 3, 64, 5, 6
+    x = torch.randn(f, c, h, w, requires_grad=True)
+    p = F.adaptive_avg_pool2d(x, 1)
+    up = F.interpolate(p, size=(h, w), mode="bilinear", align_corners=False)
+    g = torch.randn(f, c, h, w)
+    (up * g).sum().backward()
+    xt = H.to_tokens(x.detach().cuda()).contiguous().requires_grad_(True)
+    with ac(mode):
+        pt = H.AvgPoolTokFn.apply(xt, f)
+        ut = H.BroadcastTokFn.apply(pt, h * w)
+    assert rel(pt, p.reshape(f, c)) < tol and rel(H.from_tokens(ut, f, h, w), up) < tol
+    (ut.float() * H.to_tokens(g.cuda())).sum().backward()
+    assert rel(H.from_tokens(xt.grad, f, h, w), x.grad) < 2 * tol
+    # logits upsample x8 to NCHW
+    nc = 12
+    lt = torch.randn(f, nc, h, w, requires_grad=True)
+    gl = torch.randn(f, nc, 8 * h, 8 * w)
+    yl = F.interpolate(lt, (8 * h, 8 * w), mode="bilinear", align_corners=False)
+    (yl * gl).sum().backward()
+    tok = H.pad_cols(H.to_tokens(lt.detach().cuda()), 64).requires_grad_(True)
+    with ac(mode):
+        out = H.LogitsUpFn.apply(tok, (f, h, w, 8 * h, 8 * w, nc))
+    assert out.shape == yl.shape and rel(out, yl) < tol
+    (out.float() * gl.cuda()).sum().backward()
+    assert rel(H.from_tokens(tok.grad, f, h, w)[:, :nc], lt.grad) < 2 * tol
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 4e-2)])
+def test_aspp_matches_reference_golden(mode, tol):
+    g = gu.load("aspp.npz")
+    net = ASPP(num_classes=256)
+    net.load_state_dict(gu.det_fill(gu.skeleton_sd(g["keys"], g["shapes"], g["dtypes"])))
+    net = net.cuda()
+    x = torch.from_numpy(g["x"]).cuda()
+    net.train()
+    with ac(mode):
+        y = net(x)
+    assert y.shape == (2, 256, 8, 8)
+    assert rel(y, g["y_train"]) < tol
+    assert rel(net.bn_conv_3x3_2.running_mean, g["rm_after"]) < tol
+    net.eval()
+    with ac(mode), torch.no_grad():
+        assert rel(net(x), g["y_eval"]) < tol
+    net.train()
+    with pytest.raises(ValueError):
+        net(x[:1])
