@@ -110,6 +110,13 @@ int stswin_ce_fwd(int dtype, const void* logits, const long* labels, float* loss
 int stswin_ce_bwd(int dtype, const void* logits, const long* labels, const float* loss, const float* sel,
                   const float* gscale, void* dlogits, int frames, long HW, int nc, int ignore_index, void* stream);
 
+/* ---- a16/a17: label-guided pixel-contrastive similarity (pixcontrast_18/contrast/models/PixPro_swin_v5.py:71-129).
+ * Q [N][HW][C] query embeddings, K5[j] [N][HW][C] the five key maps (k, adj1, adj2, adj3, neg3), lq / lk5[j] int32
+ * labels [N][HW].  Writes pos[n][i][j] = sum_p (q_i . k_jp) [lq_i == lk_jp] and all[n][i][j] = sum_p q_i . k_jp
+ * (fp32 [N][HW][5]); the HW x HW logits / posMask / negMask tensors of :82-113 are never materialised. */
+int stswin_contrast_fwd(int dtype, const void* Q, long ldq, const void* const* K5, long ldk, const int* lq,
+                        const int* const* lk5, float* pos, float* all, int N, int HW, int C, void* stream);
+
 /* ---- device self-test of the MFMA / LDS primitives the kernels are built on; writes a report into `out`
  * (fp32, >= 64 KiB) and returns the number of failed checks (0 = all good). Used by tests only. */
 int stswin_selftest(float* out, int which, void* stream);

@@ -318,6 +318,21 @@ def ce_bwd(logits, labels, loss, sel, gscale, ignore_index):
     return d
 
 
+def contrast_fwd(q, keys, lq, lks, N, HW):
+    """q [N*HW][C], keys 5 x [N*HW][C] (same pitch), lq / lks int32 [N][HW] -> pos, all fp32 [N][HW][5]."""
+    C = q.shape[1]
+    assert len(keys) == 5 and len(lks) == 5 and all(k.dtype == q.dtype and _ld(k) == _ld(keys[0]) for k in keys)
+    pos = torch.empty(N, HW, 5, dtype=torch.float32, device=q.device)
+    tot = torch.empty(N, HW, 5, dtype=torch.float32, device=q.device)
+    K5 = (_c_void_p * 5)(*[k.data_ptr() for k in keys])
+    L5 = (_c_void_p * 5)(*[l.data_ptr() for l in lks])
+    with _Span("contrast_fwd_bf16" if q.dtype == torch.bfloat16 else "contrast_fwd_f32", 2.0 * N * HW * 5 * HW * C):
+        rc = load().stswin_contrast_fwd(_dt(q), _p(q), _c_long(_ld(q)), K5, _c_long(_ld(keys[0])), _p(lq), L5, _p(pos),
+                                        _p(tot), N, HW, C, _stream())
+    _check(rc, "contrast_fwd")
+    return pos, tot
+
+
 def selftest(which: int) -> torch.Tensor:
     out = torch.zeros(16384, dtype=torch.float32, device="cuda")
     if which == 5:
