@@ -42,6 +42,19 @@ int stswin_win_move(int dtype, const void* in, void* out, int B, int T, int H, i
 int stswin_merge_rowmap(int* map /*[4][frames*H/2*W/2]*/, int frames, int H, int W, void* stream);
 /* 3x3 convolution tap map (padding = dilation), 9 segments ky*3+kx   (ASPP.py:13-20, base18.py:73). */
 int stswin_conv3x3_rowmap(int* map /*[9][frames*H*W]*/, int frames, int H, int W, int dilation, void* stream);
+/* general k x k convolution tap maps (resnet.py:31-34: stride 1/2, dilation 1/2/4; torchvision stem layers):
+ * inverse = 0: map[t][m_out] = input pixel read by output pixel m_out through tap t (or -1 = padding);
+ * inverse = 1: map[t][n_in]  = the output pixel that reads input pixel n_in through tap t (or -1)  -> dgrad gather. */
+int stswin_conv_rowmap(int* map, int frames, int Hin, int Win, int Hout, int Wout, int k, int stride, int pad, int dilation,
+                       int inverse, void* stream);
+/* stem im2col (torchvision conv1 7x7/2 pad 3, Cin = 3; resnet.py:102): NCHW fp32 images [F][3][H][W] ->
+ * patches [F*Ho*Wo][ld] with column (ky*7+kx)*3 + c, zero padded to ld. */
+int stswin_stem_im2col(int dtype, const float* img, void* patches, long ld, int frames, int H, int W, int Ho, int Wo,
+                       void* stream);
+/* nn.MaxPool2d(3, 2, 1) on tokens [F][H][W][C] -> [F][Ho][Wo][C]; arg (uint8 [F*Ho*Wo][C]) = winning tap (first max in
+ * (ky,kx) scan order, like torch); backward gathers dy through arg (no atomics). */
+int stswin_maxpool3x3s2(int dtype, const void* in, long ldi, void* out, long ldo, unsigned char* arg, int frames, int H,
+                        int W, int Ho, int Wo, int C, int backward, void* stream);
 
 /* ---- segmented gather GEMM: C[c_rows[m]][n] = epi( sum_s A[a_rows[s][m]][0:Kseg] . B[n][s*Kseg:(s+1)*Kseg] )
  * nn.Linear of swin_512.py:115 (qkv, with the window gather fused via a_rows and the q scaling via
@@ -51,9 +64,11 @@ int stswin_conv3x3_rowmap(int* map /*[9][frames*H*W]*/, int frames, int H, int W
 int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_rows, const void* B, long ldb, void* C, long ldc,
                    const int* c_rows, void* C2, long ldc2, const float* bias, const void* R, long ldr,
                    const int* r_rows, int M, int N, int Kseg, int S, float scale, int scale_cols, int flags, void* stream);
-/* weight gradients: C[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]   (fp32 atomics; splits<=0: auto) */
+/* weight gradients: C[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]   (fp32 atomics; splits<=0: auto).
+ * bseg > 0 (convolution wgrad in one launch): column j of the B operand is column j % bseg of row
+ * bt_rows[(j / bseg) * Mk + m], i.e. tap t = j / bseg uses its own row map. */
 int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, const void* Bt, long ldb, const int* bt_rows,
-                   float* C, long ldc, int Mk, int Ni, int Nj, int splits, void* stream);
+                   float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg, void* stream);
 /* out[n] += sum_m Y[m][n]  (bias gradients) */
 int stswin_colsum(int dtype, const void* y, long ldy, float* out, int M, int N, void* stream);
 

@@ -52,8 +52,7 @@ class MLP2d(nn.Module):
     def forward_tokens(self, x, geom, lin=None):
         f, h, w = geom
         y = H.conv_bn_relu(x, self.linear1, self.bn1, geom, lin=lin)
-        return H.ConvTokFn.apply(y, self.linear2.weight, self.linear2.bias, (f, h, w, 1),
-                                 H.Layout.dense(self.linear2.in_channels), H.Layout.dense(self.linear2.out_channels))
+        return H.conv1x1_tokens(y, self.linear2, f, h, w)
 
     def forward(self, x):
         f, c, h, w = x.shape

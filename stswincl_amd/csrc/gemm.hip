@@ -259,7 +259,8 @@ struct GemmTN {
   const void* Bt; long ldb; const int* bt_rows;   // rows m x Nj columns
   float* C; long ldc;                             // [Ni][Nj] fp32, atomically accumulated
   int Mk, Ni, Nj;
-  int splits;                                     // grid.z
+  int splits;                                     // grid.y
+  int bseg;                                       // >0: Bt column j reads source column j % bseg of row bt_rows[(j / bseg)*Mk + m]
 };
 
 template <typename T>
@@ -289,12 +290,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
     return map ? (long)map[m] : (long)m;
   };
   long arow[NI], brow[NI];                          // gathered source rows of the NEXT tile to stage
+  int bcol[NI];                                     // source column of this lane's Bt chunk (constant over tiles)
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int r = (w * NI + i) * RPI + rsub;
+    const int cj = j0 + ((cphys & ~15) | ((cphys ^ swz256(r)) & 15)) * PACK;
+    bcol[i] = p.bseg > 0 ? cj % p.bseg : cj;
+  }
   auto fetch_rows = [&](int tile) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int m = tile * BM + (w * NI + i) * RPI + rsub;
       arow[i] = src_row(p.at_rows, m);
-      brow[i] = src_row(p.bt_rows, m);
+      if (p.bseg > 0) {
+        const int r = (w * NI + i) * RPI + rsub;
+        const int cj = j0 + ((cphys & ~15) | ((cphys ^ swz256(r)) & 15)) * PACK;
+        brow[i] = (m < p.Mk && cj < p.Nj) ? (long)p.bt_rows[(long)(cj / p.bseg) * p.Mk + m] : -1;
+      } else {
+        brow[i] = src_row(p.bt_rows, m);
+      }
     }
   };
   auto stage = [&](int buf) {
@@ -306,7 +320,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
       const int cs = (cphys & ~15) | ((cphys ^ swz256(r)) & 15);
       const int ci = i0 + cs * PACK, cj = j0 + cs * PACK;
       const char* sa = (arow[i] >= 0 && ci < p.Ni) ? (const char*)p.At + (arow[i] * p.lda + ci) * sizeof(T) : zero;
-      const char* sb = (brow[i] >= 0 && cj < p.Nj) ? (const char*)p.Bt + (brow[i] * p.ldb + cj) * sizeof(T) : zero;
+      const char* sb = (brow[i] >= 0 && cj < p.Nj) ? (const char*)p.Bt + (brow[i] * p.ldb + bcol[i]) * sizeof(T) : zero;
       glds16(sa, Ab + (w * NI + i) * 1024);
       glds16(sb, Bb + (w * NI + i) * 1024);
     }
@@ -407,10 +421,12 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
 }
 
 extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, const void* Bt, long ldb,
-                              const int* bt_rows, float* C, long ldc, int Mk, int Ni, int Nj, int splits, void* stream) {
+                              const int* bt_rows, float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg,
+                              void* stream) {
   if (Mk <= 0 || Ni <= 0 || Nj <= 0) return 0;
   const int pack = dtype == 0 ? 8 : 4;
   if (Ni % pack || Nj % pack || lda % pack || ldb % pack) return -1003;
+  if (bseg < 0 || (bseg > 0 && (bseg % pack || !bt_rows))) return -1004;
   const int bm = dtype == 0 ? 64 : 32;
   const int ntile = (Mk + bm - 1) / bm;
   if (splits <= 0) {   // fill ~2 waves of the chip
@@ -418,7 +434,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
     splits = (512 + tiles - 1) / tiles;
   }
   if (splits > ntile) splits = ntile;
-  GemmTN p{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, splits};
+  GemmTN p{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, splits, bseg};
   dim3 grid(((Ni + 127) / 128) * ((Nj + 127) / 128), splits);
   static int once = set_lds_once((const void*)gemm_tn_kernel<bf16>) | set_lds_once((const void*)gemm_tn_kernel<float>);
   (void)once;

@@ -63,6 +63,116 @@ __global__ void conv3x3_rowmap_kernel(int* map, int frames, int H, int W, int di
   }
 }
 
+// general k x k tap maps (forward gather and its inverse for dgrad)
+__global__ void conv_rowmap_kernel(int* map, int frames, int Hin, int Win, int Hout, int Wout, int k, int stride, int pad,
+                                   int dil, int inverse) {
+  const int Mo = frames * Hout * Wout, Mi = frames * Hin * Win;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (!inverse) {
+    if (r >= Mo) return;
+    const int x = r % Wout, y = (r / Wout) % Hout, f = r / (Wout * Hout);
+    for (int t = 0; t < k * k; ++t) {
+      const int yy = y * stride - pad + (t / k) * dil, xx = x * stride - pad + (t % k) * dil;
+      map[(long)t * Mo + r] = (yy >= 0 && yy < Hin && xx >= 0 && xx < Win) ? (f * Hin + yy) * Win + xx : -1;
+    }
+  } else {
+    if (r >= Mi) return;
+    const int x = r % Win, y = (r / Win) % Hin, f = r / (Win * Hin);
+    for (int t = 0; t < k * k; ++t) {
+      const int ny = y + pad - (t / k) * dil, nx = x + pad - (t % k) * dil;
+      int v = -1;
+      if (ny >= 0 && nx >= 0 && ny % stride == 0 && nx % stride == 0) {
+        const int yo = ny / stride, xo = nx / stride;
+        if (yo < Hout && xo < Wout) v = (f * Hout + yo) * Wout + xo;
+      }
+      map[(long)t * Mi + r] = v;
+    }
+  }
+}
+
+// stem im2col: one thread per (output pixel, tap)
+template <typename T>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* img, T* patches, long ld, int frames, int H, int W,
+                                                           int Ho, int Wo) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int TAPS = 64;                       // 49 real taps + 15 that only write the zero padding (cols 147..191)
+  if (idx >= (long)frames * Ho * Wo * TAPS) return;
+  const int t = idx % TAPS;
+  const long px = idx / TAPS;
+  const int x = px % Wo, y = (px / Wo) % Ho, f = px / ((long)Wo * Ho);
+  T* dst = patches + px * ld + t * 3;
+  if (t * 3 >= ld) return;
+  float v[3] = {0.f, 0.f, 0.f};
+  if (t < 49) {
+    const int yy = y * 2 - 3 + t / 7, xx = x * 2 - 3 + t % 7;
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+      const float* b = img + ((long)f * 3 * H + yy) * W + xx;
+      v[0] = b[0]; v[1] = b[(long)H * W]; v[2] = b[2L * H * W];
+    }
+  }
+  for (int c = 0; c < 3 && t * 3 + c < ld; ++c) dst[c] = from_f32<T>(v[c]);
+}
+
+// maxpool 3x3 stride 2 pad 1 on tokens
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* in, long ldi, T* out, long ldo, unsigned char* arg,
+                                                           int frames, int H, int W, int Ho, int Wo, int C) {
+  constexpr int PACK = TT<T>::PACK;
+  const int ppr = C / PACK;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)frames * Ho * Wo * ppr) return;
+  const int c = (idx % ppr) * PACK;
+  const long px = idx / ppr;
+  const int x = px % Wo, y = (px / Wo) % Ho, f = px / ((long)Wo * Ho);
+  float best[8]; unsigned char ba[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { best[e] = -3.0e38f; ba[e] = 255; }
+  for (int t = 0; t < 9; ++t) {
+    const int yy = 2 * y - 1 + t / 3, xx = 2 * x - 1 + t % 3;
+    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+    Vec16<T> v;
+    v.v = *(const decltype(v.v)*)(in + (((long)f * H + yy) * W + xx) * ldi + c);
+#pragma unroll
+    for (int e = 0; e < PACK; ++e) {
+      const float u = v.get(e);
+      if (u > best[e] || ba[e] == 255) { best[e] = u; ba[e] = (unsigned char)t; }
+    }
+  }
+  Vec16<T> o;
+#pragma unroll
+  for (int e = 0; e < PACK; ++e) { o.set(e, best[e]); arg[px * C + c + e] = ba[e]; }
+  *(decltype(o.v)*)(out + px * ldo + c) = o.v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dout, long ldo, T* din, long ldi, const unsigned char* arg,
+                                                           int frames, int H, int W, int Ho, int Wo, int C) {
+  constexpr int PACK = TT<T>::PACK;
+  const int ppr = C / PACK;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)frames * H * W * ppr) return;
+  const int c = (idx % ppr) * PACK;
+  const long px = idx / ppr;
+  const int x = px % W, y = (px / W) % H, f = px / ((long)W * H);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int t = 0; t < 9; ++t) {       // output pixel (yo,xo) reads (y,x) through tap t iff 2yo-1+t/3 == y
+    const int ny = y + 1 - t / 3, nx = x + 1 - t % 3;
+    if (ny < 0 || nx < 0 || (ny & 1) || (nx & 1)) continue;
+    const int yo = ny >> 1, xo = nx >> 1;
+    if (yo >= Ho || xo >= Wo) continue;
+    const long po = ((long)f * Ho + yo) * Wo + xo;
+    Vec16<T> d;
+    d.v = *(const decltype(d.v)*)(dout + po * ldo + c);
+#pragma unroll
+    for (int e = 0; e < PACK; ++e)
+      if (arg[po * C + c + e] == t) acc[e] += d.get(e);
+  }
+  Vec16<T> o;
+#pragma unroll
+  for (int e = 0; e < PACK; ++e) o.set(e, acc[e]);
+  *(decltype(o.v)*)(din + px * ldi + c) = o.v;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm over rows that may be the concatenation of S gathered segments (patch merging: S = 4).
 // One wave per row; the row lives in registers (C <= 4096); statistics two-pass in fp32 like torch.
@@ -266,6 +376,47 @@ extern "C" int stswin_conv3x3_rowmap(int* map, int frames, int H, int W, int dil
   const int M = frames * H * W;
   hipLaunchKernelGGL(conv3x3_rowmap_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, map, frames, H, W,
                      dilation);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_conv_rowmap(int* map, int frames, int Hin, int Win, int Hout, int Wout, int k, int stride, int pad,
+                                  int dilation, int inverse, void* stream) {
+  if (k <= 0 || stride <= 0) return -1108;
+  const int n = inverse ? frames * Hin * Win : frames * Hout * Wout;
+  hipLaunchKernelGGL(conv_rowmap_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, map, frames, Hin, Win,
+                     Hout, Wout, k, stride, pad, dilation, inverse);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_stem_im2col(int dtype, const float* img, void* patches, long ld, int frames, int H, int W, int Ho,
+                                  int Wo, void* stream) {
+  if (ld < 147 || ld > 192) return -1109;
+  const long n = (long)frames * Ho * Wo * 64;
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (dtype == 0) hipLaunchKernelGGL(stem_im2col_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, img, (bf16*)patches, ld, frames, H, W, Ho, Wo);
+  else hipLaunchKernelGGL(stem_im2col_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, img, (float*)patches, ld, frames, H, W, Ho, Wo);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_maxpool3x3s2(int dtype, const void* in, long ldi, void* out, long ldo, unsigned char* arg, int frames,
+                                   int H, int W, int Ho, int Wo, int C, int backward, void* stream) {
+  const int pk = dtype == 0 ? 8 : 4;
+  if (C % pk || ldi % pk || ldo % pk) return -1110;
+  hipStream_t st = (hipStream_t)stream;
+  if (!backward) {
+    const long n = (long)frames * Ho * Wo * (C / pk);
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype == 0) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)in, ldi, (bf16*)out, ldo, arg, frames, H, W, Ho, Wo, C);
+    else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)in, ldi, (float*)out, ldo, arg, frames, H, W, Ho, Wo, C);
+  } else {   /* in = d(out) [F*Ho*Wo][C] (pitch ldi), out = d(in) [F*H*W][C] (pitch ldo) */
+    const long n = (long)frames * H * W * (C / pk);
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype == 0) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)in, ldi, (bf16*)out, ldo, arg, frames, H, W, Ho, Wo, C);
+    else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)in, ldi, (float*)out, ldo, arg, frames, H, W, Ho, Wo, C);
+  }
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import hip
-from .ops import compute_dtype, conv_rowmap, _f32
+from .ops import compute_dtype, _f32
 
 KGRAN = 64  # channel padding granule (bf16 GEMM K tile; also valid for the f32 path)
 
@@ -63,7 +63,8 @@ _CW: dict = {}
 
 
 def _conv_mats(w: torch.Tensor, dt, lin: Layout, lout: Layout, dgrad: bool) -> torch.Tensor:
-    """(Cout,Cin,k,k) -> GEMM B matrix.  fwd: [Cout_p][S*Cin_p] (tap-major); dgrad: [Cin_p][S*Cout_p] with taps mirrored."""
+    """(Cout,Cin,k,k) -> GEMM B matrix.  fwd: [Cout_p][S*Cin_p] (tap-major); dgrad: [Cin_p][S*Cout_p] (the inverse
+    row map supplies the geometry, so taps keep their order)."""
     key = (id(w), dt, lin.key(), lout.key(), dgrad)
     stamp = (w._version, w.data_ptr(), tuple(w.shape))
     hit = _CW.get(key)
@@ -77,7 +78,7 @@ def _conv_mats(w: torch.Tensor, dt, lin: Layout, lout: Layout, dgrad: bool) -> t
         for ia, in_, ib in lin.segs:
             full[ob:ob + on, :, ib:ib + in_] = wt[oa:oa + on, ia:ia + in_, :].permute(0, 2, 1)
     if dgrad:
-        m = full.flip(1).permute(2, 1, 0).reshape(lin.width, S * lout.width)
+        m = full.permute(2, 1, 0).reshape(lin.width, S * lout.width)
     else:
         m = full.reshape(lout.width, S * lin.width)
     m = m.to(dt).contiguous()
@@ -88,56 +89,137 @@ def _conv_mats(w: torch.Tensor, dt, lin: Layout, lout: Layout, dgrad: bool) -> t
     return m
 
 
+_MAPS: dict = {}
+
+
+def _conv_maps(frames, Hin, Win, k, stride, pad, dil, device):
+    """(Hout, Wout, fwd map [k*k][M_out] or None, inverse map [k*k][M_in] or None); cached per geometry."""
+    Hout = (Hin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wout = (Win + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    if k == 1 and stride == 1 and pad == 0:
+        return Hout, Wout, None, None
+    key = (frames, Hin, Win, k, stride, pad, dil, str(device))
+    hit = _MAPS.get(key)
+    if hit is None:
+        hit = (hip.conv_rowmap(frames, Hin, Win, Hout, Wout, k, stride, pad, dil, False, device),
+               hip.conv_rowmap(frames, Hin, Win, Hout, Wout, k, stride, pad, dil, True, device))
+        _MAPS[key] = hit
+    return Hout, Wout, hit[0], hit[1]
+
+
 class ConvTokFn(torch.autograd.Function):
-    """k x k (k in {1,3}) stride-1 'same' convolution with dilation over NHWC tokens, as segmented gather GEMM.
-    ASPP.py:13-31 / base18.py:60-77 / PixPro_swin_v5.py:24-26."""
+    """k x k convolution (any stride / padding / dilation) over NHWC tokens as segmented gather GEMM: forward gathers
+    input pixels per tap, dgrad gathers output-gradient pixels through the inverse tap map, wgrad is ONE transposed GEMM
+    whose B operand is tap-segmented.  ASPP.py:13-31, base18.py:60-77, resnet.py:31-38, PixPro_swin_v5.py:24-26."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, geom, lin, lout):
-        frames, H, W, dil = geom
+        frames, Hin, Win, k, stride, pad, dil = geom
         dt = compute_dtype(x)
-        M = frames * H * W
-        k = weight.shape[-1]
-        S = k * k
         X = x.detach().to(dt)
-        assert X.shape == (M, lin.width) and X.stride(1) == 1
-        rows = conv_rowmap(frames, H, W, dil, x.device) if k == 3 else None
-        y = torch.empty(M, lout.width, dtype=dt, device=x.device)
-        hip.gemm_nt(X, _conv_mats(weight, dt, lin, lout, False), y, M=M, a_rows=rows, S=S,
+        Hout, Wout, fmap, imap = _conv_maps(frames, Hin, Win, k, stride, pad, dil, x.device)
+        Mi, Mo = frames * Hin * Win, frames * Hout * Wout
+        assert X.shape == (Mi, lin.width) and X.stride(1) == 1 and weight.shape[-1] == k
+        y = torch.empty(Mo, lout.width, dtype=dt, device=x.device)
+        hip.gemm_nt(X, _conv_mats(weight, dt, lin, lout, False), y, M=Mo, a_rows=fmap, S=k * k,
                     bias=lout.pad_vec(bias) if bias is not None else None)
-        ctx.geom, ctx.lin, ctx.lout, ctx.dt, ctx.in_dtype, ctx.has_bias = geom, lin, lout, dt, x.dtype, bias is not None
-        ctx.save_for_backward(X, weight, rows)
+        ctx.cfg = (k, lin, lout, dt, x.dtype, bias is not None, Mi, Mo)
+        ctx.save_for_backward(X, weight, fmap, imap)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        X, weight, rows = ctx.saved_tensors
-        frames, H, W, dil = ctx.geom
-        lin, lout, dt = ctx.lin, ctx.lout, ctx.dt
-        M = X.shape[0]
-        co, ci, k, _ = weight.shape
+        X, weight, fmap, imap = ctx.saved_tensors
+        k, lin, lout, dt, in_dtype, has_bias, Mi, Mo = ctx.cfg
+        co, ci = weight.shape[:2]
         S = k * k
         g = dy.detach().to(dt).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, lin.width, dtype=dt, device=X.device)
-            hip.gemm_nt(g, _conv_mats(weight, dt, lin, lout, True), dx, M=M, a_rows=rows, S=S)
-            dx = dx.to(ctx.in_dtype)
-        dwp = torch.zeros(lout.width, S, lin.width, dtype=torch.float32, device=X.device)
-        flat = dwp.view(lout.width, S * lin.width)
-        for s in range(S):
-            hip.gemm_tn(g, X, flat[:, s * lin.width:(s + 1) * lin.width], Mk=M,
-                        bt_rows=rows[s] if rows is not None else None)
-        dw = torch.zeros(co, ci, S, dtype=torch.float32, device=X.device)
-        for oa, on, ob in lout.segs:
-            for ia, in_, ib in lin.segs:
-                dw[oa:oa + on, ia:ia + in_, :] = dwp[ob:ob + on, :, ib:ib + in_].permute(0, 2, 1)
+            dx = torch.empty(Mi, lin.width, dtype=dt, device=X.device)
+            hip.gemm_nt(g, _conv_mats(weight, dt, lin, lout, True), dx, M=Mi, a_rows=imap, S=S)
+            dx = dx.to(in_dtype)
+        dwp = torch.zeros(lout.width, S * lin.width, dtype=torch.float32, device=X.device)
+        hip.gemm_tn(g, X, dwp, Mk=Mo, bt_rows=fmap, bseg=lin.width if fmap is not None else 0)
+        if lin.is_identity and lout.is_identity:
+            dw = dwp.view(co, S, ci).permute(0, 2, 1)
+        else:
+            dw = torch.zeros(co, ci, S, dtype=torch.float32, device=X.device)
+            d3 = dwp.view(lout.width, S, lin.width)
+            for oa, on, ob in lout.segs:
+                for ia, in_, ib in lin.segs:
+                    dw[oa:oa + on, ia:ia + in_, :] = d3[ob:ob + on, :, ib:ib + in_].permute(0, 2, 1)
         db = None
-        if ctx.has_bias:
+        if has_bias:
             dbp = torch.zeros(lout.width, dtype=torch.float32, device=X.device)
             hip.colsum(g, dbp)
             db = lout.unpad_vec(dbp)
-        return dx, dw.view(co, ci, k, k), db, None, None, None
+        return dx, dw.reshape(co, ci, k, k), db, None, None, None
+
+
+def conv_tokens(x_tok, conv: torch.nn.Conv2d, frames, Hin, Win, lin=None, lout=None):
+    """Apply an nn.Conv2d's parameters to a token matrix; returns (y_tokens, Hout, Wout)."""
+    k, stride, pad, dil = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
+    lin = lin or Layout.dense(conv.in_channels)
+    lout = lout or Layout.dense(conv.out_channels)
+    y = ConvTokFn.apply(x_tok, conv.weight, conv.bias, (frames, Hin, Win, k, stride, pad, dil), lin, lout)
+    Hout = (Hin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wout = (Win + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    return y, Hout, Wout
+
+
+class StemConvFn(torch.autograd.Function):
+    """torchvision resnet18.conv1 (7x7 / stride 2 / pad 3, Cin = 3; reference resnet.py:98-102) = im2col + GEMM.
+    The 147-wide patches (padded to 192) are rebuilt in backward instead of being kept (403 MB at B = 4)."""
+
+    @staticmethod
+    def forward(ctx, img, weight, dt):
+        F_, _, Hh, Ww = img.shape
+        Ho, Wo = (Hh + 6 - 7) // 2 + 1, (Ww + 6 - 7) // 2 + 1
+        im = img.detach().float().contiguous()
+        patches = hip.stem_im2col(im, dt, Ho, Wo)
+        wm = torch.zeros(64, 192, dtype=torch.float32, device=img.device)
+        wm[:, :147] = weight.detach().float().permute(0, 2, 3, 1).reshape(64, 147)
+        y = torch.empty(F_ * Ho * Wo, 64, dtype=dt, device=img.device)
+        hip.gemm_nt(patches, wm.to(dt), y, M=y.shape[0])
+        ctx.cfg = (dt, Ho, Wo)
+        ctx.save_for_backward(im)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (im,) = ctx.saved_tensors
+        dt, Ho, Wo = ctx.cfg
+        patches = hip.stem_im2col(im, dt, Ho, Wo)
+        dw = torch.zeros(64, 192, dtype=torch.float32, device=im.device)
+        hip.gemm_tn(dy.detach().to(dt).contiguous(), patches, dw, Mk=patches.shape[0])
+        return None, dw[:, :147].reshape(64, 7, 7, 3).permute(0, 3, 1, 2), None
+
+
+class MaxPoolTokFn(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) on tokens (torchvision resnet18.maxpool)."""
+
+    @staticmethod
+    def forward(ctx, x, geom):
+        frames, Hh, Ww = geom
+        dt = compute_dtype(x)
+        X = x.detach().to(dt).contiguous()
+        Ho, Wo = (Hh + 2 - 3) // 2 + 1, (Ww + 2 - 3) // 2 + 1
+        y = torch.empty(frames * Ho * Wo, X.shape[1], dtype=dt, device=x.device)
+        arg = torch.empty(frames * Ho * Wo, X.shape[1], dtype=torch.uint8, device=x.device)
+        hip.maxpool3x3s2(X, y, arg, frames, Hh, Ww, Ho, Wo)
+        ctx.cfg = (frames, Hh, Ww, Ho, Wo, dt, x.dtype)
+        ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        frames, Hh, Ww, Ho, Wo, dt, in_dtype = ctx.cfg
+        g = dy.detach().to(dt).contiguous()
+        dx = torch.empty(frames * Hh * Ww, g.shape[1], dtype=dt, device=g.device)
+        hip.maxpool3x3s2(g, dx, arg, frames, Hh, Ww, Ho, Wo, backward=True)
+        return dx.to(in_dtype), None
 
 
 class BNTokFn(torch.autograd.Function):
@@ -323,9 +405,14 @@ def pad_cols(t: torch.Tensor, width: int) -> torch.Tensor:
     return torch.cat([t, t.new_zeros(t.shape[0], width - t.shape[1])], dim=1)
 
 
-def conv_bn_relu(x_tok, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, lin=None, lout=None, relu=True, groups=1):
-    frames, H, W = geom
-    lin = lin or Layout.dense(conv.in_channels)
+def conv_bn_relu(x_tok, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, lin=None, lout=None, relu=True, groups=1,
+                 resid=None):
+    """conv -> BatchNorm (-> + resid) (-> ReLU) on tokens; geom = (frames, Hin, Win).  Returns the output tokens."""
+    frames, Hh, Ww = geom
     lout = lout or Layout.dense(conv.out_channels)
-    y = ConvTokFn.apply(x_tok, conv.weight, conv.bias, (frames, H, W, conv.dilation[0]), lin, lout)
-    return batchnorm_tokens(y, bn, relu=relu, groups=groups, lay=lout)
+    y, _, _ = conv_tokens(x_tok, conv, frames, Hh, Ww, lin, lout)
+    return batchnorm_tokens(y, bn, relu=relu, resid=resid, groups=groups, lay=lout)
+
+
+def conv1x1_tokens(x_tok, conv: torch.nn.Conv2d, frames, Hh, Ww, lin=None, lout=None):
+    return conv_tokens(x_tok, conv, frames, Hh, Ww, lin, lout)[0]

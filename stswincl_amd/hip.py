@@ -156,6 +156,30 @@ def conv3x3_rowmap(frames, H, W, dilation, device="cuda") -> torch.Tensor:
     return m
 
 
+def conv_rowmap(frames, Hin, Win, Hout, Wout, k, stride, pad, dil, inverse, device="cuda") -> torch.Tensor:
+    n = frames * (Hin * Win if inverse else Hout * Wout)
+    m = torch.empty(k * k, n, dtype=torch.int32, device=device)
+    _check(load().stswin_conv_rowmap(_p(m), frames, Hin, Win, Hout, Wout, k, stride, pad, dil, 1 if inverse else 0,
+                                     _stream()), "conv_rowmap")
+    return m
+
+
+def stem_im2col(img: torch.Tensor, dtype: torch.dtype, Ho: int, Wo: int, ld: int = 192) -> torch.Tensor:
+    """img fp32 NCHW [F][3][H][W] -> patches [F*Ho*Wo][ld] (7x7 / stride 2 / pad 3)."""
+    F_, c, H, W = img.shape
+    assert c == 3 and img.dtype == torch.float32 and img.is_contiguous()
+    out = torch.empty(F_ * Ho * Wo, ld, dtype=dtype, device=img.device)
+    _check(load().stswin_stem_im2col(_dt(out), _p(img), _p(out), _c_long(ld), F_, H, W, Ho, Wo, _stream()), "stem_im2col")
+    return out
+
+
+def maxpool3x3s2(src, dst, arg, frames, H, W, Ho, Wo, backward=False):
+    C = src.shape[1]
+    _check(load().stswin_maxpool3x3s2(_dt(src), _p(src), _c_long(_ld(src)), _p(dst), _c_long(_ld(dst)), _p(arg), frames, H,
+                                      W, Ho, Wo, C, 1 if backward else 0, _stream()), "maxpool3x3s2")
+    return dst
+
+
 # ----------------------------------------------------------------------------------------------- GEMMs
 def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_rows=None, c_rows=None, bias=None,
             resid=None, r_rows=None, out2=None, S: int = 1, scale: float = 1.0, scale_cols: int = 0, flags: int = 0):
@@ -179,13 +203,13 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
 
 
 def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: int, at_rows=None, bt_rows=None,
-            splits: int = 0):
+            splits: int = 0, bseg: int = 0):
     """out_f32[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]  (fp32, atomically accumulated)."""
     Ni, Nj = out_f32.shape
     assert out_f32.dtype == torch.float32 and At.dtype == Bt.dtype
     with _Span("gemm_tn_bf16" if At.dtype == torch.bfloat16 else "gemm_tn_f32", 2.0 * Mk * Ni * Nj):
         rc = load().stswin_gemm_tn(_dt(At), _p(At), _c_long(_ld(At)), _p(at_rows), _p(Bt), _c_long(_ld(Bt)),
-                                   _p(bt_rows), _p(out_f32), _c_long(_ld(out_f32)), Mk, Ni, Nj, splits, _stream())
+                                   _p(bt_rows), _p(out_f32), _c_long(_ld(out_f32)), Mk, Ni, Nj, splits, bseg, _stream())
     _check(rc, "gemm_tn")
     return out_f32
 

@@ -45,9 +45,7 @@ class ASPP(nn.Module):
         img = H.BroadcastTokFn.apply(img, h * w)
         cat = torch.cat([o1, o2, o3, o4, img.to(o1.dtype)], dim=1)
         out = H.conv_bn_relu(cat, self.conv_1x1_3, self.bn_conv_1x1_3, geom)
-        c4 = self.conv_1x1_4
-        return H.ConvTokFn.apply(out, c4.weight, c4.bias, (f, h, w, 1), H.Layout.dense(c4.in_channels),
-                                 H.Layout.dense(c4.out_channels))
+        return H.conv1x1_tokens(out, self.conv_1x1_4, f, h, w)
 
     def forward(self, feature_map):
         f, c, h, w = feature_map.shape

@@ -27,17 +27,15 @@ def decode_tokens(resnet, swin, aspp, proj1, proj2, proj3, x):
     the concat; PixPro_swin_v5.py:302-327 is the same pipeline).  The ResNet runs once per frame so that train-mode
     BatchNorm statistics stay per frame (base18.py:86-89)."""
     b, t = x.shape[:2]
-    seq = [resnet(x[:, i].contiguous(memory_format=torch.channels_last)) for i in range(t)]
-    h, w = seq[0].shape[2:]
-    c = seq[0].shape[1]
-    toks = [H.to_tokens(s) for s in seq]
-    tem = torch.stack([tk.view(b, h * w, c) for tk in toks], dim=1)          # (B, 4, L, C) tokens
+    tem, h, w = resnet.forward_frames(x)                                     # (B, 4, L, 512) tokens
+    c = tem.shape[-1]
+    res_last = tem[:, -1].reshape(b * h * w, c)
     t1_all, t2_all = swin.forward_tokens(tem)
     h2, w2 = h // 2, w // 2
     t1 = t1_all[:, -1].reshape(b * h * w, c)
     t2 = t2_all[:, -1].reshape(b * h2 * w2, 2 * c)
     a = aspp.forward_tokens(t2, (b, h2, w2))
-    p1 = H.conv_bn_relu(toks[-1], proj1[0], proj1[1], (b, h, w), lout=L48)
+    p1 = H.conv_bn_relu(res_last, proj1[0], proj1[1], (b, h, w), lout=L48)
     p2 = H.conv_bn_relu(t1, proj2[0], proj2[1], (b, h, w), lout=L48)
     p3 = H.conv_bn_relu(t2, proj3[0], proj3[1], (b, h2, w2), lout=L48)
     p3 = H.BilinearTokFn.apply(p3, (b, h2, w2, h, w))
@@ -63,6 +61,5 @@ class TswinPlus(nn.Module):
         hi, wi = x.shape[3:]
         cat, (b, h, w) = decode_tokens(self.resnet, self.swin, self.aspp, self.project1, self.project2, self.project3, x)
         y = H.conv_bn_relu(cat, self.classifier[0], self.classifier[1], (b, h, w), lin=LCAT)
-        c3 = self.classifier[3]
-        y = H.ConvTokFn.apply(y, c3.weight, c3.bias, (b, h, w, 1), H.Layout.dense(256), H.Layout.dense(self.num_classes))
+        y = H.conv1x1_tokens(y, self.classifier[3], b, h, w)
         return H.LogitsUpFn.apply(y, (b, h, w, hi, wi, self.num_classes))

@@ -1,17 +1,23 @@
-"""Drop-in for ``net.Ours.resnet`` (seg18/net/Ours/resnet.py): ResNet18 with output stride 8.
+"""MI355X-native drop-in for ``net.Ours.resnet`` (seg18/net/Ours/resnet.py): ResNet18 with output stride 8.
 
 ``self.resnet`` reproduces torchvision's ``resnet18`` children[:-4] (conv1, bn1, relu, maxpool, layer1, layer2;
-resnet.py:98-102) without depending on torchvision, so state-dict keys are ``resnet.{0,1,4.b,5.b}.*``;
-``layer4`` / ``layer5`` are the reference's own dilated BasicBlocks (resnet.py:22-53, :117-119).
-Random init (no ImageNet file is read: BASELINE.json asks for random-init weights).
+resnet.py:98-102) without depending on torchvision, so the state-dict keys are ``resnet.{0,1,4.b,5.b}.*``;
+``layer4`` / ``layer5`` are the reference's own dilated BasicBlocks (resnet.py:22-53, :117-119).  Random init (no
+ImageNet file is read: BASELINE.json asks for random-init weights).
 
-Round-1 status: convolutions / BatchNorm of this feeder run on the ROCm library path (MIOpen) in
-channels-last bf16; SURVEY.md section 8(f) row f1 schedules their HIP implicit-GEMM replacement.
+Everything runs on NHWC tokens through libstswin_hip: the stem is im2col + GEMM, every 3x3 (stride 1/2, dilation
+1/2/4) and 1x1 downsample convolution is the segmented gather GEMM, BatchNorm(+residual)+ReLU and the max-pool are
+HBM-bound kernels.  ``forward_frames`` runs the T frame passes of base18.py:86-89 as ONE batch with T BatchNorm
+statistic groups, which is numerically the per-frame computation (same batch statistics, same sequential
+running-stat updates) without 4x the launches.
 """
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
-import torch.nn.functional as F
+
+from ... import headops as H
+from ...ops import compute_dtype
 
 
 class _TVBasicBlock(nn.Module):
@@ -28,11 +34,8 @@ class _TVBasicBlock(nn.Module):
         if stride != 1 or cin != cout:
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
-    def forward(self, x):
-        idn = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        return self.relu(out + idn)
+    def forward_tokens(self, x, frames, h, w, groups):
+        return _block_tokens(self, x, frames, h, w, groups)
 
 
 def make_layer(block, in_channels, channels, num_blocks, stride=1, dilation=1):
@@ -60,10 +63,22 @@ class BasicBlock(nn.Module):
         else:
             self.downsample = nn.Sequential()
 
-    def forward(self, x):
-        out = F.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        return F.relu(out + self.downsample(x))
+    def forward_tokens(self, x, frames, h, w, groups):
+        return _block_tokens(self, x, frames, h, w, groups)
+
+
+def _block_tokens(blk, x, frames, h, w, groups):
+    """out = relu(bn2(conv2(relu(bn1(conv1(x))))) + downsample(x))   (resnet.py:42-51)."""
+    y, ho, wo = H.conv_tokens(x, blk.conv1, frames, h, w)
+    y = H.batchnorm_tokens(y, blk.bn1, relu=True, groups=groups)
+    y, _, _ = H.conv_tokens(y, blk.conv2, frames, ho, wo)
+    ds = blk.downsample
+    if ds is not None and len(ds) > 0:
+        idn, _, _ = H.conv_tokens(x, ds[0], frames, h, w)
+        idn = H.batchnorm_tokens(idn, ds[1], relu=False, groups=groups)
+    else:
+        idn = x
+    return H.batchnorm_tokens(y, blk.bn2, relu=True, resid=idn, groups=groups), ho, wo
 
 
 class ResNet_BasicBlock_OS8(nn.Module):
@@ -80,9 +95,30 @@ class ResNet_BasicBlock_OS8(nn.Module):
         self.layer4 = make_layer(BasicBlock, in_channels=128, channels=256, num_blocks=2, stride=1, dilation=2)
         self.layer5 = make_layer(BasicBlock, in_channels=256, channels=512, num_blocks=2, stride=1, dilation=4)
 
+    def forward_tokens(self, img, groups=1):
+        """img (F,3,H,W) with F = groups * (frames per statistic group), group-major -> (tokens [F*h*w][512], h, w)."""
+        f, _, hh, ww = img.shape
+        dt = compute_dtype(img)
+        x = H.StemConvFn.apply(img, self.resnet[0].weight, dt)
+        h, w = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+        x = H.batchnorm_tokens(x, self.resnet[1], relu=True, groups=groups)
+        x = H.MaxPoolTokFn.apply(x, (f, h, w))
+        h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        for layer in (self.resnet[4], self.resnet[5], self.layer4, self.layer5):
+            for blk in layer:
+                x, h, w = blk.forward_tokens(x, f, h, w, groups)
+        return x, h, w
+
+    def forward_frames(self, x):
+        """(B,T,3,H,W) -> tokens (B, T, h*w, 512): the T sequential per-frame calls of base18.py:86-89 in one batch."""
+        b, t = x.shape[:2]
+        img = x.transpose(0, 1).reshape(t * b, *x.shape[2:])          # frame-major: statistic group = frame index
+        tok, h, w = self.forward_tokens(img, groups=t)
+        return tok.view(t, b, h * w, tok.shape[1]).transpose(0, 1).contiguous(), h, w
+
     def forward(self, x):
-        c3 = self.resnet(x)
-        return self.layer5(self.layer4(c3))
+        tok, h, w = self.forward_tokens(x, groups=1)
+        return H.from_tokens(tok, x.shape[0], h, w)
 
 
 def ResNet18_OS8():

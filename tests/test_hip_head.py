@@ -23,28 +23,32 @@ def ac(mode):
 
 
 @pytest.mark.parametrize("mode,tol", MODES)
-@pytest.mark.parametrize("cin,cout,k,dil,bias", [(128, 64, 3, 1, False), (64, 128, 3, 6, True), (128, 48, 1, 1, False),
-                                                 (400, 64, 3, 1, False), (64, 12, 1, 1, True)])
-def test_conv_tokens_fwd_bwd(mode, tol, cin, cout, k, dil, bias):
+@pytest.mark.parametrize("cin,cout,k,dil,bias,stride", [(128, 64, 3, 1, False, 1), (64, 128, 3, 6, True, 1),
+                                                        (128, 48, 1, 1, False, 1), (400, 64, 3, 1, False, 1),
+                                                        (64, 12, 1, 1, True, 1), (64, 128, 3, 1, False, 2),
+                                                        (64, 128, 1, 1, False, 2), (128, 128, 3, 4, False, 1)])
+def test_conv_tokens_fwd_bwd(mode, tol, cin, cout, k, dil, bias, stride):
     torch.manual_seed(cin + cout)
     f, h, w = 2, 12, 10
-    conv = nn.Conv2d(cin, cout, k, padding=dil if k == 3 else 0, dilation=dil, bias=bias)
+    conv = nn.Conv2d(cin, cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil, bias=bias)
     x = torch.randn(f, cin, h, w, requires_grad=True)
-    g = torch.randn(f, cout, h, w)
     y = conv(x)
+    g = torch.randn_like(y)
     (y * g).sum().backward()
     lin, lout = H.Layout.dense(cin), H.Layout.dense(cout)
-    convg = nn.Conv2d(cin, cout, k, padding=dil if k == 3 else 0, dilation=dil, bias=bias).cuda()
+    convg = nn.Conv2d(cin, cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil, bias=bias).cuda()
     convg.load_state_dict(conv.state_dict())
     xt = H.pad_cols(H.to_tokens(x.detach().cuda()), lin.width).requires_grad_(True)
     with ac(mode):
-        yt = H.ConvTokFn.apply(xt, convg.weight, convg.bias, (f, h, w, dil), lin, lout)
-    yl = H.from_tokens(yt, f, h, w)[:, :cout]
+        yt, ho, wo = H.conv_tokens(xt, convg, f, h, w)
+    assert (ho, wo) == tuple(y.shape[2:])
+    yl = H.from_tokens(yt, f, ho, wo)[:, :cout]
     assert rel(yl, y) < tol
     if lout.width > cout:
         assert float(yt[:, cout:].abs().max()) == 0.0
     gt = H.pad_cols(H.to_tokens(g.cuda()), lout.width)
     (yt.float() * gt).sum().backward()
+    h, w = x.shape[2:]
     assert rel(H.from_tokens(xt.grad, f, h, w)[:, :cin], x.grad) < 2 * tol
     assert rel(convg.weight.grad, conv.weight.grad) < 2 * tol
     if bias:
@@ -138,6 +142,28 @@ def test_pool_broadcast_logits_up(mode, tol):
     assert out.shape == yl.shape and rel(out, yl) < tol
     (out.float() * gl.cuda()).sum().backward()
     assert rel(H.from_tokens(tok.grad, f, h, w)[:, :nc], lt.grad) < 2 * tol
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+def test_stem_and_maxpool(mode, tol):
+    torch.manual_seed(4)
+    f, hh, ww = 3, 36, 28
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+    img = torch.randn(f, 3, hh, ww)
+    y = F.relu(conv(img))
+    p = F.max_pool2d(y, 3, 2, 1)
+    g = torch.randn_like(p)
+    (p * g).sum().backward()
+    convg = nn.Conv2d(3, 64, 7, 2, 3, bias=False).cuda()
+    convg.load_state_dict(conv.state_dict())
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    yt = torch.relu(H.StemConvFn.apply(img.cuda(), convg.weight, dt))
+    ho, wo = y.shape[2:]
+    assert rel(H.from_tokens(yt, f, ho, wo), y) < tol
+    pt = H.MaxPoolTokFn.apply(yt, (f, ho, wo))
+    assert rel(H.from_tokens(pt, f, *p.shape[2:]), p) < tol
+    (pt.float() * H.to_tokens(g.cuda())).sum().backward()
+    assert rel(convg.weight.grad, conv.weight.grad) < 3 * tol
 
 
 @pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 4e-2)])

@@ -66,3 +66,33 @@ def test_ohem_matches_reference(tag):
     assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-5 * abs(float(g[f"{tag}_loss"]))
     loss.backward()
     assert rel(lg.grad, g[f"{tag}_dlogits"]) < 1e-4
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 5e-2)])
+def test_resnet_frames_batched_equals_per_frame_oracle(mode, tol):
+    """a12: the 4 per-frame ResNet calls of base18.py:86-89 as one batch with 4 BN groups vs the oracle's sequential calls."""
+    from oracle import stswin_oracle as O
+    from stswincl_amd.net.Ours.resnet import ResNet18_OS8
+    torch.manual_seed(3)
+    net = ResNet18_OS8()
+    sd = gu.det_fill(net.state_dict())
+    net.load_state_dict(sd)
+    x = torch.randn(2, 4, 3, 64, 96)
+    sdo = {"resnet." + k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        ref = torch.stack([O.resnet18_os8(x[:, i], sdo, "resnet.", True) for i in range(4)], 1)   # (B,4,512,h,w)
+    net = net.cuda().train()
+    xg = x.cuda()
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(mode == "bf16")):
+        tok, h, w = net.forward_frames(xg)
+    got = tok.view(2, 4, h, w, 512).permute(0, 1, 4, 2, 3)
+    assert rel(got, ref) < tol, rel(got, ref)
+    assert rel(net.layer5[1].bn2.running_mean, sdo["resnet.layer5.1.bn2.running_mean"]) < tol
+    assert int(net.resnet[1].num_batches_tracked) == 4
+    tok.float().square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    if mode == "fp32":   # single-frame module call == reference signature
+        net2 = ResNet18_OS8()
+        net2.load_state_dict(sd)
+        y = net2.cuda().train()(xg[:, 0])
+        assert rel(y, ref[:, 0]) < tol
