@@ -429,9 +429,13 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   if (bseg < 0 || (bseg > 0 && (bseg % pack || !bt_rows))) return -1004;
   const int bm = dtype == 0 ? 64 : 32;
   const int ntile = (Mk + bm - 1) / bm;
-  if (splits <= 0) {   // fill ~2 waves of the chip
+  if (splits <= 0) {   // 2 resident blocks per CU on 256 CUs: stay at or just under 512 blocks (a 513th block costs a
+                       // whole extra wave of the grid), and keep >= 8 K tiles per block so the atomic epilogue amortises
     const int tiles = ((Ni + 127) / 128) * ((Nj + 127) / 128);
-    splits = (512 + tiles - 1) / tiles;
+    splits = 512 / tiles;
+    if (splits < 1) splits = 1;
+    const int max_by_k = ntile / 8 > 0 ? ntile / 8 : 1;
+    if (splits > max_by_k) splits = max_by_k;
   }
   if (splits > ntile) splits = ntile;
   GemmTN p{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, splits, bseg};

@@ -7,13 +7,21 @@
 // ----------------------------------------------------------------------------------------- column statistics
 // sum[g][c] += sum_rows (x - pivot), sumsq[g][c] += sum_rows (x - pivot)^2, pivot = x[first row of group][c]
 // (shifted sums keep E[x^2]-E[x]^2 well conditioned).  Block = 32 column pieces x 8 row lanes.
+// Thread layout of the column-reduction / column-owner kernels: `cpb` column pieces (16 B each) x `256/cpb` row lanes,
+// cpb = min(32, C/PACK) rounded down to a power of two, so narrow matrices (C = 64) still use every thread.
+static int pick_cpb(int pieces_per_row) {
+  int c = 32;
+  while (c > pieces_per_row) c >>= 1;
+  return c < 1 ? 1 : c;
+}
+
 template <typename T, bool SQ>
 __global__ __launch_bounds__(256) void colstats_kernel(const T* x, long ldx, float* sum, float* sumsq, int C, int group_rows,
-                                                        int chunks_per_group, int rows_per_chunk) {
+                                                        int chunks_per_group, int rows_per_chunk, int cpb) {
   constexpr int PACK = TT<T>::PACK;
-  __shared__ float part[2][8][32 * 8];
-  const int cp = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = (blockIdx.x * 32 + cp) * PACK;
+  __shared__ float part[2][256 * 8];
+  const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
+  const int c = (blockIdx.x * cpb + cp) * PACK;
   const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
   const long gr0 = (long)g * group_rows;
   float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -25,7 +33,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* x, long ldx, flo
       for (int e = 0; e < PACK; ++e) pv[e] = p0.get(e);
     }
     const int r_end = min(group_rows, (ch + 1) * rows_per_chunk);
-    for (int r = ch * rows_per_chunk + rl; r < r_end; r += 8) {
+    for (int r = ch * rows_per_chunk + rl; r < r_end; r += nrl) {
       Vec16<T> in;
       in.v = *(const decltype(in.v)*)(x + (gr0 + r) * ldx + c);
 #pragma unroll
@@ -37,14 +45,13 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* x, long ldx, flo
     }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { part[0][rl][cp * 8 + e] = a1[e]; part[1][rl][cp * 8 + e] = a2[e]; }
+  for (int e = 0; e < 8; ++e) { part[0][(rl * cpb + cp) * 8 + e] = a1[e]; part[1][(rl * cpb + cp) * 8 + e] = a2[e]; }
   __syncthreads();
   if (rl == 0 && c < C) {
 #pragma unroll
     for (int e = 0; e < PACK; ++e) {
       float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { s1 += part[0][k][cp * 8 + e]; s2 += part[1][k][cp * 8 + e]; }
+      for (int k = 0; k < nrl; ++k) { s1 += part[0][(k * cpb + cp) * 8 + e]; s2 += part[1][(k * cpb + cp) * 8 + e]; }
       atomicAdd(sum + (long)g * C + c + e, s1);
       if (SQ) atomicAdd(sumsq + (long)g * C + c + e, s2);
     }
@@ -72,28 +79,40 @@ __global__ void bn_finalize_kernel(const T* x, long ldx, const float* sum, const
   if (running_mean) { running_mean[c] = rm; running_var[c] = rv; }
 }
 
-// y = act( (x-mean)*rstd*gamma + beta [+ resid] )
+// y = act( (x-mean)*rstd*gamma + beta [+ resid] ).  A thread owns one 16-byte channel piece and walks rows (stride 8
+// inside its row chunk), so the per-channel scale/shift live in registers instead of being re-loaded per piece.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, long ldx, const float* mean, const float* rstd,
                                                         const float* gamma, const float* beta, const T* resid, long ldr,
-                                                        T* y, long ldy, int M, int C, int group_rows, int relu) {
+                                                        T* y, long ldy, int C, int group_rows, int chunks_per_group,
+                                                        int rows_per_chunk, int relu, int cpb) {
   constexpr int PACK = TT<T>::PACK;
-  const int ppr = C / PACK;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)M * ppr) return;
-  const int r = idx / ppr, c = (idx % ppr) * PACK;
-  const int g = r / group_rows;
-  Vec16<T> in, rs, o;
-  in.v = *(const decltype(in.v)*)(x + (long)r * ldx + c);
-  if (resid) rs.v = *(const decltype(rs.v)*)(resid + (long)r * ldr + c);
+  const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
+  const int c = (blockIdx.x * cpb + cp) * PACK;
+  if (c >= C) return;
+  const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
+  const long gr0 = (long)g * group_rows;
+  float sc[8], sh[8];
 #pragma unroll
   for (int e = 0; e < PACK; ++e) {
-    float v = (in.get(e) - mean[(long)g * C + c + e]) * rstd[(long)g * C + c + e] * gamma[c + e] + beta[c + e];
-    if (resid) v += rs.get(e);
-    if (relu) v = fmaxf(v, 0.f);
-    o.set(e, v);
+    const float rs = rstd[(long)g * C + c + e] * gamma[c + e];
+    sc[e] = rs;
+    sh[e] = beta[c + e] - mean[(long)g * C + c + e] * rs;
   }
-  *(decltype(o.v)*)(y + (long)r * ldy + c) = o.v;
+  const int r_end = min(group_rows, (ch + 1) * rows_per_chunk);
+  for (int r = ch * rows_per_chunk + rl; r < r_end; r += nrl) {
+    Vec16<T> in, rs, o;
+    in.v = *(const decltype(in.v)*)(x + (gr0 + r) * ldx + c);
+    if (resid) rs.v = *(const decltype(rs.v)*)(resid + (gr0 + r) * ldr + c);
+#pragma unroll
+    for (int e = 0; e < PACK; ++e) {
+      float v = in.get(e) * sc[e] + sh[e];
+      if (resid) v += rs.get(e);
+      if (relu) v = fmaxf(v, 0.f);
+      o.set(e, v);
+    }
+    *(decltype(o.v)*)(y + (gr0 + r) * ldy + c) = o.v;
+  }
 }
 
 // pass 1 of the backward: s1[g][c] = sum dyr, s2[g][c] = sum dyr*xhat, dyr = dy * (y > 0 if relu)
@@ -101,11 +120,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, long lddy, const T* x, long ldx, const T* y, long ldy,
                                                              const float* mean, const float* rstd, float* s1, float* s2,
                                                              int C, int group_rows, int chunks_per_group, int rows_per_chunk,
-                                                             int relu) {
+                                                             int relu, int cpb) {
   constexpr int PACK = TT<T>::PACK;
-  __shared__ float part[2][8][32 * 8];
-  const int cp = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = (blockIdx.x * 32 + cp) * PACK;
+  __shared__ float part[2][256 * 8];
+  const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
+  const int c = (blockIdx.x * cpb + cp) * PACK;
   const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
   const long gr0 = (long)g * group_rows;
   float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -114,7 +133,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, long ld
 #pragma unroll
     for (int e = 0; e < PACK; ++e) { mu[e] = mean[(long)g * C + c + e]; rs[e] = rstd[(long)g * C + c + e]; }
     const int r_end = min(group_rows, (ch + 1) * rows_per_chunk);
-    for (int r = ch * rows_per_chunk + rl; r < r_end; r += 8) {
+    for (int r = ch * rows_per_chunk + rl; r < r_end; r += nrl) {
       Vec16<T> d, xi, yo;
       d.v = *(const decltype(d.v)*)(dy + (gr0 + r) * lddy + c);
       xi.v = *(const decltype(xi.v)*)(x + (gr0 + r) * ldx + c);
@@ -129,50 +148,59 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, long ld
     }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { part[0][rl][cp * 8 + e] = a1[e]; part[1][rl][cp * 8 + e] = a2[e]; }
+  for (int e = 0; e < 8; ++e) { part[0][(rl * cpb + cp) * 8 + e] = a1[e]; part[1][(rl * cpb + cp) * 8 + e] = a2[e]; }
   __syncthreads();
   if (rl == 0 && c < C) {
 #pragma unroll
     for (int e = 0; e < PACK; ++e) {
       float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { t1 += part[0][k][cp * 8 + e]; t2 += part[1][k][cp * 8 + e]; }
+      for (int k = 0; k < nrl; ++k) { t1 += part[0][(k * cpb + cp) * 8 + e]; t2 += part[1][(k * cpb + cp) * 8 + e]; }
       atomicAdd(s1 + (long)g * C + c + e, t1);
       atomicAdd(s2 + (long)g * C + c + e, t2);
     }
   }
 }
 
-// pass 2: dx = gamma*rstd*(dyr - [training] (s1 + xhat*s2)/n) ; dresid = dyr (optional)
+// pass 2: dx = gamma*rstd*(dyr - [training] (s1 + xhat*s2)/n) ; dresid = dyr (optional).  Column-owner threads.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* dy, long lddy, const T* x, long ldx, const T* y, long ldy,
                                                          const float* mean, const float* rstd, const float* gamma,
                                                          const float* s1, const float* s2, T* dx, long lddx, T* dres,
-                                                         long lddr, int M, int C, int group_rows, int relu, int training) {
+                                                         long lddr, int C, int group_rows, int chunks_per_group,
+                                                         int rows_per_chunk, int relu, int training, int cpb) {
   constexpr int PACK = TT<T>::PACK;
-  const int ppr = C / PACK;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)M * ppr) return;
-  const int r = idx / ppr, c = (idx % ppr) * PACK;
-  const int g = r / group_rows;
+  const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
+  const int c = (blockIdx.x * cpb + cp) * PACK;
+  if (c >= C) return;
+  const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
+  const long gr0 = (long)g * group_rows;
   const float inv_n = 1.0f / group_rows;
-  Vec16<T> d, xi, yo, o, od;
-  d.v = *(const decltype(d.v)*)(dy + (long)r * lddy + c);
-  xi.v = *(const decltype(xi.v)*)(x + (long)r * ldx + c);
-  if (relu) yo.v = *(const decltype(yo.v)*)(y + (long)r * ldy + c);
+  // dx = A*dyr + B*x + D  with  A = gamma*rstd, B = -A*rstd*s2/n, D = -A*s1/n - B*mean      (training)
+  float ka[8], kb[8], kd[8];
 #pragma unroll
   for (int e = 0; e < PACK; ++e) {
-    float dv = d.get(e);
-    if (relu && !(yo.get(e) > 0.f)) dv = 0.f;
     const long gc = (long)g * C + c + e;
-    const float xh = (xi.get(e) - mean[gc]) * rstd[gc];
-    float v = dv;
-    if (training) v -= (s1[gc] + xh * s2[gc]) * inv_n;
-    o.set(e, v * gamma[c + e] * rstd[gc]);
-    od.set(e, dv);
+    const float A = gamma[c + e] * rstd[gc];
+    ka[e] = A;
+    kb[e] = training ? -A * rstd[gc] * s2[gc] * inv_n : 0.f;
+    kd[e] = training ? -A * s1[gc] * inv_n - kb[e] * mean[gc] : 0.f;
   }
-  *(decltype(o.v)*)(dx + (long)r * lddx + c) = o.v;
-  if (dres) *(decltype(od.v)*)(dres + (long)r * lddr + c) = od.v;
+  const int r_end = min(group_rows, (ch + 1) * rows_per_chunk);
+  for (int r = ch * rows_per_chunk + rl; r < r_end; r += nrl) {
+    Vec16<T> d, xi, yo, o, od;
+    d.v = *(const decltype(d.v)*)(dy + (gr0 + r) * lddy + c);
+    xi.v = *(const decltype(xi.v)*)(x + (gr0 + r) * ldx + c);
+    if (relu) yo.v = *(const decltype(yo.v)*)(y + (gr0 + r) * ldy + c);
+#pragma unroll
+    for (int e = 0; e < PACK; ++e) {
+      float dv = d.get(e);
+      if (relu && !(yo.get(e) > 0.f)) dv = 0.f;
+      o.set(e, ka[e] * dv + kb[e] * xi.get(e) + kd[e]);
+      od.set(e, dv);
+    }
+    *(decltype(o.v)*)(dx + (gr0 + r) * lddx + c) = o.v;
+    if (dres) *(decltype(od.v)*)(dres + (gr0 + r) * lddr + c) = od.v;
+  }
 }
 
 // out[r][c] (+)= v[r / group_rows][c] * scale      (image-pool broadcast and adaptive-avg-pool backward)
@@ -387,15 +415,16 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const TL* logits, const lon
 extern "C" int stswin_colstats(int dtype, const void* x, long ldx, float* sum, float* sumsq, int M, int C, int groups,
                                void* stream) {
   if (C % PACK_OF(dtype) || ldx % PACK_OF(dtype) || groups <= 0 || M % groups) return -1401;
-  const int gr = M / groups, rpc = 256, cpg = (gr + rpc - 1) / rpc;
-  dim3 grid((C / PACK_OF(dtype) + 31) / 32, groups * cpg);
+  const int ppr = C / PACK_OF(dtype), cpb = pick_cpb(ppr);
+  const int gr = M / groups, rpc = 8 * (256 / cpb), cpg = (gr + rpc - 1) / rpc;
+  dim3 grid((ppr + cpb - 1) / cpb, groups * cpg);
   hipStream_t st = (hipStream_t)stream;
   if (sumsq)
-    DISPATCH_T(dtype, hipLaunchKernelGGL((colstats_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)x, ldx, sum, sumsq, C, gr, cpg, rpc),
-               hipLaunchKernelGGL((colstats_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, ldx, sum, sumsq, C, gr, cpg, rpc));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colstats_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb),
+               hipLaunchKernelGGL((colstats_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb));
   else
-    DISPATCH_T(dtype, hipLaunchKernelGGL((colstats_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)x, ldx, sum, sumsq, C, gr, cpg, rpc),
-               hipLaunchKernelGGL((colstats_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, ldx, sum, sumsq, C, gr, cpg, rpc));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colstats_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb),
+               hipLaunchKernelGGL((colstats_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb));
   STSWIN_CHECK_LAUNCH();
   return 0;
 }
@@ -417,11 +446,12 @@ extern "C" int stswin_bn_apply(int dtype, const void* x, long ldx, const float* 
                                int relu, void* stream) {
   const int pk = PACK_OF(dtype);
   if (C % pk || ldx % pk || ldy % pk || (resid && ldr % pk) || groups <= 0 || M % groups) return -1402;
-  const long n = (long)M * (C / pk);
-  dim3 grid((unsigned)((n + 255) / 256));
+  const int ppr = C / pk, cpb = pick_cpb(ppr);
+  const int gr = M / groups, rpc = 8 * (256 / cpb), cpg = (gr + rpc - 1) / rpc;
+  dim3 grid((ppr + cpb - 1) / cpb, groups * cpg);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, ldx, mean, rstd, gamma, beta, (const bf16*)resid, ldr, (bf16*)y, ldy, M, C, M / groups, relu),
-             hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, mean, rstd, gamma, beta, (const float*)resid, ldr, (float*)y, ldy, M, C, M / groups, relu));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, ldx, mean, rstd, gamma, beta, (const bf16*)resid, ldr, (bf16*)y, ldy, C, gr, cpg, rpc, relu, cpb),
+             hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, mean, rstd, gamma, beta, (const float*)resid, ldr, (float*)y, ldy, C, gr, cpg, rpc, relu, cpb));
   STSWIN_CHECK_LAUNCH();
   return 0;
 }
@@ -432,15 +462,16 @@ extern "C" int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x
                              void* stream) {
   const int pk = PACK_OF(dtype);
   if (C % pk || ldx % pk || lddy % pk || lddx % pk || (relu && ldy % pk) || groups <= 0 || M % groups) return -1403;
-  const int gr = M / groups, rpc = 256, cpg = (gr + rpc - 1) / rpc;
-  dim3 g1((C / pk + 31) / 32, groups * cpg);
-  const long n = (long)M * (C / pk);
-  dim3 g2((unsigned)((n + 255) / 256));
+  const int ppr = C / pk, cpb = pick_cpb(ppr);
+  const int gr = M / groups, rpc = 8 * (256 / cpb), cpg = (gr + rpc - 1) / rpc;
+  dim3 g1((ppr + cpb - 1) / cpb, groups * cpg);
+  const int rpc2 = rpc, cpg2 = cpg;
+  dim3 g2 = g1;
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu),
-             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16>, g2, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, gamma, s1, s2, (bf16*)dx, lddx, (bf16*)dresid, lddr, M, C, gr, relu, training),
-             hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, gamma, s1, s2, (float*)dx, lddx, (float*)dresid, lddr, M, C, gr, relu, training));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb),
+             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16>, g2, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, gamma, s1, s2, (bf16*)dx, lddx, (bf16*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb),
+             hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, gamma, s1, s2, (float*)dx, lddx, (float*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb));
   STSWIN_CHECK_LAUNCH();
   return 0;
 }
