@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=512)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--graph", type=int, default=-1, help="1: capture the whole step in a hipGraph and replay it; "
+                    "0: eager; -1 (default): graph when N == 1 and profiling is off")
     return ap.parse_args()
 
 
@@ -117,7 +119,8 @@ def main():
     if world > 1:   # identical initial weights on every rank
         for p in model.parameters():
             dist.broadcast(p.data, 0)
-    opt = torch.optim.Adam(model.parameters(), 1e-4)
+    use_graph = a.graph == 1 or (a.graph == -1 and world == 1 and a.no_profile)
+    opt = torch.optim.Adam(model.parameters(), 1e-4, capturable=use_graph)
     crit = OhemCELoss2D(S * S // 16)
     reducer = GradBucketReducer(model.parameters(), bucket_mb=64.0) if world > 1 else None
     torch.manual_seed(1234 + rank)            # each rank owns different clips (weak scaling)
@@ -134,6 +137,27 @@ def main():
             reducer.finish()
         opt.step()
         return loss
+
+    graph = None
+    if use_graph:
+        # hipGraph capture of the whole step (fwd + loss + bwd + Adam): every kernel of libstswin_hip is launched on the
+        # current stream with caller-owned workspaces and no host sync, so the step replays as one graph launch.
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = step()
+        eager_step = step
+
+        def step():  # noqa: F811
+            graph.replay()
+            return static_loss
 
     for _ in range(a.warmup):
         loss = step()
@@ -167,6 +191,7 @@ def main():
                                    f"x 3x{S}x{S}, swin res ({S // 8},{S // 8}), OHEM-CE, Adam; T=4 because the reference "
                                    f"asserts it (swin_512.py:313)",
                        "clips_per_gpu": B, "frames_per_clip": 4, "parallelism": f"dp{world}",
+                       "launch": "hipGraph replay of the whole step" if graph is not None else "eager launches",
                        "loss": float(loss)},
         }
         if prof:

@@ -63,7 +63,8 @@ int stswin_maxpool3x3s2(int dtype, const void* in, long ldi, void* out, long ldo
  * ASPP.py:37-50 and base18.py:60-77 as implicit GEMM over NHWC tokens.  Kseg must be a multiple of 64 (bf16) / 32 (f32). */
 int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_rows, const void* B, long ldb, void* C, long ldc,
                    const int* c_rows, void* C2, long ldc2, const float* bias, const void* R, long ldr,
-                   const int* r_rows, int M, int N, int Kseg, int S, float scale, int scale_cols, int flags, void* stream);
+                   const int* r_rows, int M, int N, int Kseg, int S, float scale, int scale_cols, int flags,
+                   float* colsum /* optional fp32 [N]: += column sums of the stored values (bias gradient) */, void* stream);
 /* weight gradients: C[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]   (fp32 atomics; splits<=0: auto).
  * bseg > 0 (convolution wgrad in one launch): column j of the B operand is column j % bseg of row
  * bt_rows[(j / bseg) * Mk + m], i.e. tap t = j / bseg uses its own row map. */
@@ -78,7 +79,8 @@ int stswin_layernorm_fwd(int dtype, const void* x, long ldx, const int* rows, in
                          const float* gamma, const float* beta, float* mean, float* rstd, int M, float eps, void* stream);
 int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const int* rows, int S, int Cseg,
                          const float* gamma, const float* mean, const float* rstd, void* dx, long lddx, float* dgamma,
-                         float* dbeta, int M, int accumulate_dx, void* stream);
+                         float* dbeta, int M, int accumulate_dx,
+                         float* dxsum /* optional fp32 [S*Cseg]: += column sums of the dx written */, void* stream);
 
 /* ---- a6: windowed attention core (swin_512.py:117-138).  qkv [nB_*T*N][3C] = q (pre-scaled) | k | v in window
  * order; biasT [heads][N][N] and maskT [nW][N][N] are the expanded relative-position bias (:122-124) and the
@@ -87,7 +89,8 @@ int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, lo
 int stswin_win_attn_fwd(int dtype, const void* qkv, long ld, void* out, long ldo, const float* biasT, const float* maskT,
                         int nB_, int nW, int T_frames, int ws, int heads, int C, void* stream);
 int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, long lddo, void* dqkv, long lddq,
-                        const float* biasT, const float* maskT, float* dbiasT, int nB_, int nW, int T_frames, int ws,
+                        const float* biasT, const float* maskT, float* dbiasT,
+                        float* dqkv_colsum /* optional fp32 [3C] */, int nB_, int nW, int T_frames, int ws,
                         int heads, int C, float scale, void* stream);
 
 /* ---- decode head on NHWC token matrices [M = frames*H*W][C]  (ASPP.py:33-52, base18.py:60-106) ---------------

@@ -21,6 +21,7 @@ struct AttnArgs {
   const float* biasT;             // [heads][N][N]   biasT[h][key n][query n]
   const float* maskT;             // [nW][N][N] or null
   float* dbiasT;                  // bwd: [heads][N][N] fp32, atomically accumulated
+  float* dqkv_colsum;             // bwd, optional: [3C] fp32 += column sums of dqkv (the qkv bias gradient)
   int nB_, nW, heads, C, N;       // nB_ = number of (clip, window) problems = B*nW
   float scale;                    // bwd: dq = scale * (dS k)
 };
@@ -327,13 +328,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
   };
-  auto store_acc = [&](T* base, int row0, float mul) {
+  auto store_acc = [&](T* base, int row0, float mul, int which) {
     if (!live) return;
 #pragma unroll
-    for (int dt = 0; dt < Cfg::DT; ++dt)
+    for (int dt = 0; dt < Cfg::DT; ++dt) {
+      float csum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        base[(long)(row0 + crow32(r, half)) * a.ldo + dt * 32 + lr] = from_f32<T>(acc[dt][r] * mul);
+      for (int r = 0; r < 16; ++r) {
+        const T o = from_f32<T>(acc[dt][r] * mul);
+        base[(long)(row0 + crow32(r, half)) * a.ldo + dt * 32 + lr] = o;
+        csum += to_f32<T>(o);
+      }
+      if (a.dqkv_colsum) {
+        csum += __shfl_xor(csum, 32);
+        if (half == 0) atomicAdd(a.dqkv_colsum + which * a.C + head * HD + dt * 32 + lr, csum);
+      }
+    }
   };
 
   // ---- dV[key][d] = sum_q P[q][key] dO[q][d]
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, dobase[(long)qq * a.lddo + dt * 32 + lr], acc[dt], 0, 0, 0);
     }
   }
-  store_acc(dvb, k0, 1.0f);
+  store_acc(dvb, k0, 1.0f, 2);
 
   // ---- dK[key][d] = sum_q dS[q][key] q_s[q][d]
   if constexpr (TT<T>::IS_BF16) {
@@ -389,7 +399,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, qbase[(long)qq * a.ld + dt * 32 + lr], acc[dt], 0, 0, 0);
     }
   }
-  store_acc(dkb, k0, 1.0f);
+  store_acc(dkb, k0, 1.0f, 1);
 
   // ---- dQ[q][d] = scale * sum_key dS[q][key] K[key][d]
   zero_acc();
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, kbase[(long)key * a.ld + dt * 32 + lr], acc[dt], 0, 0, 0);
     }
   }
-  store_acc(dqb, q0, a.scale);
+  store_acc(dqb, q0, a.scale, 0);
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -422,9 +432,12 @@ static int launch_attn(const AttnArgs& a, bool bwd, hipStream_t st) {
   const int grid = (int)((probs + Cfg::PPB - 1) / Cfg::PPB);
   const int lds = bwd ? Cfg::BWD_LDS : Cfg::FWD_LDS;
   static_assert(Cfg::BWD_LDS <= 160 * 1024, "LDS budget");
-  const void* fn = bwd ? (const void*)attn_bwd_kernel<T, NTOK, HD> : (const void*)attn_fwd_kernel<T, NTOK, HD>;
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return -(int)e;
+  // raise the dynamic-LDS limit once per instantiation (not a stream operation: keep it out of graph capture)
+  static const int attr_fwd = (int)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NTOK, HD>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::FWD_LDS);
+  static const int attr_bwd = (int)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NTOK, HD>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::BWD_LDS);
+  if (attr_fwd != 0 || attr_bwd != 0) return -(attr_fwd ? attr_fwd : attr_bwd);
   if (bwd) hipLaunchKernelGGL((attn_bwd_kernel<T, NTOK, HD>), dim3(grid), dim3(256), lds, st, a);
   else hipLaunchKernelGGL((attn_fwd_kernel<T, NTOK, HD>), dim3(grid), dim3(256), lds, st, a);
   STSWIN_CHECK_LAUNCH();
@@ -455,13 +468,13 @@ static int attn_common(int dtype, AttnArgs& a, int T_frames, int ws, bool bwd, v
 extern "C" int stswin_win_attn_fwd(int dtype, const void* qkv, long ld, void* out, long ldo, const float* biasT,
                                    const float* maskT, int nB_, int nW, int T_frames, int ws, int heads, int C,
                                    void* stream) {
-  AttnArgs a{qkv, ld, out, ldo, nullptr, 0, biasT, maskT, nullptr, nB_, nW, heads, C, 0, 1.0f};
+  AttnArgs a{qkv, ld, out, ldo, nullptr, 0, biasT, maskT, nullptr, nullptr, nB_, nW, heads, C, 0, 1.0f};
   return attn_common(dtype, a, T_frames, ws, false, stream);
 }
 
 extern "C" int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, long lddo, void* dqkv, long lddq,
-                                   const float* biasT, const float* maskT, float* dbiasT, int nB_, int nW, int T_frames,
-                                   int ws, int heads, int C, float scale, void* stream) {
-  AttnArgs a{qkv, ld, dqkv, lddq, dout, lddo, biasT, maskT, dbiasT, nB_, nW, heads, C, 0, scale};
+                                   const float* biasT, const float* maskT, float* dbiasT, float* dqkv_colsum, int nB_,
+                                   int nW, int T_frames, int ws, int heads, int C, float scale, void* stream) {
+  AttnArgs a{qkv, ld, dqkv, lddq, dout, lddo, biasT, maskT, dbiasT, dqkv_colsum, nB_, nW, heads, C, 0, scale};
   return attn_common(dtype, a, T_frames, ws, true, stream);
 }

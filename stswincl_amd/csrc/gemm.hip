@@ -34,6 +34,7 @@ struct GemmNT {
   int M, N, Kseg, S;
   float scale; int scale_cols;
   int flags;
+  float* colsum;                 // optional fp32 [N]: += column sums of the values written to C
 };
 
 template <typename T>
@@ -154,13 +155,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 
   const int c8 = (tid & 15) * 8;
   const int gn0 = n0 + c8;
-  if (gn0 >= p.N) return;
-  const int ncols = min(8, p.N - gn0);
+  const int ncols = max(0, min(8, p.N - gn0));
   const bool vec_ok = (ncols == 8);
-  float bv[8];
+  float bv[8], cs[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bv[e] = (p.bias && e < ncols) ? p.bias[gn0 + e] : 0.f;
-  for (int pass = 0; pass < 8; ++pass) {
+  for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && e < ncols) ? p.bias[gn0 + e] : 0.f; cs[e] = 0.f; }
+  for (int pass = 0; pass < 8 && ncols > 0; ++pass) {
     const int rr = pass * 16 + (tid >> 4);
     const int gm = m0 + rr;
     if (gm >= p.M) break;
@@ -223,6 +223,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] += v[e];
     if (p.flags & GF_OUT_F32) {
       float* dst = (float*)p.C + orow * p.ldc + gn0;
       if (p.flags & GF_ACCUM) {
@@ -246,6 +248,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
       } else {
         for (int e = 0; e < ncols; ++e) dst[e] = from_f32<T>(v[e]);
       }
+    }
+  }
+  if (p.colsum) {                 // fold the 16 row groups through LDS (the C image is no longer needed), 1 atomic / column
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ct[(tid >> 4) * 128 + c8 + e] = cs[e];
+    __syncthreads();
+    if (tid < 128 && n0 + tid < p.N) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += ct[k * 128 + tid];
+      atomicAdd(p.colsum + n0 + tid, t);
     }
   }
 }
@@ -405,12 +419,12 @@ static int set_lds_once(const void* fn) {
 extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_rows, const void* B, long ldb,
                               void* C, long ldc, const int* c_rows, void* C2, long ldc2, const float* bias,
                               const void* R, long ldr, const int* r_rows, int M, int N, int Kseg, int S,
-                              float scale, int scale_cols, int flags, void* stream) {
+                              float scale, int scale_cols, int flags, float* colsum, void* stream) {
   if (M <= 0 || N <= 0) return 0;
   const int bk = dtype == 0 ? 64 : 32;
   if (Kseg <= 0 || Kseg % bk || S <= 0) return -1001;
   if ((flags & GF_ACCUM) && !(flags & GF_OUT_F32)) return -1002;
-  GemmNT p{A, lda, a_rows, B, ldb, C, ldc, c_rows, C2, ldc2, bias, R, ldr, r_rows, M, N, Kseg, S, scale, scale_cols, flags};
+  GemmNT p{A, lda, a_rows, B, ldb, C, ldc, c_rows, C2, ldc2, bias, R, ldr, r_rows, M, N, Kseg, S, scale, scale_cols, flags, colsum};
   const int nblk = ((M + 127) / 128) * ((N + 127) / 128);
   static int once = set_lds_once((const void*)gemm_nt_kernel<bf16>) | set_lds_once((const void*)gemm_nt_kernel<float>);
   (void)once;

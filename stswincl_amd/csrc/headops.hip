@@ -9,6 +9,14 @@
 // (shifted sums keep E[x^2]-E[x]^2 well conditioned).  Block = 32 column pieces x 8 row lanes.
 // Thread layout of the column-reduction / column-owner kernels: `cpb` column pieces (16 B each) x `256/cpb` row lanes,
 // cpb = min(32, C/PACK) rounded down to a power of two, so narrow matrices (C = 64) still use every thread.
+// rows per block for the column-reduction kernels: as many as possible (the LDS fold and the atomics are per block)
+// while still launching >= ~1024 blocks
+static int reduce_rows_per_chunk(int group_rows, int other_blocks, int nrl) {
+  int rpc = 8 * nrl;
+  while (rpc < 64 * nrl && (long)other_blocks * ((group_rows + 2 * rpc - 1) / (2 * rpc)) >= 1024) rpc *= 2;
+  return rpc;
+}
+
 static int pick_cpb(int pieces_per_row) {
   int c = 32;
   while (c > pieces_per_row) c >>= 1;
@@ -47,13 +55,14 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* x, long ldx, flo
 #pragma unroll
   for (int e = 0; e < 8; ++e) { part[0][(rl * cpb + cp) * 8 + e] = a1[e]; part[1][(rl * cpb + cp) * 8 + e] = a2[e]; }
   __syncthreads();
-  if (rl == 0 && c < C) {
-#pragma unroll
-    for (int e = 0; e < PACK; ++e) {
+  {   // parallel fold: thread t < cpb*8 owns (column piece t/8, element t%8) and adds the nrl row-lane partials
+    const int t = threadIdx.x, fc = t >> 3, fe = t & 7;
+    const int cc = (blockIdx.x * cpb + fc) * PACK + fe;
+    if (fc < cpb && fe < PACK && cc < C) {
       float s1 = 0.f, s2 = 0.f;
-      for (int k = 0; k < nrl; ++k) { s1 += part[0][(k * cpb + cp) * 8 + e]; s2 += part[1][(k * cpb + cp) * 8 + e]; }
-      atomicAdd(sum + (long)g * C + c + e, s1);
-      if (SQ) atomicAdd(sumsq + (long)g * C + c + e, s2);
+      for (int k = 0; k < nrl; ++k) { s1 += part[0][(k * cpb + fc) * 8 + fe]; s2 += part[1][(k * cpb + fc) * 8 + fe]; }
+      atomicAdd(sum + (long)g * C + cc, s1);
+      if (SQ) atomicAdd(sumsq + (long)g * C + cc, s2);
     }
   }
 }
@@ -150,13 +159,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, long ld
 #pragma unroll
   for (int e = 0; e < 8; ++e) { part[0][(rl * cpb + cp) * 8 + e] = a1[e]; part[1][(rl * cpb + cp) * 8 + e] = a2[e]; }
   __syncthreads();
-  if (rl == 0 && c < C) {
-#pragma unroll
-    for (int e = 0; e < PACK; ++e) {
+  {
+    const int t = threadIdx.x, fc = t >> 3, fe = t & 7;
+    const int cc = (blockIdx.x * cpb + fc) * PACK + fe;
+    if (fc < cpb && fe < PACK && cc < C) {
       float t1 = 0.f, t2 = 0.f;
-      for (int k = 0; k < nrl; ++k) { t1 += part[0][(k * cpb + cp) * 8 + e]; t2 += part[1][(k * cpb + cp) * 8 + e]; }
-      atomicAdd(s1 + (long)g * C + c + e, t1);
-      atomicAdd(s2 + (long)g * C + c + e, t2);
+      for (int k = 0; k < nrl; ++k) { t1 += part[0][(k * cpb + fc) * 8 + fe]; t2 += part[1][(k * cpb + fc) * 8 + fe]; }
+      atomicAdd(s1 + (long)g * C + cc, t1);
+      atomicAdd(s2 + (long)g * C + cc, t2);
     }
   }
 }
@@ -416,7 +426,8 @@ extern "C" int stswin_colstats(int dtype, const void* x, long ldx, float* sum, f
                                void* stream) {
   if (C % PACK_OF(dtype) || ldx % PACK_OF(dtype) || groups <= 0 || M % groups) return -1401;
   const int ppr = C / PACK_OF(dtype), cpb = pick_cpb(ppr);
-  const int gr = M / groups, rpc = 8 * (256 / cpb), cpg = (gr + rpc - 1) / rpc;
+  const int gr = M / groups, rpc = reduce_rows_per_chunk(gr, groups * ((ppr + cpb - 1) / cpb), 256 / cpb);
+  const int cpg = (gr + rpc - 1) / rpc;
   dim3 grid((ppr + cpb - 1) / cpb, groups * cpg);
   hipStream_t st = (hipStream_t)stream;
   if (sumsq)
@@ -463,10 +474,11 @@ extern "C" int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x
   const int pk = PACK_OF(dtype);
   if (C % pk || ldx % pk || lddy % pk || lddx % pk || (relu && ldy % pk) || groups <= 0 || M % groups) return -1403;
   const int ppr = C / pk, cpb = pick_cpb(ppr);
-  const int gr = M / groups, rpc = 8 * (256 / cpb), cpg = (gr + rpc - 1) / rpc;
+  const int gr = M / groups, rpc = reduce_rows_per_chunk(gr, groups * ((ppr + cpb - 1) / cpb), 256 / cpb);
+  const int cpg = (gr + rpc - 1) / rpc;
   dim3 g1((ppr + cpb - 1) / cpb, groups * cpg);
-  const int rpc2 = rpc, cpg2 = cpg;
-  dim3 g2 = g1;
+  const int rpc2 = 8 * (256 / cpb), cpg2 = (gr + rpc2 - 1) / rpc2;
+  dim3 g2((ppr + cpb - 1) / cpb, groups * cpg2);
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb),
              hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb));

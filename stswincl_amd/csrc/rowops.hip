@@ -233,16 +233,17 @@ template <typename T, int NP>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, const T* x, long ldx, const int* rows,
                                                       int S, int Cseg, const float* gamma, const float* mean,
                                                       const float* rstd, T* dx, long lddx, float* dgamma,
-                                                      float* dbeta, int M, int rows_per_wave, int accumulate_dx) {
+                                                      float* dbeta, int M, int rows_per_wave, int accumulate_dx,
+                                                      float* dxsum) {
   constexpr int PACK = TT<T>::PACK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int C = S * Cseg;
-  float dg[NP][PACK], db[NP][PACK];
+  float dg[NP][PACK], db[NP][PACK], ds[NP][PACK];
 #pragma unroll
   for (int p = 0; p < NP; ++p)
 #pragma unroll
-    for (int e = 0; e < PACK; ++e) { dg[p][e] = 0.f; db[p][e] = 0.f; }
+    for (int e = 0; e < PACK; ++e) { dg[p][e] = 0.f; db[p][e] = 0.f; ds[p][e] = 0.f; }
   const int r_begin = (blockIdx.x * 4 + w) * rows_per_wave;
   for (int r = r_begin; r < min(M, r_begin + rows_per_wave); ++r) {
     const float mu = mean[r], rs = rstd[r];
@@ -283,7 +284,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, con
 #pragma unroll
         for (int e = 0; e < PACK; ++e) {
           const float val = rs * (g[p][e] - s1 - xh[p][e] * s2);
-          o.set(e, accumulate_dx ? o.get(e) + val : val);
+          const float fin = accumulate_dx ? o.get(e) + val : val;
+          o.set(e, fin);
+          ds[p][e] += fin;
         }
         *(decltype(o.v)*)dst = o.v;
       }
@@ -304,6 +307,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, con
   for (int c = threadIdx.x; c < C; c += 256) {
     atomicAdd(dgamma + c, sg[c] + sg[C + c] + sg[2 * C + c] + sg[3 * C + c]);
     atomicAdd(dbeta + c, sb[c] + sb[C + c] + sb[2 * C + c] + sb[3 * C + c]);
+  }
+  if (dxsum) {                       // column sums of the written dx (= the bias gradient of the Linear that produced x)
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int c = (p * 64 + l) * PACK;
+      if (c < C) {
+#pragma unroll
+        for (int e = 0; e < PACK; ++e) sg[w * C + c + e] = ds[p][e];
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dxsum + c, sg[c] + sg[C + c] + sg[2 * C + c] + sg[3 * C + c]);
   }
 }
 
@@ -456,13 +472,13 @@ extern "C" int stswin_layernorm_fwd(int dtype, const void* x, long ldx, const in
 template <typename T>
 static int ln_bwd_launch(const void* dy, long lddy, const void* x, long ldx, const int* rows, int S, int Cseg,
                          const float* g, const float* mean, const float* rstd, void* dx, long lddx, float* dg, float* db,
-                         int M, int acc, hipStream_t st) {
+                         int M, int acc, float* dxsum, hipStream_t st) {
   constexpr int PACK = TT<T>::PACK;
   const int C = S * Cseg, np = (C / PACK + 63) / 64;
   const int rpw = 32;
   dim3 grid((M + 4 * rpw - 1) / (4 * rpw)), blk(256);
   const size_t lds = (size_t)8 * C * sizeof(float);
-#define LN_B(NP) hipLaunchKernelGGL((ln_bwd_kernel<T, NP>), grid, blk, lds, st, (const T*)dy, lddy, (const T*)x, ldx, rows, S, Cseg, g, mean, rstd, (T*)dx, lddx, dg, db, M, rpw, acc)
+#define LN_B(NP) hipLaunchKernelGGL((ln_bwd_kernel<T, NP>), grid, blk, lds, st, (const T*)dy, lddy, (const T*)x, ldx, rows, S, Cseg, g, mean, rstd, (T*)dx, lddx, dg, db, M, rpw, acc, dxsum)
   switch (np) {
     case 1: LN_B(1); break;
     case 2: LN_B(2); break;
@@ -476,12 +492,13 @@ static int ln_bwd_launch(const void* dy, long lddy, const void* x, long ldx, con
 
 extern "C" int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const int* rows, int S,
                                     int Cseg, const float* gamma, const float* mean, const float* rstd, void* dx,
-                                    long lddx, float* dgamma, float* dbeta, int M, int accumulate_dx, void* stream) {
+                                    long lddx, float* dgamma, float* dbeta, int M, int accumulate_dx, float* dxsum,
+                                    void* stream) {
   const int pack = dtype == 0 ? 8 : 4;
   if (Cseg % pack || ldx % pack || lddy % pack || lddx % pack) return -1105;
   if ((long)S * Cseg * 8 * 4 > 65536) return -1106;
-  int rc = dtype == 0 ? ln_bwd_launch<bf16>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, accumulate_dx, (hipStream_t)stream)
-                      : ln_bwd_launch<float>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, accumulate_dx, (hipStream_t)stream);
+  int rc = dtype == 0 ? ln_bwd_launch<bf16>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, accumulate_dx, dxsum, (hipStream_t)stream)
+                      : ln_bwd_launch<float>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, accumulate_dx, dxsum, (hipStream_t)stream);
   if (rc) return rc;
   STSWIN_CHECK_LAUNCH();
   return 0;

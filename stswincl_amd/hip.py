@@ -182,7 +182,8 @@ def maxpool3x3s2(src, dst, arg, frames, H, W, Ho, Wo, backward=False):
 
 # ----------------------------------------------------------------------------------------------- GEMMs
 def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_rows=None, c_rows=None, bias=None,
-            resid=None, r_rows=None, out2=None, S: int = 1, scale: float = 1.0, scale_cols: int = 0, flags: int = 0):
+            resid=None, r_rows=None, out2=None, S: int = 1, scale: float = 1.0, scale_cols: int = 0, flags: int = 0,
+            colsum_out=None):
     """out[c_rows[m]] = epi(sum_s A[a_rows[s][m], :Kseg] @ Bw[:, s*Kseg:(s+1)*Kseg].T); see include/stswin_hip.h."""
     N, Ktot = Bw.shape
     assert Ktot % S == 0
@@ -197,7 +198,7 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
             _dt(A), _p(A), _c_long(_ld(A)), _p(a_rows), _p(Bw), _c_long(_ld(Bw)), _p(out), _c_long(_ld(out)),
             _p(c_rows), _p(out2), _c_long(_ld(out2) if out2 is not None else 0), _p(bias), _p(resid),
             _c_long(_ld(resid) if resid is not None else 0), _p(r_rows), M, N, Kseg, S, _c_float(scale), scale_cols,
-            flags, _stream())
+            flags, _p(colsum_out), _stream())
     _check(rc, "gemm_nt")
     return out
 
@@ -232,14 +233,15 @@ def layernorm_fwd(x, gamma, beta, *, M, rows=None, S=1, Cseg=None, eps=1e-5, sav
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, *, M, rows=None, S=1, Cseg=None, dx=None, accumulate=False):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, *, M, rows=None, S=1, Cseg=None, dx=None, accumulate=False,
+                  dxsum=None):
     Cseg = x.shape[1] if Cseg is None else Cseg
     if dx is None:
         dx = torch.empty_like(x)
         accumulate = False
     rc = load().stswin_layernorm_bwd(_dt(x), _p(dy), _c_long(_ld(dy)), _p(x), _c_long(_ld(x)), _p(rows), S, Cseg,
                                      _p(gamma), _p(mean), _p(rstd), _p(dx), _c_long(_ld(dx)), _p(dgamma), _p(dbeta), M,
-                                     1 if accumulate else 0, _stream())
+                                     1 if accumulate else 0, _p(dxsum), _stream())
     _check(rc, "layernorm_bwd")
     return dx
 
@@ -253,10 +255,10 @@ def win_attn_fwd(qkv, biasT, maskT, *, nB_, nW, T, ws, heads, C):
     return out
 
 
-def win_attn_bwd(qkv, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, scale):
+def win_attn_bwd(qkv, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, scale, colsum_out=None):
     dqkv = torch.empty_like(qkv)
     rc = load().stswin_win_attn_bwd(_dt(qkv), _p(qkv), _c_long(_ld(qkv)), _p(dout), _c_long(_ld(dout)), _p(dqkv),
-                                    _c_long(_ld(dqkv)), _p(biasT), _p(maskT), _p(dbiasT), nB_, nW, T, ws, heads, C,
+                                    _c_long(_ld(dqkv)), _p(biasT), _p(maskT), _p(dbiasT), _p(colsum_out), nB_, nW, T, ws, heads, C,
                                     _c_float(scale), _stream())
     _check(rc, "win_attn_bwd")
     return dqkv

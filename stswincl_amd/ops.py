@@ -139,41 +139,38 @@ class SwinBlockFn(torch.autograd.Function):
         hid = fc1_w.shape[0]
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)  # noqa: E731
         g = dout.detach().to(dt).contiguous().view(M, C)
-        # norm1
-        dn1_w, dn1_b = z(C), z(C)
-        dy2 = hip.layernorm_bwd(g, y2, _f32(n1_w), mean1, rstd1, dn1_w, dn1_b, M=M)
-        # fc2 (+ GELU')
-        dfc2_w, dfc2_b = z(C, hid), z(C)
+        # norm1 (its dx column sums are fc2's bias gradient)
+        dn1_w, dn1_b, dfc2_b = z(C), z(C), z(C)
+        dy2 = hip.layernorm_bwd(g, y2, _f32(n1_w), mean1, rstd1, dn1_w, dn1_b, M=M, dxsum=dfc2_b)
+        # fc2 (+ GELU', + fc1's bias gradient from the epilogue)
+        dfc2_w = z(C, hid)
         hip.gemm_tn(dy2, h, dfc2_w, Mk=M)
-        hip.colsum(dy2, dfc2_b)
         dh_pre = torch.empty(M, hid, dtype=dt, device=dev)
-        hip.gemm_nt(dy2, wcast(fc2_w, dt, True), dh_pre, M=M, resid=h_pre, flags=hip.GF_MUL_DGELU)
-        # fc1
         dfc1_w, dfc1_b = z(hid, C), z(hid)
+        hip.gemm_nt(dy2, wcast(fc2_w, dt, True), dh_pre, M=M, resid=h_pre, flags=hip.GF_MUL_DGELU, colsum_out=dfc1_b)
+        # fc1
         hip.gemm_tn(dh_pre, n2, dfc1_w, Mk=M)
-        hip.colsum(dh_pre, dfc1_b)
         dn2 = torch.empty(M, C, dtype=dt, device=dev)
         hip.gemm_nt(dh_pre, wcast(fc1_w, dt, True), dn2, M=M)
         del dh_pre
-        # norm2 ; dx1 = dy2 + LN'(dn2)   (accumulated in place into dy2)
-        dn2_w, dn2_b = z(C), z(C)
-        dx1 = hip.layernorm_bwd(dn2, x1, _f32(n2_w), mean2, rstd2, dn2_w, dn2_b, M=M, dx=dy2, accumulate=True)
+        # norm2 ; dx1 = dy2 + LN'(dn2) accumulated in place into dy2; its column sums are proj's bias gradient
+        dn2_w, dn2_b, dproj_b = z(C), z(C), z(C)
+        dx1 = hip.layernorm_bwd(dn2, x1, _f32(n2_w), mean2, rstd2, dn2_w, dn2_b, M=M, dx=dy2, accumulate=True,
+                                dxsum=dproj_b)
         # proj (window order on the attention side)
-        dproj_w, dproj_b = z(C, C), z(C)
+        dproj_w = z(C, C)
         hip.gemm_tn(dx1, o, dproj_w, Mk=M, at_rows=rmap)
-        hip.colsum(dx1, dproj_b)
         do = dn2  # reuse
         hip.gemm_nt(dx1, wcast(proj_w, dt, True), do, M=M, a_rows=rmap)
-        # attention core
-        dbiasT = z(heads, N, N)
+        # attention core (also yields the qkv bias gradient)
+        dbiasT, dqkv_b = z(heads, N, N), z(3 * C)
         dqkv = hip.win_attn_bwd(qkv, do, biasT, maskT, dbiasT, nB_=(M // (2 * N)), nW=nW, T=2, ws=ws, heads=heads,
-                                C=C, scale=d ** -0.5)
+                                C=C, scale=d ** -0.5, colsum_out=dqkv_b)
         dtable = z((2 * ws - 1) * (2 * ws - 1), heads)
         dtable.index_add_(0, index.reshape(-1).long(), dbiasT.permute(2, 1, 0).reshape(N * N, heads))
         # qkv
-        dqkv_w, dqkv_b = z(3 * C, C), z(3 * C)
+        dqkv_w = z(3 * C, C)
         hip.gemm_tn(dqkv, X2, dqkv_w, Mk=M, bt_rows=rmap)
-        hip.colsum(dqkv, dqkv_b)
         dx = torch.empty(M, C, dtype=dt, device=dev)
         hip.gemm_nt(dqkv, wcast(qkv_w, dt, True), dx, M=M, c_rows=rmap, resid=dx1, r_rows=rmap, flags=hip.GF_RESID)
         Bp = M // (2 * H * W)
