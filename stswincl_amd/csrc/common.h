@@ -52,10 +52,33 @@ template <typename T> DEVI T from_f32(float v);
 template <> DEVI float from_f32<float>(float v) { return v; }
 template <> DEVI bf16 from_f32<bf16>(float v) { return (bf16)v; }  // v_cvt_pk_bf16_f32, RNE, NaN-safe
 
+template <typename T> constexpr bool TT_is_bf16() { return sizeof(T) == 2; }
 DEVI float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 DEVI float dgelu_erf(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
+
+// Branch-free erf for the bf16 path (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7: exact at bf16 resolution).  erff()
+// compiles to ~47 VALU instructions plus a divergent branch; at 64 activations per thread per 128x128 tile that was
+// 3x the tile's MFMA time.  `e` returns exp(-u^2) so GELU' can reuse it (exp(-x^2/2) with u = x/sqrt2).
+DEVI float erf_as(float u, float& e) {
+  const float au = fabsf(u);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * au);
+  const float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  e = __expf(-au * au);
+  return copysignf(1.0f - p * e, u);
+}
+DEVI float gelu_fast(float x) {
+  float e;
+  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f, e));
+}
+DEVI float dgelu_fast(float x) {
+  float e;
+  const float er = erf_as(x * 0.70710678118654752440f, e);
+  return 0.5f * (1.0f + er) + x * 0.39894228040143267794f * e;
+}
+template <typename T> DEVI float gelu_t(float x) { return TT_is_bf16<T>() ? gelu_fast(x) : gelu_erf(x); }
+template <typename T> DEVI float dgelu_t(float x) { return TT_is_bf16<T>() ? dgelu_fast(x) : dgelu_erf(x); }
 
 // ---- per-type traits ----------------------------------------------------------------------------
 template <typename T> struct TT;

@@ -22,6 +22,7 @@ enum {
   GF_OUT_F32 = 8,    // C is float regardless of T
   GF_ACCUM = 16,     // C += v (only with GF_OUT_F32)
   GF_RELU = 32,
+  GF_WAVES4 = 64,    // tuning: 4 waves of 64x64 per tile instead of the default 8 waves of 64x32 (4 waves/SIMD)
 };
 
 struct GemmNT {
@@ -37,32 +38,35 @@ struct GemmNT {
   float* colsum;                 // optional fp32 [N]: += column sums of the values written to C
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
+  constexpr int WN = NW / 2;                 // wave columns; wave tile = 64 x (128 / WN)
+  constexpr int JN = 128 / WN / 16;          // 16-wide fragments per wave along N: 4 (NW=4) or 2 (NW=8)
+  constexpr int NI = 16 / NW;                // LDS-DMA instructions per wave per operand per K tile: 4 or 2
   constexpr int PACK = TT<T>::PACK;
   constexpr int BK = 8 * PACK;               // 128-byte rows
   constexpr int ROWB = 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, l = tid & 63, w = wave_id();
-  const int wr = w >> 1, wc = w & 1;
+  const int wr = w / WN, wc = w % WN;
   const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M + 127) >> 7;
   const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (t / tiles_n) << 7, n0 = (t % tiles_n) << 7;
 
   const char* zero = (const char*)g_stswin_zero;
   const int rsub = l >> 3, cphys = l & 7, csrc = cphys ^ rsub;
-  const char* abase[4]; int astep[4];
-  const char* bbase[4]; int bstep[4];
+  const char* abase[NI]; int astep[NI];
+  const char* bbase[NI]; int bstep[NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int gn = n0 + (w * 4 + i) * 8 + rsub;
+  for (int i = 0; i < NI; ++i) {
+    const int gn = n0 + (w * NI + i) * 8 + rsub;
     if (gn < p.N) { bbase[i] = (const char*)p.B + ((long)gn * p.ldb) * sizeof(T) + csrc * 16; bstep[i] = BK * sizeof(T); }
     else { bbase[i] = zero + cphys * 16; bstep[i] = 0; }
   }
   auto load_a_bases = [&](int seg) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int gm = m0 + (w * 4 + i) * 8 + rsub;
+    for (int i = 0; i < NI; ++i) {
+      const int gm = m0 + (w * NI + i) * 8 + rsub;
       long row = -1;
       if (gm < p.M) row = p.a_rows ? (long)p.a_rows[(long)seg * p.M + gm] : (long)gm;
       if (row >= 0) { abase[i] = (const char*)p.A + (row * p.lda) * sizeof(T) + csrc * 16; astep[i] = BK * sizeof(T); }
@@ -75,16 +79,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     char* Ab = smem + buf * 32768;
     char* Bb = Ab + 16384;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(abase[i] + (long)kt * astep[i], Ab + (w * 4 + i) * 1024);
+    for (int i = 0; i < NI; ++i) glds16(abase[i] + (long)kt * astep[i], Ab + (w * NI + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(bbase[i] + (long)ktg * bstep[i], Bb + (w * 4 + i) * 1024);
+    for (int i = 0; i < NI; ++i) glds16(bbase[i] + (long)ktg * bstep[i], Bb + (w * NI + i) * 1024);
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][JN];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < JN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   int seg = 0;
   load_a_bases(0);
@@ -103,40 +107,40 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     if constexpr (TT<T>::IS_BF16) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 a[4], b[4];
+        bf16x8 a[4], b[JN];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = wr * 64 + i * 16 + fr;
           a[i] = *(const bf16x8*)(Ab + row * ROWB + (((kk * 4 + fq) ^ (row & 7)) << 4));
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row = wc * 64 + j * 16 + fr;
+        for (int j = 0; j < JN; ++j) {
+          const int row = wc * (16 * JN) + j * 16 + fr;
           b[j] = *(const bf16x8*)(Bb + row * ROWB + (((kk * 4 + fq) ^ (row & 7)) << 4));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < JN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     } else {
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
-        float a[4], b[4];
+        float a[4], b[JN];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = wr * 64 + i * 16 + fr;
           a[i] = *(const float*)(Ab + row * ROWB + ((kk ^ (row & 7)) << 4) + fq * 4);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row = wc * 64 + j * 16 + fr;
+        for (int j = 0; j < JN; ++j) {
+          const int row = wc * (16 * JN) + j * 16 + fr;
           b[j] = *(const float*)(Bb + row * ROWB + ((kk ^ (row & 7)) << 4) + fq * 4);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < JN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
   }
@@ -147,10 +151,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < JN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        ct[(wr * 64 + i * 16 + 4 * fq + r) * 128 + wc * 64 + j * 16 + fr] = acc[i][j][r];
+        ct[(wr * 64 + i * 16 + 4 * fq + r) * 128 + wc * (16 * JN) + j * 16 + fr] = acc[i][j][r];
   __syncthreads();
 
   const int c8 = (tid & 15) * 8;
@@ -160,8 +164,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
   float bv[8], cs[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && e < ncols) ? p.bias[gn0 + e] : 0.f; cs[e] = 0.f; }
-  for (int pass = 0; pass < 8 && ncols > 0; ++pass) {
-    const int rr = pass * 16 + (tid >> 4);
+  constexpr int RG = NW * 4;                 // row groups per pass
+  for (int pass = 0; pass < 128 / RG && ncols > 0; ++pass) {
+    const int rr = pass * RG + (tid >> 4);
     const int gm = m0 + rr;
     if (gm >= p.M) break;
     float v[8];
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     }
     if (p.flags & GF_GELU) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+      for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
     }
     if (p.flags & (GF_RESID | GF_MUL_DGELU)) {
       const long rrow = p.r_rows ? (long)p.r_rows[gm] : (long)gm;
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
         for (int e = 0; e < 8; ++e) v[e] += rv[e];
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf(rv[e]);
+        for (int e = 0; e < 8; ++e) v[e] *= dgelu_t<T>(rv[e]);
       }
     }
     if (p.flags & GF_RELU) {
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     if (tid < 128 && n0 + tid < p.N) {
       float t = 0.f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) t += ct[k * 128 + tid];
+      for (int k = 0; k < RG; ++k) t += ct[k * 128 + tid];
       atomicAdd(p.colsum + n0 + tid, t);
     }
   }
@@ -277,17 +282,18 @@ struct GemmTN {
   int bseg;                                       // >0: Bt column j reads source column j % bseg of row bt_rows[(j / bseg)*Mk + m]
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(GemmTN p) {
+  constexpr int WN = NW / 2, JN = 128 / WN / 16;
   constexpr int PACK = TT<T>::PACK;
   constexpr int BM = TT<T>::IS_BF16 ? 64 : 32;      // contraction rows per tile
   constexpr int ROWB = 128 * sizeof(T);             // 256 / 512
   constexpr int RPI = 1024 / ROWB;                  // rows per wave-instruction: 4 / 2
-  constexpr int NI = BM / (4 * RPI);                // DMA instructions per wave per operand: 4
+  constexpr int NI = BM / (NW * RPI);               // DMA instructions per wave per operand: 4 (NW=4) / 2 (NW=8)
   constexpr int CPR = ROWB / 16;                    // chunks per row: 16 / 32
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, l = tid & 63, w = wave_id();
-  const int wr = w >> 1, wc = w & 1;
+  const int wr = w / WN, wc = w % WN;
   const int tiles_j = (p.Nj + 127) >> 7;
   const int i0 = (blockIdx.x / tiles_j) << 7, j0 = (blockIdx.x % tiles_j) << 7;
   // split the contraction range in multiples of BM
@@ -340,11 +346,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][JN];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < JN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fr = l & 15, fq = l >> 4;
   fetch_rows(t_begin);
@@ -363,50 +369,50 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
     if constexpr (TT<T>::IS_BF16) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 a[4], b[4];
+        bf16x8 a[4], b[JN];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           a[i] = cat4(lds_tr4(Ab, ROWB, kk * 32 + 8 * fq, wr * 64 + i * 16),
                       lds_tr4(Ab, ROWB, kk * 32 + 8 * fq + 4, wr * 64 + i * 16));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          b[j] = cat4(lds_tr4(Bb, ROWB, kk * 32 + 8 * fq, wc * 64 + j * 16),
-                      lds_tr4(Bb, ROWB, kk * 32 + 8 * fq + 4, wc * 64 + j * 16));
+        for (int j = 0; j < JN; ++j)
+          b[j] = cat4(lds_tr4(Bb, ROWB, kk * 32 + 8 * fq, wc * (16 * JN) + j * 16),
+                      lds_tr4(Bb, ROWB, kk * 32 + 8 * fq + 4, wc * (16 * JN) + j * 16));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < JN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     } else {
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
         const int row = kk * 4 + fq;
-        float a[4], b[4];
+        float a[4], b[JN];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int col = wr * 64 + i * 16 + fr;
           a[i] = *(const float*)(Ab + row * ROWB + ((((col >> 2) & ~15) | (((col >> 2) ^ swz256(row)) & 15)) << 4) + (col & 3) * 4);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int col = wc * 64 + j * 16 + fr;
+        for (int j = 0; j < JN; ++j) {
+          const int col = wc * (16 * JN) + j * 16 + fr;
           b[j] = *(const float*)(Bb + row * ROWB + ((((col >> 2) & ~15) | (((col >> 2) ^ swz256(row)) & 15)) << 4) + (col & 3) * 4);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < JN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < JN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gi = i0 + wr * 64 + i * 16 + 4 * fq + r;
-        const int gj = j0 + wc * 64 + j * 16 + fr;
+        const int gj = j0 + wc * (16 * JN) + j * 16 + fr;
         if (gi < p.Ni && gj < p.Nj) atomicAdd(p.C + (long)gi * p.ldc + gj, acc[i][j][r]);
       }
 }
@@ -426,10 +432,17 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
   if ((flags & GF_ACCUM) && !(flags & GF_OUT_F32)) return -1002;
   GemmNT p{A, lda, a_rows, B, ldb, C, ldc, c_rows, C2, ldc2, bias, R, ldr, r_rows, M, N, Kseg, S, scale, scale_cols, flags, colsum};
   const int nblk = ((M + 127) / 128) * ((N + 127) / 128);
-  static int once = set_lds_once((const void*)gemm_nt_kernel<bf16>) | set_lds_once((const void*)gemm_nt_kernel<float>);
+  static int once = set_lds_once((const void*)gemm_nt_kernel<bf16, 4>) | set_lds_once((const void*)gemm_nt_kernel<float, 4>) |
+                    set_lds_once((const void*)gemm_nt_kernel<bf16, 8>) | set_lds_once((const void*)gemm_nt_kernel<float, 8>);
   (void)once;
-  if (dtype == 0) hipLaunchKernelGGL(gemm_nt_kernel<bf16>, dim3(nblk), dim3(256), 65536, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(gemm_nt_kernel<float>, dim3(nblk), dim3(256), 65536, (hipStream_t)stream, p);
+  const bool w8 = (flags & GF_WAVES4) == 0;
+  if (dtype == 0) {
+    if (w8) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8>), dim3(nblk), dim3(512), 65536, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<bf16, 4>), dim3(nblk), dim3(256), 65536, (hipStream_t)stream, p);
+  } else {
+    if (w8) hipLaunchKernelGGL((gemm_nt_kernel<float, 8>), dim3(nblk), dim3(512), 65536, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<float, 4>), dim3(nblk), dim3(256), 65536, (hipStream_t)stream, p);
+  }
   STSWIN_CHECK_LAUNCH();
   return 0;
 }
@@ -438,6 +451,8 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
                               const int* bt_rows, float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg,
                               void* stream) {
   if (Mk <= 0 || Ni <= 0 || Nj <= 0) return 0;
+  const int splits_flags_w4 = (splits > 0 && (splits & (1 << 30))) ? 1 : 0;   // tuning: bit 30 selects the 4-wave variant
+  if (splits > 0) splits &= ~(1 << 30);
   const int pack = dtype == 0 ? 8 : 4;
   if (Ni % pack || Nj % pack || lda % pack || ldb % pack) return -1003;
   if (bseg < 0 || (bseg > 0 && (bseg % pack || !bt_rows))) return -1004;
@@ -454,10 +469,17 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   if (splits > ntile) splits = ntile;
   GemmTN p{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, splits, bseg};
   dim3 grid(((Ni + 127) / 128) * ((Nj + 127) / 128), splits);
-  static int once = set_lds_once((const void*)gemm_tn_kernel<bf16>) | set_lds_once((const void*)gemm_tn_kernel<float>);
+  static int once = set_lds_once((const void*)gemm_tn_kernel<bf16, 4>) | set_lds_once((const void*)gemm_tn_kernel<float, 4>) |
+                    set_lds_once((const void*)gemm_tn_kernel<bf16, 8>) | set_lds_once((const void*)gemm_tn_kernel<float, 8>);
   (void)once;
-  if (dtype == 0) hipLaunchKernelGGL(gemm_tn_kernel<bf16>, grid, dim3(256), 65536, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 65536, (hipStream_t)stream, p);
+  const bool w8 = splits_flags_w4 == 0;
+  if (dtype == 0) {
+    if (w8) hipLaunchKernelGGL((gemm_tn_kernel<bf16, 8>), grid, dim3(512), 65536, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm_tn_kernel<bf16, 4>), grid, dim3(256), 65536, (hipStream_t)stream, p);
+  } else {
+    if (w8) hipLaunchKernelGGL((gemm_tn_kernel<float, 8>), grid, dim3(512), 65536, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm_tn_kernel<float, 4>), grid, dim3(256), 65536, (hipStream_t)stream, p);
+  }
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

@@ -31,6 +31,9 @@ def test_gemm_nt_plain_and_bias(dtype, m, n, k):
     out = torch.full((m, n), float("nan"), dtype=dtype, device="cuda")
     hip.gemm_nt(a.cuda(), w.cuda(), out, M=m, bias=bias.cuda())
     _close(out, F.linear(a.float(), w.float(), bias), dtype, "bias")
+    out8 = torch.full((m, n), float("nan"), dtype=dtype, device="cuda")
+    hip.gemm_nt(a.cuda(), w.cuda(), out8, M=m, bias=bias.cuda(), flags=hip.GF_WAVES4)      # 4-wave variant, same result
+    assert torch.equal(out8, out)
     out32 = torch.zeros(m, n, device="cuda")
     hip.gemm_nt(a.cuda(), w.cuda(), out32, M=m, flags=hip.GF_OUT_F32)
     hip.gemm_nt(a.cuda(), w.cuda(), out32, M=m, flags=hip.GF_OUT_F32 | hip.GF_ACCUM)

@@ -33,8 +33,9 @@ def main():
         rows = None
         if S > 1 or "gather" in note:
             rows = torch.randint(0, M, (S, M), device=dev, dtype=torch.int32)
-        t = timeit(lambda: hip.gemm_nt(A, W, out, M=M, a_rows=rows, S=S))
-        print(f"{'nt':8s} {M:7d} {N:6d} {K:6d} {S:2d} {t * 1e3:9.1f} {2.0 * M * N * K * S / t / 1e9:8.1f}  {note}")
+        for fl, tag in ((hip.GF_WAVES4, "4w"), (0, "8w")):
+            t = timeit(lambda: hip.gemm_nt(A, W, out, M=M, a_rows=rows, S=S, flags=fl))
+            print(f"{'nt-' + tag:8s} {M:7d} {N:6d} {K:6d} {S:2d} {t * 1e3:9.1f} {2.0 * M * N * K * S / t / 1e9:8.1f}  {note}")
     tn_shapes = [(32768, 1536, 512, "dWqkv s1"), (32768, 2048, 512, "dWfc1 s1"), (32768, 512, 2048, "dWfc2 s1"),
                  (32768, 512, 512, "dWproj s1"), (8192, 4096, 1024, "dWfc1 s2"), (8192, 1024, 4096, "dWfc2 s2"),
                  (65536, 512, 4608, "resnet layer5 wgrad (bseg)"), (262144, 64, 576, "resnet layer1 wgrad (bseg)")]
@@ -49,7 +50,7 @@ def main():
         else:
             Bt = torch.randn(Mk, Nj, device=dev).to(dt)
         out = torch.zeros(Ni, Nj, device=dev)
-        for splits in (0, 2, 4, 8, 16):
+        for splits in (0, 1 << 30 | 8):
             t = timeit(lambda: hip.gemm_tn(At, Bt, out, Mk=Mk, bt_rows=rows, bseg=bseg, splits=splits))
             print(f"{'tn':8s} {Mk:7d} {Ni:6d} {Nj:6d} {splits:2d} {t * 1e3:9.1f} {2.0 * Mk * Ni * Nj / t / 1e9:8.1f}  {note} splits={splits}")
 
