@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=512)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--workload", default="seg", choices=["seg", "contrast"],
+                    help="seg (default, BASELINE configs[1]) or contrast (configs[3]: ConsistencyLoss pre-training step)")
     ap.add_argument("--graph", type=int, default=-1, help="1: capture the whole step in a hipGraph and replay it; "
                     "0: eager; -1 (default): graph when N == 1 and profiling is off")
     return ap.parse_args()
@@ -90,8 +92,92 @@ def cpu_baseline(size: int, budget_s: float = 25.0):
                       f"calibration step at 128x128: {t_cal:.1f} s"}
 
 
+def contrast_main(a):
+    """BASELINE.json configs[3] as far as the reference can run it: ConsistencyLoss (PixPro-style, 2 query + 6 momentum-key
+    encoder passes) at 256x256 (224 is illegal for the window sizes), B clips/GPU, SGD momentum (LARS is a next row).
+    Reports contrastive pairs/s = 2 directions x B x HW x 5 HW per step, and input frames/s."""
+    import types
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from stswincl_amd import hip
+    from stswincl_amd.contrast.models.PixPro_swin_v5 import ConsistencyLoss
+    from stswincl_amd.dp import GradBucketReducer
+    S, B = 256, (a.batch if a.batch != 4 else 8)
+    args = types.SimpleNamespace(pixpro_p=1.0, pixpro_momentum=0.99, pixpro_clamp_value=0.0, pixpro_transform_layer=1,
+                                 pixpro_ins_loss_weight=0.0, pixpro_pos_ratio=0.7, data="endo18", tag="1", pretrainpth=None,
+                                 num_instances=2235, batch_size=B, epochs=150, start_epoch=1)
+    torch.manual_seed(0)
+    model = ConsistencyLoss(args, input_resolution=(S // 8, S // 8)).to(dev).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, 0.05, momentum=0.9, weight_decay=1e-5)
+    reducer = GradBucketReducer(params, bucket_mb=64.0) if world > 1 else None
+    torch.manual_seed(1234 + rank)
+    ims = [torch.randn(B, 4, 3, S, S, device=dev) for _ in range(6)]
+    masks = [torch.randint(0, 12, (B, 1, S, S), device=dev).float() for _ in range(6)]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = model(*ims, *masks)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if rank == 0 and not a.no_profile:
+        hip.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = hip.profile_end() if (rank == 0 and not a.no_profile) else {}
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        hw = (S // 8) ** 2
+        pairs = world * 2 * B * hw * 5 * hw * a.steps
+        res = {"metric": "contrastive pairs/s, ConsistencyLoss fwd+bwd+SGD (2 query + 6 key encoder passes), 256x256",
+               "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"BASELINE.json configs[3]: PixPro-style ConsistencyLoss, {B} x 6 clips/GPU x T=4 x 3x{S}x{S} "
+                                      f"(224 is illegal for windows 8/4), per-sample label-guided loss as in the reference "
+                                      f"(no bank); SGD instead of LARS", "clips_per_gpu": 6 * B, "parallelism": f"dp{world}",
+                          "input_frames_per_s": world * 6 * B * 4 * a.steps / dt, "loss": float(loss)}}
+        if "contrast_fwd_bf16" in prof:
+            p = prof["contrast_fwd_bf16"]
+            tf = p["work"] / (p["ms_total"] * 1e-3) / 1e12
+            res["roofline"] = {"kernel": "contrast_fwd_bf16", "bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS,
+                               "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "traffic": None,
+                               "avg_launch_ms": p["ms_avg"], "pairs_per_s_in_kernel": p["work"] / 512.0 / (p["ms_total"] * 1e-3)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.workload == "contrast":
+        return contrast_main(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -198,8 +284,20 @@ def main():
             k = max(prof, key=lambda n: prof[n]["ms_total"])
             p = prof[k]
             tf = p["work"] / (p["ms_total"] * 1e-3) / 1e12
+            traffic = None      # HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/)
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")) as f:
+                    pmc = json.load(f)
+                if pmc.get("kernel") == k:
+                    traffic = pmc["hbm_bytes_per_launch"]
+            except Exception:
+                pass
             res["roofline"] = {"kernel": k, "bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tf / PEAK_BF16_TFLOPS, "traffic": None, "launches_per_step": p["launches"] / a.steps,
+                               "frac": tf / PEAK_BF16_TFLOPS, "traffic": traffic,
+                               "traffic_note": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc "
+                                               "passes over this command (profiles/r01_v4_pmc_*.txt)",
+                               "algorithmic_flops_per_launch": p["work"] / p["launches"],
+                               "launches_per_step": p["launches"] / a.steps,
                                "avg_launch_ms": p["ms_avg"], "ms_per_step": p["ms_total"] / a.steps,
                                "other_kernels": {n: {"ms_per_step": v["ms_total"] / a.steps,
                                                      "tflops": v["work"] / (v["ms_total"] * 1e-3) / 1e12}

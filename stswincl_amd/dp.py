@@ -106,13 +106,15 @@ class GradBucketReducer:
         for i, item in enumerate(self._flat):
             if item is None:
                 continue
-            self._work[i].wait()
             flat, bucket = item
-            ctx = torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else None
-            if ctx is not None:
-                with ctx:
+            if self.comm_stream is not None:
+                # the collective was enqueued from comm_stream: make THAT stream wait for it, scatter the averages back
+                # there, and let the compute stream join once at the end
+                with torch.cuda.stream(self.comm_stream):
+                    self._work[i].wait()
                     self._unflatten(flat, bucket)
             else:
+                self._work[i].wait()
                 self._unflatten(flat, bucket)
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
