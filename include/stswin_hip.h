@@ -109,7 +109,9 @@ int stswin_bn_apply(int dtype, const void* x, long ldx, const float* mean, const
                     void* stream);
 int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const void* y, long ldy, const float* mean,
                   const float* rstd, const float* gamma, float* s1, float* s2, void* dx, long lddx, void* dresid, long lddr,
-                  int M, int C, int groups, int relu, int training, void* stream);
+                  int M, int C, int groups, int relu, int training,
+                  int phase /* 0 both passes, 1 reduce only, 2 dx only: SyncBatchNorm all-reduces s1/s2 in between */,
+                  long rows_total /* rows per group over all ranks (0 = local) */, void* stream);
 /* out[r][c] (+)= v[r / (M/groups)][c] * scale : image-pool broadcast (ASPP.py:46) and avg-pool backward */
 int stswin_rows_broadcast(int dtype, const float* v, void* out, long ldo, int M, int C, int groups, float scale,
                           int accumulate, void* stream);

@@ -171,6 +171,12 @@ class PixPro(nn.Module):
             for pq, pk in zip(q_mod.parameters(), k_mod.parameters()):
                 pk.data.copy_(pq.data)
                 pk.requires_grad = False
+        # SyncBatchNorm over both encoders, as the reference (PixPro_swin_v5.py:215-228); with one process this is
+        # ordinary BatchNorm.  The grouped-BN kernels combine the cross-rank statistics (headops.BNTokFn).
+        for mod in (self.encoder_1, self.encoder_2, self.encoder_3, self.proj1, self.proj2, self.proj3, self.encoder_k_1,
+                    self.encoder_k_2, self.encoder_k_3, self.proj_k_1, self.proj_k_2, self.proj_k_3, self.projector,
+                    self.projector_k):
+            nn.SyncBatchNorm.convert_sync_batchnorm(mod)
         ws = _world_size()
         self.K = int(args.num_instances * 1. / ws / args.batch_size * args.epochs)
         self.k = int(args.num_instances * 1. / ws / args.batch_size * (args.start_epoch - 1))

@@ -177,14 +177,13 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* dy, long lddy, 
                                                          const float* mean, const float* rstd, const float* gamma,
                                                          const float* s1, const float* s2, T* dx, long lddx, T* dres,
                                                          long lddr, int C, int group_rows, int chunks_per_group,
-                                                         int rows_per_chunk, int relu, int training, int cpb) {
+                                                         int rows_per_chunk, int relu, int training, int cpb, float inv_n) {
   constexpr int PACK = TT<T>::PACK;
   const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
   const int c = (blockIdx.x * cpb + cp) * PACK;
   if (c >= C) return;
   const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
   const long gr0 = (long)g * group_rows;
-  const float inv_n = 1.0f / group_rows;
   // dx = A*dyr + B*x + D  with  A = gamma*rstd, B = -A*rstd*s2/n, D = -A*s1/n - B*mean      (training)
   float ka[8], kb[8], kd[8];
 #pragma unroll
@@ -470,7 +469,7 @@ extern "C" int stswin_bn_apply(int dtype, const void* x, long ldx, const float* 
 extern "C" int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const void* y, long ldy,
                              const float* mean, const float* rstd, const float* gamma, float* s1, float* s2, void* dx,
                              long lddx, void* dresid, long lddr, int M, int C, int groups, int relu, int training,
-                             void* stream) {
+                             int phase, long rows_total, void* stream) {
   const int pk = PACK_OF(dtype);
   if (C % pk || ldx % pk || lddy % pk || lddx % pk || (relu && ldy % pk) || groups <= 0 || M % groups) return -1403;
   const int ppr = C / pk, cpb = pick_cpb(ppr);
@@ -480,10 +479,13 @@ extern "C" int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x
   const int rpc2 = 8 * (256 / cpb), cpg2 = (gr + rpc2 - 1) / rpc2;
   dim3 g2((ppr + cpb - 1) / cpb, groups * cpg2);
   hipStream_t st = (hipStream_t)stream;
+  const float inv_n = 1.0f / (float)(rows_total > 0 ? rows_total : gr);
+  if (phase != 2)
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb),
              hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16>, g2, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, gamma, s1, s2, (bf16*)dx, lddx, (bf16*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb),
-             hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, gamma, s1, s2, (float*)dx, lddx, (float*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb));
+  if (phase != 1)
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16>, g2, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, gamma, s1, s2, (bf16*)dx, lddx, (bf16*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n),
+             hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, gamma, s1, s2, (float*)dx, lddx, (float*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n));
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

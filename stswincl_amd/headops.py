@@ -222,17 +222,60 @@ class MaxPoolTokFn(torch.autograd.Function):
         return dx.to(in_dtype), None
 
 
+def combine_bn_stats(mean_r: torch.Tensor, m2_r: torch.Tensor, n_r: torch.Tensor):
+    """Chan's parallel combination of per-rank statistics: mean_r, m2_r [R][G][C] (m2 = sum of squared deviations from the
+    rank's own mean), n_r [R] rows per group -> (global mean [G][C], biased variance [G][C], total count)."""
+    n = n_r.sum()
+    w = (n_r / n).view(-1, 1, 1)
+    mean = (mean_r * w).sum(0)
+    m2 = (m2_r + n_r.view(-1, 1, 1) * (mean_r - mean) ** 2).sum(0)
+    return mean, m2 / n, n
+
+
+def _sync_world(bn) -> int:
+    import torch.distributed as dist
+    if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return 1
+
+
 class BNTokFn(torch.autograd.Function):
     """nn.BatchNorm2d (+ residual add + ReLU) on tokens with `groups` independent statistic groups."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, relu, resid, groups, lay, eps, momentum):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, relu, resid, groups, lay, eps, momentum, world=1):
         dt = compute_dtype(x)
         X = x.detach().to(dt)
         M, Cp = X.shape
         assert Cp == lay.width
         gp, bp = lay.pad_vec(gamma), lay.pad_vec(beta)
-        if training:
+        rows_total = 0
+        if training and world > 1:
+            # nn.SyncBatchNorm (PixPro_swin_v5.py:215-228): batch statistics over ALL ranks.  One all-gather of
+            # (mean, M2, count) per BN instead of the reference's per-tensor collectives.
+            import torch.distributed as dist
+            n_loc = M // groups
+            s, ss = hip.colstats(X, groups=groups)
+            pivot = X.view(groups, n_loc, Cp)[:, 0, :].float()
+            mean_l = pivot + s / n_loc
+            m2_l = ss - s * s / n_loc
+            pack = torch.cat([mean_l.reshape(-1), m2_l.reshape(-1), mean_l.new_tensor([float(n_loc)])])
+            allp = [torch.empty_like(pack) for _ in range(world)]
+            dist.all_gather(allp, pack)
+            allp = torch.stack(allp)
+            gc = groups * Cp
+            mean, var, n_tot = combine_bn_stats(allp[:, :gc].view(world, groups, Cp), allp[:, gc:2 * gc].view(world, groups, Cp),
+                                                allp[:, -1])
+            rstd = torch.rsqrt(var + eps)
+            rows_total = int(n_tot.item())
+            rm, rv = lay.pad_vec(running_mean), lay.pad_vec(running_var, 1.0)
+            for g in range(groups):
+                rm = (1 - momentum) * rm + momentum * mean[g]
+                rv = (1 - momentum) * rv + momentum * var[g] * (rows_total / max(rows_total - 1, 1))
+            running_mean.copy_(lay.unpad_vec(rm))
+            running_var.copy_(lay.unpad_vec(rv))
+            mean, rstd = mean.contiguous(), rstd.contiguous()
+        elif training:
             s, ss = hip.colstats(X, groups=groups)
             if lay.is_identity:
                 mean, rstd = hip.bn_finalize(X, s, ss, running_mean, running_var, groups, eps, momentum)
@@ -247,22 +290,32 @@ class BNTokFn(torch.autograd.Function):
         y = torch.empty(M, Cp, dtype=dt, device=x.device)
         R = resid.detach().to(dt) if resid is not None else None
         hip.bn_apply(X, mean, rstd, gp, bp, y, resid=R, groups=groups, relu=relu)
-        ctx.cfg = (training, relu, groups, lay, dt, x.dtype, resid is not None)
+        ctx.cfg = (training, relu, groups, lay, dt, x.dtype, resid is not None, world, rows_total)
         ctx.save_for_backward(X, y, mean, rstd, gp)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         X, y, mean, rstd, gp = ctx.saved_tensors
-        training, relu, groups, lay, dt, in_dtype, has_res = ctx.cfg
+        training, relu, groups, lay, dt, in_dtype, has_res, world, rows_total = ctx.cfg
         g = dy.detach().to(dt).contiguous()
         dx = torch.empty_like(X)
         dres = torch.empty_like(X) if has_res else None
-        s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training)
+        if training and world > 1:
+            import torch.distributed as dist
+            s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, phase=1)
+            loc1, loc2 = s1.clone(), s2.clone()                 # weight/bias grads stay local sums (DDP averages them)
+            both = torch.stack([s1, s2])
+            dist.all_reduce(both)
+            hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, phase=2,
+                       sums=(both[0].contiguous(), both[1].contiguous()), rows_total=rows_total)
+            s1, s2 = loc1, loc2
+        else:
+            s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training)
         dgamma = lay.unpad_vec(s2.sum(0))
         dbeta = lay.unpad_vec(s1.sum(0))
         return (dx.to(in_dtype), dgamma, dbeta, None, None, None, None, dres.to(in_dtype) if has_res else None,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 def batchnorm_tokens(x, bn: torch.nn.BatchNorm2d, relu=True, resid=None, groups=1, lay: Optional[Layout] = None):
@@ -271,7 +324,7 @@ def batchnorm_tokens(x, bn: torch.nn.BatchNorm2d, relu=True, resid=None, groups=
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += groups
     return BNTokFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, relu, resid, groups, lay,
-                         bn.eps, bn.momentum if bn.momentum is not None else 0.1)
+                         bn.eps, bn.momentum if bn.momentum is not None else 0.1, _sync_world(bn) if training else 1)
 
 
 class BilinearTokFn(torch.autograd.Function):

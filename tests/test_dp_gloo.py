@@ -87,3 +87,17 @@ def test_compat_aliases_expose_reference_paths():
     assert hasattr(importlib.import_module("net.Ours.base18"), "TswinPlus")
     assert hasattr(importlib.import_module("utils.losses"), "OhemCELoss2D")
     assert hasattr(importlib.import_module("contrast.models.PixPro_swin_v5"), "ConsistencyLoss")
+
+
+def test_sync_bn_stat_combination_matches_full_batch():
+    """The cross-rank statistic merge used for SyncBatchNorm (headops.combine_bn_stats) on a split batch."""
+    from stswincl_amd.headops import combine_bn_stats
+    torch.manual_seed(0)
+    x = torch.randn(3, 50, 7) * 3 + 5                 # [groups][rows][C]
+    parts = [x[:, :20], x[:, 20:]]                    # two "ranks" with different row counts
+    mean_r = torch.stack([p.mean(1) for p in parts])
+    m2_r = torch.stack([((p - p.mean(1, keepdim=True)) ** 2).sum(1) for p in parts])
+    n_r = torch.tensor([20.0, 30.0])
+    mean, var, n = combine_bn_stats(mean_r, m2_r, n_r)
+    assert torch.allclose(mean, x.mean(1), atol=1e-5) and torch.allclose(var, x.var(1, unbiased=False), atol=1e-4)
+    assert int(n) == 50
