@@ -27,6 +27,8 @@ extern "C" {
 #define STSWIN_GF_OUT_F32 8    /* C is fp32 regardless of dtype */
 #define STSWIN_GF_ACCUM 16     /* C += v (needs OUT_F32) */
 #define STSWIN_GF_RELU 32
+#define STSWIN_GF_BIG 128       /* tuning: force the 256x256 4-stage-ring kernel (bf16) */
+#define STSWIN_GF_NOBIG 256     /* tuning: forbid it (default: chosen when >= 256 big tiles fill the chip) */
 #define STSWIN_GF_WAVES4 64     /* tuning: 4 waves of 64x64 per 128x128 tile instead of the default 8 waves of 64x32 */
 
 int stswin_abi_version(void);

@@ -22,6 +22,8 @@ enum {
   GF_OUT_F32 = 8,    // C is float regardless of T
   GF_ACCUM = 16,     // C += v (only with GF_OUT_F32)
   GF_RELU = 32,
+  GF_BIG = 128,      // tuning: force the 256x256 4-stage kernel (bf16)
+  GF_NOBIG = 256,    // tuning: forbid it
   GF_WAVES4 = 64,    // tuning: 4 waves of 64x64 per tile instead of the default 8 waves of 64x32 (4 waves/SIMD)
 };
 
@@ -37,6 +39,92 @@ struct GemmNT {
   int flags;
   float* colsum;                 // optional fp32 [N]: += column sums of the values written to C
 };
+
+// ---- epilogue of one 8-column piece of output row gm: bias, q-scale, pre-activation copy, GELU, residual / GELU',
+// ReLU, store (T or fp32, optional accumulate), column-sum accumulation.  Shared by every gemm_nt variant.
+template <typename T>
+DEVI void epi_piece(const GemmNT& p, float (&v)[8], const float (&bv)[8], float (&cs)[8], int gm, int gn0, int ncols) {
+  constexpr int PACK = TT<T>::PACK;
+  const bool vec_ok = (ncols == 8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    v[e] += bv[e];
+    if (gn0 + e < p.scale_cols) v[e] *= p.scale;
+  }
+  const long orow = p.c_rows ? (long)p.c_rows[gm] : (long)gm;
+  if (p.C2) {
+    T* dst = (T*)p.C2 + orow * p.ldc2 + gn0;
+    if (vec_ok && (p.ldc2 % PACK) == 0) {
+#pragma unroll
+      for (int h = 0; h < 8 / PACK; ++h) {
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < PACK; ++e) o.set(e, v[h * PACK + e]);
+        *(decltype(o.v)*)(dst + h * PACK) = o.v;
+      }
+    } else {
+      for (int e = 0; e < ncols; ++e) dst[e] = from_f32<T>(v[e]);
+    }
+  }
+  if (p.flags & GF_GELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
+  }
+  if (p.flags & (GF_RESID | GF_MUL_DGELU)) {
+    const long rrow = p.r_rows ? (long)p.r_rows[gm] : (long)gm;
+    const T* src = (const T*)p.R + rrow * p.ldr + gn0;
+    float rv[8];
+    if (vec_ok && (p.ldr % PACK) == 0) {
+#pragma unroll
+      for (int h = 0; h < 8 / PACK; ++h) {
+        Vec16<T> in;
+        in.v = *(const decltype(in.v)*)(src + h * PACK);
+#pragma unroll
+        for (int e = 0; e < PACK; ++e) rv[h * PACK + e] = in.get(e);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rv[e] = (e < ncols) ? to_f32<T>(src[e]) : 0.f;
+    }
+    if (p.flags & GF_RESID) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rv[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= dgelu_t<T>(rv[e]);
+    }
+  }
+  if (p.flags & GF_RELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] += v[e];
+  if (p.flags & GF_OUT_F32) {
+    float* dst = (float*)p.C + orow * p.ldc + gn0;
+    if (p.flags & GF_ACCUM) {
+      for (int e = 0; e < ncols; ++e) dst[e] += v[e];
+    } else if (vec_ok && (p.ldc % 4) == 0) {
+      *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+      *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    } else {
+      for (int e = 0; e < ncols; ++e) dst[e] = v[e];
+    }
+  } else {
+    T* dst = (T*)p.C + orow * p.ldc + gn0;
+    if (vec_ok && (p.ldc % PACK) == 0) {
+#pragma unroll
+      for (int h = 0; h < 8 / PACK; ++h) {
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < PACK; ++e) o.set(e, v[h * PACK + e]);
+        *(decltype(o.v)*)(dst + h * PACK) = o.v;
+      }
+    } else {
+      for (int e = 0; e < ncols; ++e) dst[e] = from_f32<T>(v[e]);
+    }
+  }
+  }
 
 template <typename T, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
@@ -160,7 +248,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
   const int c8 = (tid & 15) * 8;
   const int gn0 = n0 + c8;
   const int ncols = max(0, min(8, p.N - gn0));
-  const bool vec_ok = (ncols == 8);
   float bv[8], cs[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && e < ncols) ? p.bias[gn0 + e] : 0.f; cs[e] = 0.f; }
@@ -176,84 +263,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      v[e] += bv[e];
-      if (gn0 + e < p.scale_cols) v[e] *= p.scale;
-    }
-    const long orow = p.c_rows ? (long)p.c_rows[gm] : (long)gm;
-    if (p.C2) {
-      T* dst = (T*)p.C2 + orow * p.ldc2 + gn0;
-      if (vec_ok && (p.ldc2 % PACK) == 0) {
-#pragma unroll
-        for (int h = 0; h < 8 / PACK; ++h) {
-          Vec16<T> o;
-#pragma unroll
-          for (int e = 0; e < PACK; ++e) o.set(e, v[h * PACK + e]);
-          *(decltype(o.v)*)(dst + h * PACK) = o.v;
-        }
-      } else {
-        for (int e = 0; e < ncols; ++e) dst[e] = from_f32<T>(v[e]);
-      }
-    }
-    if (p.flags & GF_GELU) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
-    }
-    if (p.flags & (GF_RESID | GF_MUL_DGELU)) {
-      const long rrow = p.r_rows ? (long)p.r_rows[gm] : (long)gm;
-      const T* src = (const T*)p.R + rrow * p.ldr + gn0;
-      float rv[8];
-      if (vec_ok && (p.ldr % PACK) == 0) {
-#pragma unroll
-        for (int h = 0; h < 8 / PACK; ++h) {
-          Vec16<T> in;
-          in.v = *(const decltype(in.v)*)(src + h * PACK);
-#pragma unroll
-          for (int e = 0; e < PACK; ++e) rv[h * PACK + e] = in.get(e);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) rv[e] = (e < ncols) ? to_f32<T>(src[e]) : 0.f;
-      }
-      if (p.flags & GF_RESID) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rv[e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= dgelu_t<T>(rv[e]);
-      }
-    }
-    if (p.flags & GF_RELU) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) cs[e] += v[e];
-    if (p.flags & GF_OUT_F32) {
-      float* dst = (float*)p.C + orow * p.ldc + gn0;
-      if (p.flags & GF_ACCUM) {
-        for (int e = 0; e < ncols; ++e) dst[e] += v[e];
-      } else if (vec_ok && (p.ldc % 4) == 0) {
-        *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-        *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-      } else {
-        for (int e = 0; e < ncols; ++e) dst[e] = v[e];
-      }
-    } else {
-      T* dst = (T*)p.C + orow * p.ldc + gn0;
-      if (vec_ok && (p.ldc % PACK) == 0) {
-#pragma unroll
-        for (int h = 0; h < 8 / PACK; ++h) {
-          Vec16<T> o;
-#pragma unroll
-          for (int e = 0; e < PACK; ++e) o.set(e, v[h * PACK + e]);
-          *(decltype(o.v)*)(dst + h * PACK) = o.v;
-        }
-      } else {
-        for (int e = 0; e < ncols; ++e) dst[e] = from_f32<T>(v[e]);
-      }
-    }
+    epi_piece<T>(p, v, bv, cs, gm, gn0, ncols);
   }
   if (p.colsum) {                 // fold the 16 row groups through LDS (the C image is no longer needed), 1 atomic / column
     __syncthreads();
@@ -265,6 +275,138 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
       for (int k = 0; k < RG; ++k) t += ct[k * 128 + tid];
       atomicAdd(p.colsum + n0 + tid, t);
+    }
+  }
+}
+
+
+// =====================================================================================================
+// gemm_nt "big": 256x256x32 tile, 8 waves as 2 (M) x 4 (N) of 128x64, FOUR-stage LDS ring (4 x 32 KB) filled by
+// LDS-DMA with a prefetch distance of 3 K tiles: the loads of tiles t+1..t+2 stay in flight across the raw
+// s_barrier (counted s_waitcnt vmcnt(8/4/0) instead of draining), so a wave never waits for the tile it has just
+// requested.  128 FLOP per L2 byte (the 128x128 tile: 64), 1 workgroup per CU, 2 waves per SIMD.
+// LDS rows are 64 bytes (BK = 32 bf16): chunk' = chunk ^ ((4 - ((row >> 2) & 3)) & 3) makes every ds_read_b128
+// 16-lane group touch 16 distinct 16-byte slots.  bf16 only (the fp32 parity path uses the 128x128 kernel).
+// =====================================================================================================
+DEVI int swz64(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+
+__global__ __launch_bounds__(512) void gemm_nt_big_kernel(GemmNT p) {
+  using T = bf16;
+  constexpr int BK = 32, ROWB = 64, STAGE = 32768;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63, w = wave_id();
+  const int wr = w >> 2, wc = w & 3;
+  const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + 255) >> 8;
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (t / tiles_n) << 8, n0 = (t % tiles_n) << 8;
+
+  const char* zero = (const char*)g_stswin_zero;
+  const int rsub = l >> 2, cphys = l & 3, csrc = cphys ^ swz64(rsub);   // rows (w*2+i)*16 + rsub: (row>>2)&3 == (rsub>>2)&3
+  const char* abase[2]; int astep[2];
+  const char* bbase[2]; int bstep[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int gn = n0 + (w * 2 + i) * 16 + rsub;
+    if (gn < p.N) { bbase[i] = (const char*)p.B + ((long)gn * p.ldb) * sizeof(T) + csrc * 16; bstep[i] = BK * sizeof(T); }
+    else { bbase[i] = zero + cphys * 16; bstep[i] = 0; }
+  }
+  auto load_a_bases = [&](int seg) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int gm = m0 + (w * 2 + i) * 16 + rsub;
+      long row = -1;
+      if (gm < p.M) row = p.a_rows ? (long)p.a_rows[(long)seg * p.M + gm] : (long)gm;
+      if (row >= 0) { abase[i] = (const char*)p.A + (row * p.lda) * sizeof(T) + csrc * 16; astep[i] = BK * sizeof(T); }
+      else { abase[i] = zero + cphys * 16; astep[i] = 0; }
+    }
+  };
+  const int kps = p.Kseg / BK;
+  const int nt = p.S * kps;
+  int seg = -1;
+  auto issue = [&](int q) {                      // request K tile q into ring slot q & 3
+    const int sg = q / kps;
+    if (sg != seg) { seg = sg; load_a_bases(sg); }
+    const int kt = q - sg * kps;
+    char* Ab = smem + (q & 3) * STAGE;
+    char* Bb = Ab + 16384;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(abase[i] + (long)kt * astep[i], Ab + (w * 2 + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(bbase[i] + (long)q * bstep[i], Bb + (w * 2 + i) * 1024);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = l & 15, fq = l >> 4;
+  const int rd_off = fr * ROWB + ((fq ^ swz64(fr)) << 4);   // same for every 16-row fragment (bases are multiples of 16)
+  for (int q = 0; q < 3 && q < nt; ++q) issue(q);
+  for (int kt = 0; kt < nt; ++kt) {
+    const int newer = nt - 1 - kt;               // tiles requested after tile kt that may still be in flight
+    if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                // tile kt landed for every wave; slot (kt+3)&3 == (kt-1)&3 is free
+    if (kt + 3 < nt) issue(kt + 3);
+    const char* Ab = smem + (kt & 3) * STAGE;
+    const char* Bb = Ab + 16384;
+    bf16x8 a[8], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(Bb + (wc * 64 + j * 16) * ROWB + rd_off);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = *(const bf16x8*)(Ab + (wr * 128 + i * 16) * ROWB + rd_off);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  }
+
+  // ---------------- epilogue: two 128-row halves through a [128][256] fp32 LDS image ----------------
+  float* ct = (float*)smem;
+  const int c8 = (tid & 31) * 8;
+  const int gn0 = n0 + c8;
+  const int ncols = max(0, min(8, p.N - gn0));
+  float bv[8], cs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && e < ncols) ? p.bias[gn0 + e] : 0.f; cs[e] = 0.f; }
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if (wr == half) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ct[(i * 16 + 4 * fq + r) * 256 + wc * 64 + j * 16 + fr] = acc[i][j][r];
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 8 && ncols > 0; ++pass) {
+      const int rr = pass * 16 + (tid >> 5);
+      const int gm = m0 + half * 128 + rr;
+      if (gm >= p.M) break;
+      float v[8];
+      const f32x4 lo = *(const f32x4*)(ct + rr * 256 + c8);
+      const f32x4 hi = *(const f32x4*)(ct + rr * 256 + c8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+      epi_piece<T>(p, v, bv, cs, gm, gn0, ncols);
+    }
+  }
+  if (p.colsum) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ct[(tid >> 5) * 256 + c8 + e] = cs[e];
+    __syncthreads();
+    if (tid < 256 && n0 + tid < p.N) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tsum += ct[k * 256 + tid];
+      atomicAdd(p.colsum + n0 + tid, tsum);
     }
   }
 }
@@ -436,6 +578,20 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
                     set_lds_once((const void*)gemm_nt_kernel<bf16, 8>) | set_lds_once((const void*)gemm_nt_kernel<float, 8>);
   (void)once;
   const bool w8 = (flags & GF_WAVES4) == 0;
+  // 256x256 4-stage kernel: measured faster only where K is long and the grid fills the chip with 1 workgroup per CU
+  // (3x3 convolutions: +9..16 %); on short-K Linear shapes the 2-workgroups-per-CU 128x128 kernel hides its epilogue
+  // behind the neighbour's main loop and wins (profiles/r01_v5_gemm_shapes.txt).
+  const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+  bool big = dtype == 0 && Kseg % 32 == 0 && S >= 4 && (long)Kseg * S >= 2048 && N >= 256 && big_tiles >= 256 &&
+             !(flags & (GF_NOBIG | GF_WAVES4));
+  if ((flags & GF_BIG) && dtype == 0 && Kseg % 32 == 0) big = true;
+  if (big) {
+    static int once_big = (int)hipFuncSetAttribute((const void*)gemm_nt_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)once_big;
+    hipLaunchKernelGGL(gemm_nt_big_kernel, dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
+    STSWIN_CHECK_LAUNCH();
+    return 0;
+  }
   if (dtype == 0) {
     if (w8) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8>), dim3(nblk), dim3(512), 65536, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_nt_kernel<bf16, 4>), dim3(nblk), dim3(256), 65536, (hipStream_t)stream, p);
