@@ -475,7 +475,9 @@ static int ln_bwd_launch(const void* dy, long lddy, const void* x, long ldx, con
                          int M, int acc, float* dxsum, hipStream_t st) {
   constexpr int PACK = TT<T>::PACK;
   const int C = S * Cseg, np = (C / PACK + 63) / 64;
-  const int rpw = 32;
+  // 8 rows per wave: >= 4 waves per SIMD at M = 32768 (the serial row loop with two wave reductions per row is
+  // latency-bound); the dgamma/dbeta atomics grow to M/32 per column, still negligible
+  const int rpw = M >= 16384 ? 8 : (M >= 4096 ? 4 : 2);
   dim3 grid((M + 4 * rpw - 1) / (4 * rpw)), blk(256);
   const size_t lds = (size_t)8 * C * sizeof(float);
 #define LN_B(NP) hipLaunchKernelGGL((ln_bwd_kernel<T, NP>), grid, blk, lds, st, (const T*)dy, lddy, (const T*)x, ldx, rows, S, Cseg, g, mean, rstd, (T*)dx, lddx, dg, db, M, rpw, acc, dxsum)

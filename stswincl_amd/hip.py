@@ -268,8 +268,9 @@ def win_attn_bwd(qkv, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, s
 def colstats(x, groups=1, squares=True, M=None):
     M = x.shape[0] if M is None else M
     C = x.shape[1]
-    s = torch.zeros(groups, C, dtype=torch.float32, device=x.device)
-    ss = torch.zeros(groups, C, dtype=torch.float32, device=x.device) if squares else None
+    both = torch.zeros(2 if squares else 1, groups, C, dtype=torch.float32, device=x.device)   # one fill launch
+    s = both[0]
+    ss = both[1] if squares else None
     _check(load().stswin_colstats(_dt(x), _p(x), _c_long(_ld(x)), _p(s), _p(ss), M, C, groups, _stream()), "colstats")
     return s, ss
 
@@ -298,8 +299,8 @@ def bn_bwd(dy, x, y, mean, rstd, gamma, dx, dresid=None, groups=1, relu=True, tr
     M = x.shape[0] if M is None else M
     C = x.shape[1]
     if sums is None:
-        s1 = torch.zeros(groups, C, dtype=torch.float32, device=x.device)
-        s2 = torch.zeros(groups, C, dtype=torch.float32, device=x.device)
+        both = torch.zeros(2, groups, C, dtype=torch.float32, device=x.device)
+        s1, s2 = both[0], both[1]
     else:
         s1, s2 = sums
     _check(load().stswin_bn_bwd(_dt(x), _p(dy), _c_long(_ld(dy)), _p(x), _c_long(_ld(x)), _p(y),
