@@ -200,13 +200,14 @@ def main():
 
     S, B = a.size, a.batch
     torch.manual_seed(0)
-    model = TswinPlus(12, (S // 8, S // 8)).to(dev).to(memory_format=torch.channels_last)
+    model = TswinPlus(12, (S // 8, S // 8)).to(dev)
     model.train()
     if world > 1:   # identical initial weights on every rank
         for p in model.parameters():
             dist.broadcast(p.data, 0)
     use_graph = a.graph == 1 or (a.graph == -1 and world == 1 and a.no_profile)
-    opt = torch.optim.Adam(model.parameters(), 1e-4, capturable=use_graph)
+    from stswincl_amd.optim import FusedAdam
+    opt = FusedAdam(model.parameters(), 1e-4)          # == torch.optim.Adam (tests/test_hip_optim.py), 8 launches per step
     crit = OhemCELoss2D(S * S // 16)
     reducer = GradBucketReducer(model.parameters(), bucket_mb=64.0) if world > 1 else None
     torch.manual_seed(1234 + rank)            # each rank owns different clips (weak scaling)

@@ -140,6 +140,13 @@ int stswin_ce_bwd(int dtype, const void* logits, const long* labels, const float
 int stswin_contrast_fwd(int dtype, const void* Q, long ldq, const void* const* K5, long ldk, const int* lq,
                         const int* const* lk5, float* pos, float* all, int N, int HW, int C, void* stream);
 
+/* ---- f2: multi-tensor optimizer / EMA step, up to 48 fp32 tensors per launch (host arrays of device pointers).
+ * mode 0 = torch.optim.Adam (seg18/train_swin.py:122; c1 = 1 - b1^t, c2 = sqrt(1 - b2^t)), 1 = torch.optim.SGD with
+ * momentum b1 (train_CL_ft_mswin_sgd_minput.py:147-162; c1 != 0 marks the first step: buf = grad), 2 = EMA
+ * p = p*b1 + g*(1-b1) with g = the query parameter (PixPro_swin_v5.py:258-289). */
+int stswin_multi_tensor(int mode, int count, void* const* p, const void* const* g, void* const* m, void* const* v,
+                        const int* n, float lr, float b1, float b2, float eps, float wd, float c1, float c2, void* stream);
+
 /* ---- device self-test of the MFMA / LDS primitives the kernels are built on; writes a report into `out`
  * (fp32, >= 64 KiB) and returns the number of failed checks (0 = all good). Used by tests only. */
 int stswin_selftest(float* out, int which, void* stream);

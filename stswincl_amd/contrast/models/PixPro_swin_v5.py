@@ -196,7 +196,7 @@ class PixPro(nn.Module):
 
     @torch.no_grad()
     def _momentum_update_key_encoder(self):
-        """k <- k m + q (1-m), m = 1 - (1-m0)(cos(pi k/K)+1)/2 (PixPro_swin_v5.py:258-289), as two multi-tensor launches."""
+        """k <- k m + q (1-m), m = 1 - (1-m0)(cos(pi k/K)+1)/2 (PixPro_swin_v5.py:258-289), on the multi-tensor HIP kernel."""
         m = 1. - (1. - self.pixpro_momentum) * (math.cos(math.pi * self.k / self.K) + 1) / 2.
         self.k = self.k + 1
         qs, ks = [], []
@@ -204,8 +204,8 @@ class PixPro(nn.Module):
             for pq, pk in zip(q_mod.parameters(), k_mod.parameters()):
                 qs.append(pq.data)
                 ks.append(pk.data)
-        torch._foreach_mul_(ks, m)
-        torch._foreach_add_(ks, qs, alpha=1. - m)
+        from ...optim import ema_update
+        ema_update(ks, qs, m)
 
     def _embed(self, seq, key: bool):
         e1, e2, e3, p1, p2, p3, head = ((self.encoder_k_1, self.encoder_k_2, self.encoder_k_3, self.proj_k_1, self.proj_k_2,

@@ -1,0 +1,103 @@
+// Multi-tensor optimizer / EMA kernels: one launch updates up to 48 parameter tensors.
+// The reference steps Adam (seg18/train_swin.py:122), SGD with momentum (train_CL_ft_mswin_sgd_minput.py:147-162,
+// main_pretrain_swinv5.py:37-45 under LARS) and a Python loop of ~370 EMA updates (PixPro_swin_v5.py:258-289).
+// Pointer tables travel in the kernel arguments (no device-side table to rebuild when autograd hands out new gradient
+// tensors every step); a block finds its (tensor, chunk) by scanning the <= 48 chunk counts.
+#include "common.h"
+
+#define MT_MAX 48
+#define MT_CHUNK 8192          // elements per block
+
+struct MTArgs {
+  float* p[MT_MAX];            // parameter (fp32)            | EMA: key parameter
+  const float* g[MT_MAX];      // gradient (fp32)             | EMA: query parameter
+  float* m[MT_MAX];            // Adam exp_avg / SGD momentum buffer
+  float* v[MT_MAX];            // Adam exp_avg_sq
+  int n[MT_MAX];               // elements
+  int count;
+  float lr, b1, b2, eps, wd, c1, c2;   // c1 = 1 - b1^t, c2 = sqrt(1 - b2^t) (Adam); EMA: b1 = momentum
+  int mode;                    // 0 Adam, 1 SGD (momentum b1, dampening 0, nesterov off; first = c1 != 0), 2 EMA
+};
+
+__global__ __launch_bounds__(256) void multi_tensor_kernel(MTArgs a) {
+  int b = blockIdx.x, t = 0;
+  for (; t < a.count; ++t) {
+    const int nb = (a.n[t] + MT_CHUNK - 1) / MT_CHUNK;
+    if (b < nb) break;
+    b -= nb;
+  }
+  if (t >= a.count) return;
+  const int n = a.n[t];
+  float* __restrict__ p = a.p[t];
+  const float* __restrict__ g = a.g[t];
+  float* __restrict__ m = a.m[t];
+  float* __restrict__ v = a.v[t];
+  const int base = b * MT_CHUNK;
+  const int end = min(n, base + MT_CHUNK);
+  for (int i = base + threadIdx.x * 4; i < end; i += 256 * 4) {
+    const int cnt = min(4, end - i);
+    float pv[4], gv[4], mv[4], vv[4];
+    const bool vec = cnt == 4 && ((((uintptr_t)(p + i)) | ((uintptr_t)(g + i))) & 15) == 0 &&
+                     (a.mode == 2 || ((((uintptr_t)(m + i)) & 15) == 0 && (a.mode == 1 || (((uintptr_t)(v + i)) & 15) == 0)));
+    if (vec) {
+      *(f32x4*)pv = *(const f32x4*)(p + i);
+      *(f32x4*)gv = *(const f32x4*)(g + i);
+      if (a.mode != 2) *(f32x4*)mv = *(const f32x4*)(m + i);
+      if (a.mode == 0) *(f32x4*)vv = *(const f32x4*)(v + i);
+    } else {
+      for (int e = 0; e < cnt; ++e) {
+        pv[e] = p[i + e]; gv[e] = g[i + e];
+        if (a.mode != 2) mv[e] = m[i + e];
+        if (a.mode == 0) vv[e] = v[i + e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e >= cnt) break;
+      if (a.mode == 0) {                       // torch.optim.Adam (no amsgrad; L2 weight decay added to the gradient)
+        float gr = gv[e] + a.wd * pv[e];
+        mv[e] = a.b1 * mv[e] + (1.f - a.b1) * gr;
+        vv[e] = a.b2 * vv[e] + (1.f - a.b2) * gr * gr;
+        const float denom = sqrtf(vv[e]) / a.c2 + a.eps;
+        pv[e] -= (a.lr / a.c1) * (mv[e] / denom);
+      } else if (a.mode == 1) {                // torch.optim.SGD with momentum
+        float gr = gv[e] + a.wd * pv[e];
+        mv[e] = (a.c1 != 0.f) ? gr : a.b1 * mv[e] + gr;     // first step: buf = grad
+        pv[e] -= a.lr * (a.b1 != 0.f ? mv[e] : gr);
+      } else {                                 // EMA: key = key * m + query * (1 - m)
+        pv[e] = pv[e] * a.b1 + gv[e] * (1.f - a.b1);
+      }
+    }
+    if (vec) {
+      *(f32x4*)(p + i) = *(const f32x4*)pv;
+      if (a.mode != 2) *(f32x4*)(m + i) = *(const f32x4*)mv;
+      if (a.mode == 0) *(f32x4*)(v + i) = *(const f32x4*)vv;
+    } else {
+      for (int e = 0; e < cnt; ++e) {
+        p[i + e] = pv[e];
+        if (a.mode != 2) m[i + e] = mv[e];
+        if (a.mode == 0) v[i + e] = vv[e];
+      }
+    }
+  }
+}
+
+// ptrs: host arrays of `count` device pointers (count <= 48 per call; the caller chunks).
+extern "C" int stswin_multi_tensor(int mode, int count, void* const* p, const void* const* g, void* const* m, void* const* v,
+                                   const int* n, float lr, float b1, float b2, float eps, float wd, float c1, float c2,
+                                   void* stream) {
+  if (count <= 0) return 0;
+  if (count > MT_MAX || mode < 0 || mode > 2) return -1601;
+  MTArgs a;
+  long blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    a.p[i] = (float*)p[i]; a.g[i] = (const float*)g[i];
+    a.m[i] = m ? (float*)m[i] : nullptr; a.v[i] = v ? (float*)v[i] : nullptr;
+    a.n[i] = n[i];
+    blocks += (n[i] + MT_CHUNK - 1) / MT_CHUNK;
+  }
+  a.count = count; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = wd; a.c1 = c1; a.c2 = c2; a.mode = mode;
+  hipLaunchKernelGGL(multi_tensor_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}

@@ -364,6 +364,23 @@ def contrast_fwd(q, keys, lq, lks, N, HW):
     return pos, tot
 
 
+def multi_tensor(mode, ps, gs, ms=None, vs=None, lr=0.0, b1=0.0, b2=0.0, eps=0.0, wd=0.0, c1=1.0, c2=1.0):
+    """mode 0 Adam / 1 SGD-momentum / 2 EMA over lists of fp32 tensors (chunks of 48 tensors per launch)."""
+    lib = load()
+    st = _stream()
+    for t in ps:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise StswinHipError("multi_tensor needs contiguous fp32 GPU tensors")
+    for lo in range(0, len(ps), 48):
+        hi = min(len(ps), lo + 48)
+        k = hi - lo
+        arr = lambda ts: (_c_void_p * k)(*[t.data_ptr() for t in ts[lo:hi]]) if ts is not None else None  # noqa: E731
+        ns = (_c_int * k)(*[t.numel() for t in ps[lo:hi]])
+        _check(lib.stswin_multi_tensor(mode, k, arr(ps), arr(gs), arr(ms), arr(vs), ns, _c_float(lr), _c_float(b1),
+                                       _c_float(b2), _c_float(eps), _c_float(wd), _c_float(c1), _c_float(c2), st),
+               "multi_tensor")
+
+
 def selftest(which: int) -> torch.Tensor:
     out = torch.zeros(16384, dtype=torch.float32, device="cuda")
     if which == 5:

@@ -1,0 +1,80 @@
+"""Optimizers of the reference's training scripts on the multi-tensor HIP kernel (csrc/optim.hip).
+
+``FusedAdam`` == torch.optim.Adam(params, lr, betas, eps, weight_decay) as used by seg18/train_swin.py:122;
+``FusedSGD``  == torch.optim.SGD(params, lr, momentum, weight_decay) with per-group lr / weight_decay
+                 (train_CL_ft_mswin_sgd_minput.py:147-162; the LARS wrapper of the contrastive stage is still torch);
+``ema_update``== PixPro._momentum_update_key_encoder (PixPro_swin_v5.py:258-289) in ~8 launches instead of ~370x2.
+"""
+from __future__ import annotations
+
+import math
+from typing import Iterable, Sequence
+
+import torch
+
+from . import hip
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            ps, gs, ms, vs = [], [], [], []
+            b1, b2 = group["betas"]
+            step = None
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                step = st["step"]
+                ps.append(p.data)
+                gs.append(p.grad.contiguous() if not p.grad.is_contiguous() else p.grad)
+                ms.append(st["exp_avg"])
+                vs.append(st["exp_avg_sq"])
+            if ps:
+                hip.multi_tensor(0, ps, gs, ms, vs, lr=group["lr"], b1=b1, b2=b2, eps=group["eps"], wd=group["weight_decay"],
+                                 c1=1.0 - b1 ** step, c2=math.sqrt(1.0 - b2 ** step))
+        return loss
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            first, later = ([], [], []), ([], [], [])
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                g = p.grad.contiguous() if not p.grad.is_contiguous() else p.grad
+                if "momentum_buffer" not in st:
+                    st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    tgt = first
+                else:
+                    tgt = later
+                tgt[0].append(p.data)
+                tgt[1].append(g)
+                tgt[2].append(st["momentum_buffer"])
+            for (ps, gs, ms), c1 in ((first, 1.0), (later, 0.0)):
+                if ps:
+                    hip.multi_tensor(1, ps, gs, ms, None, lr=group["lr"], b1=group["momentum"], wd=group["weight_decay"], c1=c1)
+        return loss
+
+
+@torch.no_grad()
+def ema_update(keys: Sequence[torch.Tensor], queries: Sequence[torch.Tensor], momentum: float) -> None:
+    """key <- key * momentum + query * (1 - momentum) for every pair."""
+    hip.multi_tensor(2, [k.data for k in keys], [q.data for q in queries], b1=momentum)
