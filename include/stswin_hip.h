@@ -140,6 +140,12 @@ int stswin_ce_bwd(int dtype, const void* logits, const long* labels, const float
 int stswin_contrast_fwd(int dtype, const void* Q, long ldq, const void* const* K5, long ldk, const int* lq,
                         const int* const* lk5, float* pos, float* all, int N, int HW, int C, void* stream);
 
+/* ---- f4: inference post-processing (seg18/test.py:153-158 + utils/EndoMetric.py): labels[f][y][x] = argmax_c of the
+ * bilinear (align_corners = True) resize of NCHW logits [F][nc][h][w] to (H, W); with gt (int64 [F][H][W]) also
+ * counts[f][0|1|2][c] = |gt == c|, |pred == c|, |gt == c and pred == c|  (int32, zeroed by the caller). */
+int stswin_upsample_argmax(int dtype, const void* logits, unsigned char* labels, const long* gt, int* counts, int frames,
+                           int nc, int h, int w, int H, int W, void* stream);
+
 /* ---- f2: multi-tensor optimizer / EMA step, up to 48 fp32 tensors per launch (host arrays of device pointers).
  * mode 0 = torch.optim.Adam (seg18/train_swin.py:122; c1 = 1 - b1^t, c2 = sqrt(1 - b2^t)), 1 = torch.optim.SGD with
  * momentum b1 (train_CL_ft_mswin_sgd_minput.py:147-162; c1 != 0 marks the first step: buf = grad), 2 = EMA

@@ -17,6 +17,8 @@ _ALIASES = {
     "net.Ours.ASPP": "stswincl_amd.net.Ours.ASPP",
     "net.Ours.resnet": "stswincl_amd.net.Ours.resnet",
     "utils.losses": "stswincl_amd.utils.losses",
+    "utils.LoadModel": "stswincl_amd.utils.LoadModel",
+    "utils.EndoMetric": "stswincl_amd.utils.EndoMetric",
     "contrast.models.PixPro_swin_v5": "stswincl_amd.contrast.models.PixPro_swin_v5",
     "contrast.models.Ours.base": "stswincl_amd.contrast.models.Ours.base",
     "contrast.models.Ours.swin_tem": "stswincl_amd.net.Ours.swin_512",

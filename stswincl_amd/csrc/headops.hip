@@ -564,3 +564,62 @@ extern "C" int stswin_ce_bwd(int dtype, const void* logits, const long* labels, 
   STSWIN_CHECK_LAUNCH();
   return 0;
 }
+
+// ----------------------------------------------------------------------------------------- f4: inference post-processing
+// seg18/test.py:153-158: F.interpolate(out, (H, W), bilinear, align_corners=True) -> softmax -> argmax, then Dice / IoU
+// (utils/EndoMetric.py).  One pass: interpolate the nc logits of an output pixel in registers, take the arg-max (softmax
+// is monotone, so it is skipped), write the label, and - when ground truth is given - count per frame and class
+// |gt == c|, |pred == c| and |gt == c and pred == c| (LDS histogram per block, one atomic per non-zero bin).
+template <typename TL>
+__global__ __launch_bounds__(256) void upsample_argmax_kernel(const TL* logits, unsigned char* labels, const long* gt,
+                                                              int* counts, int F, int nc, int h, int w, int H, int W) {
+  __shared__ int hist[3 * 64];
+  for (int i = threadIdx.x; i < 3 * 64; i += 256) hist[i] = 0;
+  __syncthreads();
+  const long per_frame = (long)H * W;
+  const long blocks_per_frame = (per_frame + 255) / 256;
+  const int f = blockIdx.x / blocks_per_frame;
+  const long px = (blockIdx.x % blocks_per_frame) * 256 + threadIdx.x;
+  if (px < per_frame) {
+    const int x = px % W, y = px / W;
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const float fy = y * sy, fx = x * sx;
+    const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float wy = fy - y0, wx = fx - x0;
+    const TL* b = logits + (long)f * nc * h * w;
+    float best = -3.0e38f; int arg = 0;
+    for (int c = 0; c < nc; ++c) {
+      const TL* pl = b + (long)c * h * w;
+      const float v = (1.f - wy) * ((1.f - wx) * to_f32<TL>(pl[y0 * w + x0]) + wx * to_f32<TL>(pl[y0 * w + x1])) +
+                      wy * ((1.f - wx) * to_f32<TL>(pl[y1 * w + x0]) + wx * to_f32<TL>(pl[y1 * w + x1]));
+      if (v > best) { best = v; arg = c; }
+    }
+    labels[(long)f * per_frame + px] = (unsigned char)arg;
+    if (gt) {
+      const int g = (int)gt[(long)f * per_frame + px];
+      if (g >= 0 && g < 64) atomicAdd(&hist[g], 1);
+      atomicAdd(&hist[64 + arg], 1);
+      if (g == arg) atomicAdd(&hist[128 + arg], 1);
+    }
+  }
+  if (gt) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * 64; i += 256) {
+      const int k = i / 64, c = i % 64;
+      if (c < nc && hist[i]) atomicAdd(counts + ((long)f * 3 + k) * nc + c, hist[i]);
+    }
+  }
+}
+
+extern "C" int stswin_upsample_argmax(int dtype, const void* logits, unsigned char* labels, const long* gt, int* counts,
+                                      int frames, int nc, int h, int w, int H, int W, void* stream) {
+  if (nc <= 0 || nc > 64) return -1406;
+  const long bpf = ((long)H * W + 255) / 256;
+  dim3 grid((unsigned)(bpf * frames));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL(upsample_argmax_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)logits, labels, gt, counts, frames, nc, h, w, H, W);
+  else hipLaunchKernelGGL(upsample_argmax_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, labels, gt, counts, frames, nc, h, w, H, W);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}

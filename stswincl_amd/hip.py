@@ -364,6 +364,17 @@ def contrast_fwd(q, keys, lq, lks, N, HW):
     return pos, tot
 
 
+def upsample_argmax(logits, H, W, gt=None):
+    """NCHW logits [F][nc][h][w] -> uint8 labels [F][H][W] (+ int32 counts [F][3][nc] when gt int64 [F][H][W] is given)."""
+    F_, nc, h, w = logits.shape
+    lg = logits.contiguous()
+    labels = torch.empty(F_, H, W, dtype=torch.uint8, device=logits.device)
+    counts = torch.zeros(F_, 3, nc, dtype=torch.int32, device=logits.device) if gt is not None else None
+    _check(load().stswin_upsample_argmax(_dt(lg), _p(lg), _p(labels), _p(gt.contiguous() if gt is not None else None),
+                                         _p(counts), F_, nc, h, w, H, W, _stream()), "upsample_argmax")
+    return labels, counts
+
+
 def multi_tensor(mode, ps, gs, ms=None, vs=None, lr=0.0, b1=0.0, b2=0.0, eps=0.0, wd=0.0, c1=1.0, c2=1.0):
     """mode 0 Adam / 1 SGD-momentum / 2 EMA over lists of fp32 tensors (chunks of 48 tensors per launch)."""
     lib = load()
