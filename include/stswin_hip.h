@@ -28,6 +28,7 @@ extern "C" {
 #define STSWIN_GF_ACCUM 16     /* C += v (needs OUT_F32) */
 #define STSWIN_GF_RELU 32
 #define STSWIN_GF_BIG 128       /* tuning: force the 256x256 4-stage-ring kernel (bf16) */
+#define STSWIN_GF_MID 512       /* tuning: 256x128x32 tile, 3-stage ring, 2 workgroups per CU (bf16) */
 #define STSWIN_GF_NOBIG 256     /* tuning: forbid it (default: chosen when >= 256 big tiles fill the chip) */
 #define STSWIN_GF_WAVES4 64     /* tuning: 4 waves of 64x64 per 128x128 tile instead of the default 8 waves of 64x32 */
 

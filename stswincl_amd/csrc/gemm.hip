@@ -24,6 +24,7 @@ enum {
   GF_RELU = 32,
   GF_BIG = 128,      // tuning: force the 256x256 4-stage kernel (bf16)
   GF_NOBIG = 256,    // tuning: forbid it
+  GF_MID = 512,      // tuning: 256x128x32 tile, 3-stage ring, 2 workgroups per CU
   GF_WAVES4 = 64,    // tuning: 4 waves of 64x64 per tile instead of the default 8 waves of 64x32 (4 waves/SIMD)
 };
 
@@ -290,30 +291,53 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
 // =====================================================================================================
 DEVI int swz64(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
-__global__ __launch_bounds__(512) void gemm_nt_big_kernel(GemmNT p) {
+template <int N> DEVI void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else static_assert(N == 0, "add the literal");
+}
+
+// BM x BN x 32 tile, 8 waves as WM x WN, NST-stage ring (prefetch distance NST-1), epilogue in EH row slabs.
+//   <256,256,2,4,4>: 128 KB LDS, 1 workgroup / CU (128 FLOP per L2 byte)
+//   <256,128,4,2,3>:  72 KB LDS, 2 workgroups / CU (87 FLOP per L2 byte; the neighbour's main loop hides the epilogue)
+template <int BM, int BN, int WM, int WN, int NST, int MINW>
+__global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
   using T = bf16;
-  constexpr int BK = 32, ROWB = 64, STAGE = 32768;
+  constexpr int BK = 32, ROWB = 64;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  constexpr int TM = BM / WM, TN = BN / WN;          // wave tile
+  constexpr int FI = TM / 16, FJ = TN / 16;          // fragments per wave
+  constexpr int NIA = BM / 16 / 8, NIB = BN / 16 / 8; // LDS-DMA instructions per wave per stage (16 rows each)
+  constexpr int PER_STAGE = NIA + NIB;
+  constexpr int EROWS = (NST * STAGE) / (BN * 4) >= BM ? BM : ((NST * STAGE) / (BN * 4) / TM) * TM;   // rows per epilogue slab
+  static_assert(EROWS >= TM && BM % EROWS == 0, "epilogue slab");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, l = tid & 63, w = wave_id();
-  const int wr = w >> 2, wc = w & 3;
-  const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + 255) >> 8;
+  const int wr = w / WN, wc = w % WN;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (t / tiles_n) << 8, n0 = (t % tiles_n) << 8;
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
 
   const char* zero = (const char*)g_stswin_zero;
-  const int rsub = l >> 2, cphys = l & 3, csrc = cphys ^ swz64(rsub);   // rows (w*2+i)*16 + rsub: (row>>2)&3 == (rsub>>2)&3
-  const char* abase[2]; int astep[2];
-  const char* bbase[2]; int bstep[2];
+  const int rsub = l >> 2, cphys = l & 3, csrc = cphys ^ swz64(rsub);
+  const char* abase[NIA]; int astep[NIA];
+  const char* bbase[NIB]; int bstep[NIB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int gn = n0 + (w * 2 + i) * 16 + rsub;
+  for (int i = 0; i < NIB; ++i) {
+    const int gn = n0 + (w * NIB + i) * 16 + rsub;
     if (gn < p.N) { bbase[i] = (const char*)p.B + ((long)gn * p.ldb) * sizeof(T) + csrc * 16; bstep[i] = BK * sizeof(T); }
     else { bbase[i] = zero + cphys * 16; bstep[i] = 0; }
   }
   auto load_a_bases = [&](int seg) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int gm = m0 + (w * 2 + i) * 16 + rsub;
+    for (int i = 0; i < NIA; ++i) {
+      const int gm = m0 + (w * NIA + i) * 16 + rsub;
       long row = -1;
       if (gm < p.M) row = p.a_rows ? (long)p.a_rows[(long)seg * p.M + gm] : (long)gm;
       if (row >= 0) { abase[i] = (const char*)p.A + (row * p.lda) * sizeof(T) + csrc * 16; astep[i] = BK * sizeof(T); }
@@ -323,75 +347,79 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(GemmNT p) {
   const int kps = p.Kseg / BK;
   const int nt = p.S * kps;
   int seg = -1;
-  auto issue = [&](int q) {                      // request K tile q into ring slot q & 3
+  auto issue = [&](int q) {
     const int sg = q / kps;
     if (sg != seg) { seg = sg; load_a_bases(sg); }
     const int kt = q - sg * kps;
-    char* Ab = smem + (q & 3) * STAGE;
-    char* Bb = Ab + 16384;
+    char* Ab = smem + (q % NST) * STAGE;
+    char* Bb = Ab + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(abase[i] + (long)kt * astep[i], Ab + (w * 2 + i) * 1024);
+    for (int i = 0; i < NIA; ++i) glds16(abase[i] + (long)kt * astep[i], Ab + (w * NIA + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(bbase[i] + (long)q * bstep[i], Bb + (w * 2 + i) * 1024);
+    for (int i = 0; i < NIB; ++i) glds16(bbase[i] + (long)q * bstep[i], Bb + (w * NIB + i) * 1024);
   };
 
-  f32x4 acc[8][4];
+  f32x4 acc[FI][FJ];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < FI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fr = l & 15, fq = l >> 4;
-  const int rd_off = fr * ROWB + ((fq ^ swz64(fr)) << 4);   // same for every 16-row fragment (bases are multiples of 16)
-  for (int q = 0; q < 3 && q < nt; ++q) issue(q);
+  const int rd_off = fr * ROWB + ((fq ^ swz64(fr)) << 4);
+  for (int q = 0; q < NST - 1 && q < nt; ++q) issue(q);
   for (int kt = 0; kt < nt; ++kt) {
-    const int newer = nt - 1 - kt;               // tiles requested after tile kt that may still be in flight
-    if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                // tile kt landed for every wave; slot (kt+3)&3 == (kt-1)&3 is free
-    if (kt + 3 < nt) issue(kt + 3);
-    const char* Ab = smem + (kt & 3) * STAGE;
-    const char* Bb = Ab + 16384;
-    bf16x8 a[8], b[4];
+    const int newer = min(NST - 2, nt - 1 - kt);     // later tiles that may stay in flight
+    if (newer >= 2) wait_vmcnt<2 * PER_STAGE>();
+    else if (newer == 1) wait_vmcnt<PER_STAGE>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + NST - 1 < nt) issue(kt + NST - 1);
+    const char* Ab = smem + (kt % NST) * STAGE;
+    const char* Bb = Ab + A_BYTES;
+    bf16x8 a[FI], b[FJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(Bb + (wc * 64 + j * 16) * ROWB + rd_off);
+    for (int j = 0; j < FJ; ++j) b[j] = *(const bf16x8*)(Bb + (wc * TN + j * 16) * ROWB + rd_off);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = *(const bf16x8*)(Ab + (wr * 128 + i * 16) * ROWB + rd_off);
+    for (int i = 0; i < FI; ++i) a[i] = *(const bf16x8*)(Ab + (wr * TM + i * 16) * ROWB + rd_off);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < FI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   }
 
-  // ---------------- epilogue: two 128-row halves through a [128][256] fp32 LDS image ----------------
+  // ---------------- epilogue: BM / EROWS slabs of [EROWS][BN] fp32 through the ring memory ----------------
   float* ct = (float*)smem;
-  const int c8 = (tid & 31) * 8;
+  constexpr int CG = BN / 8;                        // column groups of 8
+  constexpr int RGP = 512 / CG;                     // rows per pass
+  const int c8 = (tid % CG) * 8;
   const int gn0 = n0 + c8;
   const int ncols = max(0, min(8, p.N - gn0));
   float bv[8], cs[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && e < ncols) ? p.bias[gn0 + e] : 0.f; cs[e] = 0.f; }
-  for (int half = 0; half < 2; ++half) {
+#pragma unroll 1
+  for (int slab = 0; slab < BM / EROWS; ++slab) {
     __syncthreads();
-    if (wr == half) {
+    if (wr * TM >= slab * EROWS && wr * TM < (slab + 1) * EROWS) {
+      const int rbase = wr * TM - slab * EROWS;
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < FJ; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ct[(i * 16 + 4 * fq + r) * 256 + wc * 64 + j * 16 + fr] = acc[i][j][r];
+          for (int r = 0; r < 4; ++r) ct[(rbase + i * 16 + 4 * fq + r) * BN + wc * TN + j * 16 + fr] = acc[i][j][r];
     }
     __syncthreads();
-    for (int pass = 0; pass < 8 && ncols > 0; ++pass) {
-      const int rr = pass * 16 + (tid >> 5);
-      const int gm = m0 + half * 128 + rr;
+    for (int pass = 0; pass < EROWS / RGP && ncols > 0; ++pass) {
+      const int rr = pass * RGP + tid / CG;
+      const int gm = m0 + slab * EROWS + rr;
       if (gm >= p.M) break;
       float v[8];
-      const f32x4 lo = *(const f32x4*)(ct + rr * 256 + c8);
-      const f32x4 hi = *(const f32x4*)(ct + rr * 256 + c8 + 4);
+      const f32x4 lo = *(const f32x4*)(ct + rr * BN + c8);
+      const f32x4 hi = *(const f32x4*)(ct + rr * BN + c8 + 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
       epi_piece<T>(p, v, bv, cs, gm, gn0, ncols);
@@ -400,12 +428,12 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(GemmNT p) {
   if (p.colsum) {
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ct[(tid >> 5) * 256 + c8 + e] = cs[e];
+    for (int e = 0; e < 8; ++e) ct[(tid / CG) * BN + c8 + e] = cs[e];
     __syncthreads();
-    if (tid < 256 && n0 + tid < p.N) {
+    if (tid < BN && n0 + tid < p.N) {
       float tsum = 0.f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) tsum += ct[k * 256 + tid];
+      for (int k = 0; k < RGP; ++k) tsum += ct[k * BN + tid];
       atomicAdd(p.colsum + n0 + tid, tsum);
     }
   }
@@ -585,10 +613,20 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
   bool big = dtype == 0 && Kseg % 32 == 0 && S >= 4 && (long)Kseg * S >= 2048 && N >= 256 && big_tiles >= 256 &&
              !(flags & (GF_NOBIG | GF_WAVES4));
   if ((flags & GF_BIG) && dtype == 0 && Kseg % 32 == 0) big = true;
-  if (big) {
-    static int once_big = (int)hipFuncSetAttribute((const void*)gemm_nt_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  const bool mid_ok = dtype == 0 && Kseg % 32 == 0 && !(flags & (GF_NOBIG | GF_WAVES4));
+  const bool mid = (flags & GF_MID) && mid_ok;
+  if (big && !mid) {
+    static int once_big = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)once_big;
-    hipLaunchKernelGGL(gemm_nt_big_kernel, dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
+    STSWIN_CHECK_LAUNCH();
+    return 0;
+  }
+  if (mid) {
+    static int once_mid = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 128, 4, 2, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+    (void)once_mid;
+    const long mid_tiles = (long)((M + 255) / 256) * ((N + 127) / 128);
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 128, 4, 2, 3, 4>), dim3((unsigned)mid_tiles), dim3(512), 73728, (hipStream_t)stream, p);
     STSWIN_CHECK_LAUNCH();
     return 0;
   }

@@ -38,6 +38,9 @@ def test_gemm_nt_plain_and_bias(dtype, m, n, k):
         outb = torch.full((m, n), float("nan"), dtype=dtype, device="cuda")
         hip.gemm_nt(a.cuda(), w.cuda(), outb, M=m, bias=bias.cuda(), flags=hip.GF_BIG)     # 256x256 4-stage-ring kernel
         _close(outb, F.linear(a.float(), w.float(), bias), dtype, "big kernel")
+        outb.fill_(float("nan"))
+        hip.gemm_nt(a.cuda(), w.cuda(), outb, M=m, bias=bias.cuda(), flags=hip.GF_MID)     # 256x128 3-stage-ring kernel
+        _close(outb, F.linear(a.float(), w.float(), bias), dtype, "mid kernel")
     out32 = torch.zeros(m, n, device="cuda")
     hip.gemm_nt(a.cuda(), w.cuda(), out32, M=m, flags=hip.GF_OUT_F32)
     hip.gemm_nt(a.cuda(), w.cuda(), out32, M=m, flags=hip.GF_OUT_F32 | hip.GF_ACCUM)
@@ -95,7 +98,7 @@ def test_gemm_nt_gather_scatter_segments(dtype):
         outb = torch.zeros(400, n, dtype=dtype, device="cuda")
         cs = torch.zeros(n, device="cuda")
         hip.gemm_nt(a.cuda(), w.cuda(), outb, M=m, a_rows=amap.cuda(), c_rows=cmap.cuda(), resid=r.cuda(),
-                    r_rows=cmap.cuda(), S=s, flags=hip.GF_RESID | hip.GF_BIG, colsum_out=cs)
+                    r_rows=cmap.cuda(), S=s, flags=hip.GF_RESID | hip.GF_MID, colsum_out=cs)
         assert torch.allclose(outb.float(), out.float(), atol=2e-2, rtol=2e-2)
         assert torch.allclose(cs.cpu(), outb.float().cpu()[cmap.long()].sum(0), atol=0.5, rtol=2e-2)
     af = a.float()
