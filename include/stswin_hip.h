@@ -73,7 +73,9 @@ int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_rows, const 
  * bseg > 0 (convolution wgrad in one launch): column j of the B operand is column j % bseg of row
  * bt_rows[(j / bseg) * Mk + m], i.e. tap t = j / bseg uses its own row map. */
 int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, const void* Bt, long ldb, const int* bt_rows,
-                   float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg, void* stream);
+                   float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg,
+                   float* workspace /* optional caller-owned scratch: split-K partials are stored there and combined by a
+                                       second kernel instead of fp32 atomics */, long workspace_floats, void* stream);
 /* out[n] += sum_m Y[m][n]  (bias gradients) */
 int stswin_colsum(int dtype, const void* y, long ldy, float* out, int M, int N, void* stream);
 

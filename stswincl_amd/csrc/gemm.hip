@@ -450,6 +450,7 @@ struct GemmTN {
   int Mk, Ni, Nj;
   int splits;                                     // grid.y
   int bseg;                                       // >0: Bt column j reads source column j % bseg of row bt_rows[(j / bseg)*Mk + m]
+  float* slabs;                                   // optional [splits][Ni][Nj] partial results (plain stores) instead of atomics
 };
 
 template <typename T, int NW>
@@ -464,12 +465,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(GemmTN p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, l = tid & 63, w = wave_id();
   const int wr = w / WN, wc = w % WN;
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so `split = bid % splits` (splits is a multiple
+  // of 8 or a power of two <= 8) puts every output tile of one contraction range on ONE XCD: its L2 then serves the
+  // tiles_i + tiles_j fold re-use of the At / Bt row panel instead of all 8 L2s fetching everything from HBM.
   const int tiles_j = (p.Nj + 127) >> 7;
-  const int i0 = (blockIdx.x / tiles_j) << 7, j0 = (blockIdx.x % tiles_j) << 7;
+  const int split_id = blockIdx.x % p.splits, tile_id = blockIdx.x / p.splits;
+  const int i0 = (tile_id / tiles_j) << 7, j0 = (tile_id % tiles_j) << 7;
   // split the contraction range in multiples of BM
   const int ntile_all = (p.Mk + BM - 1) / BM;
   const int per = (ntile_all + p.splits - 1) / p.splits;
-  const int t_begin = blockIdx.y * per, t_end = min(ntile_all, t_begin + per);
+  const int t_begin = split_id * per, t_end = min(ntile_all, t_begin + per);
   if (t_begin >= t_end) return;
 
   const char* zero = (const char*)g_stswin_zero;
@@ -583,8 +588,23 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(GemmTN p) {
       for (int r = 0; r < 4; ++r) {
         const int gi = i0 + wr * 64 + i * 16 + 4 * fq + r;
         const int gj = j0 + wc * (16 * JN) + j * 16 + fr;
-        if (gi < p.Ni && gj < p.Nj) atomicAdd(p.C + (long)gi * p.ldc + gj, acc[i][j][r]);
+        if (gi < p.Ni && gj < p.Nj) {
+          if (p.slabs) p.slabs[((long)split_id * p.Ni + gi) * p.Nj + gj] = acc[i][j][r];
+          else atomicAdd(p.C + (long)gi * p.ldc + gj, acc[i][j][r]);
+        }
       }
+}
+
+// C[i][j] += sum_s slabs[s][i][j]   (the split-K combine: plain stores + this pass cost ~half of 32 MB of fp32 atomics)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, float* C, long ldc, int Ni, int Nj, int splits) {
+  const long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (idx >= (long)Ni * Nj) return;
+  const int i = idx / Nj, j = idx % Nj;           // Nj % 4 == 0
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < splits; ++s) a += *(const f32x4*)(slabs + (long)s * Ni * Nj + idx);
+  float* dst = C + (long)i * ldc + j;
+  if ((ldc & 3) == 0) { *(f32x4*)dst = *(const f32x4*)dst + a; }
+  else { for (int e = 0; e < 4; ++e) dst[e] += a[e]; }
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -643,7 +663,7 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
 
 extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, const void* Bt, long ldb,
                               const int* bt_rows, float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg,
-                              void* stream) {
+                              float* workspace, long workspace_floats, void* stream) {
   if (Mk <= 0 || Ni <= 0 || Nj <= 0) return 0;
   const int splits_flags_w4 = (splits > 0 && (splits & (1 << 30))) ? 1 : 0;   // tuning: bit 30 selects the 4-wave variant
   if (splits > 0) splits &= ~(1 << 30);
@@ -659,10 +679,13 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
     if (splits < 1) splits = 1;
     const int max_by_k = ntile / 8 > 0 ? ntile / 8 : 1;
     if (splits > max_by_k) splits = max_by_k;
+    if (splits >= 8) splits &= ~7;                        // whole splits per XCD
+    else { int p2 = 1; while (p2 * 2 <= splits) p2 *= 2; splits = p2; }
   }
   if (splits > ntile) splits = ntile;
-  GemmTN p{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, splits, bseg};
-  dim3 grid(((Ni + 127) / 128) * ((Nj + 127) / 128), splits);
+  const bool use_slabs = workspace && splits > 1 && (long)splits * Ni * Nj <= workspace_floats;
+  GemmTN p{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, splits, bseg, use_slabs ? workspace : nullptr};
+  dim3 grid(((Ni + 127) / 128) * ((Nj + 127) / 128) * splits);
   static int once = set_lds_once((const void*)gemm_tn_kernel<bf16, 4>) | set_lds_once((const void*)gemm_tn_kernel<float, 4>) |
                     set_lds_once((const void*)gemm_tn_kernel<bf16, 8>) | set_lds_once((const void*)gemm_tn_kernel<float, 8>);
   (void)once;
@@ -673,6 +696,11 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   } else {
     if (w8) hipLaunchKernelGGL((gemm_tn_kernel<float, 8>), grid, dim3(512), 65536, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_tn_kernel<float, 4>), grid, dim3(256), 65536, (hipStream_t)stream, p);
+  }
+  if (use_slabs) {
+    const long n4 = ((long)Ni * Nj + 3) / 4;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, C, ldc,
+                       Ni, Nj, splits);
   }
   STSWIN_CHECK_LAUNCH();
   return 0;

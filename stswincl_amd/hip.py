@@ -203,14 +203,28 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
     return out
 
 
+_TN_WS = {}
+
+
+def _tn_workspace(device, floats=48 * 1024 * 1024):
+    """One scratch buffer per device for the split-K partial slabs (kernels on a stream serialise, so it can be shared)."""
+    ws = _TN_WS.get(device)
+    if ws is None:
+        ws = torch.empty(floats, dtype=torch.float32, device=device)
+        _TN_WS[device] = ws
+    return ws
+
+
 def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: int, at_rows=None, bt_rows=None,
-            splits: int = 0, bseg: int = 0):
+            splits: int = 0, bseg: int = 0, atomics: bool = False):
     """out_f32[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]  (fp32, atomically accumulated)."""
     Ni, Nj = out_f32.shape
     assert out_f32.dtype == torch.float32 and At.dtype == Bt.dtype
+    ws = None if atomics or torch.cuda.is_current_stream_capturing() and At.device not in _TN_WS else _tn_workspace(At.device)
     with _Span("gemm_tn_bf16" if At.dtype == torch.bfloat16 else "gemm_tn_f32", 2.0 * Mk * Ni * Nj):
         rc = load().stswin_gemm_tn(_dt(At), _p(At), _c_long(_ld(At)), _p(at_rows), _p(Bt), _c_long(_ld(Bt)),
-                                   _p(bt_rows), _p(out_f32), _c_long(_ld(out_f32)), Mk, Ni, Nj, splits, bseg, _stream())
+                                   _p(bt_rows), _p(out_f32), _c_long(_ld(out_f32)), Mk, Ni, Nj, splits, bseg, _p(ws),
+                                   _c_long(ws.numel() if ws is not None else 0), _stream())
     _check(rc, "gemm_tn")
     return out_f32
 

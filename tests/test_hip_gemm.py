@@ -118,6 +118,9 @@ def test_gemm_tn(dtype, mk, ni, nj, splits):
     out = torch.ones(ni, nj, device="cuda")
     hip.gemm_tn(at.cuda(), bt.cuda(), out, Mk=mk, splits=splits)
     _close(out, 1 + at.float().t() @ bt.float(), torch.float32 if dtype == torch.float32 else dtype, "tn")
+    out2 = torch.ones(ni, nj, device="cuda")
+    hip.gemm_tn(at.cuda(), bt.cuda(), out2, Mk=mk, splits=splits, atomics=True)      # atomic split-K combine
+    _close(out2, 1 + at.float().t() @ bt.float(), torch.float32 if dtype == torch.float32 else dtype, "tn atomics")
 
 
 @pytest.mark.parametrize("dtype", DT)
