@@ -29,6 +29,7 @@ extern "C" {
 #define STSWIN_GF_RELU 32
 #define STSWIN_GF_BIG 128       /* tuning: force the 256x256 4-stage-ring kernel (bf16) */
 #define STSWIN_GF_MID 512       /* tuning: 256x128x32 tile, 3-stage ring, 2 workgroups per CU (bf16) */
+#define STSWIN_GF_NOPIPE 1024   /* tuning: 256x256 ring kernel without software-pipelined LDS fragment reads */
 #define STSWIN_GF_NOBIG 256     /* tuning: forbid it (default: chosen when >= 256 big tiles fill the chip) */
 #define STSWIN_GF_WAVES4 64     /* tuning: 4 waves of 64x64 per 128x128 tile instead of the default 8 waves of 64x32 */
 

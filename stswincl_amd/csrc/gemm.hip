@@ -14,6 +14,7 @@
 // per K tile.  Epilogue goes through an fp32 LDS image so that stores / residual reads are whole 16-byte
 // row pieces (and so that scatter maps cost nothing).
 #include "common.h"
+#include <type_traits>
 
 enum {
   GF_GELU = 1,       // out = gelu(v); C2 (if any) receives v (pre-activation)
@@ -25,6 +26,7 @@ enum {
   GF_BIG = 128,      // tuning: force the 256x256 4-stage kernel (bf16)
   GF_NOBIG = 256,    // tuning: forbid it
   GF_MID = 512,      // tuning: 256x128x32 tile, 3-stage ring, 2 workgroups per CU
+  GF_NOPIPE = 1024,  // tuning: 256x256 ring without the software-pipelined fragment reads
   GF_WAVES4 = 64,    // tuning: 4 waves of 64x64 per tile instead of the default 8 waves of 64x32 (4 waves/SIMD)
 };
 
@@ -306,7 +308,7 @@ template <int N> DEVI void wait_vmcnt() {
 // BM x BN x 32 tile, 8 waves as WM x WN, NST-stage ring (prefetch distance NST-1), epilogue in EH row slabs.
 //   <256,256,2,4,4>: 128 KB LDS, 1 workgroup / CU (128 FLOP per L2 byte)
 //   <256,128,4,2,3>:  72 KB LDS, 2 workgroups / CU (87 FLOP per L2 byte; the neighbour's main loop hides the epilogue)
-template <int BM, int BN, int WM, int WN, int NST, int MINW>
+template <int BM, int BN, int WM, int WN, int NST, int MINW, bool PIPE>
 __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
   using T = bf16;
   constexpr int BK = 32, ROWB = 64;
@@ -367,75 +369,130 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
 
   const int fr = l & 15, fq = l >> 4;
   const int rd_off = fr * ROWB + ((fq ^ swz64(fr)) << 4);
-  for (int q = 0; q < NST - 1 && q < nt; ++q) issue(q);
-  for (int kt = 0; kt < nt; ++kt) {
-    const int newer = min(NST - 2, nt - 1 - kt);     // later tiles that may stay in flight
-    if (newer >= 2) wait_vmcnt<2 * PER_STAGE>();
-    else if (newer == 1) wait_vmcnt<PER_STAGE>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + NST - 1 < nt) issue(kt + NST - 1);
-    const char* Ab = smem + (kt % NST) * STAGE;
-    const char* Bb = Ab + A_BYTES;
-    bf16x8 a[FI], b[FJ];
-#pragma unroll
-    for (int j = 0; j < FJ; ++j) b[j] = *(const bf16x8*)(Bb + (wc * TN + j * 16) * ROWB + rd_off);
-#pragma unroll
-    for (int i = 0; i < FI; ++i) a[i] = *(const bf16x8*)(Ab + (wr * TM + i * 16) * ROWB + rd_off);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < FI; ++i)
-#pragma unroll
-      for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  }
-
+  auto epilogue = [&]() {
   // ---------------- epilogue: BM / EROWS slabs of [EROWS][BN] fp32 through the ring memory ----------------
-  float* ct = (float*)smem;
-  constexpr int CG = BN / 8;                        // column groups of 8
-  constexpr int RGP = 512 / CG;                     // rows per pass
-  const int c8 = (tid % CG) * 8;
-  const int gn0 = n0 + c8;
-  const int ncols = max(0, min(8, p.N - gn0));
-  float bv[8], cs[8];
+    float* ct = (float*)smem;
+    constexpr int CG = BN / 8;                        // column groups of 8
+    constexpr int RGP = 512 / CG;                     // rows per pass
+    const int c8 = (tid % CG) * 8;
+    const int gn0 = n0 + c8;
+    const int ncols = max(0, min(8, p.N - gn0));
+    float bv[8], cs[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && e < ncols) ? p.bias[gn0 + e] : 0.f; cs[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && e < ncols) ? p.bias[gn0 + e] : 0.f; cs[e] = 0.f; }
 #pragma unroll 1
-  for (int slab = 0; slab < BM / EROWS; ++slab) {
-    __syncthreads();
-    if (wr * TM >= slab * EROWS && wr * TM < (slab + 1) * EROWS) {
-      const int rbase = wr * TM - slab * EROWS;
+    for (int slab = 0; slab < BM / EROWS; ++slab) {
+      __syncthreads();
+      if (wr * TM >= slab * EROWS && wr * TM < (slab + 1) * EROWS) {
+        const int rbase = wr * TM - slab * EROWS;
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+          for (int j = 0; j < FJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ct[(rbase + i * 16 + 4 * fq + r) * BN + wc * TN + j * 16 + fr] = acc[i][j][r];
+      }
+      __syncthreads();
+      for (int pass = 0; pass < EROWS / RGP && ncols > 0; ++pass) {
+        const int rr = pass * RGP + tid / CG;
+        const int gm = m0 + slab * EROWS + rr;
+        if (gm >= p.M) break;
+        float v[8];
+        const f32x4 lo = *(const f32x4*)(ct + rr * BN + c8);
+        const f32x4 hi = *(const f32x4*)(ct + rr * BN + c8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+        epi_piece<T>(p, v, bv, cs, gm, gn0, ncols);
+      }
+    }
+    if (p.colsum) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ct[(tid / CG) * BN + c8 + e] = cs[e];
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.N) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < RGP; ++k) tsum += ct[k * BN + tid];
+        atomicAdd(p.colsum + n0 + tid, tsum);
+      }
+    }
+
+  };
+  for (int q = 0; q < NST - 1 && q < nt; ++q) issue(q);
+  if constexpr (!PIPE) {
+    for (int kt = 0; kt < nt; ++kt) {
+      const int newer = min(NST - 2, nt - 1 - kt);     // later tiles that may stay in flight
+      if (newer >= 2) wait_vmcnt<2 * PER_STAGE>();
+      else if (newer == 1) wait_vmcnt<PER_STAGE>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + NST - 1 < nt) issue(kt + NST - 1);
+      const char* Ab = smem + (kt % NST) * STAGE;
+      const char* Bb = Ab + A_BYTES;
+      bf16x8 a[FI], b[FJ];
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) b[j] = *(const bf16x8*)(Bb + (wc * TN + j * 16) * ROWB + rd_off);
+#pragma unroll
+      for (int i = 0; i < FI; ++i) a[i] = *(const bf16x8*)(Ab + (wr * TM + i * 16) * ROWB + rd_off);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < FJ; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ct[(rbase + i * 16 + 4 * fq + r) * BN + wc * TN + j * 16 + fr] = acc[i][j][r];
+        for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
-    __syncthreads();
-    for (int pass = 0; pass < EROWS / RGP && ncols > 0; ++pass) {
-      const int rr = pass * RGP + tid / CG;
-      const int gm = m0 + slab * EROWS + rr;
-      if (gm >= p.M) break;
-      float v[8];
-      const f32x4 lo = *(const f32x4*)(ct + rr * BN + c8);
-      const f32x4 hi = *(const f32x4*)(ct + rr * BN + c8 + 4);
+    epilogue();
+  } else {
+    // Ping-pong: waves w and w+4 share a SIMD (wave rows wr = 0 / 1).  With ONE barrier per stage both read their
+    // fragments at the same time (matrix pipe idle) and then serialise their MFMAs.  Here every stage has two barriers
+    // and the two wave rows run half a stage apart: while row 0 reads the fragments of tile kt, row 1 issues the MFMAs
+    // of tile kt-1; then they swap.  No extra registers (one fragment set per wave), the matrix pipe always has a
+    // wave with operands ready.  Ring safety: tile kt-1's last reader (row 1) finishes before b0(kt), after which both
+    // rows may request tile kt+3 into that slot.
+    static_assert(NST >= 4 && WM == 2, "ping-pong variant: 4-stage ring, two wave rows");
+    const bool lag = (wr == 1);                        // wave-uniform
+    bf16x8 a[FI], b[FJ];
+    auto read_frags = [&](int q) {
+      const char* Ab = smem + (q % NST) * STAGE;
+      const char* Bb = Ab + A_BYTES;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
-      epi_piece<T>(p, v, bv, cs, gm, gn0, ncols);
+      for (int j = 0; j < FJ; ++j) b[j] = *(const bf16x8*)(Bb + (wc * TN + j * 16) * ROWB + rd_off);
+#pragma unroll
+      for (int i = 0; i < FI; ++i) a[i] = *(const bf16x8*)(Ab + (wr * TM + i * 16) * ROWB + rd_off);
+    };
+    auto mma_all = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    // Both rows run the SAME loop body {barrier; request + read tile kt; barrier; MFMAs of tile kt}; the lag row enters
+    // through one extra leading barrier and the lead row leaves through one trailing barrier, so in barrier interval
+    // 2kt the lead row reads tile kt while the lag row multiplies tile kt-1, and in interval 2kt+1 the lead row
+    // multiplies tile kt while the lag row reads it.  Every wave has waited for ITS share of tile kt before barrier 2kt
+    // (lead: after its MFMAs of kt-1; lag: after its reads of kt-1), which is all that differs between the rows.
+    auto wait_tile = [&](int kt) {
+      const int newer = min(NST - 2, nt - 1 - kt);
+      if (newer >= 2) wait_vmcnt<2 * PER_STAGE>();
+      else if (newer == 1) wait_vmcnt<PER_STAGE>();
+      else wait_vmcnt<0>();
+    };
+    wait_tile(0);
+    if (lag) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nt; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      if (kt + NST - 1 < nt) issue(kt + NST - 1);
+      read_frags(kt);
+      if (lag && kt + 1 < nt) wait_tile(kt + 1);
+      __builtin_amdgcn_s_barrier();
+      mma_all();
+      if (!lag && kt + 1 < nt) wait_tile(kt + 1);
     }
-  }
-  if (p.colsum) {
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ct[(tid / CG) * BN + c8 + e] = cs[e];
-    __syncthreads();
-    if (tid < BN && n0 + tid < p.N) {
-      float tsum = 0.f;
-#pragma unroll
-      for (int k = 0; k < RGP; ++k) tsum += ct[k * BN + tid];
-      atomicAdd(p.colsum + n0 + tid, tsum);
-    }
+    if (!lag) __builtin_amdgcn_s_barrier();
+    epilogue();
   }
 }
 
@@ -626,27 +683,30 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
                     set_lds_once((const void*)gemm_nt_kernel<bf16, 8>) | set_lds_once((const void*)gemm_nt_kernel<float, 8>);
   (void)once;
   const bool w8 = (flags & GF_WAVES4) == 0;
-  // 256x256 4-stage kernel: measured faster only where K is long and the grid fills the chip with 1 workgroup per CU
-  // (3x3 convolutions: +9..16 %); on short-K Linear shapes the 2-workgroups-per-CU 128x128 kernel hides its epilogue
-  // behind the neighbour's main loop and wins (profiles/r01_v5_gemm_shapes.txt).
+  // 256x256 ping-pong ring kernel (1 workgroup per CU): faster than the 128x128 kernel wherever its tile count fills
+  // whole rounds of the 256 CUs (measured +4..24 %, profiles/r01_v7_gemm_shapes.txt); with a ragged last round
+  // (e.g. 128 or 384 tiles) the 2-workgroups-per-CU 128x128 kernel wins.
   const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
-  bool big = dtype == 0 && Kseg % 32 == 0 && S >= 4 && (long)Kseg * S >= 2048 && N >= 256 && big_tiles >= 256 &&
-             !(flags & (GF_NOBIG | GF_WAVES4));
+  const long rounds = (big_tiles + 255) / 256;
+  const bool fills = big_tiles * 10 >= rounds * 256 * 9;          // >= 90 % of the last round's slots used
+  bool big = dtype == 0 && Kseg % 32 == 0 && N >= 256 && M >= 256 && fills && !(flags & (GF_NOBIG | GF_WAVES4));
   if ((flags & GF_BIG) && dtype == 0 && Kseg % 32 == 0) big = true;
   const bool mid_ok = dtype == 0 && Kseg % 32 == 0 && !(flags & (GF_NOBIG | GF_WAVES4));
   const bool mid = (flags & GF_MID) && mid_ok;
   if (big && !mid) {
-    static int once_big = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    static int once_big = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
+                          (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)once_big;
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
+    if (flags & GF_NOPIPE) hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, false>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
     STSWIN_CHECK_LAUNCH();
     return 0;
   }
   if (mid) {
-    static int once_mid = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 128, 4, 2, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+    static int once_mid = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 128, 4, 2, 3, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
     (void)once_mid;
     const long mid_tiles = (long)((M + 255) / 256) * ((N + 127) / 128);
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 128, 4, 2, 3, 4>), dim3((unsigned)mid_tiles), dim3(512), 73728, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 128, 4, 2, 3, 4, false>), dim3((unsigned)mid_tiles), dim3(512), 73728, (hipStream_t)stream, p);
     STSWIN_CHECK_LAUNCH();
     return 0;
   }

@@ -33,7 +33,7 @@ def main():
         rows = None
         if S > 1 or "gather" in note:
             rows = torch.randint(0, M, (S, M), device=dev, dtype=torch.int32)
-        for fl, tag in ((hip.GF_NOBIG, "8w"), (hip.GF_MID, "mid"), (hip.GF_BIG, "big")):
+        for fl, tag in ((hip.GF_NOBIG, "8w"), (hip.GF_BIG | hip.GF_NOPIPE, "big"), (hip.GF_BIG, "bigpipe")):
             t = timeit(lambda: hip.gemm_nt(A, W, out, M=M, a_rows=rows, S=S, flags=fl))
             print(f"{'nt-' + tag:8s} {M:7d} {N:6d} {K:6d} {S:2d} {t * 1e3:9.1f} {2.0 * M * N * K * S / t / 1e9:8.1f}  {note}")
     tn_shapes = [(32768, 1536, 512, "dWqkv s1"), (32768, 2048, 512, "dWfc1 s1"), (32768, 512, 2048, "dWfc2 s1"),
