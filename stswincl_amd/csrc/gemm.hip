@@ -26,7 +26,9 @@ enum {
   GF_BIG = 128,      // tuning: force the 256x256 4-stage kernel (bf16)
   GF_NOBIG = 256,    // tuning: forbid it
   GF_MID = 512,      // tuning: 256x128x32 tile, 3-stage ring, 2 workgroups per CU
-  GF_NOPIPE = 1024,  // tuning: 256x256 ring without the software-pipelined fragment reads
+  GF_NOPIPE = 1024,  // tuning: 256x256 ring without the ping-pong schedule
+  GF_HALF = 2048,    // tuning: force the 256x128 ping-pong ring
+  GF_NOHALF = 4096,  // tuning: forbid it
   GF_WAVES4 = 64,    // tuning: 4 waves of 64x64 per tile instead of the default 8 waves of 64x32 (4 waves/SIMD)
 };
 
@@ -693,6 +695,21 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
   if ((flags & GF_BIG) && dtype == 0 && Kseg % 32 == 0) big = true;
   const bool mid_ok = dtype == 0 && Kseg % 32 == 0 && !(flags & (GF_NOBIG | GF_WAVES4));
   const bool mid = (flags & GF_MID) && mid_ok;
+  // 256x128 ping-pong ring (twice the tiles of the 256x256 one): for shapes whose 256x256 grid leaves CUs idle
+  const long half_tiles = (long)((M + 255) / 256) * ((N + 127) / 128);
+  const long hrounds = (half_tiles + 255) / 256;
+  const bool hfills = half_tiles * 10 >= hrounds * 256 * 9;
+  // measured slower than the 8-wave 128x128 kernel on every shape tried (128x32 wave tiles: 10 fragment reads per 16
+  // MFMAs) - kept as a forced tuning option only
+  (void)hfills;
+  const bool half = (flags & GF_HALF) && mid_ok && !mid;
+  if (half && !(flags & GF_BIG)) {
+    static int once_half = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 128, 2, 4, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    (void)once_half;
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 128, 2, 4, 4, 2, true>), dim3((unsigned)half_tiles), dim3(512), 98304, (hipStream_t)stream, p);
+    STSWIN_CHECK_LAUNCH();
+    return 0;
+  }
   if (big && !mid) {
     static int once_big = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
                           (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);

@@ -41,6 +41,12 @@ def test_gemm_nt_plain_and_bias(dtype, m, n, k):
         outb.fill_(float("nan"))
         hip.gemm_nt(a.cuda(), w.cuda(), outb, M=m, bias=bias.cuda(), flags=hip.GF_MID)     # 256x128 3-stage-ring kernel
         _close(outb, F.linear(a.float(), w.float(), bias), dtype, "mid kernel")
+        outb.fill_(float("nan"))
+        hip.gemm_nt(a.cuda(), w.cuda(), outb, M=m, bias=bias.cuda(), flags=hip.GF_HALF)    # 256x128 ping-pong ring kernel
+        _close(outb, F.linear(a.float(), w.float(), bias), dtype, "half ping-pong kernel")
+        outb.fill_(float("nan"))
+        hip.gemm_nt(a.cuda(), w.cuda(), outb, M=m, bias=bias.cuda(), flags=hip.GF_BIG | hip.GF_NOPIPE)
+        _close(outb, F.linear(a.float(), w.float(), bias), dtype, "big kernel, no ping-pong")
     out32 = torch.zeros(m, n, device="cuda")
     hip.gemm_nt(a.cuda(), w.cuda(), out32, M=m, flags=hip.GF_OUT_F32)
     hip.gemm_nt(a.cuda(), w.cuda(), out32, M=m, flags=hip.GF_OUT_F32 | hip.GF_ACCUM)

@@ -21,7 +21,8 @@ def main():
     dt = torch.bfloat16
     dev = "cuda"
     print(f"{'kernel':8s} {'M':>7s} {'N':>6s} {'K':>6s} {'S':>2s} {'us':>9s} {'TFLOP/s':>8s}  note")
-    nt_shapes = [(32768, 1536, 512, 1, "qkv s1 (gather)"), (32768, 512, 512, 1, "proj s1"), (32768, 2048, 512, 1, "fc1 s1"),
+    extra = [(8192, 1024, 1024, 1, "proj s2"), (8192, 1024, 3072, 1, "dx s2 (qkv dgrad)"), (32768, 512, 1536, 1, "dx s1 (qkv dgrad)")]
+    nt_shapes = extra + [(32768, 1536, 512, 1, "qkv s1 (gather)"), (32768, 512, 512, 1, "proj s1"), (32768, 2048, 512, 1, "fc1 s1"),
                  (32768, 512, 2048, 1, "fc2 s1"), (8192, 3072, 1024, 1, "qkv s2"), (8192, 4096, 1024, 1, "fc1 s2"),
                  (8192, 1024, 4096, 1, "fc2 s2"), (16384, 1024, 2048, 1, "patch-merge"),
                  (65536, 512, 512, 9, "resnet layer5 3x3"), (65536, 256, 256, 9, "resnet layer4 3x3"),
@@ -33,7 +34,7 @@ def main():
         rows = None
         if S > 1 or "gather" in note:
             rows = torch.randint(0, M, (S, M), device=dev, dtype=torch.int32)
-        for fl, tag in ((hip.GF_NOBIG, "8w"), (hip.GF_BIG | hip.GF_NOPIPE, "big"), (hip.GF_BIG, "bigpipe")):
+        for fl, tag in ((hip.GF_NOBIG, "8w"), (hip.GF_HALF, "half-pp"), (hip.GF_BIG, "big-pp"), (0, "auto")):
             t = timeit(lambda: hip.gemm_nt(A, W, out, M=M, a_rows=rows, S=S, flags=fl))
             print(f"{'nt-' + tag:8s} {M:7d} {N:6d} {K:6d} {S:2d} {t * 1e3:9.1f} {2.0 * M * N * K * S / t / 1e9:8.1f}  {note}")
     tn_shapes = [(32768, 1536, 512, "dWqkv s1"), (32768, 2048, 512, "dWfc1 s1"), (32768, 512, 2048, "dWfc2 s1"),
