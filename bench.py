@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=512)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--dump-prof", default=None,
+                    help="write the per-span timing table here (with STSWIN_SHAPE_PROFILE=1: one row per GEMM shape)")
     ap.add_argument("--workload", default="seg", choices=["seg", "contrast"],
                     help="seg (default, BASELINE configs[1]) or contrast (configs[3]: ConsistencyLoss pre-training step)")
     ap.add_argument("--graph", type=int, default=-1, help="1: capture the whole step in a hipGraph and replay it; "
@@ -281,6 +283,13 @@ def main():
                        "launch": "hipGraph replay of the whole step" if graph is not None else "eager launches",
                        "loss": float(loss)},
         }
+        if prof and a.dump_prof:
+            with open(a.dump_prof, "w") as f:
+                f.write(f"# {a.steps} steps; ms are totals over those steps\n")
+                for n in sorted(prof, key=lambda n: -prof[n]["ms_total"]):
+                    q = prof[n]
+                    f.write(f"{q['ms_total'] / a.steps:9.3f} ms/step {q['launches'] // a.steps:4d} x {1e3 * q['ms_avg']:8.1f} us "
+                            f"{q['work'] / max(q['ms_total'], 1e-9) / 1e9:8.1f} TF/s  {n}\n")
         if prof:
             k = max(prof, key=lambda n: prof[n]["ms_total"])
             p = prof[k]

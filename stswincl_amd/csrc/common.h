@@ -30,6 +30,18 @@ static __device__ uint4 g_stswin_zero[16];  // per-TU copy (no -fgpu-rdc); zero-
 DEVI int lane_id() { return threadIdx.x & 63; }
 DEVI int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
+// Same copy issued as raw ISA, invisible to hipcc's waitcnt pass.  Needed wherever the tile is read back with
+// ds_read_b64_tr_b16: behind the builtin the compiler puts s_waitcnt vmcnt(0) in front of every transposed read
+// (it does not for plain ds_read), which drains the copies that were meant to stay in flight.  The caller owns all
+// vmcnt waits for these copies; M0 carries the LDS base exactly as the builtin would set it.
+DEVI void glds16_raw(const void* gsrc, void* lds_wave_base) {
+  const unsigned lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds) : "memory", "m0");
+}
+
+// ---- scalar (SMEM) load of a wave-uniform int: counted by lgkmcnt, so it never stalls the LDS-DMA vmcnt pipeline ----
+DEVI int sload(const int* p, long idx) { return ((const __attribute__((address_space(4))) int*)p)[idx]; }
+
 // ---- LDS-DMA: 16 B per lane, LDS destination = wave-uniform base + lane*16 -----------------
 DEVI void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

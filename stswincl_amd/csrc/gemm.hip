@@ -539,30 +539,64 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(GemmTN p) {
   const char* zero = (const char*)g_stswin_zero;
   const int rsub = l / CPR, cphys = l % CPR;        // row within the instruction's RPI rows, physical chunk
   // per-lane row of instruction i: r = (w*NI + i)*RPI + rsub ; source chunk = cphys ^ swz256(r) (low 4 bits)
-  auto src_row = [&](const int* map, int m) -> long {
-    if (m >= p.Mk) return -1;
-    return map ? (long)map[m] : (long)m;
-  };
+  // Row indices come through SCALAR loads (wave-uniform address, lgkmcnt): an ordinary vector load here makes hipcc
+  // drain vmcnt(0) right behind the LDS-DMA it was issued after, which serialises copy and MFMA.  A wave stages
+  // NI*RPI consecutive contraction rows per tile; each lane then picks the one of its instruction's RPI rows it
+  // copies.  With bseg a 128-column tile spans at most two taps (the launcher checks it), so two index rows cover it.
   long arow[NI], brow[NI];                          // gathered source rows of the NEXT tile to stage
   int bcol[NI];                                     // source column of this lane's Bt chunk (constant over tiles)
+  bool btap1[NI];                                   // this lane's Bt chunk belongs to the tile's second tap
+  const int tap0 = p.bseg > 0 ? j0 / p.bseg : 0;
+  const int tap1 = p.bseg > 0 ? min(tap0 + 1, p.Nj / p.bseg - 1) : 0;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int r = (w * NI + i) * RPI + rsub;
     const int cj = j0 + ((cphys & ~15) | ((cphys ^ swz256(r)) & 15)) * PACK;
     bcol[i] = p.bseg > 0 ? cj % p.bseg : cj;
+    btap1[i] = p.bseg > 0 && cj / p.bseg != tap0;
   }
+  typedef int ivec __attribute__((ext_vector_type(RPI)));
+  typedef const __attribute__((address_space(4))) ivec* civec;
+  const bool vec_maps = (p.Mk % RPI) == 0;          // RPI-int scalar loads stay aligned and in range
   auto fetch_rows = [&](int tile) {
+    const int mw = tile * BM + w * (NI * RPI);      // wave-uniform
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int m = tile * BM + (w * NI + i) * RPI + rsub;
-      arow[i] = src_row(p.at_rows, m);
-      if (p.bseg > 0) {
-        const int r = (w * NI + i) * RPI + rsub;
-        const int cj = j0 + ((cphys & ~15) | ((cphys ^ swz256(r)) & 15)) * PACK;
-        brow[i] = (m < p.Mk && cj < p.Nj) ? (long)p.bt_rows[(long)(cj / p.bseg) * p.Mk + m] : -1;
+      const int mb = mw + i * RPI;
+      int va[RPI], vb0[RPI], vb1[RPI];
+      if (vec_maps && mb + RPI <= p.Mk) {
+        ivec ta, t0, t1;
+#pragma unroll
+        for (int r = 0; r < RPI; ++r) { ta[r] = mb + r; t0[r] = mb + r; t1[r] = -1; }
+        if (p.at_rows) ta = *(civec)(p.at_rows + mb);
+        if (p.bseg > 0) {
+          t0 = *(civec)(p.bt_rows + (long)tap0 * p.Mk + mb);
+          t1 = *(civec)(p.bt_rows + (long)tap1 * p.Mk + mb);
+        } else if (p.bt_rows) {
+          t0 = *(civec)(p.bt_rows + mb);
+        }
+#pragma unroll
+        for (int r = 0; r < RPI; ++r) { va[r] = ta[r]; vb0[r] = t0[r]; vb1[r] = t1[r]; }
       } else {
-        brow[i] = src_row(p.bt_rows, m);
+#pragma unroll
+        for (int r = 0; r < RPI; ++r) {
+          const int m = mb + r, mc = min(m, p.Mk - 1);
+          va[r] = p.at_rows ? sload(p.at_rows, mc) : mc;
+          vb1[r] = -1;
+          if (p.bseg > 0) {
+            vb0[r] = sload(p.bt_rows, (long)tap0 * p.Mk + mc);
+            vb1[r] = sload(p.bt_rows, (long)tap1 * p.Mk + mc);
+          } else {
+            vb0[r] = p.bt_rows ? sload(p.bt_rows, mc) : mc;
+          }
+          if (m >= p.Mk) { va[r] = -1; vb0[r] = -1; vb1[r] = -1; }
+        }
       }
+      int ra = -1, rb = -1;
+#pragma unroll
+      for (int r = 0; r < RPI; ++r)
+        if (rsub == r) { ra = va[r]; rb = btap1[i] ? vb1[r] : vb0[r]; }
+      arow[i] = ra; brow[i] = rb;
     }
   };
   auto stage = [&](int buf) {
@@ -575,8 +609,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(GemmTN p) {
       const int ci = i0 + cs * PACK, cj = j0 + cs * PACK;
       const char* sa = (arow[i] >= 0 && ci < p.Ni) ? (const char*)p.At + (arow[i] * p.lda + ci) * sizeof(T) : zero;
       const char* sb = (brow[i] >= 0 && cj < p.Nj) ? (const char*)p.Bt + (brow[i] * p.ldb + bcol[i]) * sizeof(T) : zero;
-      glds16(sa, Ab + (w * NI + i) * 1024);
-      glds16(sb, Bb + (w * NI + i) * 1024);
+      glds16_raw(sa, Ab + (w * NI + i) * 1024);     // raw: behind the builtin hipcc drains vmcnt(0) before every
+      glds16_raw(sb, Bb + (w * NI + i) * 1024);     // ds_read_b64_tr_b16, i.e. waits for the tile it has just requested
     }
   };
 
@@ -647,6 +681,164 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(GemmTN p) {
       for (int r = 0; r < 4; ++r) {
         const int gi = i0 + wr * 64 + i * 16 + 4 * fq + r;
         const int gj = j0 + wc * (16 * JN) + j * 16 + fr;
+        if (gi < p.Ni && gj < p.Nj) {
+          if (p.slabs) p.slabs[((long)split_id * p.Ni + gi) * p.Nj + gj] = acc[i][j][r];
+          else atomicAdd(p.C + (long)gi * p.ldc + gj, acc[i][j][r]);
+        }
+      }
+}
+
+
+// =====================================================================================================
+// gemm_tn "ring" (bf16): 256x256 output tile, 8 waves as 2 x 4 of 128x64, contraction in stages of 32 rows.  At / Bt
+// stage tiles [32][256] (512-byte rows, swz256 on the low 4 chunk bits) live in a 4-stage LDS ring filled by raw
+// LDS-DMA (glds16_raw: three stages stay in flight, counted vmcnt waits), operands come back through
+// ds_read_b64_tr_b16, and the two wave rows run half a stage apart (ping-pong, as gemm_nt_ring_kernel) so one
+// row's MFMAs cover the other row's LDS reads.  Gather maps are read with scalar loads one stage ahead.
+// One workgroup per CU: the launcher picks splits so that tiles x splits ~ 256.
+// =====================================================================================================
+template <bool MAPS>
+__global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
+  using T = bf16;
+  constexpr int BMK = 32, ROWB = 512, NST = 4, OP_BYTES = BMK * ROWB, STAGE = 2 * OP_BYTES, PER_STAGE = 4;
+  constexpr int FI = 8, FJ = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63, w = wave_id();
+  const int wr = w >> 2, wc = w & 3;
+  const int tiles_j = (p.Nj + 255) >> 8;
+  const int split_id = blockIdx.x % p.splits, tile_id = blockIdx.x / p.splits;
+  const int i0 = (tile_id / tiles_j) << 8, j0 = (tile_id % tiles_j) << 8;
+  const int nst_all = (p.Mk + BMK - 1) / BMK;
+  const int per = (nst_all + p.splits - 1) / p.splits;
+  const int s_begin = split_id * per, s_end = min(nst_all, s_begin + per);
+  const int nt = max(0, s_end - s_begin);
+
+  const char* zero = (const char*)g_stswin_zero;
+  // one LDS-DMA instruction = 2 rows x 512 B; wave w issues instructions w*2 + {0,1} of each operand = stage rows 4w..4w+3
+  const int rsub = l >> 5, cphys = l & 31;
+  long offA[2], offB[2];                            // byte offset of this lane's chunk inside its source row, or -1
+  bool tap1[2];
+  const int tapA0 = (MAPS && p.bseg > 0) ? j0 / p.bseg : 0;
+  const int tapA1 = (MAPS && p.bseg > 0) ? min(tapA0 + 1, p.Nj / p.bseg - 1) : 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (w * 2 + i) * 2 + rsub;
+    const int cs = (cphys & ~15) | ((cphys ^ swz256(r)) & 15);
+    const int ci = i0 + cs * 8, cj = j0 + cs * 8;
+    offA[i] = ci < p.Ni ? (long)ci * sizeof(T) : -1;
+    int sc = cj;
+    tap1[i] = false;
+    if (MAPS && p.bseg > 0) { sc = cj % p.bseg; tap1[i] = (cj / p.bseg) != tapA0; }
+    offB[i] = cj < p.Nj ? (long)sc * sizeof(T) : -1;
+  }
+  typedef int int4v __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(4))) int4v* cint4;
+  const bool vec_maps = (p.Mk & 3) == 0;
+  int ia[4], ib0[4], ib1[4];                        // SGPRs: source rows of stage rows 4w..4w+3 of the next stage to issue
+  auto load_idx = [&](int q) {
+    const int mb = (s_begin + q) * BMK + w * 4;     // wave-uniform
+    if (!MAPS) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ia[r] = mb + r < p.Mk ? mb + r : -1; ib0[r] = ia[r]; ib1[r] = -1; }
+      return;
+    }
+    if (vec_maps && mb + 4 <= p.Mk) {
+      int4v ta = {mb, mb + 1, mb + 2, mb + 3}, t0 = ta, t1 = {-1, -1, -1, -1};
+      if (p.at_rows) ta = *(cint4)(p.at_rows + mb);
+      if (p.bseg > 0) {
+        t0 = *(cint4)(p.bt_rows + (long)tapA0 * p.Mk + mb);
+        t1 = *(cint4)(p.bt_rows + (long)tapA1 * p.Mk + mb);
+      } else if (p.bt_rows) {
+        t0 = *(cint4)(p.bt_rows + mb);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ia[r] = ta[r]; ib0[r] = t0[r]; ib1[r] = t1[r]; }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mb + r, mc = min(m, p.Mk - 1);
+        ia[r] = p.at_rows ? sload(p.at_rows, mc) : mc;
+        ib1[r] = -1;
+        if (p.bseg > 0) {
+          ib0[r] = sload(p.bt_rows, (long)tapA0 * p.Mk + mc);
+          ib1[r] = sload(p.bt_rows, (long)tapA1 * p.Mk + mc);
+        } else {
+          ib0[r] = p.bt_rows ? sload(p.bt_rows, mc) : mc;
+        }
+        if (m >= p.Mk) { ia[r] = -1; ib0[r] = -1; ib1[r] = -1; }
+      }
+    }
+  };
+  auto issue = [&](int q) {                          // stage q of this split -> ring slot q & 3; consumes ia/ib*
+    char* Ab = smem + (q & 3) * STAGE;
+    char* Bb = Ab + OP_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ra = rsub ? ia[2 * i + 1] : ia[2 * i];
+      const int rb0 = rsub ? ib0[2 * i + 1] : ib0[2 * i];
+      const int rb1 = rsub ? ib1[2 * i + 1] : ib1[2 * i];
+      const int rb = tap1[i] ? rb1 : rb0;
+      const char* sa = (ra >= 0 && offA[i] >= 0) ? (const char*)p.At + (long)ra * (p.lda * (long)sizeof(T)) + offA[i] : zero;
+      const char* sb = (rb >= 0 && offB[i] >= 0) ? (const char*)p.Bt + (long)rb * (p.ldb * (long)sizeof(T)) + offB[i] : zero;
+      glds16_raw(sa, Ab + (w * 2 + i) * 1024);
+      glds16_raw(sb, Bb + (w * 2 + i) * 1024);
+    }
+  };
+
+  f32x4 acc[FI][FJ];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fr = l & 15, fq = l >> 4;
+  const bool lag = (wr == 1);
+  bf16x8 a[FI], b[FJ];
+  auto read_frags = [&](int q) {
+    const char* Ab = smem + (q & 3) * STAGE;
+    const char* Bb = Ab + OP_BYTES;
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) b[j] = cat4(lds_tr4(Bb, ROWB, 8 * fq, wc * 64 + j * 16), lds_tr4(Bb, ROWB, 8 * fq + 4, wc * 64 + j * 16));
+#pragma unroll
+    for (int i = 0; i < FI; ++i) a[i] = cat4(lds_tr4(Ab, ROWB, 8 * fq, wr * 128 + i * 16), lds_tr4(Ab, ROWB, 8 * fq + 4, wr * 128 + i * 16));
+  };
+  auto mma_all = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto wait_tile = [&](int kt) {
+    const int newer = min(NST - 2, nt - 1 - kt);
+    if (newer >= 2) wait_vmcnt<2 * PER_STAGE>();
+    else if (newer == 1) wait_vmcnt<PER_STAGE>();
+    else wait_vmcnt<0>();
+  };
+  if (nt > 0) {
+    load_idx(0);
+    for (int q = 0; q < NST - 1 && q < nt; ++q) { issue(q); load_idx(q + 1); }
+    wait_tile(0);
+    if (lag) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nt; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      if (kt + NST - 1 < nt) { issue(kt + NST - 1); load_idx(kt + NST); }
+      read_frags(kt);
+      if (lag && kt + 1 < nt) wait_tile(kt + 1);
+      __builtin_amdgcn_s_barrier();
+      mma_all();
+      if (!lag && kt + 1 < nt) wait_tile(kt + 1);
+    }
+    if (!lag) __builtin_amdgcn_s_barrier();
+  }
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + wr * 128 + i * 16 + 4 * fq + r;
+        const int gj = j0 + wc * 64 + j * 16 + fr;
         if (gi < p.Ni && gj < p.Nj) {
           if (p.slabs) p.slabs[((long)split_id * p.Ni + gi) * p.Nj + gj] = acc[i][j][r];
           else atomicAdd(p.C + (long)gi * p.ldc + gj, acc[i][j][r]);
@@ -746,13 +938,62 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   if (splits > 0) splits &= ~(1 << 30);
   const int pack = dtype == 0 ? 8 : 4;
   if (Ni % pack || Nj % pack || lda % pack || ldb % pack) return -1003;
-  if (bseg < 0 || (bseg > 0 && (bseg % pack || !bt_rows))) return -1004;
+  if (bseg < 0 || (bseg > 0 && (bseg % pack || !bt_rows || Nj % bseg))) return -1004;
+  if (bseg > 0)                                            // the kernel keeps two tap index rows per 128-column tile
+    for (int j0 = 0; j0 < Nj; j0 += 128)
+      if ((j0 + 127 < Nj ? j0 + 127 : Nj - 1) / bseg - j0 / bseg > 1) return -1005;
   const int bm = dtype == 0 ? 64 : 32;
   const int ntile = (Mk + bm - 1) / bm;
-  if (splits <= 0) {   // 2 resident blocks per CU on 256 CUs: stay at or just under 512 blocks (a 513th block costs a
-                       // whole extra wave of the grid), and keep >= 8 K tiles per block so the atomic epilogue amortises
+  // 256x256 ping-pong ring (bf16): 1 workgroup per CU, so tiles x splits should be ~256, with >= 16 stages of 32 rows per
+  // workgroup.  Chosen when both output dims are >= 256 (else the 128x128 kernel wastes less of the tile).
+  // Tuning bits of `splits`: bit 29 forces the ring with the given split count, bit 28 forbids it.
+  const bool force_ring = splits > 0 && (splits & (1 << 29));
+  const bool no_ring = splits > 0 && (splits & (1 << 28));
+  if (splits > 0) splits &= ~((1 << 29) | (1 << 28));
+  bool ring = dtype == 0 && !splits_flags_w4 && !no_ring && (force_ring || (splits <= 0 && Ni >= 256 && Nj >= 256));
+  if (ring && bseg > 0)
+    for (int j0 = 0; j0 < Nj; j0 += 256)
+      if ((j0 + 255 < Nj ? j0 + 255 : Nj - 1) / bseg - j0 / bseg > 1) ring = false;
+  if (ring) {
+    const int t256 = ((Ni + 255) / 256) * ((Nj + 255) / 256);
+    const int nst = (Mk + 31) / 32;
+    int rs = splits > 0 ? splits : 256 / t256;
+    if (splits <= 0) {
+      const int max_by_k = nst / 16 > 0 ? nst / 16 : 1;
+      if (rs > max_by_k) rs = max_by_k;
+      if (rs < 1) rs = 1;
+      while (rs > 1 && workspace && (long)rs * Ni * Nj > workspace_floats) --rs;
+      const long blocks = (long)t256 * rs;
+      if (blocks < 176 || (blocks > 256 && blocks % 256 != 0 && blocks % 256 < 200)) ring = false;
+    }
+    if (rs > nst) rs = nst;
+    if (ring) {
+      const bool slabs = workspace && rs > 1 && (long)rs * Ni * Nj <= workspace_floats;
+      GemmTN q{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, rs, bseg, slabs ? workspace : nullptr};
+      static int once_r = (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
+                          (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)once_r;
+      const dim3 grid((unsigned)(t256 * rs));
+      if (at_rows || bt_rows) hipLaunchKernelGGL(gemm_tn_ring_kernel<true>, grid, dim3(512), 131072, (hipStream_t)stream, q);
+      else hipLaunchKernelGGL(gemm_tn_ring_kernel<false>, grid, dim3(512), 131072, (hipStream_t)stream, q);
+      if (slabs) {
+        const long n4 = ((long)Ni * Nj + 3) / 4;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, C, ldc,
+                           Ni, Nj, rs);
+      }
+      STSWIN_CHECK_LAUNCH();
+      return 0;
+    }
+  }
+  if (splits <= 0) {   // 128x128 kernel, 2 resident workgroups per CU on 256 CUs: one round of <= 512 workgroups (a 513th
+                       // costs a whole extra round) with >= 8 K tiles each; gathered operands hide their latency better
+                       // with 2-4 rounds as long as a workgroup keeps >= 32 K tiles (tools/tn_sweep.py).
     const int tiles = ((Ni + 127) / 128) * ((Nj + 127) / 128);
-    splits = 512 / tiles;
+    int rounds = 1;
+    if (at_rows || bt_rows)
+      for (int r = 4; r >= 2; --r)
+        if (ntile / (r * 512 / tiles > 0 ? r * 512 / tiles : 1) >= 32) { rounds = r; break; }
+    splits = rounds * 512 / tiles;
     if (splits < 1) splits = 1;
     const int max_by_k = ntile / 8 > 0 ? ntile / 8 : 1;
     if (splits > max_by_k) splits = max_by_k;

@@ -104,6 +104,9 @@ def profile_end():
     return out
 
 
+_SHAPE_NAMES = os.environ.get("STSWIN_SHAPE_PROFILE", "0") == "1"   # tools/shape_profile.py: one span name per GEMM shape
+
+
 class _Span:
     def __init__(self, name, work):
         self.name, self.work = name, work
@@ -193,7 +196,10 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
         assert out.dtype == A.dtype
     else:
         assert out.dtype == torch.float32
-    with _Span("gemm_nt_bf16" if A.dtype == torch.bfloat16 else "gemm_nt_f32", 2.0 * M * N * Ktot):
+    name = "gemm_nt_bf16" if A.dtype == torch.bfloat16 else "gemm_nt_f32"
+    if _SHAPE_NAMES:
+        name += f" M={M} N={N} K={Kseg} S={S} a={int(a_rows is not None)} c={int(c_rows is not None)} fl={flags}"
+    with _Span(name, 2.0 * M * N * Ktot):
         rc = load().stswin_gemm_nt(
             _dt(A), _p(A), _c_long(_ld(A)), _p(a_rows), _p(Bw), _c_long(_ld(Bw)), _p(out), _c_long(_ld(out)),
             _p(c_rows), _p(out2), _c_long(_ld(out2) if out2 is not None else 0), _p(bias), _p(resid),
@@ -221,7 +227,10 @@ def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: in
     Ni, Nj = out_f32.shape
     assert out_f32.dtype == torch.float32 and At.dtype == Bt.dtype
     ws = None if atomics or torch.cuda.is_current_stream_capturing() and At.device not in _TN_WS else _tn_workspace(At.device)
-    with _Span("gemm_tn_bf16" if At.dtype == torch.bfloat16 else "gemm_tn_f32", 2.0 * Mk * Ni * Nj):
+    name = "gemm_tn_bf16" if At.dtype == torch.bfloat16 else "gemm_tn_f32"
+    if _SHAPE_NAMES:
+        name += f" Mk={Mk} Ni={Ni} Nj={Nj} bseg={bseg} a={int(at_rows is not None)} b={int(bt_rows is not None)}"
+    with _Span(name, 2.0 * Mk * Ni * Nj):
         rc = load().stswin_gemm_tn(_dt(At), _p(At), _c_long(_ld(At)), _p(at_rows), _p(Bt), _c_long(_ld(Bt)),
                                    _p(bt_rows), _p(out_f32), _c_long(_ld(out_f32)), Mk, Ni, Nj, splits, bseg, _p(ws),
                                    _c_long(ws.numel() if ws is not None else 0), _stream())
