@@ -70,25 +70,32 @@ DEVI float dgelu_erf(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
-// Branch-free erf for the bf16 path (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7: exact at bf16 resolution).  erff()
-// compiles to ~47 VALU instructions plus a divergent branch; at 64 activations per thread per 128x128 tile that was
-// 3x the tile's MFMA time.  `e` returns exp(-u^2) so GELU' can reuse it (exp(-x^2/2) with u = x/sqrt2).
-DEVI float erf_as(float u, float& e) {
-  const float au = fabsf(u);
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * au);
-  const float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  e = __expf(-au * au);
-  return copysignf(1.0f - p * e, u);
+// bf16-path GELU: Phi(x) = 0.5 + z*Q(z^2), z = clamp(x / (2.8*sqrt2), -1, 1), Q = degree-7 minimax fit of
+// 0.5*erf(2.8 z)/z constrained to Q(1) = 0.5 (tails exactly 0 / 1).  |Phi error| <= 3.9e-5, |x*Phi error| <= 1.6e-4:
+// below bf16 rounding of the activations it feeds.  No transcendental and only FMAs, so the f32x2 form compiles to
+// v_pk_fma_f32 (two activations per instruction); erff() costs ~47 VALU instructions + a divergent branch and the
+// Abramowitz-Stegun form used before still needed a quarter-rate rcp and exp per element -- at 256 activations per
+// lane per 256x256 tile that was as long as the tile's whole main loop.  GELU' adds one v_exp_f32 for the density.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define STSWIN_PHI_COEFFS 1.579097463e+00f, -4.098180595e+00f, 9.285439338e+00f, -1.537328732e+01f, 1.769340906e+01f, -1.318582850e+01f, 5.639688737e+00f, -1.040338190e+00f
+DEVI f32x2 phi_poly2(f32x2 x) {
+  constexpr float C[8] = {STSWIN_PHI_COEFFS};
+  f32x2 z = x * 0.2525381361380527f;
+  z = __builtin_elementwise_min(__builtin_elementwise_max(z, (f32x2){-1.f, -1.f}), (f32x2){1.f, 1.f});
+  const f32x2 s = z * z;
+  f32x2 q = {C[7], C[7]};
+#pragma unroll
+  for (int i = 6; i >= 0; --i) q = __builtin_elementwise_fma(q, s, (f32x2){C[i], C[i]});
+  return __builtin_elementwise_fma(z, q, (f32x2){0.5f, 0.5f});
 }
-DEVI float gelu_fast(float x) {
-  float e;
-  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f, e));
+DEVI f32x2 gelu_fast2(f32x2 x) { return x * phi_poly2(x); }
+DEVI f32x2 dgelu_fast2(f32x2 x) {
+  const f32x2 h = x * x * -0.72134752044448170368f;          // -x^2/2 * log2(e)
+  const f32x2 dens = {__builtin_amdgcn_exp2f(h[0]), __builtin_amdgcn_exp2f(h[1])};
+  return __builtin_elementwise_fma(x * 0.39894228040143267794f, dens, phi_poly2(x));
 }
-DEVI float dgelu_fast(float x) {
-  float e;
-  const float er = erf_as(x * 0.70710678118654752440f, e);
-  return 0.5f * (1.0f + er) + x * 0.39894228040143267794f * e;
-}
+DEVI float gelu_fast(float x) { return gelu_fast2((f32x2){x, x})[0]; }
+DEVI float dgelu_fast(float x) { return dgelu_fast2((f32x2){x, x})[0]; }
 template <typename T> DEVI float gelu_t(float x) { return TT_is_bf16<T>() ? gelu_fast(x) : gelu_erf(x); }
 template <typename T> DEVI float dgelu_t(float x) { return TT_is_bf16<T>() ? dgelu_fast(x) : dgelu_erf(x); }
 

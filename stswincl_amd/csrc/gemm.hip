@@ -14,6 +14,8 @@
 // per K tile.  Epilogue goes through an fp32 LDS image so that stores / residual reads are whole 16-byte
 // row pieces (and so that scatter maps cost nothing).
 #include "common.h"
+#include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 
 enum {
@@ -29,6 +31,7 @@ enum {
   GF_NOPIPE = 1024,  // tuning: 256x256 ring without the ping-pong schedule
   GF_HALF = 2048,    // tuning: force the 256x128 ping-pong ring
   GF_NOHALF = 4096,  // tuning: forbid it
+  GF_NOREGEPI = 1 << 22,  // tuning: 256x256 ring with the LDS-staged fp32 epilogue instead of the register epilogue
   GF_WAVES4 = 64,    // tuning: 4 waves of 64x64 per tile instead of the default 8 waves of 64x32 (4 waves/SIMD)
 };
 
@@ -47,8 +50,20 @@ struct GemmNT {
 
 // ---- epilogue of one 8-column piece of output row gm: bias, q-scale, pre-activation copy, GELU, residual / GELU',
 // ReLU, store (T or fp32, optional accumulate), column-sum accumulation.  Shared by every gemm_nt variant.
+// `rpre` (optional): the 8 residual / pre-activation values of this piece, fetched by epi_prefetch ahead of the LDS
+// round trip so that the row loop does not pay one dependent global-load latency per pass.
 template <typename T>
-DEVI void epi_piece(const GemmNT& p, float (&v)[8], const float (&bv)[8], float (&cs)[8], int gm, int gn0, int ncols) {
+DEVI void epi_prefetch(const GemmNT& p, Vec16<T> (&dst)[8 / TT<T>::PACK], int gm, int gn0) {
+  constexpr int PACK = TT<T>::PACK;
+  const long rrow = p.r_rows ? (long)p.r_rows[gm] : (long)gm;
+  const T* src = (const T*)p.R + rrow * p.ldr + gn0;
+#pragma unroll
+  for (int h = 0; h < 8 / PACK; ++h) dst[h].v = *(const decltype(dst[h].v)*)(src + h * PACK);
+}
+
+template <typename T>
+DEVI void epi_piece(const GemmNT& p, float (&v)[8], const float (&bv)[8], float (&cs)[8], int gm, int gn0, int ncols,
+                    const Vec16<T> (&rpre)[8 / TT<T>::PACK], bool use_pre) {
   constexpr int PACK = TT<T>::PACK;
   const bool vec_ok = (ncols == 8);
 #pragma unroll
@@ -79,7 +94,12 @@ DEVI void epi_piece(const GemmNT& p, float (&v)[8], const float (&bv)[8], float 
     const long rrow = p.r_rows ? (long)p.r_rows[gm] : (long)gm;
     const T* src = (const T*)p.R + rrow * p.ldr + gn0;
     float rv[8];
-    if (vec_ok && (p.ldr % PACK) == 0) {
+    if (use_pre) {
+#pragma unroll
+      for (int h = 0; h < 8 / PACK; ++h)
+#pragma unroll
+        for (int e = 0; e < PACK; ++e) rv[h * PACK + e] = rpre[h].get(e);
+    } else if (vec_ok && (p.ldr % PACK) == 0) {
 #pragma unroll
       for (int h = 0; h < 8 / PACK; ++h) {
         Vec16<T> in;
@@ -117,7 +137,8 @@ DEVI void epi_piece(const GemmNT& p, float (&v)[8], const float (&bv)[8], float 
     }
   } else {
     T* dst = (T*)p.C + orow * p.ldc + gn0;
-    if (vec_ok && (p.ldc % PACK) == 0) {
+    if (p.flags & (1 << 20)) { if (v[0] == 123.456f) dst[0] = from_f32<T>(v[1]); }   // DBG: no stores
+    else if (vec_ok && (p.ldc % PACK) == 0) {
 #pragma unroll
       for (int h = 0; h < 8 / PACK; ++h) {
         Vec16<T> o;
@@ -239,6 +260,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
   }
 
   // ---------------- epilogue: accumulators -> fp32 LDS image -> row-wise 16-byte pieces ----------------
+  const int c8 = (tid & 15) * 8;
+  const int gn0 = n0 + c8;
+  const int ncols = max(0, min(8, p.N - gn0));
+  constexpr int RG = NW * 4;                 // row groups per pass
+  constexpr int NPASS = 128 / RG;
+  // residual / pre-activation pieces of all passes are requested now and land during the LDS round trip
+  const bool pre_r = (p.flags & (GF_RESID | GF_MUL_DGELU)) && ncols == 8 && (p.ldr % PACK) == 0;
+  Vec16<T> rp[NPASS][8 / PACK];
+  if (pre_r) {
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int gm = m0 + pass * RG + (tid >> 4);
+      if (gm < p.M) epi_prefetch<T>(p, rp[pass], gm, gn0);
+    }
+  }
   __syncthreads();
   float* ct = (float*)smem;                  // [128][128]
 #pragma unroll
@@ -250,17 +286,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
         ct[(wr * 64 + i * 16 + 4 * fq + r) * 128 + wc * (16 * JN) + j * 16 + fr] = acc[i][j][r];
   __syncthreads();
 
-  const int c8 = (tid & 15) * 8;
-  const int gn0 = n0 + c8;
-  const int ncols = max(0, min(8, p.N - gn0));
   float bv[8], cs[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && e < ncols) ? p.bias[gn0 + e] : 0.f; cs[e] = 0.f; }
-  constexpr int RG = NW * 4;                 // row groups per pass
-  for (int pass = 0; pass < 128 / RG && ncols > 0; ++pass) {
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
     const int rr = pass * RG + (tid >> 4);
     const int gm = m0 + rr;
-    if (gm >= p.M) break;
+    if (gm >= p.M || ncols <= 0) break;
     float v[8];
     {
       const f32x4 lo = *(const f32x4*)(ct + rr * 128 + c8);
@@ -268,7 +301,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
     }
-    epi_piece<T>(p, v, bv, cs, gm, gn0, ncols);
+    epi_piece<T>(p, v, bv, cs, gm, gn0, ncols, rp[pass], pre_r);
   }
   if (p.colsum) {                 // fold the 16 row groups through LDS (the C image is no longer needed), 1 atomic / column
     __syncthreads();
@@ -310,7 +343,7 @@ template <int N> DEVI void wait_vmcnt() {
 // BM x BN x 32 tile, 8 waves as WM x WN, NST-stage ring (prefetch distance NST-1), epilogue in EH row slabs.
 //   <256,256,2,4,4>: 128 KB LDS, 1 workgroup / CU (128 FLOP per L2 byte)
 //   <256,128,4,2,3>:  72 KB LDS, 2 workgroups / CU (87 FLOP per L2 byte; the neighbour's main loop hides the epilogue)
-template <int BM, int BN, int WM, int WN, int NST, int MINW, bool PIPE>
+template <int BM, int BN, int WM, int WN, int NST, int MINW, bool PIPE, bool SWAP = false>
 __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
   using T = bf16;
   constexpr int BK = 32, ROWB = 64;
@@ -372,6 +405,15 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
   const int fr = l & 15, fq = l >> 4;
   const int rd_off = fr * ROWB + ((fq ^ swz64(fr)) << 4);
   auto epilogue = [&]() {
+    if (p.flags & (1 << 21)) {        // DBG: no epilogue at all (keeps the accumulators alive)
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (t == 123.456f) ((T*)p.C)[tid] = from_f32<T>(t);
+      return;
+    }
   // ---------------- epilogue: BM / EROWS slabs of [EROWS][BN] fp32 through the ring memory ----------------
     float* ct = (float*)smem;
     constexpr int CG = BN / 8;                        // column groups of 8
@@ -382,8 +424,18 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
     float bv[8], cs[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && e < ncols) ? p.bias[gn0 + e] : 0.f; cs[e] = 0.f; }
+    constexpr int NPASS = EROWS / RGP;
+    const bool pre_r = (p.flags & (GF_RESID | GF_MUL_DGELU)) && ncols == 8 && (p.ldr % 8) == 0;
+    Vec16<T> rp[NPASS][1];
 #pragma unroll 1
     for (int slab = 0; slab < BM / EROWS; ++slab) {
+      if (pre_r) {      // this slab's residual / pre-activation pieces: in flight across the LDS round trip below
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+          const int gm = m0 + slab * EROWS + pass * RGP + tid / CG;
+          if (gm < p.M) epi_prefetch<T>(p, rp[pass], gm, gn0);
+        }
+      }
       __syncthreads();
       if (wr * TM >= slab * EROWS && wr * TM < (slab + 1) * EROWS) {
         const int rbase = wr * TM - slab * EROWS;
@@ -395,16 +447,17 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
             for (int r = 0; r < 4; ++r) ct[(rbase + i * 16 + 4 * fq + r) * BN + wc * TN + j * 16 + fr] = acc[i][j][r];
       }
       __syncthreads();
-      for (int pass = 0; pass < EROWS / RGP && ncols > 0; ++pass) {
+#pragma unroll
+      for (int pass = 0; pass < NPASS; ++pass) {
         const int rr = pass * RGP + tid / CG;
         const int gm = m0 + slab * EROWS + rr;
-        if (gm >= p.M) break;
+        if (gm >= p.M || ncols <= 0) break;
         float v[8];
         const f32x4 lo = *(const f32x4*)(ct + rr * BN + c8);
         const f32x4 hi = *(const f32x4*)(ct + rr * BN + c8 + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
-        epi_piece<T>(p, v, bv, cs, gm, gn0, ncols);
+        epi_piece<T>(p, v, bv, cs, gm, gn0, ncols, rp[pass], pre_r);
       }
     }
     if (p.colsum) {
@@ -420,6 +473,137 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
       }
     }
 
+  };
+
+  // ---------------- register epilogue (SWAP kernels): all per-element work happens on the accumulators ----------------
+  // Lane (fr, fq) of fragment (i, j) holds C[m0 + wr*TM + i*16 + fr][n0 + wc*TN + j*16 + 4fq + 0..3]: bias, q-scale, GELU,
+  // residual / GELU' (8-byte loads of R in the same layout), ReLU and the column sums are applied in registers, the
+  // bf16 result goes through ONE [BM][BN] bf16 LDS image (ds_write_b64, chunk ^= (row & 15) << 1: conflict-free both
+  // ways) and leaves as whole 16-byte row pieces.  The LDS-staged fp32 epilogue above spent 7.4 us per 256x256 tile
+  // (2 slabs x 128 ds_write_b32 per lane + ~90 VALU per 8-column piece) against 12 us of main loop at K = 512.
+  auto epilogue_reg = [&]() {
+    constexpr int PITCH = BN * 2, CPRW = BN / 8, RPP = 512 / CPRW, NPASS = BM / RPP;
+    char* img = smem;
+    const int colb = n0 + wc * TN + 4 * fq;           // + j*16: first of this lane's 4 columns
+    f32x4 bj[FJ];
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+      const int gn = colb + j * 16;
+      bj[j] = (p.bias && gn < p.N) ? *(const f32x4*)(p.bias + gn) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool has_r = (p.flags & (GF_RESID | GF_MUL_DGELU)) != 0;
+    const bool has_scale = p.scale_cols > 0;
+    auto pre_act = [&](int i, int j) -> f32x4 {
+      f32x4 v = acc[i][j] + bj[j];
+      if (has_scale) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (colb + j * 16 + e < p.scale_cols) v[e] *= p.scale;
+      }
+      return v;
+    };
+    auto put = [&](int i, int j, f32x4 v) {
+      const int row = wr * TM + i * 16 + fr;
+      const int chunk = (wc * TN + j * 16 + 4 * fq) >> 3;
+      Vec16<T> dummy; (void)dummy;
+      bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+      *(bf16x4*)(img + row * PITCH + (((chunk ^ (fr << 1)) & (CPRW - 1)) << 4) + (fq & 1) * 8) = o;
+    };
+    // output rows of this thread's readback pieces (c_rows is a scatter map): fetched before the LDS round trip
+    const int rb_row = tid / CPRW, rb_chunk = tid % CPRW;
+    const bool rb_col_ok = n0 + rb_chunk * 8 < p.N;
+    auto readback = [&](void* Cout, long ldo) {
+      long orow[NPASS];
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int gm = m0 + ps * RPP + rb_row;
+        orow[ps] = (gm < p.M && rb_col_ok) ? (p.c_rows ? (long)p.c_rows[gm] : (long)gm) : -1;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int row = ps * RPP + rb_row;
+        if (orow[ps] >= 0) {
+          const bf16x8 val = *(const bf16x8*)(img + row * PITCH + (((rb_chunk ^ ((row & 15) << 1)) & (CPRW - 1)) << 4));
+          if (p.flags & (1 << 20)) { if ((float)val[0] == 123.456f) *(bf16x8*)((T*)Cout + orow[ps] * ldo + n0 + rb_chunk * 8) = val; }
+          else
+          *(bf16x8*)((T*)Cout + orow[ps] * ldo + n0 + rb_chunk * 8) = val;
+        }
+      }
+    };
+    if (p.flags & (1 << 21)) {        // DBG: no epilogue at all (keeps the accumulators alive)
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (t == 123.456f) ((T*)p.C)[tid] = from_f32<T>(t);
+      return;
+    }
+    __syncthreads();                                   // every wave is done with the ring stages
+    if (p.C2) {                                        // pre-activation copy (fc1 forward keeps it for GELU')
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) put(i, j, pre_act(i, j));
+      readback(p.C2, p.ldc2);
+      __syncthreads();
+    }
+    f32x4 cs[FJ];
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x4 rcur[FJ], rnext[FJ];
+    auto load_r = [&](int i, bf16x4 (&dst)[FJ]) {
+      const int gm = m0 + wr * TM + i * 16 + fr;
+      const long rrow = gm < p.M ? (p.r_rows ? (long)p.r_rows[gm] : (long)gm) : -1;
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) {
+        const int gn = colb + j * 16;
+        if (rrow >= 0 && gn < p.N) dst[j] = *(const bf16x4*)((const T*)p.R + rrow * p.ldr + gn);
+        else dst[j] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+      }
+    };
+    if (has_r) load_r(0, rcur);
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+      if (has_r && i + 1 < FI) load_r(i + 1, rnext);
+      const bool row_ok = m0 + wr * TM + i * 16 + fr < p.M;
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) {
+        f32x4 v = pre_act(i, j);
+        if (p.flags & GF_GELU) {
+          const f32x2 lo = gelu_fast2((f32x2){v[0], v[1]}), hi = gelu_fast2((f32x2){v[2], v[3]});
+          v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
+        }
+        if (has_r) {
+          const f32x4 r = {(float)rcur[j][0], (float)rcur[j][1], (float)rcur[j][2], (float)rcur[j][3]};
+          if (p.flags & GF_RESID) v += r;
+          else {
+            const f32x2 lo = dgelu_fast2((f32x2){r[0], r[1]}), hi = dgelu_fast2((f32x2){r[2], r[3]});
+            v *= (f32x4){lo[0], lo[1], hi[0], hi[1]};
+          }
+        }
+        if (p.flags & GF_RELU) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
+        if (p.colsum && row_ok) cs[j] += v;
+        put(i, j, v);
+      }
+      if (has_r && i + 1 < FI) {
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) rcur[j] = rnext[j];
+      }
+    }
+    readback(p.C, p.ldc);
+    if (p.colsum) {                                    // fold the 16 rows (fr) of each lane group, then one atomic per column
+#pragma unroll
+      for (int j = 0; j < FJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = cs[j][e];
+          t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+          const int gn = colb + j * 16 + e;
+          if (fr == 0 && gn < p.N) atomicAdd(p.colsum + gn, t);
+        }
+    }
   };
   for (int q = 0; q < NST - 1 && q < nt; ++q) issue(q);
   if constexpr (!PIPE) {
@@ -468,7 +652,12 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
 #pragma unroll
       for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FJ; ++j) {
+          // SWAP: the weight fragment is the MFMA row operand, so a lane ends up with 4 consecutive COLUMNS of one
+          // output row (C[fr][4fq..4fq+3]) instead of 4 consecutive rows of one column - what epilogue_reg wants
+          if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
       __builtin_amdgcn_s_setprio(0);
     };
     // Both rows run the SAME loop body {barrier; request + read tile kt; barrier; MFMAs of tile kt}; the lag row enters
@@ -494,7 +683,8 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
       if (!lag && kt + 1 < nt) wait_tile(kt + 1);
     }
     if (!lag) __builtin_amdgcn_s_barrier();
-    epilogue();
+    if constexpr (SWAP) epilogue_reg();
+    else epilogue();
   }
 }
 
@@ -906,7 +1096,14 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     static int once_big = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
                           (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)once_big;
+    // register epilogue (operand-swapped MFMA): bf16 output, every row piece 16-byte aligned, R readable in 8-byte pieces
+    const bool regepi = !(flags & (GF_OUT_F32 | GF_ACCUM | GF_NOREGEPI)) && N % 8 == 0 && ldc % 8 == 0 && (!C2 || ldc2 % 8 == 0) &&
+                        (!R || ldr % 4 == 0) && ((uintptr_t)C % 16 == 0) && (!C2 || (uintptr_t)C2 % 16 == 0) &&
+                        (!R || (uintptr_t)R % 8 == 0) && (!bias || (uintptr_t)bias % 16 == 0);
+    static int once_swap = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)once_swap;
     if (flags & GF_NOPIPE) hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, false>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
+    else if (regepi) hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
     STSWIN_CHECK_LAUNCH();
     return 0;

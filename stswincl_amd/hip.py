@@ -18,6 +18,7 @@ HEADER_PATH = os.path.join(_ROOT, "include", "stswin_hip.h")
 _lib: Optional[ctypes.CDLL] = None
 
 GF_GELU, GF_RESID, GF_MUL_DGELU, GF_OUT_F32, GF_ACCUM, GF_RELU, GF_WAVES4, GF_BIG, GF_NOBIG, GF_MID, GF_NOPIPE, GF_HALF, GF_NOHALF = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
+GF_NOREGEPI = 1 << 22
 
 _c_int, _c_long, _c_float, _c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 
