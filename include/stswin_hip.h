@@ -94,13 +94,16 @@ int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, lo
 /* ---- a6: windowed attention core (swin_512.py:117-138).  qkv [nB_*T*N][3C] = q (pre-scaled) | k | v in window
  * order; biasT [heads][N][N] and maskT [nW][N][N] are the expanded relative-position bias (:122-124) and the
  * SW-MSA mask (:126-131), both transposed to [key][query]; out [nB_*T*N][C] is the (B_, T*N, heads*d) layout of :136.
- * bwd: dqkv gets (scale*dS k | dS^T q_s | P^T dO); dbiasT is atomically accumulated. */
+ * bwd: dqkv gets (scale*dS k | dS^T q_s | P^T dO); dbiasT [heads][N][N] is atomically accumulated.
+ * bias_windows = 1: biasT is [heads][N][N] and maskT (or NULL) is added per window as in :126-131.
+ * bias_windows = nW: biasT is [nW][heads][N][N] = bias + mask already summed by the caller, maskT must be NULL
+ * (one table read per score instead of two). */
 int stswin_win_attn_fwd(int dtype, const void* qkv, long ld, void* out, long ldo, const float* biasT, const float* maskT,
-                        int nB_, int nW, int T_frames, int ws, int heads, int C, void* stream);
+                        int nB_, int nW, int T_frames, int ws, int heads, int C, int bias_windows, void* stream);
 int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, long lddo, void* dqkv, long lddq,
                         const float* biasT, const float* maskT, float* dbiasT,
                         float* dqkv_colsum /* optional fp32 [3C] */, int nB_, int nW, int T_frames, int ws,
-                        int heads, int C, float scale, void* stream);
+                        int heads, int C, float scale, int bias_windows, void* stream);
 
 /* ---- decode head on NHWC token matrices [M = frames*H*W][C]  (ASPP.py:33-52, base18.py:60-106) ---------------
  * Grouped BatchNorm2d: rows are `groups` equal groups with separate batch statistics (1 for the head; the number of

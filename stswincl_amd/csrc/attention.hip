@@ -24,6 +24,7 @@ struct AttnArgs {
   float* dqkv_colsum;             // bwd, optional: [3C] fp32 += column sums of dqkv (the qkv bias gradient)
   int nB_, nW, heads, C, N;       // nB_ = number of (clip, window) problems = B*nW
   float scale;                    // bwd: dq = scale * (dS k)
+  int bias_windows;               // 1: biasT is [heads][N][N]; nW: biasT is [nW][heads][N][N] with the mask already added
 };
 
 template <int CPR> DEVI int swz_cpr(int row) {
@@ -91,7 +92,9 @@ struct AttnCfg {
 };
 
 // ---- S^T (+bias, +mask) and softmax for this wave's 32 queries: returns normalised P^T in p[KT] -------------
-template <typename T, int NTOK, int HD>
+// NC: ws*ws when known at compile time (0 = read a.N): with it the compiler sees which table addresses repeat over the
+// T frames of a window (kn = key mod N) and loads each bias value once instead of T times.
+template <typename T, int NTOK, int HD, int NC>
 DEVI void scores_softmax(f32x16 (&p)[NTOK / 32], const AttnArgs& a, const char* Kt, const T* qbase, const T* kbase,
                          int q0, int head, int widx) {
   using Cfg = AttnCfg<T, NTOK, HD>;
@@ -119,9 +122,9 @@ DEVI void scores_softmax(f32x16 (&p)[NTOK / 32], const AttnArgs& a, const char* 
     }
   }
   // + bias + mask (transposed tables: [key n][query n], lanes contiguous in query)
-  const int N = a.N;
+  const int N = NC ? NC : a.N;
   const int qn = (q0 + lr) % N;
-  const float* bt = a.biasT + (long)head * N * N + qn;
+  const float* bt = a.biasT + ((long)(a.bias_windows > 1 ? widx : 0) * a.heads + head) * N * N + qn;
   const float* mt = a.maskT ? a.maskT + (long)widx * N * N + qn : nullptr;
   float mx = -3.0e38f;
 #pragma unroll
@@ -180,7 +183,7 @@ template <typename T, int ROWB> DEVI float tile_elem_f32(const char* tile, int r
 }
 
 // ====================================================================================================
-template <typename T, int NTOK, int HD>
+template <typename T, int NTOK, int HD, int NC>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   using Cfg = AttnCfg<T, NTOK, HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   if (!live) return;   // (no barrier below is reached by a subset of a PROBLEM's waves only when QW == 1)
 
   f32x16 p[Cfg::KT];
-  scores_softmax<T, NTOK, HD>(p, a, Kt, qbase, kbase, q0, head, b_ % a.nW);
+  scores_softmax<T, NTOK, HD, NC>(p, a, Kt, qbase, kbase, q0, head, b_ % a.nW);
   store_qk_tile<T, NTOK>(Pt, p, q0);   // rows q0..q0+31 are private to this wave
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own LDS writes visible to own reads
 
@@ -244,14 +247,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
 // ====================================================================================================
 // Backward: dq = scale * dS k ; dk = dS^T q_s ; dv = P^T dO ; dbias += fold(dS) ;  dS = P o (dP - rowsum(P o dP)).
-template <typename T, int NTOK, int HD>
+// Persistent over problems: a workgroup walks problem groups blockIdx.x, blockIdx.x + gridDim.x, ... and the launcher
+// makes gridDim.x * PPB a multiple of `heads`, so a lane meets the same (head, query n, key n) and the same dqkv columns
+// in every iteration.  The relative-position-bias gradient and the qkv-bias column sums are therefore summed in
+// registers across iterations and leave as ONE atomic per lane-entry per workgroup: issued per problem they were 33 M
+// (stage 1) / 2 M (stage 2) fp32 atomics onto 16 K / 1 K addresses and cost 25 % / 65 % of the kernel.
+template <typename T, int NTOK, int HD, int NC>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   using Cfg = AttnCfg<T, NTOK, HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int l = threadIdx.x & 63, lr = l & 31, half = l >> 5, w = wave_id();
   const int sp = w / Cfg::QW, qt = w % Cfg::QW;
-  const long prob = (long)blockIdx.x * Cfg::PPB + sp;
-  const int b_ = min((int)(prob / a.heads), a.nB_ - 1), head = prob % a.heads;
+  const long ngroups = ((long)a.nB_ * a.heads + Cfg::PPB - 1) / Cfg::PPB;
+  const int head = (int)(((long)blockIdx.x * Cfg::PPB + sp) % a.heads);
+  f32x16 dbacc[Cfg::KT];
+  float csacc[3][Cfg::DT];
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dbacc[kt][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int dt = 0; dt < Cfg::DT; ++dt) csacc[i][dt] = 0.f;
+  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  const long prob = grp * Cfg::PPB + sp;
+  const int b_ = min((int)(prob / a.heads), a.nB_ - 1);
   const bool live = prob / a.heads < a.nB_;      // dead problems recompute a live one and skip every store
   const long rowbase = (long)b_ * NTOK;
   const T* qbase = (const T*)a.qkv + rowbase * a.ld + head * HD;
@@ -270,7 +291,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     __syncthreads();
   }
   f32x16 p[Cfg::KT], dp[Cfg::KT];
-  scores_softmax<T, NTOK, HD>(p, a, Kt, qbase, kbase, q0, head, b_ % a.nW);
+  scores_softmax<T, NTOK, HD, NC>(p, a, Kt, qbase, kbase, q0, head, b_ % a.nW);
   // dP^T = V dO^T
 #pragma unroll
   for (int kt = 0; kt < Cfg::KT; ++kt)
@@ -304,14 +325,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   for (int kt = 0; kt < Cfg::KT; ++kt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dp[kt][r] = p[kt][r] * (dp[kt][r] - delta);     // dp now holds dS^T
-  // relative-position-bias gradient (expanded, transposed table)
-  if (live && a.dbiasT) {
-    const int N = a.N, qn = (q0 + lr) % N;
-    float* db = a.dbiasT + (long)head * N * N + qn;
+  // relative-position-bias gradient (expanded, transposed table): summed over this workgroup's problems in registers
+  if (live) {
 #pragma unroll
     for (int kt = 0; kt < Cfg::KT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) atomicAdd(db + ((kt * 32 + crow32(r, half)) % N) * N, dp[kt][r]);
+      for (int r = 0; r < 16; ++r) dbacc[kt][r] += dp[kt][r];
   }
   store_qk_tile<T, NTOK>(Pt, p, q0);
   store_qk_tile<T, NTOK>(St, dp, q0);
@@ -339,10 +358,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         base[(long)(row0 + crow32(r, half)) * a.ldo + dt * 32 + lr] = o;
         csum += to_f32<T>(o);
       }
-      if (a.dqkv_colsum) {
-        csum += __shfl_xor(csum, 32);
-        if (half == 0) atomicAdd(a.dqkv_colsum + which * a.C + head * HD + dt * 32 + lr, csum);
-      }
+      csacc[which][dt] += csum;
     }
   };
 
@@ -422,10 +438,30 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     }
   }
   store_acc(dqb, q0, a.scale, 0);
+  __syncthreads();                               // the next problem's tiles overwrite K / dS
+  }
+  if (a.dbiasT) {
+    const int N = NC ? NC : a.N, qn = (qt * 32 + lr) % N;
+    float* db = a.dbiasT + (long)head * N * N + qn;
+#pragma unroll
+    for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) atomicAdd(db + ((kt * 32 + crow32(r, half)) % N) * N, dbacc[kt][r]);
+  }
+  if (a.dqkv_colsum) {
+#pragma unroll
+    for (int which = 0; which < 3; ++which)
+#pragma unroll
+      for (int dt = 0; dt < Cfg::DT; ++dt) {
+        float csum = csacc[which][dt];
+        csum += __shfl_xor(csum, 32);
+        if (half == 0) atomicAdd(a.dqkv_colsum + which * a.C + head * HD + dt * 32 + lr, csum);
+      }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
-template <typename T, int NTOK, int HD>
+template <typename T, int NTOK, int HD, int NC>
 static int launch_attn(const AttnArgs& a, bool bwd, hipStream_t st) {
   using Cfg = AttnCfg<T, NTOK, HD>;
   const long probs = (long)a.nB_ * a.heads;
@@ -433,20 +469,35 @@ static int launch_attn(const AttnArgs& a, bool bwd, hipStream_t st) {
   const int lds = bwd ? Cfg::BWD_LDS : Cfg::FWD_LDS;
   static_assert(Cfg::BWD_LDS <= 160 * 1024, "LDS budget");
   // raise the dynamic-LDS limit once per instantiation (not a stream operation: keep it out of graph capture)
-  static const int attr_fwd = (int)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NTOK, HD>,
+  static const int attr_fwd = (int)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NTOK, HD, NC>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::FWD_LDS);
-  static const int attr_bwd = (int)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NTOK, HD>,
+  static const int attr_bwd = (int)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NTOK, HD, NC>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::BWD_LDS);
   if (attr_fwd != 0 || attr_bwd != 0) return -(attr_fwd ? attr_fwd : attr_bwd);
-  if (bwd) hipLaunchKernelGGL((attn_bwd_kernel<T, NTOK, HD>), dim3(grid), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((attn_fwd_kernel<T, NTOK, HD>), dim3(grid), dim3(256), lds, st, a);
+  if (bwd) {
+    // persistent: as many workgroups as fit the chip at once (LDS bound), rounded so that grid * PPB is a multiple of heads
+    const int per_cu = (160 * 1024) / Cfg::BWD_LDS > 0 ? (160 * 1024) / Cfg::BWD_LDS : 1;
+    int g = 256 * per_cu;
+    int step = a.heads;                          // smallest g granularity with (g * PPB) % heads == 0
+    for (int d = Cfg::PPB; d > 1; --d)
+      if (Cfg::PPB % d == 0 && a.heads % d == 0) { step = a.heads / d; break; }
+    if (g > grid) g = grid;
+    g = (g / step) * step;
+    if (g < step) g = step;
+    hipLaunchKernelGGL((attn_bwd_kernel<T, NTOK, HD, NC>), dim3(g), dim3(256), lds, st, a);
+  } else {
+    hipLaunchKernelGGL((attn_fwd_kernel<T, NTOK, HD, NC>), dim3(grid), dim3(256), lds, st, a);
+  }
   STSWIN_CHECK_LAUNCH();
   return 0;
 }
 
 template <typename T>
 static int dispatch_attn(const AttnArgs& a, int ntok, int hd, bool bwd, hipStream_t st) {
-#define CASE(NT, D) if (ntok == NT && hd == D) return launch_attn<T, NT, D>(a, bwd, st)
+  // the reference model's two stages with ws*ws known at compile time (pair attention: 2 frames per window)
+  if (ntok == 128 && hd == 128 && a.N == 64) return launch_attn<T, 128, 128, 64>(a, bwd, st);
+  if (ntok == 32 && hd == 256 && a.N == 16) return launch_attn<T, 32, 256, 16>(a, bwd, st);
+#define CASE(NT, D) if (ntok == NT && hd == D) return launch_attn<T, NT, D, 0>(a, bwd, st)
   CASE(128, 128); CASE(32, 256);      // the reference model (stage 1 / stage 2)
   CASE(128, 32);  CASE(32, 64);       // reduced-width test configuration (dim 128)
   CASE(128, 64);  CASE(32, 128);
@@ -467,14 +518,17 @@ static int attn_common(int dtype, AttnArgs& a, int T_frames, int ws, bool bwd, v
 
 extern "C" int stswin_win_attn_fwd(int dtype, const void* qkv, long ld, void* out, long ldo, const float* biasT,
                                    const float* maskT, int nB_, int nW, int T_frames, int ws, int heads, int C,
-                                   void* stream) {
-  AttnArgs a{qkv, ld, out, ldo, nullptr, 0, biasT, maskT, nullptr, nullptr, nB_, nW, heads, C, 0, 1.0f};
+                                   int bias_windows, void* stream) {
+  if (bias_windows != 1 && (bias_windows != nW || maskT)) return -1204;
+  AttnArgs a{qkv, ld, out, ldo, nullptr, 0, biasT, maskT, nullptr, nullptr, nB_, nW, heads, C, 0, 1.0f, bias_windows};
   return attn_common(dtype, a, T_frames, ws, false, stream);
 }
 
 extern "C" int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, long lddo, void* dqkv, long lddq,
                                    const float* biasT, const float* maskT, float* dbiasT, float* dqkv_colsum, int nB_,
-                                   int nW, int T_frames, int ws, int heads, int C, float scale, void* stream) {
-  AttnArgs a{qkv, ld, dqkv, lddq, dout, lddo, biasT, maskT, dbiasT, dqkv_colsum, nB_, nW, heads, C, 0, scale};
+                                   int nW, int T_frames, int ws, int heads, int C, float scale, int bias_windows,
+                                   void* stream) {
+  if (bias_windows != 1 && (bias_windows != nW || maskT)) return -1204;
+  AttnArgs a{qkv, ld, dqkv, lddq, dout, lddo, biasT, maskT, dbiasT, dqkv_colsum, nB_, nW, heads, C, 0, scale, bias_windows};
   return attn_common(dtype, a, T_frames, ws, true, stream);
 }

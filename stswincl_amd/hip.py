@@ -85,23 +85,30 @@ def _ld(t: torch.Tensor) -> int:
 # ----------------------------------------------------------------------------------------------- live profiling
 # bench.py brackets every launch of the dominant kernels with HIP events recorded on the launch stream (torch's
 # current stream IS the stream the kernels are launched on) and reads them back after the timed region.
+# Two event records per launch cost ~1.7 ms of host time per training step (480 spans), which would make the timed
+# region launch-bound; `stride` > 1 brackets only every stride-th launch of each kernel family (a stride coprime with
+# the launches per step visits every launch site over `stride` steps), the others are only counted.
 _PROFILE = None
+_PROFILE_STRIDE = 1
+_PROFILE_COUNT = {}
 
 
-def profile_begin():
-    global _PROFILE
-    _PROFILE = {}
+def profile_begin(stride: int = 1):
+    global _PROFILE, _PROFILE_STRIDE, _PROFILE_COUNT
+    _PROFILE, _PROFILE_STRIDE, _PROFILE_COUNT = {}, max(1, int(stride)), {}
 
 
 def profile_end():
-    """-> {kernel: dict(launches, ms_total, ms_avg, work)} where work = algorithmic flops (or bytes) summed."""
+    """-> {kernel: dict(launches, sampled, ms_total, ms_avg, work)}: ms_total / work cover the `sampled` launches that
+    were bracketed by events (work = their algorithmic flops or bytes), `launches` counts every launch."""
     global _PROFILE
     prof, _PROFILE = _PROFILE, None
     torch.cuda.synchronize()
     out = {}
     for name, recs in (prof or {}).items():
         ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-        out[name] = dict(launches=len(recs), ms_total=ms, ms_avg=ms / max(len(recs), 1), work=sum(w for _, _, w in recs))
+        out[name] = dict(launches=_PROFILE_COUNT.get(name, len(recs)), sampled=len(recs), ms_total=ms,
+                         ms_avg=ms / max(len(recs), 1), work=sum(w for _, _, w in recs))
     return out
 
 
@@ -113,13 +120,17 @@ class _Span:
         self.name, self.work = name, work
 
     def __enter__(self):
+        self.a = None
         if _PROFILE is not None:
-            self.a = torch.cuda.Event(enable_timing=True)
-            self.a.record()
+            n = _PROFILE_COUNT.get(self.name, 0)
+            _PROFILE_COUNT[self.name] = n + 1
+            if n % _PROFILE_STRIDE == 0:
+                self.a = torch.cuda.Event(enable_timing=True)
+                self.a.record()
         return self
 
     def __exit__(self, *exc):
-        if _PROFILE is not None:
+        if self.a is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
             _PROFILE.setdefault(self.name, []).append((self.a, b, self.work))
@@ -271,10 +282,18 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, *, M, rows=None, S=1,
 
 
 # ----------------------------------------------------------------------------------------------- attention
+def _bias_windows(biasT, maskT, nW):
+    """biasT [heads][N][N] (+ optional maskT) or the pre-summed per-window table [nW][heads][N][N] (maskT None)."""
+    if biasT.dim() == 4:
+        assert maskT is None and biasT.shape[0] == nW
+        return nW
+    return 1
+
+
 def win_attn_fwd(qkv, biasT, maskT, *, nB_, nW, T, ws, heads, C):
     out = torch.empty(qkv.shape[0], C, dtype=qkv.dtype, device=qkv.device)
     rc = load().stswin_win_attn_fwd(_dt(qkv), _p(qkv), _c_long(_ld(qkv)), _p(out), _c_long(_ld(out)), _p(biasT),
-                                    _p(maskT), nB_, nW, T, ws, heads, C, _stream())
+                                    _p(maskT), nB_, nW, T, ws, heads, C, _bias_windows(biasT, maskT, nW), _stream())
     _check(rc, "win_attn_fwd")
     return out
 
@@ -283,7 +302,7 @@ def win_attn_bwd(qkv, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, s
     dqkv = torch.empty_like(qkv)
     rc = load().stswin_win_attn_bwd(_dt(qkv), _p(qkv), _c_long(_ld(qkv)), _p(dout), _c_long(_ld(dout)), _p(dqkv),
                                     _c_long(_ld(dqkv)), _p(biasT), _p(maskT), _p(dbiasT), _p(colsum_out), nB_, nW, T, ws, heads, C,
-                                    _c_float(scale), _stream())
+                                    _c_float(scale), _bias_windows(biasT, maskT, nW), _stream())
     _check(rc, "win_attn_bwd")
     return dqkv
 

@@ -119,7 +119,11 @@ class SwinBlockFn(torch.autograd.Function):
         qkv = torch.empty(M, 3 * C, dtype=dt, device=dev)
         hip.gemm_nt(X2, wcast(qkv_w, dt), qkv, M=M, a_rows=rmap, bias=_f32(qkv_b), scale=scale, scale_cols=C)
         biasT = expand_bias_T(table, index, N, heads)
-        maskT = attn_mask.detach().float().transpose(1, 2).contiguous() if (shift > 0 and attn_mask is not None) else None
+        maskT = None
+        if shift > 0 and attn_mask is not None:
+            # one [nW][heads][N][N] table = bias + SW-MSA mask (swin_512.py:122-131): the kernels then read one value per
+            # score instead of two (the separate mask read cost +60 % on the stage-1 forward kernel)
+            biasT = biasT.unsqueeze(0) + attn_mask.detach().float().transpose(1, 2).unsqueeze(1)
         o = hip.win_attn_fwd(qkv, biasT, maskT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads, C=C)
         x1 = torch.empty(M, C, dtype=dt, device=dev)
         hip.gemm_nt(o, wcast(proj_w, dt), x1, M=M, c_rows=rmap, bias=_f32(proj_b), resid=X2, r_rows=rmap,
