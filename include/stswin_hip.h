@@ -74,7 +74,11 @@ int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_rows, const 
                    float* colsum /* optional fp32 [N]: += column sums of the stored values (bias gradient) */, void* stream);
 /* weight gradients: C[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]   (fp32 atomics; splits<=0: auto).
  * bseg > 0 (convolution wgrad in one launch): column j of the B operand is column j % bseg of row
- * bt_rows[(j / bseg) * Mk + m], i.e. tap t = j / bseg uses its own row map. */
+ * bt_rows[(j / bseg) * Mk + m], i.e. tap t = j / bseg uses its own row map.
+ * Bits of a positive `splits`: STSWIN_TN_OVERWRITE (1<<27) stores C = result instead of accumulating (C may be
+ * uninitialised; saves the caller's zero fill); bits 28-30 are tuning overrides (forbid / force the 256x256 ring kernel,
+ * 4-wave 128x128 variant) used by tools/tn_sweep.py; the low bits are the split count, 0 = automatic. */
+#define STSWIN_TN_OVERWRITE (1 << 27)
 int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, const void* Bt, long ldb, const int* bt_rows,
                    float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg,
                    float* workspace /* optional caller-owned scratch: split-K partials are stored there and combined by a

@@ -1037,14 +1037,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
 }
 
 // C[i][j] += sum_s slabs[s][i][j]   (the split-K combine: plain stores + this pass cost ~half of 32 MB of fp32 atomics)
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, float* C, long ldc, int Ni, int Nj, int splits) {
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, float* C, long ldc, int Ni, int Nj, int splits,
+                                                        int overwrite) {
   const long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (idx >= (long)Ni * Nj) return;
   const int i = idx / Nj, j = idx % Nj;           // Nj % 4 == 0
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < splits; ++s) a += *(const f32x4*)(slabs + (long)s * Ni * Nj + idx);
   float* dst = C + (long)i * ldc + j;
-  if ((ldc & 3) == 0) { *(f32x4*)dst = *(const f32x4*)dst + a; }
+  if (overwrite) {
+    if ((ldc & 3) == 0) *(f32x4*)dst = a;
+    else { for (int e = 0; e < 4; ++e) dst[e] = a[e]; }
+  } else if ((ldc & 3) == 0) { *(f32x4*)dst = *(const f32x4*)dst + a; }
   else { for (int e = 0; e < 4; ++e) dst[e] += a[e]; }
 }
 
@@ -1131,6 +1135,8 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
                               const int* bt_rows, float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg,
                               float* workspace, long workspace_floats, void* stream) {
   if (Mk <= 0 || Ni <= 0 || Nj <= 0) return 0;
+  const int overwrite = (splits > 0 && (splits & (1 << 27))) ? 1 : 0;         // C = result instead of C += result
+  if (splits > 0) splits &= ~(1 << 27);
   const int splits_flags_w4 = (splits > 0 && (splits & (1 << 30))) ? 1 : 0;   // tuning: bit 30 selects the 4-wave variant
   if (splits > 0) splits &= ~(1 << 30);
   const int pack = dtype == 0 ? 8 : 4;
@@ -1166,6 +1172,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
     if (rs > nst) rs = nst;
     if (ring) {
       const bool slabs = workspace && rs > 1 && (long)rs * Ni * Nj <= workspace_floats;
+      if (overwrite && !slabs) (void)hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)Nj * sizeof(float), (size_t)Ni, (hipStream_t)stream);
       GemmTN q{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, rs, bseg, slabs ? workspace : nullptr};
       static int once_r = (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
                           (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -1176,7 +1183,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
       if (slabs) {
         const long n4 = ((long)Ni * Nj + 3) / 4;
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, C, ldc,
-                           Ni, Nj, rs);
+                           Ni, Nj, rs, overwrite);
       }
       STSWIN_CHECK_LAUNCH();
       return 0;
@@ -1199,6 +1206,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   }
   if (splits > ntile) splits = ntile;
   const bool use_slabs = workspace && splits > 1 && (long)splits * Ni * Nj <= workspace_floats;
+  if (overwrite && !use_slabs) (void)hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)Nj * sizeof(float), (size_t)Ni, (hipStream_t)stream);
   GemmTN p{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, splits, bseg, use_slabs ? workspace : nullptr};
   dim3 grid(((Ni + 127) / 128) * ((Nj + 127) / 128) * splits);
   static int once = set_lds_once((const void*)gemm_tn_kernel<bf16, 4>) | set_lds_once((const void*)gemm_tn_kernel<float, 4>) |
@@ -1215,7 +1223,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   if (use_slabs) {
     const long n4 = ((long)Ni * Nj + 3) / 4;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, C, ldc,
-                       Ni, Nj, splits);
+                       Ni, Nj, splits, overwrite);
   }
   STSWIN_CHECK_LAUNCH();
   return 0;

@@ -139,8 +139,8 @@ class ConvTokFn(torch.autograd.Function):
             dx = torch.empty(Mi, lin.width, dtype=dt, device=X.device)
             hip.gemm_nt(g, _conv_mats(weight, dt, lin, lout, True), dx, M=Mi, a_rows=imap, S=S)
             dx = dx.to(in_dtype)
-        dwp = torch.zeros(lout.width, S * lin.width, dtype=torch.float32, device=X.device)
-        hip.gemm_tn(g, X, dwp, Mk=Mo, bt_rows=fmap, bseg=lin.width if fmap is not None else 0)
+        dwp = torch.empty(lout.width, S * lin.width, dtype=torch.float32, device=X.device)
+        hip.gemm_tn(g, X, dwp, Mk=Mo, bt_rows=fmap, bseg=lin.width if fmap is not None else 0, overwrite=True)
         if lin.is_identity and lout.is_identity:
             dw = dwp.view(co, S, ci).permute(0, 2, 1)
         else:
@@ -191,8 +191,8 @@ class StemConvFn(torch.autograd.Function):
         (im,) = ctx.saved_tensors
         dt, Ho, Wo = ctx.cfg
         patches = hip.stem_im2col(im, dt, Ho, Wo)
-        dw = torch.zeros(64, 192, dtype=torch.float32, device=im.device)
-        hip.gemm_tn(dy.detach().to(dt).contiguous(), patches, dw, Mk=patches.shape[0])
+        dw = torch.empty(64, 192, dtype=torch.float32, device=im.device)
+        hip.gemm_tn(dy.detach().to(dt).contiguous(), patches, dw, Mk=patches.shape[0], overwrite=True)
         return None, dw[:, :147].reshape(64, 7, 7, 3).permute(0, 3, 1, 2), None
 
 
@@ -312,17 +312,47 @@ class BNTokFn(torch.autograd.Function):
             s1, s2 = loc1, loc2
         else:
             s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training)
-        dgamma = lay.unpad_vec(s2.sum(0))
-        dbeta = lay.unpad_vec(s1.sum(0))
+        dgamma = lay.unpad_vec(s2[0] if groups == 1 else s2.sum(0))
+        dbeta = lay.unpad_vec(s1[0] if groups == 1 else s1.sum(0))
         return (dx.to(in_dtype), dgamma, dbeta, None, None, None, None, dres.to(in_dtype) if has_res else None,
                 None, None, None, None, None)
+
+
+_NBT_PENDING = None
+
+
+class deferred_bn_counters:
+    """Inside this context the num_batches_tracked increments of every batchnorm_tokens call (30 one-element add kernels
+    per forward of the segmentation model) are collected and applied by ONE torch._foreach_add_ on exit."""
+
+    def __enter__(self):
+        global _NBT_PENDING
+        self.prev, _NBT_PENDING = _NBT_PENDING, []
+        return self
+
+    def __exit__(self, *exc):
+        global _NBT_PENDING
+        pend, _NBT_PENDING = _NBT_PENDING, self.prev
+        if pend:
+            if self.prev is not None:
+                self.prev.extend(pend)
+            else:
+                by_inc = {}
+                for t, inc in pend:
+                    by_inc.setdefault(inc, []).append(t)
+                for inc, ts in by_inc.items():
+                    torch._foreach_add_(ts, inc)
+        return False
 
 
 def batchnorm_tokens(x, bn: torch.nn.BatchNorm2d, relu=True, resid=None, groups=1, lay: Optional[Layout] = None):
     lay = lay or Layout.dense(bn.num_features)
     training = bn.training or bn.running_mean is None
     if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += groups
+        if _NBT_PENDING is not None:
+            _NBT_PENDING.append((bn.num_batches_tracked, groups))
+        else:
+            bn.num_batches_tracked += groups
     return BNTokFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, relu, resid, groups, lay,
                          bn.eps, bn.momentum if bn.momentum is not None else 0.1, _sync_world(bn) if training else 1)
 

@@ -19,6 +19,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 GF_GELU, GF_RESID, GF_MUL_DGELU, GF_OUT_F32, GF_ACCUM, GF_RELU, GF_WAVES4, GF_BIG, GF_NOBIG, GF_MID, GF_NOPIPE, GF_HALF, GF_NOHALF = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
 GF_NOREGEPI = 1 << 22
+TN_OVERWRITE = 1 << 27
 
 _c_int, _c_long, _c_float, _c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 
@@ -234,8 +235,11 @@ def _tn_workspace(device, floats=48 * 1024 * 1024):
 
 
 def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: int, at_rows=None, bt_rows=None,
-            splits: int = 0, bseg: int = 0, atomics: bool = False):
-    """out_f32[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]  (fp32, atomically accumulated)."""
+            splits: int = 0, bseg: int = 0, atomics: bool = False, overwrite: bool = False):
+    """out_f32[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]  (fp32); overwrite=True stores instead of adding, so
+    out_f32 may come from torch.empty."""
+    if overwrite:
+        splits |= TN_OVERWRITE
     Ni, Nj = out_f32.shape
     assert out_f32.dtype == torch.float32 and At.dtype == Bt.dtype
     ws = None if atomics or torch.cuda.is_current_stream_capturing() and At.device not in _TN_WS else _tn_workspace(At.device)

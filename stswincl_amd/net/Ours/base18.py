@@ -59,7 +59,8 @@ class TswinPlus(nn.Module):
 
     def forward(self, x):
         hi, wi = x.shape[3:]
-        cat, (b, h, w) = decode_tokens(self.resnet, self.swin, self.aspp, self.project1, self.project2, self.project3, x)
-        y = H.conv_bn_relu(cat, self.classifier[0], self.classifier[1], (b, h, w), lin=LCAT)
-        y = H.conv1x1_tokens(y, self.classifier[3], b, h, w)
+        with H.deferred_bn_counters():
+            cat, (b, h, w) = decode_tokens(self.resnet, self.swin, self.aspp, self.project1, self.project2, self.project3, x)
+            y = H.conv_bn_relu(cat, self.classifier[0], self.classifier[1], (b, h, w), lin=LCAT)
+            y = H.conv1x1_tokens(y, self.classifier[3], b, h, w)
         return H.LogitsUpFn.apply(y, (b, h, w, hi, wi, self.num_classes))

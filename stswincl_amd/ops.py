@@ -78,15 +78,16 @@ def clear_caches() -> None:
     _WCACHE.clear()
 
 
-def zeros_like_list(shapes, device):
+def zeros_like_list(shapes, device, fill=True):
     """One fp32 zero-fill for many small gradient / statistic buffers (a fill launch costs ~5 us of GPU time each; a Swin
-    block backward needs 13 of them).  Returns views of one flat buffer, 64-byte aligned starts."""
+    block backward needs 13 of them).  Returns views of one flat buffer, 64-byte aligned starts.  fill=False: one
+    uninitialised allocation (for buffers a kernel overwrites)."""
     sizes = [int(torch.Size(sh).numel()) for sh in shapes]
     offs, tot = [], 0
     for n in sizes:
         offs.append(tot)
         tot += (n + 15) // 16 * 16
-    flat = torch.zeros(tot, dtype=torch.float32, device=device)
+    flat = (torch.zeros if fill else torch.empty)(tot, dtype=torch.float32, device=device)
     return [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
 
 
@@ -154,18 +155,19 @@ class SwinBlockFn(torch.autograd.Function):
         dev = X2.device
         hid = fc1_w.shape[0]
         tsz = (2 * ws - 1) * (2 * ws - 1)
-        (dn1_w, dn1_b, dfc2_b, dfc2_w, dfc1_w, dfc1_b, dn2_w, dn2_b, dproj_b, dproj_w, dbiasT, dqkv_b, dtable,
-         dqkv_w) = zeros_like_list([(C,), (C,), (C,), (C, hid), (hid, C), (hid,), (C,), (C,), (C,), (C, C), (heads, N, N),
-                                    (3 * C,), (tsz, heads), (3 * C, C)], dev)
+        (dn1_w, dn1_b, dfc2_b, dfc1_b, dn2_w, dn2_b, dproj_b, dbiasT, dqkv_b, dtable) = zeros_like_list(
+            [(C,), (C,), (C,), (hid,), (C,), (C,), (C,), (heads, N, N), (3 * C,), (tsz, heads)], dev)
+        # the weight gradients are written by gemm_tn(overwrite=True): no zero fill for the large buffers
+        dfc2_w, dfc1_w, dproj_w, dqkv_w = zeros_like_list([(C, hid), (hid, C), (C, C), (3 * C, C)], dev, fill=False)
         g = dout.detach().to(dt).contiguous().view(M, C)
         # norm1 (its dx column sums are fc2's bias gradient)
         dy2 = hip.layernorm_bwd(g, y2, _f32(n1_w), mean1, rstd1, dn1_w, dn1_b, M=M, dxsum=dfc2_b)
         # fc2 (+ GELU', + fc1's bias gradient from the epilogue)
-        hip.gemm_tn(dy2, h, dfc2_w, Mk=M)
+        hip.gemm_tn(dy2, h, dfc2_w, Mk=M, overwrite=True)
         dh_pre = torch.empty(M, hid, dtype=dt, device=dev)
         hip.gemm_nt(dy2, wcast(fc2_w, dt, True), dh_pre, M=M, resid=h_pre, flags=hip.GF_MUL_DGELU, colsum_out=dfc1_b)
         # fc1
-        hip.gemm_tn(dh_pre, n2, dfc1_w, Mk=M)
+        hip.gemm_tn(dh_pre, n2, dfc1_w, Mk=M, overwrite=True)
         dn2 = torch.empty(M, C, dtype=dt, device=dev)
         hip.gemm_nt(dh_pre, wcast(fc1_w, dt, True), dn2, M=M)
         del dh_pre
@@ -173,7 +175,7 @@ class SwinBlockFn(torch.autograd.Function):
         dx1 = hip.layernorm_bwd(dn2, x1, _f32(n2_w), mean2, rstd2, dn2_w, dn2_b, M=M, dx=dy2, accumulate=True,
                                 dxsum=dproj_b)
         # proj (window order on the attention side)
-        hip.gemm_tn(dx1, o, dproj_w, Mk=M, at_rows=rmap)
+        hip.gemm_tn(dx1, o, dproj_w, Mk=M, at_rows=rmap, overwrite=True)
         do = dn2  # reuse
         hip.gemm_nt(dx1, wcast(proj_w, dt, True), do, M=M, a_rows=rmap)
         # attention core (also yields the qkv bias gradient)
@@ -181,7 +183,7 @@ class SwinBlockFn(torch.autograd.Function):
                                 C=C, scale=d ** -0.5, colsum_out=dqkv_b)
         dtable.index_add_(0, index.reshape(-1).long(), dbiasT.permute(2, 1, 0).reshape(N * N, heads))
         # qkv
-        hip.gemm_tn(dqkv, X2, dqkv_w, Mk=M, bt_rows=rmap)
+        hip.gemm_tn(dqkv, X2, dqkv_w, Mk=M, bt_rows=rmap, overwrite=True)
         dx = torch.empty(M, C, dtype=dt, device=dev)
         hip.gemm_nt(dqkv, wcast(qkv_w, dt, True), dx, M=M, c_rows=rmap, resid=dx1, r_rows=rmap, flags=hip.GF_RESID)
         Bp = M // (2 * H * W)
@@ -219,8 +221,8 @@ class PatchMergeFn(torch.autograd.Function):
         M4 = n.shape[0]
         dev = X2.device
         g = dy.detach().to(dt).contiguous().view(M4, 2 * C)
-        dred = torch.zeros(2 * C, 4 * C, dtype=torch.float32, device=dev)
-        hip.gemm_tn(g, n, dred, Mk=M4)
+        dred = torch.empty(2 * C, 4 * C, dtype=torch.float32, device=dev)
+        hip.gemm_tn(g, n, dred, Mk=M4, overwrite=True)
         dn = torch.empty(M4, 4 * C, dtype=dt, device=dev)
         hip.gemm_nt(g, wcast(red_w, dt, True), dn, M=M4)
         dg = torch.zeros(4 * C, dtype=torch.float32, device=dev)
@@ -313,8 +315,8 @@ class LinearFn(torch.autograd.Function):
             # possible, so compute it with the GEMM epilogue on the weight-gradient path instead
             dpre = (g.float() * _dgelu(aux.float())).to(dt)
             g = dpre
-        dw = torch.zeros(Nn, K, dtype=torch.float32, device=X2.device)
-        hip.gemm_tn(g, X2, dw, Mk=M)
+        dw = torch.empty(Nn, K, dtype=torch.float32, device=X2.device)
+        hip.gemm_tn(g, X2, dw, Mk=M, overwrite=True)
         db = None
         if ctx.has_b:
             db = torch.zeros(Nn, dtype=torch.float32, device=X2.device)
