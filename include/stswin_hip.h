@@ -106,7 +106,10 @@ int stswin_win_attn_fwd(int dtype, const void* qkv, long ld, void* out, long ldo
                         int nB_, int nW, int T_frames, int ws, int heads, int C, int bias_windows, void* stream);
 int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, long lddo, void* dqkv, long lddq,
                         const float* biasT, const float* maskT, float* dbiasT,
-                        float* dqkv_colsum /* optional fp32 [3C] */, int nB_, int nW, int T_frames, int ws,
+                        float* dqkv_q_colsum /* optional fp32 [C]: += column sums of the dq third (q bias gradient).
+                           The other two thirds need no pass over dqkv: sum_rows dk = 0 exactly (rows of dS sum to
+                           zero) and sum_rows dv = column sums of dout (softmax rows sum to one) */,
+                        int nB_, int nW, int T_frames, int ws,
                         int heads, int C, float scale, int bias_windows, void* stream);
 
 /* ---- decode head on NHWC token matrices [M = frames*H*W][C]  (ASPP.py:33-52, base18.py:60-106) ---------------

@@ -21,7 +21,7 @@ struct AttnArgs {
   const float* biasT;             // [heads][N][N]   biasT[h][key n][query n]
   const float* maskT;             // [nW][N][N] or null
   float* dbiasT;                  // bwd: [heads][N][N] fp32, atomically accumulated
-  float* dqkv_colsum;             // bwd, optional: [3C] fp32 += column sums of dqkv (the qkv bias gradient)
+  float* dqkv_colsum;             // bwd, optional: [C] fp32 += column sums of the dq third of dqkv (see include/stswin_hip.h)
   int nB_, nW, heads, C, N;       // nB_ = number of (clip, window) problems = B*nW
   float scale;                    // bwd: dq = scale * (dS k)
   int bias_windows;               // 1: biasT is [heads][N][N]; nW: biasT is [nW][heads][N][N] with the mask already added
@@ -237,7 +237,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, vbase[(long)(2 * kk + half) * a.ld + dt * 32 + lr], o[dt], 0, 0, 0);
     }
   }
-  // O[query = crow32(r)][d = 32 dt + lr] -> out[rowbase + q0 + query][head*HD + d]
+  // O[query = crow32(r)][d = 32 dt + lr] -> out[rowbase + q0 + query][head*HD + d].  (The transposed product V^T P^T
+  // would give every lane 8-byte pieces, but a store instruction then touches 32 rows x 16 B instead of 2 rows x 64 B and
+  // measured 9 % SLOWER on the stage-1 shape: bytes per touched cache line matter more than the instruction count.)
   T* ob = (T*)a.out + (rowbase + q0) * a.ldo + head * HD;
 #pragma unroll
   for (int dt = 0; dt < Cfg::DT; ++dt)
@@ -261,15 +263,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   const long ngroups = ((long)a.nB_ * a.heads + Cfg::PPB - 1) / Cfg::PPB;
   const int head = (int)(((long)blockIdx.x * Cfg::PPB + sp) % a.heads);
   f32x16 dbacc[Cfg::KT];
-  float csacc[3][Cfg::DT];
+  float csacc[Cfg::DT];
 #pragma unroll
   for (int kt = 0; kt < Cfg::KT; ++kt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dbacc[kt][r] = 0.f;
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int dt = 0; dt < Cfg::DT; ++dt) csacc[i][dt] = 0.f;
+  for (int dt = 0; dt < Cfg::DT; ++dt) csacc[dt] = 0.f;
   for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
   const long prob = grp * Cfg::PPB + sp;
   const int b_ = min((int)(prob / a.heads), a.nB_ - 1);
@@ -347,19 +347,29 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
   };
-  auto store_acc = [&](T* base, int row0, float mul, int which) {
-    if (!live) return;
+  // dQ keeps the untransposed product (registers = query rows): its column sums - the q third of the qkv bias gradient -
+  // are then in-lane.  `csacc` carries them across this workgroup's problems.
+  auto store_acc = [&](T* base, int row0, float mul) {
 #pragma unroll
     for (int dt = 0; dt < Cfg::DT; ++dt) {
       float csum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const T o = from_f32<T>(acc[dt][r] * mul);
-        base[(long)(row0 + crow32(r, half)) * a.ldo + dt * 32 + lr] = o;
+        if (live) base[(long)(row0 + crow32(r, half)) * a.ldo + dt * 32 + lr] = o;
         csum += to_f32<T>(o);
       }
-      csacc[which][dt] += csum;
+      if (live) csacc[dt] += csum;
     }
+  };
+  // dV / dK need no column sums: sum_key dK = 0 (rows of dS sum to zero) and sum_key dV = column sums of dO (softmax
+  // rows sum to one), which the caller takes from the GEMM that produced dO.
+  auto store_acc_plain = [&](T* base, int row0) {
+    if (!live) return;
+#pragma unroll
+    for (int dt = 0; dt < Cfg::DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) base[(long)(row0 + crow32(r, half)) * a.ldo + dt * 32 + lr] = from_f32<T>(acc[dt][r]);
   };
 
   // ---- dV[key][d] = sum_q P[q][key] dO[q][d]
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, dobase[(long)qq * a.lddo + dt * 32 + lr], acc[dt], 0, 0, 0);
     }
   }
-  store_acc(dvb, k0, 1.0f, 2);
+  store_acc_plain(dvb, k0);
 
   // ---- dK[key][d] = sum_q dS[q][key] q_s[q][d]
   if constexpr (TT<T>::IS_BF16) {
@@ -415,7 +425,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, qbase[(long)qq * a.ld + dt * 32 + lr], acc[dt], 0, 0, 0);
     }
   }
-  store_acc(dkb, k0, 1.0f, 1);
+  store_acc_plain(dkb, k0);
 
   // ---- dQ[q][d] = scale * sum_key dS[q][key] K[key][d]
   zero_acc();
@@ -437,26 +447,35 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, kbase[(long)key * a.ld + dt * 32 + lr], acc[dt], 0, 0, 0);
     }
   }
-  store_acc(dqb, q0, a.scale, 0);
+  store_acc(dqb, q0, a.scale);
   __syncthreads();                               // the next problem's tiles overwrite K / dS
   }
   if (a.dbiasT) {
     const int N = NC ? NC : a.N, qn = (qt * 32 + lr) % N;
     float* db = a.dbiasT + (long)head * N * N + qn;
+    if constexpr (NC == 16 && NTOK == 32) {
+      // 16-entry windows: registers r and r+8 and lanes lr and lr+16 hit the same table entry - fold them first
+      // (1 K addresses take every atomic of this kernel; 4x fewer of them)
 #pragma unroll
-    for (int kt = 0; kt < Cfg::KT; ++kt)
+      for (int r = 0; r < 8; ++r) {
+        float v = dbacc[0][r] + dbacc[0][r + 8];
+        v += __shfl_xor(v, 16);
+        if (lr < 16) atomicAdd(db + (crow32(r, half) % 16) * 16, v);
+      }
+    } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) atomicAdd(db + ((kt * 32 + crow32(r, half)) % N) * N, dbacc[kt][r]);
+      for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(db + ((kt * 32 + crow32(r, half)) % N) * N, dbacc[kt][r]);
+    }
   }
   if (a.dqkv_colsum) {
 #pragma unroll
-    for (int which = 0; which < 3; ++which)
-#pragma unroll
-      for (int dt = 0; dt < Cfg::DT; ++dt) {
-        float csum = csacc[which][dt];
-        csum += __shfl_xor(csum, 32);
-        if (half == 0) atomicAdd(a.dqkv_colsum + which * a.C + head * HD + dt * 32 + lr, csum);
-      }
+    for (int dt = 0; dt < Cfg::DT; ++dt) {
+      float csum = csacc[dt];
+      csum += __shfl_xor(csum, 32);
+      if (half == 0) atomicAdd(a.dqkv_colsum + head * HD + dt * 32 + lr, csum);
+    }
   }
 }
 

@@ -177,8 +177,9 @@ class SwinBlockFn(torch.autograd.Function):
         # proj (window order on the attention side)
         hip.gemm_tn(dx1, o, dproj_w, Mk=M, at_rows=rmap, overwrite=True)
         do = dn2  # reuse
-        hip.gemm_nt(dx1, wcast(proj_w, dt, True), do, M=M, a_rows=rmap)
-        # attention core (also yields the qkv bias gradient)
+        # (dv third of the qkv bias gradient = column sums of dO: softmax rows sum to one; the dk third is exactly zero)
+        hip.gemm_nt(dx1, wcast(proj_w, dt, True), do, M=M, a_rows=rmap, colsum_out=dqkv_b[2 * C:])
+        # attention core (also yields the dq third of the qkv bias gradient)
         dqkv = hip.win_attn_bwd(qkv, do, biasT, maskT, dbiasT, nB_=(M // (2 * N)), nW=nW, T=2, ws=ws, heads=heads,
                                 C=C, scale=d ** -0.5, colsum_out=dqkv_b)
         dtable.index_add_(0, index.reshape(-1).long(), dbiasT.permute(2, 1, 0).reshape(N * N, heads))
