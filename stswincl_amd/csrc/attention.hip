@@ -74,6 +74,25 @@ template <int ROWB> DEVI bf16x8 frag_tr(const char* tile, int ks, int col_tile) 
   return cat4(r[0], r[1]);
 }
 
+// Same transposed read with the contraction rows in the order a lane HOLDS a 32x32 MFMA result: k-slot e of lane half h
+// is row kbase + 4h + (e & 3) + 8 (e >> 2) (= crow32 of accumulator registers 8m..8m+7 with kbase = 32 kt + 16 m).  With
+// it the probabilities go from the score accumulators straight into the next MFMA as its other operand - any k order
+// is fine as long as both operands use the same one - instead of through an LDS tile.
+template <int ROWB> DEVI bf16x8 frag_tr_perm(const char* tile, int kbase, int col_tile) {
+  const int l = threadIdx.x & 63;
+  const int k0 = kbase + 4 * (l >> 5), col0 = 32 * col_tile + 16 * ((l >> 4) & 1);
+  const int lam = l & 15, q = lam >> 2, p = lam & 3;
+  bf16x4 r[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int row = k0 + 8 * e + q, col = col0 + 4 * p;
+    const char* addr = tile + tile_off<ROWB>(row, col >> 3) + ((col & 7) << 1);
+    short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)addr);
+    r[e] = __builtin_bit_cast(bf16x4, t);
+  }
+  return cat4(r[0], r[1]);
+}
+
 DEVI int crow32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }   // C-map row of register r
 
 template <typename T, int NTOK, int HD>
@@ -86,7 +105,7 @@ struct AttnCfg {
   static constexpr int PRB = NTOK * sizeof(T);    // P/dS tile row bytes
   static constexpr int KV_BYTES = TT<T>::IS_BF16 ? NTOK * RB : 0;
   static constexpr int P_BYTES = NTOK * PRB;      // per problem, all query tiles
-  static constexpr int FWD_LDS = PPB * (2 * KV_BYTES + P_BYTES);
+  static constexpr int FWD_LDS = TT<T>::IS_BF16 ? PPB * 2 * KV_BYTES : PPB * P_BYTES;   // bf16 forward keeps P in registers
   static constexpr int BWD_LDS = PPB * (2 * KV_BYTES + 2 * P_BYTES);
   static_assert(NTOK % 32 == 0 && HD % 32 == 0 && (QW == 1 || QW == 2 || QW == 4), "shape");
 };
@@ -196,9 +215,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const T* qbase = (const T*)a.qkv + rowbase * a.ld + head * HD;
   const T* kbase = qbase + a.C;
   const T* vbase = qbase + 2 * a.C;
-  char* Kt = smem + sp * (2 * Cfg::KV_BYTES + Cfg::P_BYTES);
+  char* Kt = smem + sp * (TT<T>::IS_BF16 ? 2 * Cfg::KV_BYTES : Cfg::P_BYTES);
   char* Vt = Kt + Cfg::KV_BYTES;
-  char* Pt = Vt + Cfg::KV_BYTES;
+  char* Pt = Kt;                                   // f32 only (no K / V tiles there)
   const int q0 = qt * 32;
   if constexpr (TT<T>::IS_BF16) {
     if (live) {
@@ -212,8 +231,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
   f32x16 p[Cfg::KT];
   scores_softmax<T, NTOK, HD, NC>(p, a, Kt, qbase, kbase, q0, head, b_ % a.nW);
-  store_qk_tile<T, NTOK>(Pt, p, q0);   // rows q0..q0+31 are private to this wave
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own LDS writes visible to own reads
 
   f32x16 o[Cfg::DT];
 #pragma unroll
@@ -221,14 +238,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   if constexpr (TT<T>::IS_BF16) {
+    // O = P V with P taken from the score accumulators: this lane's query row, k-slots in accumulator order
 #pragma unroll
-    for (int ks = 0; ks < NTOK / 16; ++ks) {
-      const bf16x8 pa = frag_row<Cfg::PRB>(Pt, q0 + lr, ks, half);
+    for (int kt = 0; kt < Cfg::KT; ++kt)
 #pragma unroll
-      for (int dt = 0; dt < Cfg::DT; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<Cfg::RB>(Vt, ks, dt), o[dt], 0, 0, 0);
-    }
+      for (int m = 0; m < 2; ++m) {
+        bf16x8 pa;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pa[e] = (bf16)p[kt][8 * m + e];
+#pragma unroll
+        for (int dt = 0; dt < Cfg::DT; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr_perm<Cfg::RB>(Vt, kt * 32 + 16 * m, dt), o[dt], 0, 0, 0);
+      }
   } else {
+    store_qk_tile<T, NTOK>(Pt, p, q0);   // rows q0..q0+31 are private to this wave
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own LDS writes visible to own reads
 #pragma unroll 4
     for (int kk = 0; kk < NTOK / 2; ++kk) {
       const float pa = tile_elem_f32<T, Cfg::PRB>(Pt, q0 + lr, 2 * kk + half);
