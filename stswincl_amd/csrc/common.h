@@ -39,6 +39,10 @@ DEVI void glds16_raw(const void* gsrc, void* lds_wave_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds) : "memory", "m0");
 }
 
+// An empty volatile asm inside a wave-uniform `if` body keeps hipcc from if-converting it into always-executed VALU
+// selects (the epilogue's rarely-set flag branches cost 12 VALU per fragment that way, taken or not).
+#define NO_IFCVT asm volatile("" ::: "memory")
+
 // ---- scalar (SMEM) load of a wave-uniform int: counted by lgkmcnt, so it never stalls the LDS-DMA vmcnt pipeline ----
 DEVI int sload(const int* p, long idx) { return ((const __attribute__((address_space(4))) int*)p)[idx]; }
 

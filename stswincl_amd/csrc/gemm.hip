@@ -31,6 +31,9 @@ enum {
   GF_NOPIPE = 1024,  // tuning: 256x256 ring without the ping-pong schedule
   GF_HALF = 2048,    // tuning: force the 256x128 ping-pong ring
   GF_NOHALF = 4096,  // tuning: forbid it
+  GF_STREAM = 1 << 25,    // tuning: persistent streaming 256x256 variant (measured no faster: both wave rows idle through each other's epilogue)
+  GF_DUO = 1 << 24,       // tuning: 128x256 tiles, 4 waves, two workgroups per CU
+  GF_NOSTREAM = 1 << 23,  // tuning: 256x256 ring without the persistent streaming variant
   GF_NOREGEPI = 1 << 22,  // tuning: 256x256 ring with the LDS-staged fp32 epilogue instead of the register epilogue
   GF_WAVES4 = 64,    // tuning: 4 waves of 64x64 per tile instead of the default 8 waves of 64x32 (4 waves/SIMD)
 };
@@ -344,16 +347,18 @@ template <int N> DEVI void wait_vmcnt() {
 //   <256,256,2,4,4>: 128 KB LDS, 1 workgroup / CU (128 FLOP per L2 byte)
 //   <256,128,4,2,3>:  72 KB LDS, 2 workgroups / CU (87 FLOP per L2 byte; the neighbour's main loop hides the epilogue)
 template <int BM, int BN, int WM, int WN, int NST, int MINW, bool PIPE, bool SWAP = false>
-__global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
+__global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT p) {
   using T = bf16;
   constexpr int BK = 32, ROWB = 64;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
   constexpr int TM = BM / WM, TN = BN / WN;          // wave tile
   constexpr int FI = TM / 16, FJ = TN / 16;          // fragments per wave
-  constexpr int NIA = BM / 16 / 8, NIB = BN / 16 / 8; // LDS-DMA instructions per wave per stage (16 rows each)
+  constexpr int NWV = WM * WN, NTHR = NWV * 64;     // waves / threads per workgroup (8 / 512, or 4 / 256)
+  constexpr int NIA = BM / 16 / NWV, NIB = BN / 16 / NWV; // LDS-DMA instructions per wave per stage (16 rows each)
   constexpr int PER_STAGE = NIA + NIB;
-  constexpr int EROWS = (NST * STAGE) / (BN * 4) >= BM ? BM : ((NST * STAGE) / (BN * 4) / TM) * TM;   // rows per epilogue slab
-  static_assert(EROWS >= TM && BM % EROWS == 0, "epilogue slab");
+  constexpr int EROWS = SWAP ? BM : ((NST * STAGE) / (BN * 4) >= BM ? BM : ((NST * STAGE) / (BN * 4) / TM) * TM);   // rows per epilogue slab
+  static_assert(SWAP || (EROWS >= TM && BM % EROWS == 0), "epilogue slab");
+  static_assert(!SWAP || BM * BN * 2 <= NST * STAGE, "register epilogue image");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, l = tid & 63, w = wave_id();
   const int wr = w / WN, wc = w % WN;
@@ -404,6 +409,11 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
 
   const int fr = l & 15, fq = l >> 4;
   const int rd_off = fr * ROWB + ((fq ^ swz64(fr)) << 4);
+  const bool dbg_ts = (p.flags & (1 << 19)) != 0;     // DBG: p.colsum is a u64 [blocks][8] timestamp buffer (100 MHz clock)
+  auto stamp = [&](int slot) {
+    if (dbg_ts && tid == 0) ((unsigned long long*)p.colsum)[(long)blockIdx.x * 8 + slot] = wall_clock64();
+  };
+  stamp(0);
   auto epilogue = [&]() {
     if (p.flags & (1 << 21)) {        // DBG: no epilogue at all (keeps the accumulators alive)
       float t = 0.f;
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
   // ---------------- epilogue: BM / EROWS slabs of [EROWS][BN] fp32 through the ring memory ----------------
     float* ct = (float*)smem;
     constexpr int CG = BN / 8;                        // column groups of 8
-    constexpr int RGP = 512 / CG;                     // rows per pass
+    constexpr int RGP = NTHR / CG;                    // rows per pass
     const int c8 = (tid % CG) * 8;
     const int gn0 = n0 + c8;
     const int ncols = max(0, min(8, p.N - gn0));
@@ -478,23 +488,32 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
   // ---------------- register epilogue (SWAP kernels): all per-element work happens on the accumulators ----------------
   // Lane (fr, fq) of fragment (i, j) holds C[m0 + wr*TM + i*16 + fr][n0 + wc*TN + j*16 + 4fq + 0..3]: bias, q-scale, GELU,
   // residual / GELU' (8-byte loads of R in the same layout), ReLU and the column sums are applied in registers, the
-  // bf16 result goes through ONE [BM][BN] bf16 LDS image (ds_write_b64, chunk ^= (row & 15) << 1: conflict-free both
+  // bf16 result goes through ONE [BM][BN] bf16 LDS image (ds_write_b64, chunk ^= row & 15: conflict-free both
   // ways) and leaves as whole 16-byte row pieces.  The LDS-staged fp32 epilogue above spent 7.4 us per 256x256 tile
   // (2 slabs x 128 ds_write_b32 per lane + ~90 VALU per 8-column piece) against 12 us of main loop at K = 512.
-  auto epilogue_reg = [&]() {
-    constexpr int PITCH = BN * 2, CPRW = BN / 8, RPP = 512 / CPRW, NPASS = BM / RPP;
+  // The per-tile flag combination is resolved ONCE (epi_dispatch below) into a straight-line instantiation of this body:
+  // with the flags tested per fragment the 32 fragments of a wave spent 3.6 us of a 24 us tile in scalar branches
+  // (tools/gemm_timeline.py).  MD >= 0: compile-time mode bits; MD < 0: generic fallback testing the runtime flags.
+  enum { E_BIAS = 1, E_SCALE = 2, E_GELU = 4, E_C2 = 8, E_RESID = 16, E_DGELU = 32, E_COLSUM = 64, E_RELU = 128 };
+  auto epilogue_body = [&](auto tag) {
+    constexpr int MD = decltype(tag)::value;
+#define EPI_HAS(bit, rt) (MD >= 0 ? ((MD & (bit)) != 0) : (rt))
+    constexpr int PITCH = BN * 2, CPRW = BN / 8, RPP = NTHR / CPRW, NPASS = BM / RPP;
     char* img = smem;
+    const bool has_bias = EPI_HAS(E_BIAS, p.bias != nullptr), has_scale = EPI_HAS(E_SCALE, p.scale_cols > 0);
+    const bool do_gelu = EPI_HAS(E_GELU, (p.flags & GF_GELU) != 0), has_c2 = EPI_HAS(E_C2, p.C2 != nullptr);
+    const bool do_resid = EPI_HAS(E_RESID, (p.flags & GF_RESID) != 0), do_dgelu = EPI_HAS(E_DGELU, (p.flags & GF_MUL_DGELU) != 0);
+    const bool do_cs = EPI_HAS(E_COLSUM, p.colsum != nullptr) && !dbg_ts, do_relu = EPI_HAS(E_RELU, (p.flags & GF_RELU) != 0);
+    const bool has_r = do_resid || do_dgelu;
     const int colb = n0 + wc * TN + 4 * fq;           // + j*16: first of this lane's 4 columns
     f32x4 bj[FJ];
+    if (has_bias) {
 #pragma unroll
-    for (int j = 0; j < FJ; ++j) {
-      const int gn = colb + j * 16;
-      bj[j] = (p.bias && gn < p.N) ? *(const f32x4*)(p.bias + gn) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < FJ; ++j) bj[j] = *(const f32x4*)(p.bias + min(colb + j * 16, p.N - 4));   // columns >= N are never stored
     }
-    const bool has_r = (p.flags & (GF_RESID | GF_MUL_DGELU)) != 0;
-    const bool has_scale = p.scale_cols > 0;
     auto pre_act = [&](int i, int j) -> f32x4 {
-      f32x4 v = acc[i][j] + bj[j];
+      f32x4 v = acc[i][j];
+      if (has_bias) v += bj[j];
       if (has_scale) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -505,63 +524,55 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
     auto put = [&](int i, int j, f32x4 v) {
       const int row = wr * TM + i * 16 + fr;
       const int chunk = (wc * TN + j * 16 + 4 * fq) >> 3;
-      Vec16<T> dummy; (void)dummy;
       bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-      *(bf16x4*)(img + row * PITCH + (((chunk ^ (fr << 1)) & (CPRW - 1)) << 4) + (fq & 1) * 8) = o;
+      *(bf16x4*)(img + row * PITCH + (((chunk ^ fr) & (CPRW - 1)) << 4) + (fq & 1) * 8) = o;
     };
     // output rows of this thread's readback pieces (c_rows is a scatter map): fetched before the LDS round trip
     const int rb_row = tid / CPRW, rb_chunk = tid % CPRW;
     const bool rb_col_ok = n0 + rb_chunk * 8 < p.N;
     auto readback = [&](void* Cout, long ldo) {
-      long orow[NPASS];
+      int orow[NPASS];
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
         const int gm = m0 + ps * RPP + rb_row;
-        orow[ps] = (gm < p.M && rb_col_ok) ? (p.c_rows ? (long)p.c_rows[gm] : (long)gm) : -1;
+        orow[ps] = (gm < p.M && rb_col_ok) ? (p.c_rows ? p.c_rows[gm] : gm) : -1;
       }
       __syncthreads();
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
         const int row = ps * RPP + rb_row;
         if (orow[ps] >= 0) {
-          const bf16x8 val = *(const bf16x8*)(img + row * PITCH + (((rb_chunk ^ ((row & 15) << 1)) & (CPRW - 1)) << 4));
-          if (p.flags & (1 << 20)) { if ((float)val[0] == 123.456f) *(bf16x8*)((T*)Cout + orow[ps] * ldo + n0 + rb_chunk * 8) = val; }
-          else
-          *(bf16x8*)((T*)Cout + orow[ps] * ldo + n0 + rb_chunk * 8) = val;
+          const bf16x8 val = *(const bf16x8*)(img + row * PITCH + (((rb_chunk ^ (row & 15)) & (CPRW - 1)) << 4));
+          *(bf16x8*)((T*)Cout + (long)orow[ps] * ldo + n0 + rb_chunk * 8) = val;
         }
       }
     };
-    if (p.flags & (1 << 21)) {        // DBG: no epilogue at all (keeps the accumulators alive)
-      float t = 0.f;
-#pragma unroll
-      for (int i = 0; i < FI; ++i)
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-      if (t == 123.456f) ((T*)p.C)[tid] = from_f32<T>(t);
-      return;
-    }
+    stamp(3);
     __syncthreads();                                   // every wave is done with the ring stages
-    if (p.C2) {                                        // pre-activation copy (fc1 forward keeps it for GELU')
+    stamp(4);
+    if (has_c2) {                                      // pre-activation copy (fc1 forward keeps it for GELU')
 #pragma unroll
       for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < FJ; ++j) put(i, j, pre_act(i, j));
+        for (int j = 0; j < FJ; ++j) { put(i, j, pre_act(i, j)); __builtin_amdgcn_sched_barrier(0); }
       readback(p.C2, p.ldc2);
       __syncthreads();
+      // launder the bias registers: otherwise hipcc keeps all 128 bias-added values of the pass above for the pass
+      // below (common subexpression) and spills them
+      if (has_bias) {
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) asm volatile("" : "+v"(bj[j]));
+      }
     }
     f32x4 cs[FJ];
 #pragma unroll
     for (int j = 0; j < FJ; ++j) cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x4 rcur[FJ], rnext[FJ];
     auto load_r = [&](int i, bf16x4 (&dst)[FJ]) {
-      const int gm = m0 + wr * TM + i * 16 + fr;
-      const long rrow = gm < p.M ? (p.r_rows ? (long)p.r_rows[gm] : (long)gm) : -1;
+      const int gm = min(m0 + wr * TM + i * 16 + fr, p.M - 1);        // rows >= M / columns >= N: clamped, never stored
+      const long rrow = p.r_rows ? (long)p.r_rows[gm] : (long)gm;
 #pragma unroll
-      for (int j = 0; j < FJ; ++j) {
-        const int gn = colb + j * 16;
-        if (rrow >= 0 && gn < p.N) dst[j] = *(const bf16x4*)((const T*)p.R + rrow * p.ldr + gn);
-        else dst[j] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-      }
+      for (int j = 0; j < FJ; ++j) dst[j] = *(const bf16x4*)((const T*)p.R + rrow * p.ldr + min(colb + j * 16, p.N - 4));
     };
     if (has_r) load_r(0, rcur);
 #pragma unroll
@@ -571,29 +582,33 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
 #pragma unroll
       for (int j = 0; j < FJ; ++j) {
         f32x4 v = pre_act(i, j);
-        if (p.flags & GF_GELU) {
+        if (do_gelu) {
           const f32x2 lo = gelu_fast2((f32x2){v[0], v[1]}), hi = gelu_fast2((f32x2){v[2], v[3]});
           v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
         }
         if (has_r) {
           const f32x4 r = {(float)rcur[j][0], (float)rcur[j][1], (float)rcur[j][2], (float)rcur[j][3]};
-          if (p.flags & GF_RESID) v += r;
+          if (do_resid) v += r;
           else {
             const f32x2 lo = dgelu_fast2((f32x2){r[0], r[1]}), hi = dgelu_fast2((f32x2){r[2], r[3]});
             v *= (f32x4){lo[0], lo[1], hi[0], hi[1]};
           }
         }
-        if (p.flags & GF_RELU) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
-        if (p.colsum && row_ok) cs[j] += v;
+        if (do_relu) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
+        if (do_cs) { if (row_ok) cs[j] += v; }
         put(i, j, v);
+        if (do_gelu || do_dgelu) __builtin_amdgcn_sched_barrier(0);   // one fragment's polynomial temporaries at a time
       }
       if (has_r && i + 1 < FI) {
 #pragma unroll
         for (int j = 0; j < FJ; ++j) rcur[j] = rnext[j];
       }
+      __builtin_amdgcn_sched_barrier(0);              // keep fragment rows apart: interleaved they spill
     }
+    stamp(5);
     readback(p.C, p.ldc);
-    if (p.colsum) {                                    // fold the 16 rows (fr) of each lane group, then one atomic per column
+    stamp(6);
+    if (do_cs) {                                       // fold the 16 rows (fr) of each lane group, then one atomic per column
 #pragma unroll
       for (int j = 0; j < FJ; ++j)
 #pragma unroll
@@ -603,6 +618,32 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
           const int gn = colb + j * 16 + e;
           if (fr == 0 && gn < p.N) atomicAdd(p.colsum + gn, t);
         }
+    }
+#undef EPI_HAS
+  };
+  auto epilogue_reg = [&]() {
+    if (p.flags & (1 << 21)) {        // DBG: no epilogue at all (keeps the accumulators alive)
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (t == 123.456f) ((T*)p.C)[tid] = from_f32<T>(t);
+      return;
+    }
+    const int mode = (p.bias ? E_BIAS : 0) | (p.scale_cols > 0 ? E_SCALE : 0) | ((p.flags & GF_GELU) ? E_GELU : 0) |
+                     (p.C2 ? E_C2 : 0) | ((p.flags & GF_RESID) ? E_RESID : 0) | ((p.flags & GF_MUL_DGELU) ? E_DGELU : 0) |
+                     (p.colsum ? E_COLSUM : 0) | ((p.flags & GF_RELU) ? E_RELU : 0);
+    switch (mode) {                                   // the combinations the Swin / conv paths issue; anything else: generic
+      case 0: epilogue_body(std::integral_constant<int, 0>{}); break;
+      case E_BIAS: epilogue_body(std::integral_constant<int, E_BIAS>{}); break;
+      case E_BIAS | E_SCALE: epilogue_body(std::integral_constant<int, E_BIAS | E_SCALE>{}); break;
+      case E_BIAS | E_GELU | E_C2: epilogue_body(std::integral_constant<int, E_BIAS | E_GELU | E_C2>{}); break;
+      case E_BIAS | E_RESID: epilogue_body(std::integral_constant<int, E_BIAS | E_RESID>{}); break;
+      case E_RESID: epilogue_body(std::integral_constant<int, E_RESID>{}); break;
+      case E_DGELU | E_COLSUM: epilogue_body(std::integral_constant<int, E_DGELU | E_COLSUM>{}); break;
+      case E_COLSUM: epilogue_body(std::integral_constant<int, E_COLSUM>{}); break;
+      default: epilogue_body(std::integral_constant<int, -1>{}); break;
     }
   };
   for (int q = 0; q < NST - 1 && q < nt; ++q) issue(q);
@@ -625,10 +666,14 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
 #pragma unroll
       for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FJ; ++j) {
+          if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
       __builtin_amdgcn_s_setprio(0);
     }
-    epilogue();
+    if constexpr (SWAP) epilogue_reg();
+    else epilogue();
   } else {
     // Ping-pong: waves w and w+4 share a SIMD (wave rows wr = 0 / 1).  With ONE barrier per stage both read their
     // fragments at the same time (matrix pipe idle) and then serialise their MFMAs.  Here every stage has two barriers
@@ -671,7 +716,9 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
       else if (newer == 1) wait_vmcnt<PER_STAGE>();
       else wait_vmcnt<0>();
     };
+    stamp(1);
     wait_tile(0);
+    stamp(2);
     if (lag) __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nt; ++kt) {
       __builtin_amdgcn_s_barrier();
@@ -686,6 +733,274 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_ring_kernel(GemmNT p) {
     if constexpr (SWAP) epilogue_reg();
     else epilogue();
   }
+}
+
+
+// =====================================================================================================
+// gemm_nt "stream" (bf16, S = 1, no A gather): the 256x256 ping-pong ring kernel made PERSISTENT.  A workgroup owns tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ... and the 4-stage LDS ring streams straight across tile boundaries: the first
+// three K stages of the next tile are requested while the last stages of the current one are multiplied, so no tile
+// pays the ~2 us prologue, the workgroup relaunch gap, or a drained pipeline.  Between its last MFMA of a tile and its
+// first fragment read of the next, each wave row runs the register epilogue (operand-swapped MFMA: 4 consecutive output
+// columns per lane) through a WAVE-PRIVATE 8 KB image in a fifth 32 KB LDS region - no workgroup barrier, the other
+// wave row keeps multiplying - and its global stores drain while the next tile's stages are consumed.
+// Measured on the non-persistent kernel at K = 512: 12 us of main loop + 14 us of prologue / epilogue / store drain /
+// relaunch per tile (tools/epi_ksweep.py).
+// vmcnt: epilogue loads/stores share the counter with the LDS-DMA stream.  Before its first epilogue memory operation a
+// wave waits for ALL its outstanding stage copies (they are 1-3 stages old), then skips the next two counted waits (those
+// stages are known to have landed); every later counted wait is conservative with stores in flight, never wrong.
+// =====================================================================================================
+__global__ __launch_bounds__(512, 2) void gemm_nt_stream_kernel(GemmNT p) {
+  using T = bf16;
+  constexpr int BM = 256, BN = 256, BK = 32, ROWB = 64, NST = 4;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  constexpr int TM = 128, TN = 64, FI = 8, FJ = 4, NIA = 2, NIB = 2, PER_STAGE = NIA + NIB;
+  constexpr int IMG = NST * STAGE;                   // byte offset of the epilogue image region (8 waves x 8 KB used 4 at a time)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63, w = wave_id();
+  const int wr = w >> 2, wc = w & 3;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+  const int nt = p.Kseg / BK;
+  const int nk = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1)
+  const int TS = nk * nt;                            // stages of this workgroup's stream
+
+  const char* zero = (const char*)g_stswin_zero;
+  const char* abase[NIA]; int astep[NIA];
+  const char* bbase[NIB]; int bstep[NIB];
+  auto set_issue_tile = [&](int k) {
+    const int t = xcd_remap((int)blockIdx.x + k * (int)gridDim.x, ntiles);
+    const int mi = (t / tiles_n) * BM, ni = (t % tiles_n) * BN;
+    // lane constants are re-derived here (opaque to the optimiser): hoisted out of the stream loop they were spilled to
+    // scratch, and a scratch reload is a vmcnt(0) - i.e. a drained LDS-DMA pipeline - once per tile
+    int lane = l;
+    asm volatile("" : "+v"(lane));
+    const int rsub = lane >> 2, cphys = lane & 3, csrc = cphys ^ swz64(rsub);
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int gn = ni + (w * NIB + i) * 16 + rsub;
+      if (gn < p.N) { bbase[i] = (const char*)p.B + ((long)gn * p.ldb) * sizeof(T) + csrc * 16; bstep[i] = BK * sizeof(T); }
+      else { bbase[i] = zero + cphys * 16; bstep[i] = 0; }
+    }
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const int gm = mi + (w * NIA + i) * 16 + rsub;
+      if (gm < p.M) { abase[i] = (const char*)p.A + ((long)gm * p.lda) * sizeof(T) + csrc * 16; astep[i] = BK * sizeof(T); }
+      else { abase[i] = zero + cphys * 16; astep[i] = 0; }
+    }
+  };
+  int ik = 0, is = 0;                                // issue cursor: tile number of this workgroup, stage within it
+  set_issue_tile(0);
+  auto issue_next = [&](int g) {                     // stage g of the stream -> ring slot g & 3
+    char* Ab = smem + (g & (NST - 1)) * STAGE;
+    char* Bb = Ab + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) glds16_raw(abase[i] + (long)is * astep[i], Ab + (w * NIA + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) glds16_raw(bbase[i] + (long)is * bstep[i], Bb + (w * NIB + i) * 1024);
+    if (++is == nt) {
+      is = 0;
+      if (++ik < nk) set_issue_tile(ik);
+    }
+  };
+
+  f32x4 acc[FI][FJ];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
+  const int fr = l & 15, fq = l >> 4;
+  const int rd_off = fr * ROWB + ((fq ^ swz64(fr)) << 4);
+  const bool lag = (wr == 1);                        // wave-uniform
+  bf16x8 a[FI], b[FJ];
+  auto read_frags = [&](int g) {
+    const char* Ab = smem + (g & (NST - 1)) * STAGE;
+    const char* Bb = Ab + A_BYTES;
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) b[j] = *(const bf16x8*)(Bb + (wc * TN + j * 16) * ROWB + rd_off);
+#pragma unroll
+    for (int i = 0; i < FI; ++i) a[i] = *(const bf16x8*)(Ab + (wr * TM + i * 16) * ROWB + rd_off);
+  };
+  auto mma_all = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  int skip = 0;                                      // counted waits to skip (stages verified by the epilogue's vmcnt(0))
+  auto wait_stage = [&](int g1) {                    // stage g1 of the stream has landed (this wave's share)
+    if (g1 >= TS) return;
+    if (skip > 0) { --skip; return; }
+    const int newer = min(NST - 2, TS - 1 - g1);
+    if (newer >= 2) wait_vmcnt<2 * PER_STAGE>();
+    else if (newer == 1) wait_vmcnt<PER_STAGE>();
+    else wait_vmcnt<0>();
+  };
+
+  // ---------------- per-tile register epilogue of this wave (its 128 x 64 sub-tile), wave-private LDS image ----------------
+  auto epilogue = [&](int k) {
+    const int t = xcd_remap((int)blockIdx.x + k * (int)gridDim.x, ntiles);
+    const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+    if (p.flags & (1 << 21)) {        // DBG: no epilogue at all (keeps the accumulators alive)
+      float tt = 0.f;
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) tt += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (tt == 123.456f) ((T*)p.C)[tid] = from_f32<T>(tt);
+      zero_acc();
+      return;
+    }
+    wait_vmcnt<0>();                                 // every stage copy of this wave has landed; epilogue memory ops may follow
+    skip = 2;
+    int lane = l;                                    // epilogue lane constants: derived here, not kept live (and spilled)
+    asm volatile("" : "+v"(lane));                   // across the stream loop
+    const int fr = lane & 15, fq = lane >> 4;
+    char* img = smem + IMG + wc * 8192;              // [64 rows][128 B], 16-byte chunk ^= row & 7
+    const int colb = n0 + wc * TN + 4 * fq;          // + j*16: first of this lane's 4 columns
+    f32x4 bj[FJ];
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+      const int gn = colb + j * 16;
+      bj[j] = p.bias ? *(const f32x4*)(p.bias + (gn < p.N ? gn : 0)) : (f32x4){0.f, 0.f, 0.f, 0.f};   // (columns >= N are never stored)
+    }
+    const bool has_r = (p.flags & (GF_RESID | GF_MUL_DGELU)) != 0;
+    const bool has_scale = p.scale_cols > 0;
+    auto pre_act = [&](int i, int j) -> f32x4 {
+      f32x4 v = acc[i][j];
+      if (p.bias) { NO_IFCVT; v += bj[j]; }
+      if (has_scale) {
+        NO_IFCVT;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (colb + j * 16 + e < p.scale_cols) v[e] *= p.scale;
+      }
+      return v;
+    };
+    auto put = [&](int ih, int j, f32x4 v) {          // ih = fragment row within the half (0..3)
+      const int row = ih * 16 + fr;
+      const int chunk = 2 * j + (fq >> 1);
+      bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+      *(bf16x4*)(img + row * 128 + ((chunk ^ (fr & 7)) << 4) + (fq & 1) * 8) = o;
+    };
+    const int rb_row = lane >> 3, rb_chunk = lane & 7;
+    const bool rb_col_ok = n0 + wc * TN + rb_chunk * 8 < p.N;
+    auto readback = [&](int h2, void* Cout, long ldo) { // rows of half h2: m0 + wr*128 + h2*64 + 0..63
+      // all 8 scatter indices first (unpredicated: a predicated load stays "pending" for hipcc across the loop back edge
+      // and costs a vmcnt(0) in the main loop), so that the stores below are not interleaved with index-load waits
+      int orow32[8];
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int gm = m0 + wr * TM + h2 * 64 + ps * 8 + rb_row;
+        orow32[ps] = p.c_rows ? p.c_rows[min(gm, p.M - 1)] : gm;
+      }
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int row = ps * 8 + rb_row;
+        const int gm = m0 + wr * TM + h2 * 64 + row;
+        if (gm < p.M && rb_col_ok) {
+          const bf16x8 val = *(const bf16x8*)(img + row * 128 + ((rb_chunk ^ (row & 7)) << 4));
+          if (p.flags & (1 << 20)) { if ((float)val[0] == 123.456f) *(bf16x8*)((T*)Cout + (long)orow32[ps] * ldo + n0 + wc * TN + rb_chunk * 8) = val; }
+          else
+          *(bf16x8*)((T*)Cout + (long)orow32[ps] * ldo + n0 + wc * TN + rb_chunk * 8) = val;
+        }
+      }
+    };
+    f32x4 cs[FJ];
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x4 rcur[FJ], rnext[FJ];
+    auto load_r = [&](int i, bf16x4 (&dst)[FJ]) {
+      const int gm = min(m0 + wr * TM + i * 16 + fr, p.M - 1);      // rows >= M / columns >= N: clamped, never stored
+      const long rrow = p.r_rows ? (long)p.r_rows[gm] : (long)gm;
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) {
+        const int gn = colb + j * 16;
+        dst[j] = *(const bf16x4*)((const T*)p.R + rrow * p.ldr + (gn < p.N ? gn : 0));
+      }
+    };
+    if (p.C2) {                                       // pre-activation copy (fc1 forward keeps it for GELU')
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+        for (int ih = 0; ih < 4; ++ih)
+#pragma unroll
+          for (int j = 0; j < FJ; ++j) put(ih, j, pre_act(h2 * 4 + ih, j));
+        readback(h2, p.C2, p.ldc2);
+      }
+    }
+    if (has_r) load_r(0, rcur);
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+      for (int ih = 0; ih < 4; ++ih) {
+        const int i = h2 * 4 + ih;
+        if (has_r && i + 1 < FI) load_r(i + 1, rnext);
+        const bool row_ok = m0 + wr * TM + i * 16 + fr < p.M;
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+          f32x4 v = pre_act(i, j);
+          if (p.flags & GF_GELU) {
+            const f32x2 lo = gelu_fast2((f32x2){v[0], v[1]}), hi = gelu_fast2((f32x2){v[2], v[3]});
+            v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
+          }
+          if (has_r) {
+            const f32x4 r = {(float)rcur[j][0], (float)rcur[j][1], (float)rcur[j][2], (float)rcur[j][3]};
+            if (p.flags & GF_RESID) v += r;
+            else {
+              const f32x2 lo = dgelu_fast2((f32x2){r[0], r[1]}), hi = dgelu_fast2((f32x2){r[2], r[3]});
+              v *= (f32x4){lo[0], lo[1], hi[0], hi[1]};
+            }
+          }
+          if (p.flags & GF_RELU) { NO_IFCVT; v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f}); }
+          if (p.colsum) { NO_IFCVT; if (row_ok) cs[j] += v; }
+          put(ih, j, v);
+        }
+        if (has_r && i + 1 < FI) {
+#pragma unroll
+          for (int j = 0; j < FJ; ++j) rcur[j] = rnext[j];
+        }
+      }
+      readback(h2, p.C, p.ldc);
+    }
+    if (p.colsum) {                                   // fold the 16 rows (fr) of each lane group, then one atomic per column
+#pragma unroll
+      for (int j = 0; j < FJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float tsum = cs[j][e];
+          tsum += __shfl_xor(tsum, 1); tsum += __shfl_xor(tsum, 2); tsum += __shfl_xor(tsum, 4); tsum += __shfl_xor(tsum, 8);
+          const int gn = colb + j * 16 + e;
+          if (fr == 0 && gn < p.N) atomicAdd(p.colsum + gn, tsum);
+        }
+    }
+    zero_acc();
+  };
+
+  // ---------------- the stream ----------------
+  for (int q = 0; q < NST - 1 && q < TS; ++q) issue_next(q);
+  wait_stage(0);
+  if (lag) __builtin_amdgcn_s_barrier();
+  int ck = 0, cs_ = 0;                                // compute cursor: tile number, stage within it
+  for (int g = 0; g < TS; ++g) {
+    __builtin_amdgcn_s_barrier();
+    if (g + NST - 1 < TS) issue_next(g + NST - 1);
+    read_frags(g);
+    if (lag) wait_stage(g + 1);
+    __builtin_amdgcn_s_barrier();
+    mma_all();
+    if (!lag) wait_stage(g + 1);
+    if (++cs_ == nt) {                               // this wave's accumulators hold a finished tile
+      cs_ = 0;
+      epilogue(ck);
+      ++ck;
+    }
+  }
+  if (!lag) __builtin_amdgcn_s_barrier();
 }
 
 // =====================================================================================================
@@ -1106,6 +1421,26 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
                         (!R || (uintptr_t)R % 8 == 0) && (!bias || (uintptr_t)bias % 16 == 0);
     static int once_swap = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)once_swap;
+    // persistent streaming variant: plain Linear GEMMs (S = 1, no A gather) with the register epilogue
+    const bool streamk = regepi && S == 1 && !a_rows && (flags & GF_STREAM) && !(flags & (GF_NOPIPE | GF_NOSTREAM));
+    if (streamk) {
+      static int once_stream = (int)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+      (void)once_stream;
+      const unsigned grid = (unsigned)(big_tiles < 256 ? big_tiles : 256);
+      hipLaunchKernelGGL(gemm_nt_stream_kernel, dim3(grid), dim3(512), 163840, (hipStream_t)stream, p);
+      STSWIN_CHECK_LAUNCH();
+      return 0;
+    }
+    // "duo": 128x256 tiles, 4 waves of 128x64 (the same wave tile), 3-stage ring of 24 KB, TWO independent workgroups per
+    // CU: while one is in its epilogue / store drain / prologue the other one multiplies
+    if (regepi && (flags & GF_DUO)) {
+      static int once_duo = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<128, 256, 1, 4, 3, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+      (void)once_duo;
+      const long duo_tiles = (long)((M + 127) / 128) * ((N + 255) / 256);
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<128, 256, 1, 4, 3, 2, false, true>), dim3((unsigned)duo_tiles), dim3(256), 73728, (hipStream_t)stream, p);
+      STSWIN_CHECK_LAUNCH();
+      return 0;
+    }
     if (flags & GF_NOPIPE) hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, false>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
     else if (regepi) hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);

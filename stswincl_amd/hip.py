@@ -19,6 +19,9 @@ _lib: Optional[ctypes.CDLL] = None
 
 GF_GELU, GF_RESID, GF_MUL_DGELU, GF_OUT_F32, GF_ACCUM, GF_RELU, GF_WAVES4, GF_BIG, GF_NOBIG, GF_MID, GF_NOPIPE, GF_HALF, GF_NOHALF = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
 GF_NOREGEPI = 1 << 22
+GF_NOSTREAM = 1 << 23
+GF_DUO = 1 << 24
+GF_STREAM = 1 << 25
 TN_OVERWRITE = 1 << 27
 
 _c_int, _c_long, _c_float, _c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p

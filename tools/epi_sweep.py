@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Epilogue-heavy gemm_nt shapes of the Swin MLP (GELU + pre-activation copy, residual, GELU' product) timed per
-kernel variant: 8w = 128x128 8-wave, big = 256x256 ping-pong ring (register epilogue), big-lds = same with the LDS-staged
-fp32 epilogue."""
+kernel variant: 8w = 128x128 8-wave, stream = persistent 256x256 ping-pong ring, ring = one tile per workgroup (register
+epilogue), ring-lds = same with the LDS-staged fp32 epilogue."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,7 +24,7 @@ def timeit(fn, iters=20):
 def main():
     dt, dev = torch.bfloat16, "cuda"
     shapes = [(65536, 2048, 512, "fc1 s1"), (16384, 4096, 1024, "fc1 s2"), (65536, 512, 2048, "fc2 s1"), (65536, 512, 512, "proj s1")]
-    variants = (("auto", 0), ("8w", hip.GF_NOBIG), ("big", hip.GF_BIG), ("big-lds", hip.GF_BIG | hip.GF_NOREGEPI))
+    variants = (("auto", 0), ("8w", hip.GF_NOBIG), ("stream", hip.GF_BIG | hip.GF_STREAM), ("duo", hip.GF_BIG | hip.GF_DUO), ("ring", hip.GF_BIG | hip.GF_NOSTREAM), ("ring-lds", hip.GF_BIG | hip.GF_NOREGEPI))
     print(f"{'shape':10s} {'epilogue':10s} " + " ".join(f"{n:>8s}" for n, _ in variants) + "   (us)")
     for M, N, K, note in shapes:
         A = torch.randn(M, K, device=dev).to(dt)
