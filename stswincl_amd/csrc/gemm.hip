@@ -401,11 +401,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     for (int i = 0; i < NIB; ++i) glds16(bbase[i] + (long)q * bstep[i], Bb + (w * NIB + i) * 1024);
   };
 
-  f32x4 acc[FI][FJ];
-#pragma unroll
-  for (int i = 0; i < FI; ++i)
-#pragma unroll
-    for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[FI][FJ];                                 // zeroed AFTER the prologue copies are requested (below)
 
   const int fr = l & 15, fq = l >> 4;
   const int rd_off = fr * ROWB + ((fq ^ swz64(fr)) << 4);
@@ -647,6 +643,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     }
   };
   for (int q = 0; q < NST - 1 && q < nt; ++q) issue(q);
+  __builtin_amdgcn_sched_barrier(0);                 // first get the copies going, then spend 128 v_mov on the accumulators
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if constexpr (!PIPE) {
     for (int kt = 0; kt < nt; ++kt) {
       const int newer = min(NST - 2, nt - 1 - kt);     // later tiles that may stay in flight
