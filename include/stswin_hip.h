@@ -27,6 +27,9 @@ extern "C" {
 #define STSWIN_GF_OUT_F32 8    /* C is fp32 regardless of dtype */
 #define STSWIN_GF_ACCUM 16     /* C += v (needs OUT_F32) */
 #define STSWIN_GF_RELU 32
+#define STSWIN_GF_MUL_R 8192     /* v *= R[r_rows[m]][n]  (R = GELU' values saved by STSWIN_GF_C2_DGELU) */
+#define STSWIN_GF_C2_DGELU 16384 /* with GF_GELU: C2 receives gelu'(v) instead of v - the fc1 forward then hands the backward
+                                    its multiplier and the backward epilogue is one multiply */
 #define STSWIN_GF_BIG 128       /* tuning: force the 256x256 4-stage-ring kernel (bf16) */
 #define STSWIN_GF_MID 512       /* tuning: 256x128x32 tile, 3-stage ring, 2 workgroups per CU (bf16) */
 #define STSWIN_GF_NOPIPE 1024   /* tuning: 256x256 ring kernel without software-pipelined LDS fragment reads */

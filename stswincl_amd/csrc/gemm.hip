@@ -25,6 +25,9 @@ enum {
   GF_OUT_F32 = 8,    // C is float regardless of T
   GF_ACCUM = 16,     // C += v (only with GF_OUT_F32)
   GF_RELU = 32,
+  GF_MUL_R = 8192,        // v *= R[r_rows[m]][n]                  (R = saved GELU' values, see GF_C2_DGELU)
+  GF_C2_DGELU = 16384,    // with GF_GELU: C2 receives gelu'(v) instead of the pre-activation v, so that the backward
+                          // epilogue is one multiply (the polynomial Phi is shared with the forward GELU)
   GF_BIG = 128,      // tuning: force the 256x256 4-stage kernel (bf16)
   GF_NOBIG = 256,    // tuning: forbid it
   GF_MID = 512,      // tuning: 256x128x32 tile, 3-stage ring, 2 workgroups per CU
@@ -76,24 +79,27 @@ DEVI void epi_piece(const GemmNT& p, float (&v)[8], const float (&bv)[8], float 
   }
   const long orow = p.c_rows ? (long)p.c_rows[gm] : (long)gm;
   if (p.C2) {
+    float c2v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c2v[e] = (p.flags & GF_C2_DGELU) ? dgelu_t<T>(v[e]) : v[e];
     T* dst = (T*)p.C2 + orow * p.ldc2 + gn0;
     if (vec_ok && (p.ldc2 % PACK) == 0) {
 #pragma unroll
       for (int h = 0; h < 8 / PACK; ++h) {
         Vec16<T> o;
 #pragma unroll
-        for (int e = 0; e < PACK; ++e) o.set(e, v[h * PACK + e]);
+        for (int e = 0; e < PACK; ++e) o.set(e, c2v[h * PACK + e]);
         *(decltype(o.v)*)(dst + h * PACK) = o.v;
       }
     } else {
-      for (int e = 0; e < ncols; ++e) dst[e] = from_f32<T>(v[e]);
+      for (int e = 0; e < ncols; ++e) dst[e] = from_f32<T>(c2v[e]);
     }
   }
   if (p.flags & GF_GELU) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
   }
-  if (p.flags & (GF_RESID | GF_MUL_DGELU)) {
+  if (p.flags & (GF_RESID | GF_MUL_DGELU | GF_MUL_R)) {
     const long rrow = p.r_rows ? (long)p.r_rows[gm] : (long)gm;
     const T* src = (const T*)p.R + rrow * p.ldr + gn0;
     float rv[8];
@@ -117,6 +123,9 @@ DEVI void epi_piece(const GemmNT& p, float (&v)[8], const float (&bv)[8], float 
     if (p.flags & GF_RESID) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += rv[e];
+    } else if (p.flags & GF_MUL_R) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= rv[e];
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= dgelu_t<T>(rv[e]);
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
   constexpr int RG = NW * 4;                 // row groups per pass
   constexpr int NPASS = 128 / RG;
   // residual / pre-activation pieces of all passes are requested now and land during the LDS round trip
-  const bool pre_r = (p.flags & (GF_RESID | GF_MUL_DGELU)) && ncols == 8 && (p.ldr % PACK) == 0;
+  const bool pre_r = (p.flags & (GF_RESID | GF_MUL_DGELU | GF_MUL_R)) && ncols == 8 && (p.ldr % PACK) == 0;
   Vec16<T> rp[NPASS][8 / PACK];
   if (pre_r) {
 #pragma unroll
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && e < ncols) ? p.bias[gn0 + e] : 0.f; cs[e] = 0.f; }
     constexpr int NPASS = EROWS / RGP;
-    const bool pre_r = (p.flags & (GF_RESID | GF_MUL_DGELU)) && ncols == 8 && (p.ldr % 8) == 0;
+    const bool pre_r = (p.flags & (GF_RESID | GF_MUL_DGELU | GF_MUL_R)) && ncols == 8 && (p.ldr % 8) == 0;
     Vec16<T> rp[NPASS][1];
 #pragma unroll 1
     for (int slab = 0; slab < BM / EROWS; ++slab) {
@@ -490,7 +499,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   // The per-tile flag combination is resolved ONCE (epi_dispatch below) into a straight-line instantiation of this body:
   // with the flags tested per fragment the 32 fragments of a wave spent 3.6 us of a 24 us tile in scalar branches
   // (tools/gemm_timeline.py).  MD >= 0: compile-time mode bits; MD < 0: generic fallback testing the runtime flags.
-  enum { E_BIAS = 1, E_SCALE = 2, E_GELU = 4, E_C2 = 8, E_RESID = 16, E_DGELU = 32, E_COLSUM = 64, E_RELU = 128 };
+  enum { E_BIAS = 1, E_SCALE = 2, E_GELU = 4, E_C2 = 8, E_RESID = 16, E_DGELU = 32, E_COLSUM = 64, E_RELU = 128, E_MULR = 256, E_C2D = 512 };
   auto epilogue_body = [&](auto tag) {
     constexpr int MD = decltype(tag)::value;
 #define EPI_HAS(bit, rt) (MD >= 0 ? ((MD & (bit)) != 0) : (rt))
@@ -500,7 +509,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     const bool do_gelu = EPI_HAS(E_GELU, (p.flags & GF_GELU) != 0), has_c2 = EPI_HAS(E_C2, p.C2 != nullptr);
     const bool do_resid = EPI_HAS(E_RESID, (p.flags & GF_RESID) != 0), do_dgelu = EPI_HAS(E_DGELU, (p.flags & GF_MUL_DGELU) != 0);
     const bool do_cs = EPI_HAS(E_COLSUM, p.colsum != nullptr) && !dbg_ts, do_relu = EPI_HAS(E_RELU, (p.flags & GF_RELU) != 0);
-    const bool has_r = do_resid || do_dgelu;
+    const bool do_mulr = EPI_HAS(E_MULR, (p.flags & GF_MUL_R) != 0), c2_dgelu = EPI_HAS(E_C2D, (p.flags & GF_C2_DGELU) != 0);
+    const bool has_r = do_resid || do_dgelu || do_mulr;
     const int colb = n0 + wc * TN + 4 * fq;           // + j*16: first of this lane's 4 columns
     f32x4 bj[FJ];
     if (has_bias) {
@@ -550,7 +560,15 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
 #pragma unroll
       for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < FJ; ++j) { put(i, j, pre_act(i, j)); __builtin_amdgcn_sched_barrier(0); }
+        for (int j = 0; j < FJ; ++j) {
+          f32x4 v = pre_act(i, j);
+          if (c2_dgelu) {                              // keep gelu'(pre) for the backward multiply instead of pre itself
+            const f32x2 lo = dgelu_fast2((f32x2){v[0], v[1]}), hi = dgelu_fast2((f32x2){v[2], v[3]});
+            v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
+          }
+          put(i, j, v);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       readback(p.C2, p.ldc2);
       __syncthreads();
       // launder the bias registers: otherwise hipcc keeps all 128 bias-added values of the pass above for the pass
@@ -585,6 +603,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
         if (has_r) {
           const f32x4 r = {(float)rcur[j][0], (float)rcur[j][1], (float)rcur[j][2], (float)rcur[j][3]};
           if (do_resid) v += r;
+          else if (do_mulr) v *= r;
           else {
             const f32x2 lo = dgelu_fast2((f32x2){r[0], r[1]}), hi = dgelu_fast2((f32x2){r[2], r[3]});
             v *= (f32x4){lo[0], lo[1], hi[0], hi[1]};
@@ -629,7 +648,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     }
     const int mode = (p.bias ? E_BIAS : 0) | (p.scale_cols > 0 ? E_SCALE : 0) | ((p.flags & GF_GELU) ? E_GELU : 0) |
                      (p.C2 ? E_C2 : 0) | ((p.flags & GF_RESID) ? E_RESID : 0) | ((p.flags & GF_MUL_DGELU) ? E_DGELU : 0) |
-                     (p.colsum ? E_COLSUM : 0) | ((p.flags & GF_RELU) ? E_RELU : 0);
+                     (p.colsum ? E_COLSUM : 0) | ((p.flags & GF_RELU) ? E_RELU : 0) | ((p.flags & GF_MUL_R) ? E_MULR : 0) |
+                     ((p.flags & GF_C2_DGELU) ? E_C2D : 0);
     switch (mode) {                                   // the combinations the Swin / conv paths issue; anything else: generic
       case 0: epilogue_body(std::integral_constant<int, 0>{}); break;
       case E_BIAS: epilogue_body(std::integral_constant<int, E_BIAS>{}); break;
@@ -637,6 +657,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
       case E_BIAS | E_GELU | E_C2: epilogue_body(std::integral_constant<int, E_BIAS | E_GELU | E_C2>{}); break;
       case E_BIAS | E_RESID: epilogue_body(std::integral_constant<int, E_BIAS | E_RESID>{}); break;
       case E_RESID: epilogue_body(std::integral_constant<int, E_RESID>{}); break;
+      case E_BIAS | E_GELU | E_C2 | E_C2D: epilogue_body(std::integral_constant<int, E_BIAS | E_GELU | E_C2 | E_C2D>{}); break;
+      case E_MULR | E_COLSUM: epilogue_body(std::integral_constant<int, E_MULR | E_COLSUM>{}); break;
       case E_DGELU | E_COLSUM: epilogue_body(std::integral_constant<int, E_DGELU | E_COLSUM>{}); break;
       case E_COLSUM: epilogue_body(std::integral_constant<int, E_COLSUM>{}); break;
       default: epilogue_body(std::integral_constant<int, -1>{}); break;

@@ -170,7 +170,9 @@ def conv_tokens(x_tok, conv: torch.nn.Conv2d, frames, Hin, Win, lin=None, lout=N
 
 class StemConvFn(torch.autograd.Function):
     """torchvision resnet18.conv1 (7x7 / stride 2 / pad 3, Cin = 3; reference resnet.py:98-102) = im2col + GEMM.
-    The 147-wide patches (padded to 192) are rebuilt in backward instead of being kept (403 MB at B = 4)."""
+    The 147-wide patches (padded to 192) are kept for the weight gradient when they are <= 2 GB (403 MB at B = 4 clips of
+    512x512: nothing on a 288 GB part, and rebuilding them costs as much as the GEMM that uses them); larger ones are
+    rebuilt in backward."""
 
     @staticmethod
     def forward(ctx, img, weight, dt):
@@ -182,15 +184,17 @@ class StemConvFn(torch.autograd.Function):
         wm[:, :147] = weight.detach().float().permute(0, 2, 3, 1).reshape(64, 147)
         y = torch.empty(F_ * Ho * Wo, 64, dtype=dt, device=img.device)
         hip.gemm_nt(patches, wm.to(dt), y, M=y.shape[0])
-        ctx.cfg = (dt, Ho, Wo)
-        ctx.save_for_backward(im)
+        keep = patches.numel() * patches.element_size() <= (2 << 30)
+        ctx.cfg = (dt, Ho, Wo, keep)
+        ctx.save_for_backward(patches if keep else im)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (im,) = ctx.saved_tensors
-        dt, Ho, Wo = ctx.cfg
-        patches = hip.stem_im2col(im, dt, Ho, Wo)
+        (saved,) = ctx.saved_tensors
+        dt, Ho, Wo, keep = ctx.cfg
+        patches = saved if keep else hip.stem_im2col(saved, dt, Ho, Wo)
+        im = saved
         dw = torch.empty(64, 192, dtype=torch.float32, device=im.device)
         hip.gemm_tn(dy.detach().to(dt).contiguous(), patches, dw, Mk=patches.shape[0], overwrite=True)
         return None, dw[:, :147].reshape(64, 7, 7, 3).permute(0, 3, 1, 2), None

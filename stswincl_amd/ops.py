@@ -132,7 +132,8 @@ class SwinBlockFn(torch.autograd.Function):
         n2, mean2, rstd2 = hip.layernorm_fwd(x1, _f32(n2_w), _f32(n2_b), M=M)
         h = torch.empty(M, fc1_w.shape[0], dtype=dt, device=dev)
         h_pre = torch.empty_like(h)
-        hip.gemm_nt(n2, wcast(fc1_w, dt), h, M=M, bias=_f32(fc1_b), out2=h_pre, flags=hip.GF_GELU)
+        # out2 = gelu'(fc1 pre-activation): the backward epilogue is then a plain multiply (Phi is shared with the GELU here)
+        hip.gemm_nt(n2, wcast(fc1_w, dt), h, M=M, bias=_f32(fc1_b), out2=h_pre, flags=hip.GF_GELU | hip.GF_C2_DGELU)
         y2 = torch.empty(M, C, dtype=dt, device=dev)
         hip.gemm_nt(h, wcast(fc2_w, dt), y2, M=M, bias=_f32(fc2_b), resid=x1, flags=hip.GF_RESID)
         out, mean1, rstd1 = hip.layernorm_fwd(y2, _f32(n1_w), _f32(n1_b), M=M)
@@ -165,7 +166,7 @@ class SwinBlockFn(torch.autograd.Function):
         # fc2 (+ GELU', + fc1's bias gradient from the epilogue)
         hip.gemm_tn(dy2, h, dfc2_w, Mk=M, overwrite=True)
         dh_pre = torch.empty(M, hid, dtype=dt, device=dev)
-        hip.gemm_nt(dy2, wcast(fc2_w, dt, True), dh_pre, M=M, resid=h_pre, flags=hip.GF_MUL_DGELU, colsum_out=dfc1_b)
+        hip.gemm_nt(dy2, wcast(fc2_w, dt, True), dh_pre, M=M, resid=h_pre, flags=hip.GF_MUL_R, colsum_out=dfc1_b)
         # fc1
         hip.gemm_tn(dh_pre, n2, dfc1_w, Mk=M, overwrite=True)
         dn2 = torch.empty(M, C, dtype=dt, device=dev)

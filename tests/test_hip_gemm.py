@@ -86,6 +86,65 @@ def test_gemm_nt_epilogues(dtype):
     _close(out, F.relu(lin), dtype, "relu")
 
 
+def test_gemm_nt_ring_register_epilogues():
+    """256x256 ring kernel (forced): every mode-specialised register epilogue against fp32 torch, ragged M, row maps."""
+    torch.manual_seed(11)
+    dtype = torch.bfloat16
+    m, n, k = 600, 512, 128
+    a = torch.randn(m, k).to(dtype)
+    w = (torch.randn(n, k) / k ** 0.5).to(dtype)
+    bias = torch.randn(n)
+    r = torch.randn(m, n).to(dtype)
+    ac, wc, rc, bc = a.cuda(), w.cuda(), r.cuda(), bias.cuda()
+    lin0 = F.linear(a.float(), w.float())
+    lin = lin0 + bias
+    BIG = hip.GF_BIG
+    out = torch.empty(m, n, dtype=dtype, device="cuda")
+    pre = torch.empty(m, n, dtype=dtype, device="cuda")
+    hip.gemm_nt(ac, wc, out, M=m, flags=BIG)
+    _close(out, lin0, dtype, "plain")
+    hip.gemm_nt(ac, wc, out, M=m, bias=bc, flags=BIG)
+    _close(out, lin, dtype, "bias")
+    hip.gemm_nt(ac, wc, out, M=m, bias=bc, out2=pre, flags=BIG | hip.GF_GELU)
+    _close(pre, lin, dtype, "pre-activation")
+    _close(out, F.gelu(lin), dtype, "gelu")
+    x = lin.clone().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    hip.gemm_nt(ac, wc, out, M=m, bias=bc, out2=pre, flags=BIG | hip.GF_GELU | hip.GF_C2_DGELU)
+    _close(pre, x.grad, dtype, "gelu' as second output")
+    _close(out, F.gelu(lin), dtype, "gelu (with gelu' output)")
+    hip.gemm_nt(ac, wc, out, M=m, bias=bc, resid=rc, flags=BIG | hip.GF_RESID)
+    _close(out, lin + r.float(), dtype, "bias + resid")
+    hip.gemm_nt(ac, wc, out, M=m, resid=rc, flags=BIG | hip.GF_RESID)
+    _close(out, lin0 + r.float(), dtype, "resid")
+    xr = r.float().requires_grad_(True)
+    F.gelu(xr).sum().backward()
+    cs = torch.zeros(n, device="cuda")
+    hip.gemm_nt(ac, wc, out, M=m, resid=rc, flags=BIG | hip.GF_MUL_DGELU, colsum_out=cs)
+    _close(out, lin0 * xr.grad, dtype, "dgelu")
+    ref_cs = out.float().sum(0)
+    assert float((cs - ref_cs).abs().max()) <= 2e-3 * float(ref_cs.abs().max()) + 1e-2, "dgelu colsum"
+    cs.zero_()
+    hip.gemm_nt(ac, wc, out, M=m, resid=rc, flags=BIG | hip.GF_MUL_R, colsum_out=cs)
+    _close(out, lin0 * r.float(), dtype, "mul_r")
+    ref_cs = out.float().sum(0)
+    assert float((cs - ref_cs).abs().max()) <= 2e-3 * float(ref_cs.abs().max()) + 1e-2, "mul_r colsum"
+    hip.gemm_nt(ac, wc, out, M=m, bias=bc, scale=0.25, scale_cols=96, flags=BIG)
+    exp = lin.clone()
+    exp[:, :96] *= 0.25
+    _close(out, exp, dtype, "scale_cols")
+    hip.gemm_nt(ac, wc, out, M=m, bias=bc, flags=BIG | hip.GF_RELU)      # generic (runtime-flag) body
+    _close(out, F.relu(lin), dtype, "relu")
+    # scatter / gather row maps with the residual (proj + window_reverse + shortcut)
+    cmap = torch.randperm(700)[:m].to(torch.int32).cuda()
+    r2 = torch.randn(700, n).to(dtype).cuda()
+    out2 = torch.zeros(700, n, dtype=dtype, device="cuda")
+    hip.gemm_nt(ac, wc, out2, M=m, bias=bc, c_rows=cmap, resid=r2, r_rows=cmap, flags=BIG | hip.GF_RESID)
+    ref = torch.zeros(700, n)
+    ref[cmap.cpu().long()] = lin + r2.float().cpu()[cmap.cpu().long()]
+    _close(out2, ref, dtype, "scatter + gathered resid")
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_gemm_nt_gather_scatter_segments(dtype):
     torch.manual_seed(6)
