@@ -104,11 +104,14 @@ def contrast_main(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("STSWIN_BENCH_SHARE_GPU") == "1":     # functional test of the N > 1 path on a 1-GPU box (gloo backend)
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group(os.environ.get("STSWIN_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
+                                **({"device_id": dev} if os.environ.get("STSWIN_DIST_BACKEND", "nccl") == "nccl" else {}))
     from stswincl_amd import hip
     from stswincl_amd.contrast.models.PixPro_swin_v5 import ConsistencyLoss
     from stswincl_amd.dp import GradBucketReducer
@@ -185,11 +188,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("STSWIN_BENCH_SHARE_GPU") == "1":     # functional test of the N > 1 path on a 1-GPU box (gloo backend)
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group(os.environ.get("STSWIN_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
+                                **({"device_id": dev} if os.environ.get("STSWIN_DIST_BACKEND", "nccl") == "nccl" else {}))
 
     import __graft_entry__ as ge
     if rank == 0 and not os.path.exists(ge.LIB):
