@@ -34,6 +34,7 @@ enum {
   GF_NOPIPE = 1024,  // tuning: 256x256 ring without the ping-pong schedule
   GF_HALF = 2048,    // tuning: force the 256x128 ping-pong ring
   GF_NOHALF = 4096,  // tuning: forbid it
+  GF_NONARROW = 1 << 26,  // tuning: forbid the 256x64 tile for N <= 64
   GF_STREAM = 1 << 25,    // tuning: persistent streaming 256x256 variant (measured no faster: both wave rows idle through each other's epilogue)
   GF_DUO = 1 << 24,       // tuning: 128x256 tiles, 4 waves, two workgroups per CU
   GF_NOSTREAM = 1 << 23,  // tuning: 256x256 ring without the persistent streaming variant
@@ -164,35 +165,39 @@ DEVI void epi_piece(const GemmNT& p, float (&v)[8], const float (&bv)[8], float 
   }
   }
 
-template <typename T, int NW>
+// BM x BN tile (128x128 by default; 256x64 for N <= 64 so that narrow convolutions do not multiply a half-empty tile),
+// NW waves as (BM/64) x WN, wave tile 64 x (BN/WN).
+template <typename T, int NW, int BM = 128, int BN = 128>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
-  constexpr int WN = NW / 2;                 // wave columns; wave tile = 64 x (128 / WN)
-  constexpr int JN = 128 / WN / 16;          // 16-wide fragments per wave along N: 4 (NW=4) or 2 (NW=8)
-  constexpr int NI = 16 / NW;                // LDS-DMA instructions per wave per operand per K tile: 4 or 2
+  constexpr int WM = BM / 64, WN = NW / WM;  // wave rows / columns; wave tile = 64 x (BN / WN)
+  constexpr int JN = BN / WN / 16;           // 16-wide fragments per wave along N: 4 (NW=4) or 2 (NW=8)
+  constexpr int NIA = BM / 8 / NW, NIB = BN / 8 / NW;   // LDS-DMA instructions per wave per operand per K tile (8 rows each)
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  static_assert(WM * WN == NW && JN >= 1 && NIA >= 1 && NIB >= 1 && BM * BN * 4 <= 2 * STAGE, "tile shape");
   constexpr int PACK = TT<T>::PACK;
   constexpr int BK = 8 * PACK;               // 128-byte rows
   constexpr int ROWB = 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, l = tid & 63, w = wave_id();
   const int wr = w / WN, wc = w % WN;
-  const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M + 127) >> 7;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (t / tiles_n) << 7, n0 = (t % tiles_n) << 7;
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
 
   const char* zero = (const char*)g_stswin_zero;
   const int rsub = l >> 3, cphys = l & 7, csrc = cphys ^ rsub;
-  const char* abase[NI]; int astep[NI];
-  const char* bbase[NI]; int bstep[NI];
+  const char* abase[NIA]; int astep[NIA];
+  const char* bbase[NIB]; int bstep[NIB];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int gn = n0 + (w * NI + i) * 8 + rsub;
+  for (int i = 0; i < NIB; ++i) {
+    const int gn = n0 + (w * NIB + i) * 8 + rsub;
     if (gn < p.N) { bbase[i] = (const char*)p.B + ((long)gn * p.ldb) * sizeof(T) + csrc * 16; bstep[i] = BK * sizeof(T); }
     else { bbase[i] = zero + cphys * 16; bstep[i] = 0; }
   }
   auto load_a_bases = [&](int seg) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int gm = m0 + (w * NI + i) * 8 + rsub;
+    for (int i = 0; i < NIA; ++i) {
+      const int gm = m0 + (w * NIA + i) * 8 + rsub;
       long row = -1;
       if (gm < p.M) row = p.a_rows ? (long)p.a_rows[(long)seg * p.M + gm] : (long)gm;
       if (row >= 0) { abase[i] = (const char*)p.A + (row * p.lda) * sizeof(T) + csrc * 16; astep[i] = BK * sizeof(T); }
@@ -202,12 +207,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
   const int kps = p.Kseg / BK;               // K tiles per segment
   const int nt = p.S * kps;
   auto stage = [&](int ktg, int kt, int buf) {
-    char* Ab = smem + buf * 32768;
-    char* Bb = Ab + 16384;
+    char* Ab = smem + buf * STAGE;
+    char* Bb = Ab + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) glds16(abase[i] + (long)kt * astep[i], Ab + (w * NI + i) * 1024);
+    for (int i = 0; i < NIA; ++i) glds16(abase[i] + (long)kt * astep[i], Ab + (w * NIA + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) glds16(bbase[i] + (long)ktg * bstep[i], Bb + (w * NI + i) * 1024);
+    for (int i = 0; i < NIB; ++i) glds16(bbase[i] + (long)ktg * bstep[i], Bb + (w * NIB + i) * 1024);
   };
 
   f32x4 acc[4][JN];
@@ -228,8 +233,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
       if (nseg != seg) { seg = nseg; load_a_bases(seg); }
       stage(ktg + 1, (ktg + 1) - nseg * kps, (ktg + 1) & 1);
     }
-    const char* Ab = smem + (ktg & 1) * 32768;
-    const char* Bb = Ab + 16384;
+    const char* Ab = smem + (ktg & 1) * STAGE;
+    const char* Bb = Ab + A_BYTES;
     if constexpr (TT<T>::IS_BF16) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -272,30 +277,31 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
   }
 
   // ---------------- epilogue: accumulators -> fp32 LDS image -> row-wise 16-byte pieces ----------------
-  const int c8 = (tid & 15) * 8;
+  constexpr int CG = BN / 8;                 // 8-column groups per row
+  const int c8 = (tid % CG) * 8;
   const int gn0 = n0 + c8;
   const int ncols = max(0, min(8, p.N - gn0));
-  constexpr int RG = NW * 4;                 // row groups per pass
-  constexpr int NPASS = 128 / RG;
+  constexpr int RG = NW * 64 / CG;           // rows per pass
+  constexpr int NPASS = BM / RG;
   // residual / pre-activation pieces of all passes are requested now and land during the LDS round trip
   const bool pre_r = (p.flags & (GF_RESID | GF_MUL_DGELU | GF_MUL_R)) && ncols == 8 && (p.ldr % PACK) == 0;
   Vec16<T> rp[NPASS][8 / PACK];
   if (pre_r) {
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
-      const int gm = m0 + pass * RG + (tid >> 4);
+      const int gm = m0 + pass * RG + tid / CG;
       if (gm < p.M) epi_prefetch<T>(p, rp[pass], gm, gn0);
     }
   }
   __syncthreads();
-  float* ct = (float*)smem;                  // [128][128]
+  float* ct = (float*)smem;                  // [BM][BN]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < JN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        ct[(wr * 64 + i * 16 + 4 * fq + r) * 128 + wc * (16 * JN) + j * 16 + fr] = acc[i][j][r];
+        ct[(wr * 64 + i * 16 + 4 * fq + r) * BN + wc * (16 * JN) + j * 16 + fr] = acc[i][j][r];
   __syncthreads();
 
   float bv[8], cs[8];
@@ -303,13 +309,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
   for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && e < ncols) ? p.bias[gn0 + e] : 0.f; cs[e] = 0.f; }
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
-    const int rr = pass * RG + (tid >> 4);
+    const int rr = pass * RG + tid / CG;
     const int gm = m0 + rr;
     if (gm >= p.M || ncols <= 0) break;
     float v[8];
     {
-      const f32x4 lo = *(const f32x4*)(ct + rr * 128 + c8);
-      const f32x4 hi = *(const f32x4*)(ct + rr * 128 + c8 + 4);
+      const f32x4 lo = *(const f32x4*)(ct + rr * BN + c8);
+      const f32x4 hi = *(const f32x4*)(ct + rr * BN + c8 + 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
     }
@@ -318,12 +324,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
   if (p.colsum) {                 // fold the 16 row groups through LDS (the C image is no longer needed), 1 atomic / column
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ct[(tid >> 4) * 128 + c8 + e] = cs[e];
+    for (int e = 0; e < 8; ++e) ct[(tid / CG) * BN + c8 + e] = cs[e];
     __syncthreads();
-    if (tid < 128 && n0 + tid < p.N) {
+    if (tid < BN && n0 + tid < p.N) {
       float t = 0.f;
 #pragma unroll
-      for (int k = 0; k < RG; ++k) t += ct[k * 128 + tid];
+      for (int k = 0; k < RG; ++k) t += ct[k * BN + tid];
       atomicAdd(p.colsum + n0 + tid, t);
     }
   }
@@ -1475,6 +1481,17 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     (void)once_mid;
     const long mid_tiles = (long)((M + 255) / 256) * ((N + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 128, 4, 2, 3, 4, false>), dim3((unsigned)mid_tiles), dim3(512), 73728, (hipStream_t)stream, p);
+    STSWIN_CHECK_LAUNCH();
+    return 0;
+  }
+  // narrow outputs (ResNet stem / layer1: N = 64): 256x64 tiles instead of 128x128 ones whose second half multiplies zeros
+  if (N <= 64 && M >= 256 && w8 && !(flags & GF_NONARROW)) {
+    static int once_n = (int)hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16, 8, 256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920) |
+                        (int)hipFuncSetAttribute((const void*)gemm_nt_kernel<float, 8, 256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+    (void)once_n;
+    const int nb = ((M + 255) / 256) * ((N + 63) / 64);
+    if (dtype == 0) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8, 256, 64>), dim3(nb), dim3(512), 81920, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<float, 8, 256, 64>), dim3(nb), dim3(512), 81920, (hipStream_t)stream, p);
     STSWIN_CHECK_LAUNCH();
     return 0;
   }

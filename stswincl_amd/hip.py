@@ -23,6 +23,7 @@ GF_NOREGEPI = 1 << 22
 GF_NOSTREAM = 1 << 23
 GF_DUO = 1 << 24
 GF_STREAM = 1 << 25
+GF_NONARROW = 1 << 26
 TN_OVERWRITE = 1 << 27
 
 _c_int, _c_long, _c_float, _c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p

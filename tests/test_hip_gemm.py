@@ -22,7 +22,7 @@ def _close(got, exp, dtype, what=""):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 512), (200, 136, 128), (37, 48, 192), (130, 12, 256),
-                                   (1024, 1536, 512)])
+                                   (1024, 1536, 512), (700, 64, 192), (512, 40, 64)])
 def test_gemm_nt_plain_and_bias(dtype, m, n, k):
     torch.manual_seed(m + n + k)
     a = torch.randn(m, k).to(dtype)
