@@ -63,6 +63,11 @@ int stswin_stem_im2col(int dtype, const float* img, void* patches, long ld, int 
                        void* stream);
 /* nn.MaxPool2d(3, 2, 1) on tokens [F][H][W][C] -> [F][Ho][Wo][C]; arg (uint8 [F*Ho*Wo][C]) = winning tap (first max in
  * (ky,kx) scan order, like torch); backward gathers dy through arg (no atomics). */
+/* (Cout, Cin, k, k) fp32 nn.Conv2d weight -> the bf16 / fp32 GEMM operand matrices of the token convolutions in one launch:
+ * fwd [cop][S][cip] (tap-major K of stswin_gemm_nt) and, if not NULL, dgrad [cip][S][cop].  omap[cop] / imap[cip] = source
+ * channel of each padded channel position or -1 (zero).  (ASPP.py:37-50, base18.py:60-77, resnet.py convolutions) */
+int stswin_conv_pack(int dtype, const float* w, void* fwd, void* dgrad, const int* omap, const int* imap, int co, int ci, int S,
+                     int cop, int cip, void* stream);
 int stswin_maxpool3x3s2(int dtype, const void* in, long ldi, void* out, long ldo, unsigned char* arg, int frames, int H,
                         int W, int Ho, int Wo, int C, int backward, void* stream);
 

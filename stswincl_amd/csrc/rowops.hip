@@ -128,6 +128,24 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* img, T* p
   }
 }
 
+// conv weight packing: (Cout, Cin, k, k) fp32 parameter -> the two GEMM operand matrices of the token convolutions in one
+// launch: fwd [Cout_p][S][Cin_p] (B operand of y = X W^T, tap-major K) and dgrad [Cin_p][S][Cout_p].  omap / imap give the
+// source channel of every padded channel position (-1 = zero padding; concatenated layouts have gaps).  Replaces, per
+// convolution and step, a zero fill + slice copies + a cast for each of the two matrices (6 launches of a few us).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float* w, T* fwd, T* dg, const int* omap, const int* imap,
+                                                         int co, int ci, int S, int cop, int cip) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)cop * S * cip) return;
+  const int ip = idx % cip, s = (idx / cip) % S, op = idx / ((long)cip * S);
+  const int so = omap[op], si = imap[ip];
+  float v = 0.f;
+  if (so >= 0 && si >= 0) v = w[((long)so * ci + si) * S + s];
+  const T o = from_f32<T>(v);
+  fwd[idx] = o;
+  if (dg) dg[((long)ip * S + s) * cop + op] = o;
+}
+
 // maxpool 3x3 stride 2 pad 1 on tokens
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* in, long ldi, T* out, long ldo, unsigned char* arg,
@@ -431,6 +449,17 @@ extern "C" int stswin_stem_im2col(int dtype, const float* img, void* patches, lo
   dim3 grid((unsigned)(want < 256 * 32 ? want : 256 * 32));
   if (dtype == 0) hipLaunchKernelGGL(stem_im2col_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, img, (bf16*)patches, ld, frames, H, W, Ho, Wo);
   else hipLaunchKernelGGL(stem_im2col_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, img, (float*)patches, ld, frames, H, W, Ho, Wo);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_conv_pack(int dtype, const float* w, void* fwd, void* dgrad, const int* omap, const int* imap, int co,
+                                int ci, int S, int cop, int cip, void* stream) {
+  if (co <= 0 || ci <= 0 || S <= 0 || cop <= 0 || cip <= 0) return -1111;
+  const long n = (long)cop * S * cip;
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (dtype == 0) hipLaunchKernelGGL(conv_pack_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16*)fwd, (bf16*)dgrad, omap, imap, co, ci, S, cop, cip);
+  else hipLaunchKernelGGL(conv_pack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, w, (float*)fwd, (float*)dgrad, omap, imap, co, ci, S, cop, cip);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

@@ -58,35 +58,37 @@ class Layout:
     def key(self):
         return (tuple(self.segs), self.width)
 
+    def index_map(self, device) -> torch.Tensor:
+        """int32 [width]: logical channel of every padded position, -1 for padding (cached per device)."""
+        cache = self.__dict__.setdefault("_imaps", {})
+        m = cache.get(device)
+        if m is None:
+            m = torch.full((self.width,), -1, dtype=torch.int32)
+            for a, n, b in self.segs:
+                m[b:b + n] = torch.arange(a, a + n, dtype=torch.int32)
+            m = m.to(device)
+            cache[device] = m
+        return m
+
 
 _CW: dict = {}
 
 
 def _conv_mats(w: torch.Tensor, dt, lin: Layout, lout: Layout, dgrad: bool) -> torch.Tensor:
     """(Cout,Cin,k,k) -> GEMM B matrix.  fwd: [Cout_p][S*Cin_p] (tap-major); dgrad: [Cin_p][S*Cout_p] (the inverse
-    row map supplies the geometry, so taps keep their order)."""
-    key = (id(w), dt, lin.key(), lout.key(), dgrad)
+    row map supplies the geometry, so taps keep their order).  Both come from ONE hip.conv_pack launch per weight
+    version (the torch formulation - zero fill, slice copies, cast, twice - was ~6 launches per convolution and step)."""
+    key = (id(w), dt, lin.key(), lout.key())
     stamp = (w._version, w.data_ptr(), tuple(w.shape))
     hit = _CW.get(key)
-    if hit is not None and hit[0]() is w and hit[1] == stamp:
-        return hit[2]
-    co, ci, k, _ = w.shape
-    S = k * k
-    wt = w.detach().float().reshape(co, ci, S)
-    full = torch.zeros(lout.width, S, lin.width, dtype=torch.float32, device=w.device)   # [co_p][s][ci_p]
-    for oa, on, ob in lout.segs:
-        for ia, in_, ib in lin.segs:
-            full[ob:ob + on, :, ib:ib + in_] = wt[oa:oa + on, ia:ia + in_, :].permute(0, 2, 1)
-    if dgrad:
-        m = full.permute(2, 1, 0).reshape(lin.width, S * lout.width)
-    else:
-        m = full.reshape(lout.width, S * lin.width)
-    m = m.to(dt).contiguous()
-    if len(_CW) > 2048:
-        for kk in [kk for kk, v in _CW.items() if v[0]() is None]:
-            del _CW[kk]
-    _CW[key] = (weakref.ref(w), stamp, m)
-    return m
+    if hit is None or hit[0]() is not w or hit[1] != stamp:
+        fwd, dg = hip.conv_pack(w, dt, lout.index_map(w.device), lin.index_map(w.device))
+        if len(_CW) > 2048:
+            for kk in [kk for kk, v in _CW.items() if v[0]() is None]:
+                del _CW[kk]
+        hit = (weakref.ref(w), stamp, fwd, dg)
+        _CW[key] = hit
+    return hit[3] if dgrad else hit[2]
 
 
 _MAPS: dict = {}

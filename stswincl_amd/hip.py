@@ -185,6 +185,18 @@ def conv_rowmap(frames, Hin, Win, Hout, Wout, k, stride, pad, dil, inverse, devi
     return m
 
 
+def conv_pack(w: torch.Tensor, dt: torch.dtype, omap: torch.Tensor, imap: torch.Tensor, want_dgrad: bool = True):
+    """(Cout,Cin,k,k) fp32 -> (fwd [cop][S*cip], dgrad [cip][S*cop] or None) in dtype dt; see include/stswin_hip.h."""
+    co, ci, k, _ = w.shape
+    S, cop, cip = k * k, omap.numel(), imap.numel()
+    wf = w.detach().float().contiguous()
+    fwd = torch.empty(cop, S * cip, dtype=dt, device=w.device)
+    dg = torch.empty(cip, S * cop, dtype=dt, device=w.device) if want_dgrad else None
+    _check(load().stswin_conv_pack(0 if dt == torch.bfloat16 else 1, _p(wf), _p(fwd), _p(dg), _p(omap), _p(imap), co, ci, S,
+                                   cop, cip, _stream()), "conv_pack")
+    return fwd, dg
+
+
 def stem_im2col(img: torch.Tensor, dtype: torch.dtype, Ho: int, Wo: int, ld: int = 192) -> torch.Tensor:
     """img fp32 NCHW [F][3][H][W] -> patches [F*Ho*Wo][ld] (7x7 / stride 2 / pad 3)."""
     F_, c, H, W = img.shape

@@ -9,6 +9,7 @@ reference's state-dict); a bf16 (and transposed) copy is cached per parameter ve
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Dict, Optional, Tuple
 
@@ -55,22 +56,43 @@ def conv_rowmap(frames, H, W, dil, device) -> torch.Tensor:
     return m
 
 
+_IDMAPS: dict = {}
+
+
+def _identity_map(n: int, device) -> torch.Tensor:
+    m = _IDMAPS.get((n, device))
+    if m is None:
+        m = torch.arange(n, dtype=torch.int32, device=device)
+        _IDMAPS[(n, device)] = m
+    return m
+
+
 def wcast(p: torch.Tensor, dtype: torch.dtype, transpose: bool = False) -> torch.Tensor:
-    """Compute-dtype (optionally transposed) contiguous copy of a parameter, cached until the parameter changes."""
-    key = (id(p), dtype, transpose)
+    """Compute-dtype (optionally transposed) contiguous copy of a parameter, cached until the parameter changes.
+    2-D fp32 weights on the GPU get BOTH copies (W for the forward GEMM, W^T for the input-gradient GEMM) from one
+    hip.conv_pack launch (a Linear weight is a 1x1 convolution weight with identity channel maps); the torch
+    formulation took 1 + 2 launches per weight and step."""
+    key = (id(p), dtype)
     hit = _WCACHE.get(key)
     stamp = (p._version, p.data_ptr(), tuple(p.shape), p.device)
-    if hit is not None and hit[0]() is p and hit[1] == stamp:
+    if hit is None or hit[0]() is not p or hit[1] != stamp:
+        w = p.detach()
+        if (w.dim() == 2 and w.is_cuda and w.dtype == torch.float32 and dtype in (torch.bfloat16, torch.float32)
+                and os.environ.get("STSWIN_TORCH_PACK") != "1"):   # (env switch: A/B against the torch formulation)
+            n, k = w.shape
+            fwd, tr = hip.conv_pack(w.view(n, k, 1, 1), dtype, _identity_map(n, w.device), _identity_map(k, w.device))
+        else:
+            fwd, tr = w.to(dtype).contiguous(), None
+        if len(_WCACHE) > 4096:          # drop entries whose parameter died (ids get recycled)
+            for k_ in [k_ for k_, v in _WCACHE.items() if v[0]() is None]:
+                del _WCACHE[k_]
+        hit = [weakref.ref(p), stamp, fwd, tr]
+        _WCACHE[key] = hit
+    if not transpose:
         return hit[2]
-    w = p.detach()
-    if transpose:
-        w = w.t()
-    w = w.to(dtype).contiguous()
-    if len(_WCACHE) > 4096:          # drop entries whose parameter died (ids get recycled)
-        for k in [k for k, v in _WCACHE.items() if v[0]() is None]:
-            del _WCACHE[k]
-    _WCACHE[key] = (weakref.ref(p), stamp, w)
-    return w
+    if hit[3] is None:
+        hit[3] = p.detach().t().to(dtype).contiguous()
+    return hit[3]
 
 
 def clear_caches() -> None:
