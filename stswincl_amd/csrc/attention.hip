@@ -106,7 +106,9 @@ struct AttnCfg {
   static constexpr int KV_BYTES = TT<T>::IS_BF16 ? NTOK * RB : 0;
   static constexpr int P_BYTES = NTOK * PRB;      // per problem, all query tiles
   static constexpr int FWD_LDS = TT<T>::IS_BF16 ? PPB * 2 * KV_BYTES : PPB * P_BYTES;   // bf16 forward keeps P in registers
-  static constexpr int BWD_LDS = PPB * (2 * KV_BYTES + 2 * P_BYTES);
+  // backward tile prefetch (bf16, one problem per workgroup): a third K/V-sized buffer when it still fits 160 KB
+  static constexpr bool BWD_PF = TT<T>::IS_BF16 && PPB == 1 && 3 * KV_BYTES + 2 * P_BYTES <= 160 * 1024;
+  static constexpr int BWD_LDS = BWD_PF ? 3 * KV_BYTES + 2 * P_BYTES : PPB * (2 * KV_BYTES + 2 * P_BYTES);
   static_assert(NTOK % 32 == 0 && HD % 32 == 0 && (QW == 1 || QW == 2 || QW == 4), "shape");
 };
 
@@ -143,18 +145,29 @@ DEVI void scores_softmax(f32x16 (&p)[NTOK / 32], const AttnArgs& a, const char* 
   // + bias + mask (transposed tables: [key n][query n], lanes contiguous in query)
   const int N = NC ? NC : a.N;
   const int qn = (q0 + lr) % N;
-  const float* bt = a.biasT + ((long)(a.bias_windows > 1 ? widx : 0) * a.heads + head) * N * N + qn;
+  const float* bt = a.biasT + ((long)((a.bias_windows & 0xffffff) > 1 ? widx : 0) * a.heads + head) * N * N + qn;
   const float* mt = a.maskT ? a.maskT + (long)widx * N * N + qn : nullptr;
+  // All table values are requested first and consumed afterwards.  (With the optional mask tested per element the loop
+  // was load - branch - wait - add, 32 dependent L2 round trips: 11.7 of the backward kernel's 24 us per problem.)
+  float tb[Cfg::KT][16];
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tb[kt][r] = bt[((kt * 32 + crow32(r, half)) % N) * N];
+  if (mt) {
+#pragma unroll
+    for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tb[kt][r] += mt[((kt * 32 + crow32(r, half)) % N) * N];
+  }
   float mx = -3.0e38f;
 #pragma unroll
   for (int kt = 0; kt < Cfg::KT; ++kt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int kn = (kt * 32 + crow32(r, half)) % N;
-      float s = p[kt][r] + bt[kn * N];
-      if (mt) s += mt[kn * N];
-      p[kt][r] = s;
-      mx = fmaxf(mx, s);
+      const float sc = p[kt][r] + tb[kt][r];
+      p[kt][r] = sc;
+      mx = fmaxf(mx, sc);
     }
   mx = fmaxf(mx, __shfl_xor(mx, 32));
   float sum = 0.f;
@@ -294,6 +307,26 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) dbacc[kt][r] = 0.f;
 #pragma unroll
   for (int dt = 0; dt < Cfg::DT; ++dt) csacc[dt] = 0.f;
+  // Tile prefetch (Cfg::BWD_PF): three K/V-sized LDS buffers rotate through the roles  K | V -> Q | dO -> next K  so that
+  // every LDS-DMA copy is requested one phase before it is needed: dO while the scores are computed, Q while dV is
+  // multiplied, the next problem's K during dK / dQ and its V at the very end (it is first used after the next S^T).
+  // Without it each of the three re-stagings of a problem exposed a full copy latency with one wave per SIMD.
+  constexpr bool PF = Cfg::BWD_PF;
+  const bool dbg_ts = (a.bias_windows & (1 << 30)) != 0;
+  auto stamp = [&](int slot) {
+    if (dbg_ts && threadIdx.x == 0) ((unsigned long long*)a.dqkv_colsum)[(long)blockIdx.x * 16 + slot] = wall_clock64();
+  };
+  int kbuf = 0, xbuf = 2;                        // PF: buffer holding K / the spare one (dO, then the next K); V and Q use buffer 1
+  auto problem_rowbase = [&](long g) -> long {
+    const long pr = g * Cfg::PPB + sp;
+    return (long)min((int)(pr / a.heads), a.nB_ - 1) * NTOK;
+  };
+  if constexpr (PF) {
+    const long rb0 = problem_rowbase(blockIdx.x);
+    const T* q0b = (const T*)a.qkv + rb0 * a.ld + head * HD;
+    stage_tile<NTOK, Cfg::RB>(smem, (const char*)(q0b + a.C), a.ld * sizeof(T), qt, Cfg::QW);
+    stage_tile<NTOK, Cfg::RB>(smem + Cfg::KV_BYTES, (const char*)(q0b + 2 * a.C), a.ld * sizeof(T), qt, Cfg::QW);
+  }
   for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
   const long prob = grp * Cfg::PPB + sp;
   const int b_ = min((int)(prob / a.heads), a.nB_ - 1);
@@ -303,19 +336,26 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   const T* kbase = qbase + a.C;
   const T* vbase = qbase + 2 * a.C;
   const T* dobase = (const T*)a.dout + rowbase * a.lddo + head * HD;
-  char* Kt = smem + sp * (2 * Cfg::KV_BYTES + 2 * Cfg::P_BYTES);
-  char* Vt = Kt + Cfg::KV_BYTES;                 // V, later dO, later Q
-  char* Pt = Vt + Cfg::KV_BYTES;
+  char* Kt = PF ? smem + kbuf * Cfg::KV_BYTES : smem + sp * (2 * Cfg::KV_BYTES + 2 * Cfg::P_BYTES);
+  char* Vt = PF ? smem + Cfg::KV_BYTES : Kt + Cfg::KV_BYTES;            // V, later Q (not PF: V, dO, Q)
+  char* Xt = PF ? smem + xbuf * Cfg::KV_BYTES : Vt;                       // dO
+  char* Pt = PF ? smem + 3 * Cfg::KV_BYTES : Vt + Cfg::KV_BYTES;
   char* St = Pt + Cfg::P_BYTES;                  // dS
   const int q0 = qt * 32;
+  stamp(0);
   if constexpr (TT<T>::IS_BF16) {
-    stage_tile<NTOK, Cfg::RB>(Kt, (const char*)kbase, a.ld * sizeof(T), qt, Cfg::QW);
-    stage_tile<NTOK, Cfg::RB>(Vt, (const char*)vbase, a.ld * sizeof(T), qt, Cfg::QW);
+    if constexpr (!PF) {
+      stage_tile<NTOK, Cfg::RB>(Kt, (const char*)kbase, a.ld * sizeof(T), qt, Cfg::QW);
+      stage_tile<NTOK, Cfg::RB>(Vt, (const char*)vbase, a.ld * sizeof(T), qt, Cfg::QW);
+    }
     wait_vm0();
     __syncthreads();
+    if constexpr (PF) stage_tile<NTOK, Cfg::RB>(Xt, (const char*)dobase, a.lddo * sizeof(T), qt, Cfg::QW);
   }
+  stamp(1);
   f32x16 p[Cfg::KT], dp[Cfg::KT];
   scores_softmax<T, NTOK, HD, NC>(p, a, Kt, qbase, kbase, q0, head, b_ % a.nW);
+  stamp(2);
   // dP^T = V dO^T
 #pragma unroll
   for (int kt = 0; kt < Cfg::KT; ++kt)
@@ -339,6 +379,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         dp[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vbase[(long)(kt * 32 + lr) * a.ld + 2 * kk + half], dv, dp[kt], 0, 0, 0);
     }
   }
+  stamp(3);
   float delta = 0.f;
 #pragma unroll
   for (int kt = 0; kt < Cfg::KT; ++kt)
@@ -358,6 +399,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   }
   store_qk_tile<T, NTOK>(Pt, p, q0);
   store_qk_tile<T, NTOK>(St, dp, q0);
+  stamp(4);
   __syncthreads();                               // P, dS complete; every wave is done with V
   T* dqb = (T*)a.out + rowbase * a.ldo + head * HD;
   T* dkb = dqb + a.C;
@@ -398,10 +440,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
 
   // ---- dV[key][d] = sum_q P[q][key] dO[q][d]
   if constexpr (TT<T>::IS_BF16) {
-    stage_tile<NTOK, Cfg::RB>(Vt, (const char*)dobase, a.lddo * sizeof(T), qt, Cfg::QW);
-    wait_vm0();
-    __syncthreads();
+    if constexpr (PF) {
+      wait_vm0();                                // dO (requested before the scores) has landed
+      __syncthreads();
+      stage_tile<NTOK, Cfg::RB>(Vt, (const char*)qbase, a.ld * sizeof(T), qt, Cfg::QW);   // V is dead: Q for dK
+    } else {
+      stage_tile<NTOK, Cfg::RB>(Vt, (const char*)dobase, a.lddo * sizeof(T), qt, Cfg::QW);
+      wait_vm0();
+      __syncthreads();
+    }
   }
+  stamp(5);
   zero_acc();
   if constexpr (TT<T>::IS_BF16) {
 #pragma unroll
@@ -409,7 +458,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
       const bf16x8 pa = frag_tr<Cfg::PRB>(Pt, ks, qt);
 #pragma unroll
       for (int dt = 0; dt < Cfg::DT; ++dt)
-        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<Cfg::RB>(Vt, ks, dt), acc[dt], 0, 0, 0);
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<Cfg::RB>(Xt, ks, dt), acc[dt], 0, 0, 0);
     }
   } else {
 #pragma unroll 4
@@ -421,10 +470,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, dobase[(long)qq * a.lddo + dt * 32 + lr], acc[dt], 0, 0, 0);
     }
   }
-  store_acc_plain(dvb, k0);
+  stamp(6);
+  if constexpr (PF) {
+    wait_vm0();                                  // Q has landed (waited for BEFORE the dV stores are issued)
+    __syncthreads();                             // ... and every wave is done with the dO tile
+    store_acc_plain(dvb, k0);
+    if (grp + gridDim.x < ngroups) {             // the next problem's K into the buffer dO just left
+      const T* nq = (const T*)a.qkv + problem_rowbase(grp + gridDim.x) * a.ld + head * HD;
+      stage_tile<NTOK, Cfg::RB>(Xt, (const char*)(nq + a.C), a.ld * sizeof(T), qt, Cfg::QW);
+    }
+  } else {
+    store_acc_plain(dvb, k0);
+  }
 
+  stamp(7);
   // ---- dK[key][d] = sum_q dS[q][key] q_s[q][d]
-  if constexpr (TT<T>::IS_BF16) {
+  if constexpr (TT<T>::IS_BF16 && !PF) {
     __syncthreads();                             // all waves finished reading the dO tile
     stage_tile<NTOK, Cfg::RB>(Vt, (const char*)qbase, a.ld * sizeof(T), qt, Cfg::QW);
     wait_vm0();
@@ -450,6 +511,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     }
   }
   store_acc_plain(dkb, k0);
+  stamp(8);
 
   // ---- dQ[q][d] = scale * sum_key dS[q][key] K[key][d]
   zero_acc();
@@ -472,7 +534,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     }
   }
   store_acc(dqb, q0, a.scale);
+  stamp(9);
   __syncthreads();                               // the next problem's tiles overwrite K / dS
+  stamp(10);
+  if constexpr (PF) {
+    if (grp + gridDim.x < ngroups) {             // next V into buffer 1 (Q is dead); first needed after the next S^T
+      const T* nq = (const T*)a.qkv + problem_rowbase(grp + gridDim.x) * a.ld + head * HD;
+      stage_tile<NTOK, Cfg::RB>(smem + Cfg::KV_BYTES, (const char*)(nq + 2 * a.C), a.ld * sizeof(T), qt, Cfg::QW);
+    }
+    const int tb = kbuf; kbuf = xbuf; xbuf = tb;   // the spare buffer now holds the next K
+  }
   }
   if (a.dbiasT) {
     const int N = NC ? NC : a.N, qn = (qt * 32 + lr) % N;
@@ -493,7 +564,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) atomicAdd(db + ((kt * 32 + crow32(r, half)) % N) * N, dbacc[kt][r]);
     }
   }
-  if (a.dqkv_colsum) {
+  if (a.dqkv_colsum && !dbg_ts) {
 #pragma unroll
     for (int dt = 0; dt < Cfg::DT; ++dt) {
       float csum = csacc[dt];
@@ -571,7 +642,9 @@ extern "C" int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const vo
                                    const float* biasT, const float* maskT, float* dbiasT, float* dqkv_colsum, int nB_,
                                    int nW, int T_frames, int ws, int heads, int C, float scale, int bias_windows,
                                    void* stream) {
+  const int dbg = bias_windows & (1 << 30);    // DBG (tools/attn_timeline.py): dqkv_colsum is a u64 [workgroups][16] timestamp buffer
+  bias_windows &= ~(1 << 30);
   if (bias_windows != 1 && (bias_windows != nW || maskT)) return -1204;
-  AttnArgs a{qkv, ld, dqkv, lddq, dout, lddo, biasT, maskT, dbiasT, dqkv_colsum, nB_, nW, heads, C, 0, scale, bias_windows};
+  AttnArgs a{qkv, ld, dqkv, lddq, dout, lddo, biasT, maskT, dbiasT, dqkv_colsum, nB_, nW, heads, C, 0, scale, bias_windows | dbg};
   return attn_common(dtype, a, T_frames, ws, true, stream);
 }

@@ -319,11 +319,11 @@ def win_attn_fwd(qkv, biasT, maskT, *, nB_, nW, T, ws, heads, C):
     return out
 
 
-def win_attn_bwd(qkv, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, scale, colsum_out=None):
+def win_attn_bwd(qkv, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, scale, colsum_out=None, debug_ts=False):
     dqkv = torch.empty_like(qkv)
     rc = load().stswin_win_attn_bwd(_dt(qkv), _p(qkv), _c_long(_ld(qkv)), _p(dout), _c_long(_ld(dout)), _p(dqkv),
                                     _c_long(_ld(dqkv)), _p(biasT), _p(maskT), _p(dbiasT), _p(colsum_out), nB_, nW, T, ws, heads, C,
-                                    _c_float(scale), _bias_windows(biasT, maskT, nW), _stream())
+                                    _c_float(scale), _bias_windows(biasT, maskT, nW) | ((1 << 30) if debug_ts else 0), _stream())
     _check(rc, "win_attn_bwd")
     return dqkv
 
