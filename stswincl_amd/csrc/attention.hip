@@ -115,9 +115,20 @@ struct AttnCfg {
 // ---- S^T (+bias, +mask) and softmax for this wave's 32 queries: returns normalised P^T in p[KT] -------------
 // NC: ws*ws when known at compile time (0 = read a.N): with it the compiler sees which table addresses repeat over the
 // T frames of a window (kn = key mod N) and loads each bias value once instead of T times.
+// Row fragments (16-byte pieces of this lane's query / dO row) straight from global memory: requested BEFORE the wait for
+// the LDS-DMA tiles so that their (first-touch, HBM) latency overlaps the tile copies.
+template <typename T, int HD>
+DEVI void load_row_frags(bf16x8 (&f)[HD / 16], const T* base, long ld, int row) {
+  const int half = (threadIdx.x & 63) >> 5;
+  if constexpr (TT<T>::IS_BF16) {
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) f[ks] = *(const bf16x8*)(base + (long)row * ld + 16 * ks + 8 * half);
+  }
+}
+
 template <typename T, int NTOK, int HD, int NC>
 DEVI void scores_softmax(f32x16 (&p)[NTOK / 32], const AttnArgs& a, const char* Kt, const T* qbase, const T* kbase,
-                         int q0, int head, int widx) {
+                         int q0, int head, int widx, const bf16x8 (&qf)[HD / 16]) {
   using Cfg = AttnCfg<T, NTOK, HD>;
   const int l = threadIdx.x & 63, lr = l & 31, half = l >> 5;
 #pragma unroll
@@ -125,9 +136,6 @@ DEVI void scores_softmax(f32x16 (&p)[NTOK / 32], const AttnArgs& a, const char* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[kt][r] = 0.f;
   if constexpr (TT<T>::IS_BF16) {
-    bf16x8 qf[HD / 16];
-#pragma unroll
-    for (int ks = 0; ks < HD / 16; ++ks) qf[ks] = *(const bf16x8*)(qbase + (long)(q0 + lr) * a.ld + 16 * ks + 8 * half);
 #pragma unroll
     for (int kt = 0; kt < Cfg::KT; ++kt)
 #pragma unroll
@@ -232,10 +240,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   char* Vt = Kt + Cfg::KV_BYTES;
   char* Pt = Kt;                                   // f32 only (no K / V tiles there)
   const int q0 = qt * 32;
+  bf16x8 qf[HD / 16];
   if constexpr (TT<T>::IS_BF16) {
     if (live) {
       stage_tile<NTOK, Cfg::RB>(Kt, (const char*)kbase, a.ld * sizeof(T), qt, Cfg::QW);
       stage_tile<NTOK, Cfg::RB>(Vt, (const char*)vbase, a.ld * sizeof(T), qt, Cfg::QW);
+      load_row_frags<T, HD>(qf, qbase, a.ld, q0 + lr);
     }
     wait_vm0();
     __syncthreads();
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   if (!live) return;   // (no barrier below is reached by a subset of a PROBLEM's waves only when QW == 1)
 
   f32x16 p[Cfg::KT];
-  scores_softmax<T, NTOK, HD, NC>(p, a, Kt, qbase, kbase, q0, head, b_ % a.nW);
+  scores_softmax<T, NTOK, HD, NC>(p, a, Kt, qbase, kbase, q0, head, b_ % a.nW, qf);
 
   f32x16 o[Cfg::DT];
 #pragma unroll
@@ -343,6 +353,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   char* St = Pt + Cfg::P_BYTES;                  // dS
   const int q0 = qt * 32;
   stamp(0);
+  bf16x8 qf[HD / 16], df[HD / 16];
+  load_row_frags<T, HD>(qf, qbase, a.ld, q0 + lr);        // Q (and dO) row pieces: in flight during the tile wait
+  if constexpr (!PF) load_row_frags<T, HD>(df, dobase, a.lddo, q0 + lr);   // (PF: dO pieces come from the LDS tile below)
   if constexpr (TT<T>::IS_BF16) {
     if constexpr (!PF) {
       stage_tile<NTOK, Cfg::RB>(Kt, (const char*)kbase, a.ld * sizeof(T), qt, Cfg::QW);
@@ -354,17 +367,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   }
   stamp(1);
   f32x16 p[Cfg::KT], dp[Cfg::KT];
-  scores_softmax<T, NTOK, HD, NC>(p, a, Kt, qbase, kbase, q0, head, b_ % a.nW);
+  scores_softmax<T, NTOK, HD, NC>(p, a, Kt, qbase, kbase, q0, head, b_ % a.nW, qf);
   stamp(2);
+  if constexpr (PF) {                            // the dO tile requested before the scores has landed: row pieces from LDS
+    wait_vm0();
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) df[ks] = frag_row<Cfg::RB>(Xt, q0 + lr, ks, half);
+  }
   // dP^T = V dO^T
 #pragma unroll
   for (int kt = 0; kt < Cfg::KT; ++kt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dp[kt][r] = 0.f;
   if constexpr (TT<T>::IS_BF16) {
-    bf16x8 df[HD / 16];
-#pragma unroll
-    for (int ks = 0; ks < HD / 16; ++ks) df[ks] = *(const bf16x8*)(dobase + (long)(q0 + lr) * a.lddo + 16 * ks + 8 * half);
 #pragma unroll
     for (int kt = 0; kt < Cfg::KT; ++kt)
 #pragma unroll
