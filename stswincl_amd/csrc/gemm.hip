@@ -1246,6 +1246,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
   const int per = (nst_all + p.splits - 1) / p.splits;
   const int s_begin = split_id * per, s_end = min(nst_all, s_begin + per);
   const int nt = max(0, s_end - s_begin);
+  const bool dbg_ts = p.ldc < 0;                       // DBG (tools/gemm_timeline.py tn): C is a u64 [workgroups][8] timestamp buffer
+  auto stamp = [&](int slot) {
+    if (dbg_ts && threadIdx.x == 0) ((unsigned long long*)p.C)[(long)blockIdx.x * 8 + slot] = wall_clock64();
+  };
+  stamp(0);
 
   const char* zero = (const char*)g_stswin_zero;
   // one LDS-DMA instruction = 2 rows x 512 B; wave w issues instructions w*2 + {0,1} of each operand = stage rows 4w..4w+3
@@ -1352,7 +1357,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
   if (nt > 0) {
     load_idx(0);
     for (int q = 0; q < NST - 1 && q < nt; ++q) { issue(q); load_idx(q + 1); }
+    stamp(1);
     wait_tile(0);
+    stamp(2);
     if (lag) __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nt; ++kt) {
       __builtin_amdgcn_s_barrier();
@@ -1365,6 +1372,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
     }
     if (!lag) __builtin_amdgcn_s_barrier();
   }
+  stamp(3);
+  if (dbg_ts) return;
 #pragma unroll
   for (int i = 0; i < FI; ++i)
 #pragma unroll

@@ -252,7 +252,7 @@ def _tn_workspace(device, floats=48 * 1024 * 1024):
 
 
 def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: int, at_rows=None, bt_rows=None,
-            splits: int = 0, bseg: int = 0, atomics: bool = False, overwrite: bool = False):
+            splits: int = 0, bseg: int = 0, atomics: bool = False, overwrite: bool = False, debug_ts: bool = False):
     """out_f32[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]  (fp32); overwrite=True stores instead of adding, so
     out_f32 may come from torch.empty."""
     if overwrite:
@@ -265,7 +265,7 @@ def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: in
         name += f" Mk={Mk} Ni={Ni} Nj={Nj} bseg={bseg} a={int(at_rows is not None)} b={int(bt_rows is not None)}"
     with _Span(name, 2.0 * Mk * Ni * Nj):
         rc = load().stswin_gemm_tn(_dt(At), _p(At), _c_long(_ld(At)), _p(at_rows), _p(Bt), _c_long(_ld(Bt)),
-                                   _p(bt_rows), _p(out_f32), _c_long(_ld(out_f32)), Mk, Ni, Nj, splits, bseg, _p(ws),
+                                   _p(bt_rows), _p(out_f32), _c_long(-1 if debug_ts else _ld(out_f32)), Mk, Ni, Nj, splits, bseg, _p(ws),
                                    _c_long(ws.numel() if ws is not None else 0), _stream())
     _check(rc, "gemm_tn")
     return out_f32

@@ -5,6 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from stswincl_amd import hip
+TN_MODE = len(sys.argv) > 1 and sys.argv[1] == "tn"
 M, N, K = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (65536, 2048, 512)))
 A = torch.randn(M, K, device="cuda").bfloat16()
 W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
@@ -29,3 +30,32 @@ starts = t[:, 0].sort().values
 print("  start times of workgroups 0,255,256,511,512 (sorted):", [round(float(starts[i]), 1) for i in (0, 255, 256, 511, 512) if i < nblk])
 ends = t[:, 6].sort().values
 print("  end times (sorted) 255, 511:", [round(float(ends[i]), 1) for i in (255, 511) if i < nblk])
+
+
+def tn_timeline(Mk=65536, Ni=2048, Nj=512, mapped=False):
+    """Same for the gemm_tn ring kernel (debug: ldc < 0 makes C a timestamp buffer and skips the epilogue)."""
+    At = torch.randn(Mk, Ni, device="cuda").bfloat16()
+    Bt = torch.randn(Mk, Nj, device="cuda").bfloat16()
+    side = int((Mk // 16) ** 0.5)
+    rmap = hip.win_rowmap(4, 4, side, side, 8, 4) if mapped else None
+    nblk = 256
+    for _ in range(3):
+        ts = torch.zeros(Ni, Nj, dtype=torch.float32, device="cuda")
+        hip.gemm_tn(At, Bt, ts, Mk=Mk, bt_rows=rmap, atomics=True, debug_ts=True)
+    torch.cuda.synchronize()
+    raw = ts.view(torch.int64).view(-1)[: nblk * 8].view(nblk, 8).cpu().double()
+    raw = raw[raw[:, 3] > 0]
+    t = raw / 100.0
+    d = t[:, 1:4] - t[:, 0:3]
+    nst = Mk // 32
+    print(f"gemm_tn ring Mk={Mk} Ni={Ni} Nj={Nj} mapped={mapped}: {len(t)} workgroups")
+    for i, n in enumerate(["prologue issue", "first stage wait", "main loop"]):
+        print(f"  {n:18s} {float(d[:, i].mean()):7.2f} us")
+    tiles = ((Ni + 255) // 256) * ((Nj + 255) // 256)
+    splits = max(1, len(t) // tiles)
+    print(f"  stages per workgroup ~{nst // splits}: {float(d[:, 2].mean()) / (nst / splits):.3f} us per 32-row stage")
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "tn":
+    tn_timeline(mapped=False)
+    tn_timeline(Ni=1536, mapped=True)
