@@ -51,6 +51,13 @@ DEVI void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// ---- buffer-addressed LDS-DMA: descriptor base (wave-uniform) + per-lane 32-bit byte offset + scalar byte offset.  The
+// descriptor claims 4 GB - 2 bytes, so an offset of 0xFFFFFFFF is out of range and the copy delivers zeros (edge rows,
+// convolution padding).  Kept inside __device__ helpers: the resource type does not exist in the host pass.
+DEVI void glds16_buf(const void* base, unsigned lane_off, int scalar_off, void* lds_wave_base) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)0xFFFFFFFE, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, lane_off, scalar_off, 0, 0);
+}
 DEVI void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- swizzles ---------------------------------------------------------------------------------

@@ -381,15 +381,18 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
 
-  const char* zero = (const char*)g_stswin_zero;
+  // Copies are BUFFER-addressed LDS-DMA: a 128-bit descriptor in SGPRs per operand, one 32-bit byte offset per lane and
+  // copy instruction (row * pitch + swizzled chunk), and the K position as the instruction's scalar offset.  A stage
+  // request is then 4 instructions and a few SALU ops: no per-lane 64-bit pointer arithmetic in the read phase, whose VALU
+  // instructions come straight out of the partner wave's MFMA issue slots (tools/probes/pingpong_probe.hip: 0.61 us per
+  // stage with an empty read phase, 0.79 with 48 VALU in it; this kernel ran 0.85).  Rows that do not exist (tile edge,
+  // convolution padding = map entry -1) get offset 0xFFFFFFFF, which the descriptor's range check turns into zeros.
   const int rsub = l >> 2, cphys = l & 3, csrc = cphys ^ swz64(rsub);
-  const char* abase[NIA]; int astep[NIA];
-  const char* bbase[NIB]; int bstep[NIB];
+  unsigned aoff[NIA], boff[NIB];
 #pragma unroll
   for (int i = 0; i < NIB; ++i) {
     const int gn = n0 + (w * NIB + i) * 16 + rsub;
-    if (gn < p.N) { bbase[i] = (const char*)p.B + ((long)gn * p.ldb) * sizeof(T) + csrc * 16; bstep[i] = BK * sizeof(T); }
-    else { bbase[i] = zero + cphys * 16; bstep[i] = 0; }
+    boff[i] = gn < p.N ? (unsigned)gn * (unsigned)(p.ldb * sizeof(T)) + csrc * 16 : 0xFFFFFFFFu;
   }
   auto load_a_bases = [&](int seg) {
 #pragma unroll
@@ -397,23 +400,24 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
       const int gm = m0 + (w * NIA + i) * 16 + rsub;
       long row = -1;
       if (gm < p.M) row = p.a_rows ? (long)p.a_rows[(long)seg * p.M + gm] : (long)gm;
-      if (row >= 0) { abase[i] = (const char*)p.A + (row * p.lda) * sizeof(T) + csrc * 16; astep[i] = BK * sizeof(T); }
-      else { abase[i] = zero + cphys * 16; astep[i] = 0; }
+      const unsigned long off = (unsigned long)row * (unsigned long)(p.lda * sizeof(T)) + csrc * 16;
+      if (row >= 0 && off >= 0xFFFFFFF0ul) __builtin_trap();        // operand beyond the 4 GB a 32-bit offset reaches
+      aoff[i] = row >= 0 ? (unsigned)off : 0xFFFFFFFFu;
     }
   };
   const int kps = p.Kseg / BK;
   const int nt = p.S * kps;
   int seg = -1;
   auto issue = [&](int q) {
-    const int sg = q / kps;
+    int sg = 0, kt = q;
+    if (p.S > 1) { sg = q / kps; kt = q - sg * kps; }
     if (sg != seg) { seg = sg; load_a_bases(sg); }
-    const int kt = q - sg * kps;
     char* Ab = smem + (q % NST) * STAGE;
     char* Bb = Ab + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < NIA; ++i) glds16(abase[i] + (long)kt * astep[i], Ab + (w * NIA + i) * 1024);
+    for (int i = 0; i < NIA; ++i) glds16_buf(p.A, aoff[i], kt * (BK * (int)sizeof(T)), Ab + (w * NIA + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < NIB; ++i) glds16(bbase[i] + (long)q * bstep[i], Bb + (w * NIB + i) * 1024);
+    for (int i = 0; i < NIB; ++i) glds16_buf(p.B, boff[i], q * (BK * (int)sizeof(T)), Bb + (w * NIB + i) * 1024);
   };
 
   f32x4 acc[FI][FJ];                                 // zeroed AFTER the prologue copies are requested (below)
@@ -749,14 +753,30 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     wait_tile(0);
     stamp(2);
     if (lag) __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nt; ++kt) {
+    // Steady state without a single data-dependent branch in the body: both rows wait for THEIR share of stage kt+1
+    // right after their fragment reads (it was requested two iterations earlier, so the counted wait does not stall),
+    // every iteration requests a stage, the wait count is the constant "two younger stages".  The last NST-1
+    // iterations (nothing left to request, shrinking wait counts) run in the general form below.  The in-order wave
+    // pays ~20 cycles per scalar branch; the general body has ten of them per stage (measured 0.85 us per stage against
+    // 0.62 for the same loop without them, tools/probes/pingpong_probe.hip).
+    int kt = 0;
+    if (p.S == 1) {
+      for (; kt + NST - 1 < nt; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        issue(kt + NST - 1);
+        read_frags(kt);
+        wait_vmcnt<2 * PER_STAGE>();
+        __builtin_amdgcn_s_barrier();
+        mma_all();
+      }
+    }
+    for (; kt < nt; ++kt) {
       __builtin_amdgcn_s_barrier();
       if (kt + NST - 1 < nt) issue(kt + NST - 1);
       read_frags(kt);
-      if (lag && kt + 1 < nt) wait_tile(kt + 1);
+      if (kt + 1 < nt) wait_tile(kt + 1);
       __builtin_amdgcn_s_barrier();
       mma_all();
-      if (!lag && kt + 1 < nt) wait_tile(kt + 1);
     }
     if (!lag) __builtin_amdgcn_s_barrier();
     if constexpr (SWAP) epilogue_reg();
