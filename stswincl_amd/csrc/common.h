@@ -58,6 +58,22 @@ DEVI void glds16_buf(const void* base, unsigned lane_off, int scalar_off, void* 
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)0xFFFFFFFE, 0x00020000);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, lane_off, scalar_off, 0, 0);
 }
+// The same copy as raw ISA (invisible to hipcc's waitcnt pass: needed where ds_read_b64_tr_b16 follows, see glds16_raw).
+typedef int buf_rsrc_t __attribute__((ext_vector_type(4)));
+DEVI buf_rsrc_t make_buf_rsrc(const void* base) {      // raw buffer, stride 0, 4 GB - 2 bytes in range
+  const unsigned long a = (unsigned long)base;
+  buf_rsrc_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+  r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+  r[2] = (int)0xFFFFFFFE;
+  r[3] = 0x00020000;
+  return r;
+}
+DEVI void glds16_buf_raw(const buf_rsrc_t& rs, unsigned lane_off, unsigned scalar_off, void* lds_wave_base) {
+  const unsigned lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(lane_off), "s"(rs), "s"(scalar_off), "s"(lds)
+               : "memory", "m0");
+}
 DEVI void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- swizzles ---------------------------------------------------------------------------------

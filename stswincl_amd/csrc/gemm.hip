@@ -1272,10 +1272,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
   };
   stamp(0);
 
-  const char* zero = (const char*)g_stswin_zero;
-  // one LDS-DMA instruction = 2 rows x 512 B; wave w issues instructions w*2 + {0,1} of each operand = stage rows 4w..4w+3
+  // one LDS-DMA instruction = 2 rows x 512 B; wave w issues instructions w*2 + {0,1} of each operand = stage rows 4w..4w+3.
+  // Buffer-addressed (raw ISA, see glds16_buf_raw): per lane a 32-bit offset = source row * pitch + column bytes, or
+  // 0xFFFFFFFF (out of range -> zeros) for missing rows / columns; without gather maps the row part is the scalar offset.
   const int rsub = l >> 5, cphys = l & 31;
-  long offA[2], offB[2];                            // byte offset of this lane's chunk inside its source row, or -1
+  const buf_rsrc_t rsA = make_buf_rsrc(p.At), rsB = make_buf_rsrc(p.Bt);
+  const unsigned pitchA = (unsigned)(p.lda * sizeof(T)), pitchB = (unsigned)(p.ldb * sizeof(T));
+  const int limA = (int)(0xFFFF0000u / pitchA), limB = (int)(0xFFFF0000u / pitchB);   // rows a 32-bit offset can reach
+  if (!MAPS && (p.Mk > limA || p.Mk > limB)) __builtin_trap();
+  unsigned offA[2], offB[2];                        // byte offset of this lane's chunk inside its source row, or 0xFFFFFFFF
   bool tap1[2];
   const int tapA0 = (MAPS && p.bseg > 0) ? j0 / p.bseg : 0;
   const int tapA1 = (MAPS && p.bseg > 0) ? min(tapA0 + 1, p.Nj / p.bseg - 1) : 0;
@@ -1284,11 +1289,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
     const int r = (w * 2 + i) * 2 + rsub;
     const int cs = (cphys & ~15) | ((cphys ^ swz256(r)) & 15);
     const int ci = i0 + cs * 8, cj = j0 + cs * 8;
-    offA[i] = ci < p.Ni ? (long)ci * sizeof(T) : -1;
+    offA[i] = ci < p.Ni ? (unsigned)(ci * sizeof(T)) : 0xFFFFFFFFu;
     int sc = cj;
     tap1[i] = false;
     if (MAPS && p.bseg > 0) { sc = cj % p.bseg; tap1[i] = (cj / p.bseg) != tapA0; }
-    offB[i] = cj < p.Nj ? (long)sc * sizeof(T) : -1;
+    offB[i] = cj < p.Nj ? (unsigned)(sc * sizeof(T)) : 0xFFFFFFFFu;
+    if (!MAPS) {                                    // plain: fold the lane's row-in-stage into the offset once
+      if (offA[i] != 0xFFFFFFFFu) offA[i] += (unsigned)r * pitchA;
+      if (offB[i] != 0xFFFFFFFFu) offB[i] += (unsigned)r * pitchB;
+    }
   }
   typedef int int4v __attribute__((ext_vector_type(4)));
   typedef const __attribute__((address_space(4))) int4v* cint4;
@@ -1331,16 +1340,35 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
   auto issue = [&](int q) {                          // stage q of this split -> ring slot q & 3; consumes ia/ib*
     char* Ab = smem + (q & 3) * STAGE;
     char* Bb = Ab + OP_BYTES;
+    if (!MAPS) {
+      const int mb = (s_begin + q) * BMK;            // first contraction row of the stage (wave-uniform)
+      if (mb + BMK <= p.Mk) {                         // whole stage in range: the row is the scalar offset
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          glds16_buf_raw(rsA, offA[i], (unsigned)mb * pitchA, Ab + (w * 2 + i) * 1024);
+          glds16_buf_raw(rsB, offB[i], (unsigned)mb * pitchB, Bb + (w * 2 + i) * 1024);
+        }
+      } else {                                        // ragged last stage: rows >= Mk read zeros
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bool in = mb + (w * 2 + i) * 2 + rsub < p.Mk;
+          glds16_buf_raw(rsA, in ? offA[i] : 0xFFFFFFFFu, (unsigned)mb * pitchA, Ab + (w * 2 + i) * 1024);
+          glds16_buf_raw(rsB, in ? offB[i] : 0xFFFFFFFFu, (unsigned)mb * pitchB, Bb + (w * 2 + i) * 1024);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int ra = rsub ? ia[2 * i + 1] : ia[2 * i];
       const int rb0 = rsub ? ib0[2 * i + 1] : ib0[2 * i];
       const int rb1 = rsub ? ib1[2 * i + 1] : ib1[2 * i];
       const int rb = tap1[i] ? rb1 : rb0;
-      const char* sa = (ra >= 0 && offA[i] >= 0) ? (const char*)p.At + (long)ra * (p.lda * (long)sizeof(T)) + offA[i] : zero;
-      const char* sb = (rb >= 0 && offB[i] >= 0) ? (const char*)p.Bt + (long)rb * (p.ldb * (long)sizeof(T)) + offB[i] : zero;
-      glds16_raw(sa, Ab + (w * 2 + i) * 1024);
-      glds16_raw(sb, Bb + (w * 2 + i) * 1024);
+      if (ra > limA || rb > limB) __builtin_trap();   // operand beyond the 4 GB a 32-bit offset reaches
+      const unsigned va = (ra >= 0 && offA[i] != 0xFFFFFFFFu) ? (unsigned)ra * pitchA + offA[i] : 0xFFFFFFFFu;
+      const unsigned vb = (rb >= 0 && offB[i] != 0xFFFFFFFFu) ? (unsigned)rb * pitchB + offB[i] : 0xFFFFFFFFu;
+      glds16_buf_raw(rsA, va, 0u, Ab + (w * 2 + i) * 1024);
+      glds16_buf_raw(rsB, vb, 0u, Bb + (w * 2 + i) * 1024);
     }
   };
 
@@ -1381,14 +1409,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
     wait_tile(0);
     stamp(2);
     if (lag) __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nt; ++kt) {
+    // steady state without data-dependent branches (see gemm_nt_ring_kernel): both rows wait for their share of stage
+    // kt+1 right behind their fragment reads, with the constant "two younger stages" count
+    int kt = 0;
+    for (; kt + NST - 1 < nt; ++kt) {
       __builtin_amdgcn_s_barrier();
-      if (kt + NST - 1 < nt) { issue(kt + NST - 1); load_idx(kt + NST); }
+      issue(kt + NST - 1);
+      load_idx(kt + NST);
       read_frags(kt);
-      if (lag && kt + 1 < nt) wait_tile(kt + 1);
+      wait_vmcnt<2 * PER_STAGE>();
       __builtin_amdgcn_s_barrier();
       mma_all();
-      if (!lag && kt + 1 < nt) wait_tile(kt + 1);
+    }
+    for (; kt < nt; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      read_frags(kt);
+      if (kt + 1 < nt) wait_tile(kt + 1);
+      __builtin_amdgcn_s_barrier();
+      mma_all();
     }
     if (!lag) __builtin_amdgcn_s_barrier();
   }
