@@ -60,12 +60,12 @@ DEVI void glds16_buf(const void* base, unsigned lane_off, int scalar_off, void* 
 }
 // The same copy as raw ISA (invisible to hipcc's waitcnt pass: needed where ds_read_b64_tr_b16 follows, see glds16_raw).
 typedef int buf_rsrc_t __attribute__((ext_vector_type(4)));
-DEVI buf_rsrc_t make_buf_rsrc(const void* base) {      // raw buffer, stride 0, 4 GB - 2 bytes in range
+DEVI buf_rsrc_t make_buf_rsrc(const void* base) {      // raw buffer, stride 0, offsets < 0xFFFF0000 in range, above: zeros
   const unsigned long a = (unsigned long)base;
   buf_rsrc_t r;
   r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
   r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
-  r[2] = (int)0xFFFFFFFE;
+  r[2] = (int)0xFFFF0000;
   r[3] = 0x00020000;
   return r;
 }

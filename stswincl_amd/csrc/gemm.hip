@@ -1251,8 +1251,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(GemmTN p) {
 // row's MFMAs cover the other row's LDS reads.  Gather maps are read with scalar loads one stage ahead.
 // One workgroup per CU: the launcher picks splits so that tiles x splits ~ 256.
 // =====================================================================================================
-template <bool MAPS>
+// MODE: 0 no gather maps, 1 at_rows only, 2 bt_rows only, 3 bt_rows with per-tap maps (bseg).  The launcher sends everything
+// else (both maps, Mk not a multiple of 32 with maps) to the 128x128 kernel: with the map handling resolved at compile time a
+// stage costs one or two scalar index loads, a dozen scalar multiplies / selects and 2 VALU per copy; written with runtime
+// tests it was 18 scalar branches and ~150 SALU instructions per stage, longer than the partner row's MFMA phase.
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
+  constexpr bool MAPS = MODE != 0, MAP_A = MODE == 1, MAP_B = MODE >= 2, TAPS = MODE == 3;
   using T = bf16;
   constexpr int BMK = 32, ROWB = 512, NST = 4, OP_BYTES = BMK * ROWB, STAGE = 2 * OP_BYTES, PER_STAGE = 4;
   constexpr int FI = 8, FJ = 4;
@@ -1266,7 +1271,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
   const int per = (nst_all + p.splits - 1) / p.splits;
   const int s_begin = split_id * per, s_end = min(nst_all, s_begin + per);
   const int nt = max(0, s_end - s_begin);
-  const bool dbg_ts = p.ldc < 0;                       // DBG (tools/gemm_timeline.py tn): C is a u64 [workgroups][8] timestamp buffer
+  const bool dbg_ts = p.ldc == -1;                       // DBG (tools/gemm_timeline.py tn): C is a u64 [workgroups][8] timestamp buffer
   auto stamp = [&](int slot) {
     if (dbg_ts && threadIdx.x == 0) ((unsigned long long*)p.C)[(long)blockIdx.x * 8 + slot] = wall_clock64();
   };
@@ -1279,11 +1284,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
   const buf_rsrc_t rsA = make_buf_rsrc(p.At), rsB = make_buf_rsrc(p.Bt);
   const unsigned pitchA = (unsigned)(p.lda * sizeof(T)), pitchB = (unsigned)(p.ldb * sizeof(T));
   const int limA = (int)(0xFFFF0000u / pitchA), limB = (int)(0xFFFF0000u / pitchB);   // rows a 32-bit offset can reach
-  if (!MAPS && (p.Mk > limA || p.Mk > limB)) __builtin_trap();
+  if ((!MAP_A && p.Mk > limA) || (!MAP_B && p.Mk > limB)) __builtin_trap();
+  const bool ragged_cols = (p.Ni & 255) != 0 || (p.Nj & 255) != 0;
   unsigned offA[2], offB[2];                        // byte offset of this lane's chunk inside its source row, or 0xFFFFFFFF
   bool tap1[2];
-  const int tapA0 = (MAPS && p.bseg > 0) ? j0 / p.bseg : 0;
-  const int tapA1 = (MAPS && p.bseg > 0) ? min(tapA0 + 1, p.Nj / p.bseg - 1) : 0;
+  const int tapA0 = TAPS ? j0 / p.bseg : 0;
+  const int tapA1 = TAPS ? min(tapA0 + 1, p.Nj / p.bseg - 1) : 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = (w * 2 + i) * 2 + rsub;
@@ -1292,83 +1298,69 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
     offA[i] = ci < p.Ni ? (unsigned)(ci * sizeof(T)) : 0xFFFFFFFFu;
     int sc = cj;
     tap1[i] = false;
-    if (MAPS && p.bseg > 0) { sc = cj % p.bseg; tap1[i] = (cj / p.bseg) != tapA0; }
+    if (TAPS) { sc = cj % p.bseg; tap1[i] = (cj / p.bseg) != tapA0; }
     offB[i] = cj < p.Nj ? (unsigned)(sc * sizeof(T)) : 0xFFFFFFFFu;
-    if (!MAPS) {                                    // plain: fold the lane's row-in-stage into the offset once
-      if (offA[i] != 0xFFFFFFFFu) offA[i] += (unsigned)r * pitchA;
-      if (offB[i] != 0xFFFFFFFFu) offB[i] += (unsigned)r * pitchB;
-    }
+    // an operand without a map: the lane's row-in-stage is folded into the offset once, the stage's first row is the
+    // copy's scalar offset
+    if (!MAP_A && offA[i] != 0xFFFFFFFFu) offA[i] += (unsigned)r * pitchA;
+    if (!MAP_B && offB[i] != 0xFFFFFFFFu) offB[i] += (unsigned)r * pitchB;
   }
   typedef int int4v __attribute__((ext_vector_type(4)));
   typedef const __attribute__((address_space(4))) int4v* cint4;
-  const bool vec_maps = (p.Mk & 3) == 0;
-  int ia[4], ib0[4], ib1[4];                        // SGPRs: source rows of stage rows 4w..4w+3 of the next stage to issue
-  auto load_idx = [&](int q) {
-    const int mb = (s_begin + q) * BMK + w * 4;     // wave-uniform
-    if (!MAPS) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { ia[r] = mb + r < p.Mk ? mb + r : -1; ib0[r] = ia[r]; ib1[r] = -1; }
-      return;
-    }
-    if (vec_maps && mb + 4 <= p.Mk) {
-      int4v ta = {mb, mb + 1, mb + 2, mb + 3}, t0 = ta, t1 = {-1, -1, -1, -1};
-      if (p.at_rows) ta = *(cint4)(p.at_rows + mb);
-      if (p.bseg > 0) {
-        t0 = *(cint4)(p.bt_rows + (long)tapA0 * p.Mk + mb);
-        t1 = *(cint4)(p.bt_rows + (long)tapA1 * p.Mk + mb);
-      } else if (p.bt_rows) {
-        t0 = *(cint4)(p.bt_rows + mb);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { ia[r] = ta[r]; ib0[r] = t0[r]; ib1[r] = t1[r]; }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = mb + r, mc = min(m, p.Mk - 1);
-        ia[r] = p.at_rows ? sload(p.at_rows, mc) : mc;
-        ib1[r] = -1;
-        if (p.bseg > 0) {
-          ib0[r] = sload(p.bt_rows, (long)tapA0 * p.Mk + mc);
-          ib1[r] = sload(p.bt_rows, (long)tapA1 * p.Mk + mc);
-        } else {
-          ib0[r] = p.bt_rows ? sload(p.bt_rows, mc) : mc;
-        }
-        if (m >= p.Mk) { ia[r] = -1; ib0[r] = -1; ib1[r] = -1; }
-      }
+  // Gather indices live in SGPR sets (source rows of the wave's stage rows 4w..4w+3; second set = second tap).  A scalar
+  // load from the map takes longer than one loop iteration to come back (measured: +0.45 us per stage when the set is
+  // requested one iteration ahead) and SMEM returns out of order, so any wait is a wait for ALL requests: the steady loop
+  // below runs two iterations per trip and requests the NEXT trip's pair of sets at its top, i.e. two / three iterations
+  // before their use and with no other scalar request in between.
+  struct IdxSet { int4v x0, x1; };
+  IdxSet SA0, SA1, SB0, SB1;
+  int ixmax = 0;                                    // largest index seen: range-checked once, after the loop
+  auto load_idx = [&](IdxSet& d, int q) {            // (maps: Mk % 32 == 0, so every stage is whole and 16-byte aligned)
+    d.x0 = (int4v){0, 0, 0, 0}; d.x1 = (int4v){-1, -1, -1, -1};
+    if constexpr (MAPS) {
+      if (q >= nt) return;
+      const int mb = (s_begin + q) * BMK + w * 4;   // wave-uniform
+      const int* map = MAP_A ? p.at_rows : p.bt_rows;
+      d.x0 = *(cint4)(map + (TAPS ? (long)tapA0 * p.Mk : 0L) + mb);
+      if constexpr (TAPS) d.x1 = *(cint4)(map + (long)tapA1 * p.Mk + mb);
     }
   };
-  auto issue = [&](int q) {                          // stage q of this split -> ring slot q & 3; consumes ia/ib*
+  auto issue = [&](int q, const IdxSet& ix) {        // stage q of this split -> ring slot q & 3
+    const int4v ix0 = ix.x0, ix1 = ix.x1;
     char* Ab = smem + (q & 3) * STAGE;
     char* Bb = Ab + OP_BYTES;
-    if (!MAPS) {
-      const int mb = (s_begin + q) * BMK;            // first contraction row of the stage (wave-uniform)
-      if (mb + BMK <= p.Mk) {                         // whole stage in range: the row is the scalar offset
+    const int mb = (s_begin + q) * BMK;              // first contraction row of the stage (wave-uniform)
+    const bool whole = mb + BMK <= p.Mk;             // (always true with maps)
+    unsigned s0[4], s1[4];
+    if constexpr (MAPS) {
+      const unsigned pitch = MAP_A ? pitchA : pitchB;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          glds16_buf_raw(rsA, offA[i], (unsigned)mb * pitchA, Ab + (w * 2 + i) * 1024);
-          glds16_buf_raw(rsB, offB[i], (unsigned)mb * pitchB, Bb + (w * 2 + i) * 1024);
-        }
-      } else {                                        // ragged last stage: rows >= Mk read zeros
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const bool in = mb + (w * 2 + i) * 2 + rsub < p.Mk;
-          glds16_buf_raw(rsA, in ? offA[i] : 0xFFFFFFFFu, (unsigned)mb * pitchA, Ab + (w * 2 + i) * 1024);
-          glds16_buf_raw(rsB, in ? offB[i] : 0xFFFFFFFFu, (unsigned)mb * pitchB, Bb + (w * 2 + i) * 1024);
-        }
+      for (int r = 0; r < 4; ++r) {
+        ixmax = max(ixmax, max(ix0[r], ix1[r]));
+        s0[r] = ix0[r] >= 0 ? (unsigned)ix0[r] * pitch : 0xFFFF0000u;         // -1 (padding) -> out of range -> zeros
+        s1[r] = ix1[r] >= 0 ? (unsigned)ix1[r] * pitch : 0xFFFF0000u;
       }
-      return;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int ra = rsub ? ia[2 * i + 1] : ia[2 * i];
-      const int rb0 = rsub ? ib0[2 * i + 1] : ib0[2 * i];
-      const int rb1 = rsub ? ib1[2 * i + 1] : ib1[2 * i];
-      const int rb = tap1[i] ? rb1 : rb0;
-      if (ra > limA || rb > limB) __builtin_trap();   // operand beyond the 4 GB a 32-bit offset reaches
-      const unsigned va = (ra >= 0 && offA[i] != 0xFFFFFFFFu) ? (unsigned)ra * pitchA + offA[i] : 0xFFFFFFFFu;
-      const unsigned vb = (rb >= 0 && offB[i] != 0xFFFFFFFFu) ? (unsigned)rb * pitchB + offB[i] : 0xFFFFFFFFu;
-      glds16_buf_raw(rsA, va, 0u, Ab + (w * 2 + i) * 1024);
-      glds16_buf_raw(rsB, vb, 0u, Bb + (w * 2 + i) * 1024);
+      unsigned va = offA[i], vb = offB[i], sa = (unsigned)mb * pitchA, sb = (unsigned)mb * pitchB;
+      if constexpr (MAP_A) { va = (rsub ? s0[2 * i + 1] : s0[2 * i]) + offA[i]; sa = 0u; }
+      if constexpr (MAP_B) {
+        const unsigned v0 = rsub ? s0[2 * i + 1] : s0[2 * i];
+        if constexpr (TAPS) { const unsigned v1 = rsub ? s1[2 * i + 1] : s1[2 * i]; vb = (tap1[i] ? v1 : v0) + offB[i]; }
+        else vb = v0 + offB[i];
+        sb = 0u;
+      }
+      if (ragged_cols) {                              // lanes whose column does not exist (uniform test, rare)
+        if (offA[i] == 0xFFFFFFFFu) va = 0xFFFFFFFFu;
+        if (offB[i] == 0xFFFFFFFFu) vb = 0xFFFFFFFFu;
+      }
+      if (!whole) {                                   // ragged last stage (no maps): rows >= Mk read zeros
+        const bool in = mb + (w * 2 + i) * 2 + rsub < p.Mk;
+        if (!in) { va = 0xFFFFFFFFu; vb = 0xFFFFFFFFu; }
+      }
+      glds16_buf_raw(rsA, va, sa, Ab + (w * 2 + i) * 1024);
+      glds16_buf_raw(rsB, vb, sb, Bb + (w * 2 + i) * 1024);
     }
   };
 
@@ -1403,19 +1395,36 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
     else wait_vmcnt<0>();
   };
   if (nt > 0) {
-    load_idx(0);
-    for (int q = 0; q < NST - 1 && q < nt; ++q) { issue(q); load_idx(q + 1); }
+    for (int q = 0; q < NST - 1 && q < nt; ++q) { load_idx(SA0, q); issue(q, SA0); }   // prologue: blocking index loads
+    load_idx(SA0, NST - 1);                            // sets for iterations 0 and 1 of the steady loop
+    load_idx(SA1, NST);
     stamp(1);
     wait_tile(0);
     stamp(2);
     if (lag) __builtin_amdgcn_s_barrier();
     // steady state without data-dependent branches (see gemm_nt_ring_kernel): both rows wait for their share of stage
     // kt+1 right behind their fragment reads, with the constant "two younger stages" count
-    int kt = 0;
-    for (; kt + NST - 1 < nt; ++kt) {
+    auto body = [&](int kt, const IdxSet& cur, IdxSet* n0, IdxSet* n1) {
       __builtin_amdgcn_s_barrier();
-      issue(kt + NST - 1);
-      load_idx(kt + NST);
+      if (n0) { load_idx(*n0, kt + 2 + NST - 1); load_idx(*n1, kt + 3 + NST - 1); }   // for the iterations kt+2 and kt+3
+      issue(kt + NST - 1, cur);
+      read_frags(kt);
+      wait_vmcnt<2 * PER_STAGE>();
+      __builtin_amdgcn_s_barrier();
+      mma_all();
+    };
+    int kt = 0;
+    for (; kt + 2 + NST - 1 <= nt; kt += 2) {          // 2 iterations per trip; the pair requested here is used in the next trip
+      body(kt, SA0, &SB0, &SB1);
+      body(kt + 1, SA1, nullptr, nullptr);
+      SA0 = SB0; SA1 = SB1;                           // (requested two iterations ago: landed)
+    }
+    // remainder (< 2 requesting iterations): SA0 / SA1 hold the sets of kt and kt+1
+    for (int r = 0; kt + NST - 1 < nt; ++kt, ++r) {
+      __builtin_amdgcn_s_barrier();
+      if (r == 0) issue(kt + NST - 1, SA0);
+      else if (r == 1) issue(kt + NST - 1, SA1);
+      else { load_idx(SB0, kt + NST - 1); issue(kt + NST - 1, SB0); }
       read_frags(kt);
       wait_vmcnt<2 * PER_STAGE>();
       __builtin_amdgcn_s_barrier();
@@ -1430,8 +1439,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
     }
     if (!lag) __builtin_amdgcn_s_barrier();
   }
+  if (MAPS && ixmax > (MAP_A ? limA : limB)) __builtin_trap();   // gathered operand beyond the 4 GB a 32-bit offset reaches
   stamp(3);
-  if (dbg_ts) return;
+  if (p.ldc < 0) return;                               // debug / timing runs: no result
 #pragma unroll
   for (int i = 0; i < FI; ++i)
 #pragma unroll
@@ -1596,6 +1606,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   const bool no_ring = splits > 0 && (splits & (1 << 28));
   if (splits > 0) splits &= ~((1 << 29) | (1 << 28));
   bool ring = dtype == 0 && !splits_flags_w4 && !no_ring && (force_ring || (splits <= 0 && Ni >= 256 && Nj >= 256));
+  if (ring && (at_rows || bt_rows) && ((at_rows && bt_rows) || Mk % 32 != 0)) ring = false;   // map modes of the ring kernel
   if (ring && bseg > 0)
     for (int j0 = 0; j0 < Nj; j0 += 256)
       if ((j0 + 255 < Nj ? j0 + 255 : Nj - 1) / bseg - j0 / bseg > 1) ring = false;
@@ -1616,12 +1627,16 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
       const bool slabs = workspace && rs > 1 && (long)rs * Ni * Nj <= workspace_floats;
       if (overwrite && !slabs) (void)hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)Nj * sizeof(float), (size_t)Ni, (hipStream_t)stream);
       GemmTN q{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, rs, bseg, slabs ? workspace : nullptr};
-      static int once_r = (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
-                          (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      static int once_r = (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
+                          (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
+                          (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
+                          (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       (void)once_r;
       const dim3 grid((unsigned)(t256 * rs));
-      if (at_rows || bt_rows) hipLaunchKernelGGL(gemm_tn_ring_kernel<true>, grid, dim3(512), 131072, (hipStream_t)stream, q);
-      else hipLaunchKernelGGL(gemm_tn_ring_kernel<false>, grid, dim3(512), 131072, (hipStream_t)stream, q);
+      if (at_rows) hipLaunchKernelGGL(gemm_tn_ring_kernel<1>, grid, dim3(512), 131072, (hipStream_t)stream, q);
+      else if (bt_rows && bseg > 0) hipLaunchKernelGGL(gemm_tn_ring_kernel<3>, grid, dim3(512), 131072, (hipStream_t)stream, q);
+      else if (bt_rows) hipLaunchKernelGGL(gemm_tn_ring_kernel<2>, grid, dim3(512), 131072, (hipStream_t)stream, q);
+      else hipLaunchKernelGGL(gemm_tn_ring_kernel<0>, grid, dim3(512), 131072, (hipStream_t)stream, q);
       if (slabs) {
         const long n4 = ((long)Ni * Nj + 3) / 4;
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, C, ldc,

@@ -265,7 +265,7 @@ def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: in
         name += f" Mk={Mk} Ni={Ni} Nj={Nj} bseg={bseg} a={int(at_rows is not None)} b={int(bt_rows is not None)}"
     with _Span(name, 2.0 * Mk * Ni * Nj):
         rc = load().stswin_gemm_tn(_dt(At), _p(At), _c_long(_ld(At)), _p(at_rows), _p(Bt), _c_long(_ld(Bt)),
-                                   _p(bt_rows), _p(out_f32), _c_long(-1 if debug_ts else _ld(out_f32)), Mk, Ni, Nj, splits, bseg, _p(ws),
+                                   _p(bt_rows), _p(out_f32), _c_long((-1 if debug_ts is True else -int(debug_ts)) if debug_ts else _ld(out_f32)), Mk, Ni, Nj, splits, bseg, _p(ws),
                                    _c_long(ws.numel() if ws is not None else 0), _stream())
     _check(rc, "gemm_tn")
     return out_f32
