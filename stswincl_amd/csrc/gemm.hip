@@ -804,7 +804,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_stream_kernel(GemmNT p) {
   constexpr int BM = 256, BN = 256, BK = 32, ROWB = 64, NST = 4;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
   constexpr int TM = 128, TN = 64, FI = 8, FJ = 4, NIA = 2, NIB = 2, PER_STAGE = NIA + NIB;
-  constexpr int IMG = NST * STAGE;                   // byte offset of the epilogue image region (8 waves x 8 KB used 4 at a time)
+  constexpr int IMG = NST * STAGE;                   // byte offset of the epilogue image region (4 x 8 KB, one wave row at a time)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, l = tid & 63, w = wave_id();
   const int wr = w >> 2, wc = w & 3;
@@ -813,28 +813,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_stream_kernel(GemmNT p) {
   const int nk = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1)
   const int TS = nk * nt;                            // stages of this workgroup's stream
 
-  const char* zero = (const char*)g_stswin_zero;
-  const char* abase[NIA]; int astep[NIA];
-  const char* bbase[NIB]; int bstep[NIB];
+  // buffer-addressed copies (see gemm_nt_ring_kernel): per lane and copy one 32-bit offset, rebuilt at every tile switch
+  // of the ISSUE cursor (which runs NST-1 stages ahead of the multiplying cursor)
+  unsigned aoff[NIA], boff[NIB];
   auto set_issue_tile = [&](int k) {
     const int t = xcd_remap((int)blockIdx.x + k * (int)gridDim.x, ntiles);
     const int mi = (t / tiles_n) * BM, ni = (t % tiles_n) * BN;
-    // lane constants are re-derived here (opaque to the optimiser): hoisted out of the stream loop they were spilled to
-    // scratch, and a scratch reload is a vmcnt(0) - i.e. a drained LDS-DMA pipeline - once per tile
-    int lane = l;
+    int lane = l;                                    // lane constants re-derived here (opaque): kept live they get spilled
     asm volatile("" : "+v"(lane));
     const int rsub = lane >> 2, cphys = lane & 3, csrc = cphys ^ swz64(rsub);
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
       const int gn = ni + (w * NIB + i) * 16 + rsub;
-      if (gn < p.N) { bbase[i] = (const char*)p.B + ((long)gn * p.ldb) * sizeof(T) + csrc * 16; bstep[i] = BK * sizeof(T); }
-      else { bbase[i] = zero + cphys * 16; bstep[i] = 0; }
+      boff[i] = gn < p.N ? (unsigned)gn * (unsigned)(p.ldb * sizeof(T)) + csrc * 16 : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
       const int gm = mi + (w * NIA + i) * 16 + rsub;
-      if (gm < p.M) { abase[i] = (const char*)p.A + ((long)gm * p.lda) * sizeof(T) + csrc * 16; astep[i] = BK * sizeof(T); }
-      else { abase[i] = zero + cphys * 16; astep[i] = 0; }
+      aoff[i] = gm < p.M ? (unsigned)gm * (unsigned)(p.lda * sizeof(T)) + csrc * 16 : 0xFFFFFFFFu;
     }
   };
   int ik = 0, is = 0;                                // issue cursor: tile number of this workgroup, stage within it
@@ -843,9 +839,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_stream_kernel(GemmNT p) {
     char* Ab = smem + (g & (NST - 1)) * STAGE;
     char* Bb = Ab + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < NIA; ++i) glds16_raw(abase[i] + (long)is * astep[i], Ab + (w * NIA + i) * 1024);
+    for (int i = 0; i < NIA; ++i) glds16_buf(p.A, aoff[i], is * (BK * (int)sizeof(T)), Ab + (w * NIA + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < NIB; ++i) glds16_raw(bbase[i] + (long)is * bstep[i], Bb + (w * NIB + i) * 1024);
+    for (int i = 0; i < NIB; ++i) glds16_buf(p.B, boff[i], is * (BK * (int)sizeof(T)), Bb + (w * NIB + i) * 1024);
     if (++is == nt) {
       is = 0;
       if (++ik < nk) set_issue_tile(ik);
@@ -860,11 +856,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_stream_kernel(GemmNT p) {
       for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
   zero_acc();
-  const int fr = l & 15, fq = l >> 4;
-  const int rd_off = fr * ROWB + ((fq ^ swz64(fr)) << 4);
   const bool lag = (wr == 1);                        // wave-uniform
   bf16x8 a[FI], b[FJ];
   auto read_frags = [&](int g) {
+    const int fr = l & 15, fq = l >> 4;
+    const int rd_off = fr * ROWB + ((fq ^ swz64(fr)) << 4);
     const char* Ab = smem + (g & (NST - 1)) * STAGE;
     const char* Bb = Ab + A_BYTES;
 #pragma unroll
@@ -880,50 +876,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_stream_kernel(GemmNT p) {
       for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
-  int skip = 0;                                      // counted waits to skip (stages verified by the epilogue's vmcnt(0))
-  auto wait_stage = [&](int g1) {                    // stage g1 of the stream has landed (this wave's share)
-    if (g1 >= TS) return;
-    if (skip > 0) { --skip; return; }
-    const int newer = min(NST - 2, TS - 1 - g1);
-    if (newer >= 2) wait_vmcnt<2 * PER_STAGE>();
-    else if (newer == 1) wait_vmcnt<PER_STAGE>();
-    else wait_vmcnt<0>();
-  };
 
   // ---------------- per-tile register epilogue of this wave (its 128 x 64 sub-tile), wave-private LDS image ----------------
-  auto epilogue = [&](int k) {
-    const int t = xcd_remap((int)blockIdx.x + k * (int)gridDim.x, ntiles);
-    const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
-    if (p.flags & (1 << 21)) {        // DBG: no epilogue at all (keeps the accumulators alive)
-      float tt = 0.f;
-#pragma unroll
-      for (int i = 0; i < FI; ++i)
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) tt += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-      if (tt == 123.456f) ((T*)p.C)[tid] = from_f32<T>(tt);
-      zero_acc();
-      return;
-    }
-    wait_vmcnt<0>();                                 // every stage copy of this wave has landed; epilogue memory ops may follow
-    skip = 2;
+  enum { E_BIAS = 1, E_SCALE = 2, E_GELU = 4, E_C2 = 8, E_RESID = 16, E_DGELU = 32, E_COLSUM = 64, E_RELU = 128, E_MULR = 256, E_C2D = 512 };
+  auto epilogue_body = [&](auto tag, int m0, int n0) {
+    constexpr int MD = decltype(tag)::value;
+#define EPI_HAS(bit, rt) (MD >= 0 ? ((MD & (bit)) != 0) : (rt))
+    const bool has_bias = EPI_HAS(E_BIAS, p.bias != nullptr), has_scale = EPI_HAS(E_SCALE, p.scale_cols > 0);
+    const bool do_gelu = EPI_HAS(E_GELU, (p.flags & GF_GELU) != 0), has_c2 = EPI_HAS(E_C2, p.C2 != nullptr);
+    const bool do_resid = EPI_HAS(E_RESID, (p.flags & GF_RESID) != 0), do_dgelu = EPI_HAS(E_DGELU, (p.flags & GF_MUL_DGELU) != 0);
+    const bool do_cs = EPI_HAS(E_COLSUM, p.colsum != nullptr), do_relu = EPI_HAS(E_RELU, (p.flags & GF_RELU) != 0);
+    const bool do_mulr = EPI_HAS(E_MULR, (p.flags & GF_MUL_R) != 0), c2_dgelu = EPI_HAS(E_C2D, (p.flags & GF_C2_DGELU) != 0);
+    const bool has_r = do_resid || do_dgelu || do_mulr;
     int lane = l;                                    // epilogue lane constants: derived here, not kept live (and spilled)
     asm volatile("" : "+v"(lane));                   // across the stream loop
     const int fr = lane & 15, fq = lane >> 4;
     char* img = smem + IMG + wc * 8192;              // [64 rows][128 B], 16-byte chunk ^= row & 7
     const int colb = n0 + wc * TN + 4 * fq;          // + j*16: first of this lane's 4 columns
     f32x4 bj[FJ];
+    if (has_bias) {
 #pragma unroll
-    for (int j = 0; j < FJ; ++j) {
-      const int gn = colb + j * 16;
-      bj[j] = p.bias ? *(const f32x4*)(p.bias + (gn < p.N ? gn : 0)) : (f32x4){0.f, 0.f, 0.f, 0.f};   // (columns >= N are never stored)
+      for (int j = 0; j < FJ; ++j) bj[j] = *(const f32x4*)(p.bias + min(colb + j * 16, p.N - 4));   // columns >= N are never stored
     }
-    const bool has_r = (p.flags & (GF_RESID | GF_MUL_DGELU)) != 0;
-    const bool has_scale = p.scale_cols > 0;
     auto pre_act = [&](int i, int j) -> f32x4 {
       f32x4 v = acc[i][j];
-      if (p.bias) { NO_IFCVT; v += bj[j]; }
+      if (has_bias) v += bj[j];
       if (has_scale) {
-        NO_IFCVT;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (colb + j * 16 + e < p.scale_cols) v[e] *= p.scale;
@@ -939,26 +917,44 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_stream_kernel(GemmNT p) {
     const int rb_row = lane >> 3, rb_chunk = lane & 7;
     const bool rb_col_ok = n0 + wc * TN + rb_chunk * 8 < p.N;
     auto readback = [&](int h2, void* Cout, long ldo) { // rows of half h2: m0 + wr*128 + h2*64 + 0..63
-      // all 8 scatter indices first (unpredicated: a predicated load stays "pending" for hipcc across the loop back edge
-      // and costs a vmcnt(0) in the main loop), so that the stores below are not interleaved with index-load waits
       int orow32[8];
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) {
         const int gm = m0 + wr * TM + h2 * 64 + ps * 8 + rb_row;
-        orow32[ps] = p.c_rows ? p.c_rows[min(gm, p.M - 1)] : gm;
-      }
+        orow32[ps] = p.c_rows ? p.c_rows[min(gm, p.M - 1)] : gm;      // unpredicated on purpose (a predicated load stays
+      }                                                               // "pending" for hipcc across the loop back edge)
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) {
         const int row = ps * 8 + rb_row;
         const int gm = m0 + wr * TM + h2 * 64 + row;
         if (gm < p.M && rb_col_ok) {
           const bf16x8 val = *(const bf16x8*)(img + row * 128 + ((rb_chunk ^ (row & 7)) << 4));
-          if (p.flags & (1 << 20)) { if ((float)val[0] == 123.456f) *(bf16x8*)((T*)Cout + (long)orow32[ps] * ldo + n0 + wc * TN + rb_chunk * 8) = val; }
-          else
           *(bf16x8*)((T*)Cout + (long)orow32[ps] * ldo + n0 + wc * TN + rb_chunk * 8) = val;
         }
       }
     };
+    if (has_c2) {                                     // second output: pre-activation, or gelu'(pre) for the backward multiply
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+        for (int ih = 0; ih < 4; ++ih)
+#pragma unroll
+          for (int j = 0; j < FJ; ++j) {
+            f32x4 v = pre_act(h2 * 4 + ih, j);
+            if (c2_dgelu) {
+              const f32x2 lo = dgelu_fast2((f32x2){v[0], v[1]}), hi = dgelu_fast2((f32x2){v[2], v[3]});
+              v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
+            }
+            put(ih, j, v);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        readback(h2, p.C2, p.ldc2);
+      }
+      if (has_bias) {                                 // launder: keep hipcc from holding 128 bias-added values for the pass below
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) asm volatile("" : "+v"(bj[j]));
+      }
+    }
     f32x4 cs[FJ];
 #pragma unroll
     for (int j = 0; j < FJ; ++j) cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -967,21 +963,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_stream_kernel(GemmNT p) {
       const int gm = min(m0 + wr * TM + i * 16 + fr, p.M - 1);      // rows >= M / columns >= N: clamped, never stored
       const long rrow = p.r_rows ? (long)p.r_rows[gm] : (long)gm;
 #pragma unroll
-      for (int j = 0; j < FJ; ++j) {
-        const int gn = colb + j * 16;
-        dst[j] = *(const bf16x4*)((const T*)p.R + rrow * p.ldr + (gn < p.N ? gn : 0));
-      }
+      for (int j = 0; j < FJ; ++j) dst[j] = *(const bf16x4*)((const T*)p.R + rrow * p.ldr + min(colb + j * 16, p.N - 4));
     };
-    if (p.C2) {                                       // pre-activation copy (fc1 forward keeps it for GELU')
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-        for (int ih = 0; ih < 4; ++ih)
-#pragma unroll
-          for (int j = 0; j < FJ; ++j) put(ih, j, pre_act(h2 * 4 + ih, j));
-        readback(h2, p.C2, p.ldc2);
-      }
-    }
     if (has_r) load_r(0, rcur);
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
@@ -993,30 +976,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_stream_kernel(GemmNT p) {
 #pragma unroll
         for (int j = 0; j < FJ; ++j) {
           f32x4 v = pre_act(i, j);
-          if (p.flags & GF_GELU) {
+          if (do_gelu) {
             const f32x2 lo = gelu_fast2((f32x2){v[0], v[1]}), hi = gelu_fast2((f32x2){v[2], v[3]});
             v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
           }
           if (has_r) {
             const f32x4 r = {(float)rcur[j][0], (float)rcur[j][1], (float)rcur[j][2], (float)rcur[j][3]};
-            if (p.flags & GF_RESID) v += r;
+            if (do_resid) v += r;
+            else if (do_mulr) v *= r;
             else {
               const f32x2 lo = dgelu_fast2((f32x2){r[0], r[1]}), hi = dgelu_fast2((f32x2){r[2], r[3]});
               v *= (f32x4){lo[0], lo[1], hi[0], hi[1]};
             }
           }
-          if (p.flags & GF_RELU) { NO_IFCVT; v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f}); }
-          if (p.colsum) { NO_IFCVT; if (row_ok) cs[j] += v; }
+          if (do_relu) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
+          if (do_cs) { if (row_ok) cs[j] += v; }
           put(ih, j, v);
+          if (do_gelu || do_dgelu) __builtin_amdgcn_sched_barrier(0);
         }
         if (has_r && i + 1 < FI) {
 #pragma unroll
           for (int j = 0; j < FJ; ++j) rcur[j] = rnext[j];
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       readback(h2, p.C, p.ldc);
     }
-    if (p.colsum) {                                   // fold the 16 rows (fr) of each lane group, then one atomic per column
+    if (do_cs) {                                      // fold the 16 rows (fr) of each lane group, then one atomic per column
 #pragma unroll
       for (int j = 0; j < FJ; ++j)
 #pragma unroll
@@ -1027,27 +1013,72 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_stream_kernel(GemmNT p) {
           if (fr == 0 && gn < p.N) atomicAdd(p.colsum + gn, tsum);
         }
     }
+#undef EPI_HAS
+  };
+  const int epi_mode = (p.bias ? E_BIAS : 0) | (p.scale_cols > 0 ? E_SCALE : 0) | ((p.flags & GF_GELU) ? E_GELU : 0) |
+                       (p.C2 ? E_C2 : 0) | ((p.flags & GF_RESID) ? E_RESID : 0) | ((p.flags & GF_MUL_DGELU) ? E_DGELU : 0) |
+                       (p.colsum ? E_COLSUM : 0) | ((p.flags & GF_RELU) ? E_RELU : 0) | ((p.flags & GF_MUL_R) ? E_MULR : 0) |
+                       ((p.flags & GF_C2_DGELU) ? E_C2D : 0);
+  int skip = 0;                                      // counted waits to skip (stages verified by the epilogue's vmcnt(0))
+  auto epilogue = [&](int k) {
+    const int t = xcd_remap((int)blockIdx.x + k * (int)gridDim.x, ntiles);
+    const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+    wait_vmcnt<0>();                                 // every stage copy of this wave has landed; epilogue memory ops may follow
+    skip = 2;
+    switch (epi_mode) {
+      case 0: epilogue_body(std::integral_constant<int, 0>{}, m0, n0); break;
+      case E_BIAS: epilogue_body(std::integral_constant<int, E_BIAS>{}, m0, n0); break;
+      case E_BIAS | E_GELU | E_C2 | E_C2D: epilogue_body(std::integral_constant<int, E_BIAS | E_GELU | E_C2 | E_C2D>{}, m0, n0); break;
+      case E_BIAS | E_RESID: epilogue_body(std::integral_constant<int, E_BIAS | E_RESID>{}, m0, n0); break;
+      case E_RESID: epilogue_body(std::integral_constant<int, E_RESID>{}, m0, n0); break;
+      case E_MULR | E_COLSUM: epilogue_body(std::integral_constant<int, E_MULR | E_COLSUM>{}, m0, n0); break;
+      default: epilogue_body(std::integral_constant<int, -1>{}, m0, n0); break;
+    }
     zero_acc();
   };
 
   // ---------------- the stream ----------------
+  auto wait_stage = [&](int g1) {                    // stage g1 of the stream has landed (this wave's share)
+    if (g1 >= TS) return;
+    if (skip > 0) { --skip; return; }
+    const int newer = min(NST - 2, TS - 1 - g1);
+    if (newer >= 2) wait_vmcnt<2 * PER_STAGE>();
+    else if (newer == 1) wait_vmcnt<PER_STAGE>();
+    else wait_vmcnt<0>();
+  };
   for (int q = 0; q < NST - 1 && q < TS; ++q) issue_next(q);
   wait_stage(0);
   if (lag) __builtin_amdgcn_s_barrier();
-  int ck = 0, cs_ = 0;                                // compute cursor: tile number, stage within it
-  for (int g = 0; g < TS; ++g) {
-    __builtin_amdgcn_s_barrier();
-    if (g + NST - 1 < TS) issue_next(g + NST - 1);
-    read_frags(g);
-    if (lag) wait_stage(g + 1);
-    __builtin_amdgcn_s_barrier();
-    mma_all();
-    if (!lag) wait_stage(g + 1);
-    if (++cs_ == nt) {                               // this wave's accumulators hold a finished tile
-      cs_ = 0;
-      epilogue(ck);
-      ++ck;
+  int g = 0;
+  for (int ck = 0; ck < nk; ++ck) {                  // one tile of this workgroup per trip
+    const int gend = g + nt;
+    // stages 0 and 1 of a tile: the waits may be the "known landed" ones after an epilogue
+    for (int r = 0; r < 2 && g < gend; ++r, ++g) {
+      __builtin_amdgcn_s_barrier();
+      if (g + NST - 1 < TS) issue_next(g + NST - 1);
+      read_frags(g);
+      wait_stage(g + 1);
+      __builtin_amdgcn_s_barrier();
+      mma_all();
     }
+    // branch-free steady state of the tile (every iteration requests a stage, constant wait count)
+    const int gsteady = min(gend, TS - (NST - 1));
+    for (; g < gsteady; ++g) {
+      __builtin_amdgcn_s_barrier();
+      issue_next(g + NST - 1);
+      read_frags(g);
+      wait_vmcnt<2 * PER_STAGE>();
+      __builtin_amdgcn_s_barrier();
+      mma_all();
+    }
+    for (; g < gend; ++g) {                           // the stream's last stages (nothing left to request)
+      __builtin_amdgcn_s_barrier();
+      read_frags(g);
+      wait_stage(g + 1);
+      __builtin_amdgcn_s_barrier();
+      mma_all();
+    }
+    epilogue(ck);
   }
   if (!lag) __builtin_amdgcn_s_barrier();
 }

@@ -86,8 +86,10 @@ def test_gemm_nt_epilogues(dtype):
     _close(out, F.relu(lin), dtype, "relu")
 
 
-def test_gemm_nt_ring_register_epilogues():
-    """256x256 ring kernel (forced): every mode-specialised register epilogue against fp32 torch, ragged M, row maps."""
+@pytest.mark.parametrize("variant", ["ring", "stream"])
+def test_gemm_nt_ring_register_epilogues(variant):
+    """256x256 ring kernel (forced; also its persistent streaming variant): every mode-specialised register epilogue
+    against fp32 torch, ragged M, row maps."""
     torch.manual_seed(11)
     dtype = torch.bfloat16
     m, n, k = 600, 512, 128
@@ -98,7 +100,7 @@ def test_gemm_nt_ring_register_epilogues():
     ac, wc, rc, bc = a.cuda(), w.cuda(), r.cuda(), bias.cuda()
     lin0 = F.linear(a.float(), w.float())
     lin = lin0 + bias
-    BIG = hip.GF_BIG
+    BIG = hip.GF_BIG | (hip.GF_STREAM if variant == "stream" else 0)
     out = torch.empty(m, n, dtype=dtype, device="cuda")
     pre = torch.empty(m, n, dtype=dtype, device="cuda")
     hip.gemm_nt(ac, wc, out, M=m, flags=BIG)
