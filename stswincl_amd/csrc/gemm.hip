@@ -389,6 +389,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   // convolution padding = map entry -1) get offset 0xFFFFFFFF, which the descriptor's range check turns into zeros.
   const int rsub = l >> 2, cphys = l & 3, csrc = cphys ^ swz64(rsub);
   unsigned aoff[NIA], boff[NIB];
+  const long arow_lim = (long)(0xFFFFFF00u / (unsigned)(p.lda * sizeof(T))) - 1;   // rows a 32-bit byte offset can reach
+  bool arow_bad = false;                            // a gathered row beyond that: trap at the end (fail loudly, not wrongly)
 #pragma unroll
   for (int i = 0; i < NIB; ++i) {
     const int gn = n0 + (w * NIB + i) * 16 + rsub;
@@ -400,9 +402,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
       const int gm = m0 + (w * NIA + i) * 16 + rsub;
       long row = -1;
       if (gm < p.M) row = p.a_rows ? (long)p.a_rows[(long)seg * p.M + gm] : (long)gm;
-      const unsigned long off = (unsigned long)row * (unsigned long)(p.lda * sizeof(T)) + csrc * 16;
-      if (row >= 0 && off >= 0xFFFFFFF0ul) __builtin_trap();        // operand beyond the 4 GB a 32-bit offset reaches
-      aoff[i] = row >= 0 ? (unsigned)off : 0xFFFFFFFFu;
+      aoff[i] = (row >= 0 && row <= arow_lim) ? (unsigned)row * (unsigned)(p.lda * sizeof(T)) + csrc * 16 : 0xFFFFFFFFu;
+      arow_bad |= row > arow_lim;
     }
   };
   const int kps = p.Kseg / BK;
@@ -770,15 +771,17 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
         mma_all();
       }
     }
-    for (; kt < nt; ++kt) {
+    for (; kt < nt; ++kt) {                            // general form (tap-segmented A, and the last NST-1 stages)
       __builtin_amdgcn_s_barrier();
       if (kt + NST - 1 < nt) issue(kt + NST - 1);
       read_frags(kt);
-      if (kt + 1 < nt) wait_tile(kt + 1);
+      if (lag && kt + 1 < nt) wait_tile(kt + 1);
       __builtin_amdgcn_s_barrier();
       mma_all();
-    }
+      if (!lag && kt + 1 < nt) wait_tile(kt + 1);       // (the lead row waits after its MFMAs: at a tap switch the fresh
+    }                                                   //  index loads of issue() would otherwise be waited for at once)
     if (!lag) __builtin_amdgcn_s_barrier();
+    if (arow_bad) __builtin_trap();
     if constexpr (SWAP) epilogue_reg();
     else epilogue();
   }
