@@ -30,6 +30,10 @@ extern "C" {
 #define STSWIN_GF_MUL_R 8192     /* v *= R[r_rows[m]][n]  (R = GELU' values saved by STSWIN_GF_C2_DGELU) */
 #define STSWIN_GF_C2_DGELU 16384 /* with GF_GELU: C2 receives gelu'(v) instead of v - the fc1 forward then hands the backward
                                     its multiplier and the backward epilogue is one multiply */
+#define STSWIN_GF_CS_PARTIAL 32768 /* `colsum` is a caller-owned fp32 table [2*ceil(M/256)][N] instead of the fp32 [N] accumulator: row b
+                                    * receives (plain stores, no atomics) the column sums of output rows 128b..128b+127;
+                                    * stswin_cs_reduce then adds the rows into the bias gradient.  M/128 same-address atomics cost
+                                    * 38 us on a 65536 x 512 output; the table + reduce cost ~5 us (N % 4 == 0). */
 #define STSWIN_GF_BIG 128       /* tuning: force the 256x256 4-stage-ring kernel (bf16) */
 #define STSWIN_GF_MID 512       /* tuning: 256x128x32 tile, 3-stage ring, 2 workgroups per CU (bf16) */
 #define STSWIN_GF_NOPIPE 1024   /* tuning: 256x256 ring kernel without software-pipelined LDS fragment reads */
@@ -80,6 +84,8 @@ int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_rows, const 
                    const int* c_rows, void* C2, long ldc2, const float* bias, const void* R, long ldr,
                    const int* r_rows, int M, int N, int Kseg, int S, float scale, int scale_cols, int flags,
                    float* colsum /* optional fp32 [N]: += column sums of the stored values (bias gradient) */, void* stream);
+/* out[n] += sum_b partials[b][n], b < 2*ceil(M/256): second half of a STSWIN_GF_CS_PARTIAL stswin_gemm_nt (same M, N). */
+int stswin_cs_reduce(const float* partials, int M, int N, float* out, void* stream);
 /* weight gradients: C[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]   (fp32 atomics; splits<=0: auto).
  * bseg > 0 (convolution wgrad in one launch): column j of the B operand is column j % bseg of row
  * bt_rows[(j / bseg) * Mk + m], i.e. tap t = j / bseg uses its own row map.
@@ -154,6 +160,13 @@ int stswin_logits_upsample(int dtype, const void* tokens, long ldt, void* nchw, 
  * pixels with loss > sel[0] (>= when sel[2] != 0); sel/gscale live on the device, so no host sync is needed. */
 int stswin_ce_fwd(int dtype, const void* logits, const long* labels, float* loss, float* stats, int frames, long HW, int nc,
                   int ignore_index, float thresh, void* stream);
+/* The selection of losses.py:35-39 without the sort: value[0] = OHEM loss, sel[3] = (cut, 1/count, inclusive) for ce_bwd.
+ * stats = output of ce_fwd; if stats[0] = #(loss > thresh) > n_min the threshold branch is taken, otherwise the mean of the
+ * n_min largest losses is computed by an exact 3-level radix select (counts + sums per bin).  work: caller-owned scratch
+ * of >= STSWIN_OHEM_WORK_BYTES bytes (zeroed by the call). */
+#define STSWIN_OHEM_WORK_BYTES (3 * 2048 * 8 + 48)
+int stswin_ohem_select(const float* loss, long n, long n_min, float thresh, const float* stats, void* work, long work_bytes,
+                       float* value, float* sel, void* stream);
 int stswin_ce_bwd(int dtype, const void* logits, const long* labels, const float* loss, const float* sel,
                   const float* gscale, void* dlogits, int frames, long HW, int nc, int ignore_index, void* stream);
 

@@ -121,6 +121,14 @@ DEVI f32x2 dgelu_fast2(f32x2 x) {
   const f32x2 dens = {__builtin_amdgcn_exp2f(h[0]), __builtin_amdgcn_exp2f(h[1])};
   return __builtin_elementwise_fma(x * 0.39894228040143267794f, dens, phi_poly2(x));
 }
+// gelu and gelu' of the same argument share the polynomial (the fc1 forward epilogue produces both)
+DEVI void gelu_dgelu_fast2(f32x2 x, f32x2& g, f32x2& d) {
+  const f32x2 phi = phi_poly2(x);
+  const f32x2 h = x * x * -0.72134752044448170368f;
+  const f32x2 dens = {__builtin_amdgcn_exp2f(h[0]), __builtin_amdgcn_exp2f(h[1])};
+  g = x * phi;
+  d = __builtin_elementwise_fma(x * 0.39894228040143267794f, dens, phi);
+}
 DEVI float gelu_fast(float x) { return gelu_fast2((f32x2){x, x})[0]; }
 DEVI float dgelu_fast(float x) { return dgelu_fast2((f32x2){x, x})[0]; }
 template <typename T> DEVI float gelu_t(float x) { return TT_is_bf16<T>() ? gelu_fast(x) : gelu_erf(x); }

@@ -37,6 +37,7 @@ enum {
   GF_NONARROW = 1 << 26,  // tuning: forbid the 256x64 tile for N <= 64
   GF_STREAM = 1 << 25,    // tuning: persistent streaming 256x256 variant (measured no faster: both wave rows idle through each other's epilogue)
   GF_DUO = 1 << 24,       // tuning: 128x256 tiles, 4 waves, two workgroups per CU
+  GF_CS_PARTIAL = 1 << 15,  // colsum is fp32 [2*ceil(M/256)][N]: row b = column sums of output rows 128b..128b+127, stored (not added)
   GF_NOSTREAM = 1 << 23,  // tuning: 256x256 ring without the persistent streaming variant
   GF_NOREGEPI = 1 << 22,  // tuning: 256x256 ring with the LDS-staged fp32 epilogue instead of the register epilogue
   GF_WAVES4 = 64,    // tuning: 4 waves of 64x64 per tile instead of the default 8 waves of 64x32 (4 waves/SIMD)
@@ -54,6 +55,18 @@ struct GemmNT {
   int flags;
   float* colsum;                 // optional fp32 [N]: += column sums of the values written to C
 };
+
+// Column sum `v` of output rows [128*blk, 128*blk + 128*nblk) of column gn.  Default: one fp32 atomic per (tile, column) -
+// M/128 same-address atomics serialise at ~40 ns each (38 us on a 65536 x 512 output).  GF_CS_PARTIAL: plain stores into
+// per-block rows that cs_reduce_kernel sums afterwards (every (block, column) cell is written by exactly one tile).
+__device__ __forceinline__ void cs_emit(const GemmNT& p, int blk, int nblk, int gn, float v) {
+  if (p.flags & GF_CS_PARTIAL) {
+    p.colsum[(long)blk * p.N + gn] = v;
+    if (nblk == 2) p.colsum[(long)(blk + 1) * p.N + gn] = 0.f;
+  } else {
+    atomicAdd(p.colsum + gn, v);
+  }
+}
 
 // ---- epilogue of one 8-column piece of output row gm: bias, q-scale, pre-activation copy, GELU, residual / GELU',
 // ReLU, store (T or fp32, optional accumulate), column-sum accumulation.  Shared by every gemm_nt variant.
@@ -330,7 +343,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
       float t = 0.f;
 #pragma unroll
       for (int k = 0; k < RG; ++k) t += ct[k * BN + tid];
-      atomicAdd(p.colsum + n0 + tid, t);
+      cs_emit(p, m0 / 128, BM / 128, n0 + tid, t);
     }
   }
 }
@@ -354,6 +367,7 @@ template <int N> DEVI void wait_vmcnt() {
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else static_assert(N == 0, "add the literal");
 }
@@ -495,7 +509,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
         float tsum = 0.f;
 #pragma unroll
         for (int k = 0; k < RGP; ++k) tsum += ct[k * BN + tid];
-        atomicAdd(p.colsum + n0 + tid, tsum);
+        cs_emit(p, m0 / 128, BM / 128, n0 + tid, tsum);
       }
     }
 
@@ -544,6 +558,15 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
       bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
       *(bf16x4*)(img + row * PITCH + (((chunk ^ fr) & (CPRW - 1)) << 4) + (fq & 1) * 8) = o;
     };
+    auto put_pk = [&](int i, int j, bf16x4 o) {
+      const int row = wr * TM + i * 16 + fr;
+      const int chunk = (wc * TN + j * 16 + 4 * fq) >> 3;
+      *(bf16x4*)(img + row * PITCH + (((chunk ^ fr) & (CPRW - 1)) << 4) + (fq & 1) * 8) = o;
+    };
+    // fc1 forward (GELU to C, GELU' to C2): one pass computes both from one polynomial, the GELU' tile waits as packed
+    // bf16 in the registers the accumulators vacate and goes through the image after C has left
+    constexpr bool FUSED_C2D = MD >= 0 && (MD & E_C2) && (MD & E_C2D) && (MD & E_GELU) && !(MD & (E_RESID | E_DGELU | E_MULR));
+    bf16x4 dpk[FUSED_C2D ? FI : 1][FUSED_C2D ? FJ : 1];
     // output rows of this thread's readback pieces (c_rows is a scatter map): fetched before the LDS round trip
     const int rb_row = tid / CPRW, rb_chunk = tid % CPRW;
     const bool rb_col_ok = n0 + rb_chunk * 8 < p.N;
@@ -567,7 +590,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     stamp(3);
     __syncthreads();                                   // every wave is done with the ring stages
     stamp(4);
-    if (has_c2) {                                      // pre-activation copy (fc1 forward keeps it for GELU')
+    if (has_c2 && !FUSED_C2D) {                        // pre-activation copy (fc1 forward keeps it for GELU')
 #pragma unroll
       for (int i = 0; i < FI; ++i)
 #pragma unroll
@@ -592,27 +615,51 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     f32x4 cs[FJ];
 #pragma unroll
     for (int j = 0; j < FJ; ++j) cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x4 rcur[FJ], rnext[FJ];
-    auto load_r = [&](int i, bf16x4 (&dst)[FJ]) {
-      const int gm = min(m0 + wr * TM + i * 16 + fr, p.M - 1);        // rows >= M / columns >= N: clamped, never stored
-      const long rrow = p.r_rows ? (long)p.r_rows[gm] : (long)gm;
+    // R (residual / GELU' factor) in the fragment layout, RAHEAD fragment rows in flight: the row indices come first as
+    // one batch (an index load next to each row's loads puts a vmcnt(0) - the join of the `r_rows ?` branch - between the
+    // rows), row i + RAHEAD is requested when row i has been consumed, into the registers its accumulators vacate.  (All
+    // FI rows at once cost 64 registers and spilled the column sums; with R in L2 the loads are free, from HBM the 32 MB
+    // that the 256 lock-stepped workgroups request per round take ~6 us whatever the depth - tools/epi_decomp.py.)
+    constexpr int RAHEAD = 4;
+    bf16x4 rr[FI][FJ];
+    int rrow[FI];
+    auto load_r = [&](int i) {
 #pragma unroll
-      for (int j = 0; j < FJ; ++j) dst[j] = *(const bf16x4*)((const T*)p.R + rrow * p.ldr + min(colb + j * 16, p.N - 4));
+      for (int j = 0; j < FJ; ++j) rr[i][j] = *(const bf16x4*)((const T*)p.R + (long)rrow[i] * p.ldr + min(colb + j * 16, p.N - 4));
     };
-    if (has_r) load_r(0, rcur);
+    if (has_r) {
+#pragma unroll
+      for (int i = 0; i < FI; ++i) rrow[i] = min(m0 + wr * TM + i * 16 + fr, p.M - 1);   // rows >= M / columns >= N: clamped, never stored
+      if (p.r_rows) {
+#pragma unroll
+        for (int i = 0; i < FI; ++i) rrow[i] = p.r_rows[rrow[i]];
+      }
+#pragma unroll
+      for (int i = 0; i < RAHEAD && i < FI; ++i) load_r(i);
+    }
 #pragma unroll
     for (int i = 0; i < FI; ++i) {
-      if (has_r && i + 1 < FI) load_r(i + 1, rnext);
       const bool row_ok = m0 + wr * TM + i * 16 + fr < p.M;
 #pragma unroll
       for (int j = 0; j < FJ; ++j) {
         f32x4 v = pre_act(i, j);
-        if (do_gelu) {
+        if constexpr (FUSED_C2D) {
+          // the two volatile asms pin this fragment between its neighbours: without them the polynomials of all 32
+          // fragments are hoisted ahead of the first store and 340 registers spill
+          asm volatile("" : "+v"(v));
+          f32x2 glo, ghi, dlo, dhi;
+          gelu_dgelu_fast2((f32x2){v[0], v[1]}, glo, dlo);
+          gelu_dgelu_fast2((f32x2){v[2], v[3]}, ghi, dhi);
+          bf16x4 dq = {(bf16)dlo[0], (bf16)dlo[1], (bf16)dhi[0], (bf16)dhi[1]};
+          asm volatile("" : "+v"(dq));
+          dpk[i][j] = dq;
+          v = (f32x4){glo[0], glo[1], ghi[0], ghi[1]};
+        } else if (do_gelu) {
           const f32x2 lo = gelu_fast2((f32x2){v[0], v[1]}), hi = gelu_fast2((f32x2){v[2], v[3]});
           v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
         }
         if (has_r) {
-          const f32x4 r = {(float)rcur[j][0], (float)rcur[j][1], (float)rcur[j][2], (float)rcur[j][3]};
+          const f32x4 r = {(float)rr[i][j][0], (float)rr[i][j][1], (float)rr[i][j][2], (float)rr[i][j][3]};
           if (do_resid) v += r;
           else if (do_mulr) v *= r;
           else {
@@ -625,16 +672,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
         put(i, j, v);
         if (do_gelu || do_dgelu) __builtin_amdgcn_sched_barrier(0);   // one fragment's polynomial temporaries at a time
       }
-      if (has_r && i + 1 < FI) {
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) rcur[j] = rnext[j];
-      }
+      if (has_r && i + RAHEAD < FI) load_r(i + RAHEAD);
       __builtin_amdgcn_sched_barrier(0);              // keep fragment rows apart: interleaved they spill
     }
-    stamp(5);
-    readback(p.C, p.ldc);
-    stamp(6);
-    if (do_cs) {                                       // fold the 16 rows (fr) of each lane group, then one atomic per column
+    // Column sums leave BEFORE the C stores are issued: stores count in vmcnt, so any later wait on a load (a scratch
+    // reload of cs[], the index of an atomic) would sit out the whole store drain of the tile (7 us per tile measured).
+    if (do_cs) {                                       // fold the 16 rows (fr) of each lane group, then one value per column
 #pragma unroll
       for (int j = 0; j < FJ; ++j)
 #pragma unroll
@@ -642,8 +685,22 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
           float t = cs[j][e];
           t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
           const int gn = colb + j * 16 + e;
-          if (fr == 0 && gn < p.N) atomicAdd(p.colsum + gn, t);
+          if (fr == 0 && gn < p.N) {                   // (register epilogue = SWAP kernels only: TM is 128 there)
+            if (TM % 128 == 0) cs_emit(p, (m0 + wr * TM) / 128, TM / 128, gn, t);
+            else atomicAdd(p.colsum + gn, t);
+          }
         }
+    }
+    stamp(5);
+    readback(p.C, p.ldc);
+    stamp(6);
+    if constexpr (FUSED_C2D) {
+      __syncthreads();                                 // every wave has read its pieces of the C image
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) put_pk(i, j, dpk[i][j]);
+      readback(p.C2, p.ldc2);
     }
 #undef EPI_HAS
   };
@@ -1013,7 +1070,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_stream_kernel(GemmNT p) {
           float tsum = cs[j][e];
           tsum += __shfl_xor(tsum, 1); tsum += __shfl_xor(tsum, 2); tsum += __shfl_xor(tsum, 4); tsum += __shfl_xor(tsum, 8);
           const int gn = colb + j * 16 + e;
-          if (fr == 0 && gn < p.N) atomicAdd(p.colsum + gn, tsum);
+          if (fr == 0 && gn < p.N) {
+            if (TM % 128 == 0) cs_emit(p, (m0 + wr * TM) / 128, TM / 128, gn, tsum);
+            else atomicAdd(p.colsum + gn, tsum);
+          }
         }
     }
 #undef EPI_HAS
@@ -1512,6 +1572,36 @@ static int set_lds_once(const void* fn) {
   return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
 }
 
+// out[n] += sum_b part[b][n] over the `rows` 128-row blocks written by a GF_CS_PARTIAL gemm_nt.  Block: 64 columns (16 lanes x
+// float4) x 16 row lanes; grid.y splits the rows, so `out` sees grid.y atomics per column instead of M/128.
+__global__ __launch_bounds__(256) void cs_reduce_kernel(const float* part, int rows, int N, float* out) {
+  __shared__ f32x4 fold[16][16];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = (blockIdx.x * 16 + cl) * 4;
+  const int per = (rows + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (c < N)
+    for (int r = r0 + rl; r < r1; r += 16) a += *(const f32x4*)(part + (long)r * N + c);
+  fold[rl][cl] = a;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) a += fold[k][cl];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(out + c + e, a[e]);
+  }
+}
+
+extern "C" int stswin_cs_reduce(const float* partials, int M, int N, float* out, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (N % 4) return -1004;
+  const int rows = 2 * ((M + 255) / 256);
+  hipLaunchKernelGGL(cs_reduce_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)max(1, min(8, rows / 32))), dim3(256), 0,
+                     (hipStream_t)stream, partials, rows, N, out);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_rows, const void* B, long ldb,
                               void* C, long ldc, const int* c_rows, void* C2, long ldc2, const float* bias,
                               const void* R, long ldr, const int* r_rows, int M, int N, int Kseg, int S,
@@ -1520,6 +1610,8 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
   const int bk = dtype == 0 ? 64 : 32;
   if (Kseg <= 0 || Kseg % bk || S <= 0) return -1001;
   if ((flags & GF_ACCUM) && !(flags & GF_OUT_F32)) return -1002;
+  if ((flags & GF_CS_PARTIAL) && colsum && ((M + 127) / 128) % 2)   // 128-row tiles never touch the last row of the [2*ceil(M/256)][N] table
+    (void)hipMemsetAsync(colsum + (long)(2 * ((M + 255) / 256) - 1) * N, 0, sizeof(float) * N, (hipStream_t)stream);
   GemmNT p{A, lda, a_rows, B, ldb, C, ldc, c_rows, C2, ldc2, bias, R, ldr, r_rows, M, N, Kseg, S, scale, scale_cols, flags, colsum};
   const int nblk = ((M + 127) / 128) * ((N + 127) / 128);
   static int once = set_lds_once((const void*)gemm_nt_kernel<bf16, 4>) | set_lds_once((const void*)gemm_nt_kernel<float, 4>) |

@@ -565,6 +565,113 @@ extern "C" int stswin_ce_bwd(int dtype, const void* logits, const long* labels, 
   return 0;
 }
 
+// ----------------------------------------------------------------------------------------- a15: OHEM selection
+// OhemCELoss2D (seg18/utils/losses.py:32-40) sorts all B*H*W pixel losses to read loss[n_min] and, when that is not above
+// the threshold, to average the n_min largest.  Here: #(loss > thresh) comes from ce_fwd (the branch test), and the mean
+// of the n_min largest from an exact 3-level radix select over the float bits (losses are >= 0, so the bit patterns
+// order like the values): per level a 2048-bin (11 + 11 + 10 bits) histogram of counts AND sums, restricted to the
+// prefix found by the previous level, gives the k-th largest value and the sum of everything above it:
+//   mean = (sum_above + k_rem * kth) / n_min.
+// Three passes over the 4 MB loss vector (L2 resident) + one block of bookkeeping instead of a 1 M-element top-k; every
+// pass returns at once when the threshold branch is taken (stats[0] > n_min).
+struct OhemWork {                       // 4-byte words, zeroed by the launcher
+  unsigned cnt[3][2048];
+  float sum[3][2048];
+  unsigned state[3][4];                 // per level: prefix, k (still to take at this level), sum above (float bits)
+};
+
+// k-th largest over `nbins` bins (from the top): bin with count(above) < k <= count(above) + count(bin); 256 threads
+__device__ void ohem_scan(const unsigned* cnt, const float* sum, int nbins, unsigned k, unsigned* out /* LDS [3]: bin, k_rem, sum bits */) {
+  __shared__ unsigned pc[256];
+  __shared__ float ps[256];
+  const int t = threadIdx.x, per = nbins / 256;
+  unsigned c = 0;
+  float sm = 0.f;
+  for (int b = 0; b < per; ++b) { c += cnt[nbins - 1 - (t * per + b)]; sm += sum[nbins - 1 - (t * per + b)]; }
+  pc[t] = c; ps[t] = sm;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {                 // inclusive scan over threads (thread 0 = highest bins)
+    const unsigned c2 = t >= d ? pc[t - d] : 0u;
+    const float s2 = t >= d ? ps[t - d] : 0.f;
+    __syncthreads();
+    pc[t] += c2; ps[t] += s2;
+    __syncthreads();
+  }
+  const unsigned incl = pc[t], excl = incl - c;
+  if (excl < k && k <= incl) {                         // exactly one thread
+    unsigned above = excl;
+    float sabove = ps[t] - sm;
+    for (int b = 0; b < per; ++b) {
+      const int bin = nbins - 1 - (t * per + b);
+      const unsigned cb = cnt[bin];
+      if (above + cb >= k) { out[0] = (unsigned)bin; out[1] = k - above; out[2] = __float_as_uint(sabove); break; }
+      above += cb; sabove += sum[bin];
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void ohem_hist_kernel(const float* loss, long n, long n_min, const float* stats, OhemWork* wk, int level) {
+  if (stats[0] > (float)n_min) return;                 // threshold branch: the top-k mean is not needed
+  __shared__ unsigned hc[2048];
+  __shared__ float hs[2048];
+  __shared__ unsigned sc[3];
+  for (int i = threadIdx.x; i < 2048; i += 256) { hc[i] = 0u; hs[i] = 0.f; }
+  unsigned prefix = 0;
+  if (level > 0) {
+    const unsigned k = level == 1 ? (unsigned)n_min : wk->state[1][1];
+    ohem_scan(wk->cnt[level - 1], wk->sum[level - 1], 2048, k, sc);
+    const unsigned up = level == 1 ? 0u : wk->state[1][0];
+    prefix = level == 1 ? sc[0] : ((up << 11) | sc[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const float sprev = level == 1 ? 0.f : __uint_as_float(wk->state[1][2]);
+      wk->state[level][0] = prefix; wk->state[level][1] = sc[1]; wk->state[level][2] = __float_as_uint(sprev + __uint_as_float(sc[2]));
+    }
+  }
+  __syncthreads();
+  const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
+  const unsigned mask = level == 2 ? 1023u : 2047u;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = loss[i];
+    const unsigned key = __float_as_uint(v) & 0x7fffffffu;
+    const bool in = level == 0 || (level == 1 ? (key >> 21) == prefix : (key >> 10) == prefix);
+    if (in) { const unsigned b = (key >> shift) & mask; atomicAdd(&hc[b], 1u); atomicAdd(&hs[b], v); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2048; i += 256)
+    if (hc[i]) { atomicAdd(&wk->cnt[level][i], hc[i]); atomicAdd(&wk->sum[level][i], hs[i]); }
+}
+
+__global__ __launch_bounds__(256) void ohem_final_kernel(long n_min, float thresh, const float* stats, const OhemWork* wk, float* value,
+                                                         float* sel) {
+  const float n_hard = stats[0];
+  if (n_hard > (float)n_min) {                         // loss[n_min] > thresh: mean over loss > thresh
+    if (threadIdx.x == 0) { const float inv = 1.f / fmaxf(n_hard, 1.f); value[0] = stats[1] * inv; sel[0] = thresh; sel[1] = inv; sel[2] = 0.f; }
+    return;
+  }
+  __shared__ unsigned sc[3];
+  ohem_scan(wk->cnt[2], wk->sum[2], 1024, wk->state[2][1], sc);
+  if (threadIdx.x == 0) {
+    const float kth = __uint_as_float((wk->state[2][0] << 10) | sc[0]);
+    const float total = __uint_as_float(wk->state[2][2]) + __uint_as_float(sc[2]) + (float)sc[1] * kth;
+    value[0] = total / (float)n_min; sel[0] = kth; sel[1] = 1.f / (float)n_min; sel[2] = 1.f;
+  }
+}
+
+extern "C" int stswin_ohem_select(const float* loss, long n, long n_min, float thresh, const float* stats, void* work,
+                                  long work_bytes, float* value, float* sel, void* stream) {
+  if (n <= 0 || n_min <= 0 || n_min > n) return -1301;
+  if (work_bytes < (long)sizeof(OhemWork)) return -1302;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(work, 0, sizeof(OhemWork), st) != hipSuccess) return -1303;
+  const unsigned grid = (unsigned)max(1L, min(512L, (n + 4095) / 4096));
+  for (int level = 0; level < 3; ++level)
+    hipLaunchKernelGGL(ohem_hist_kernel, dim3(grid), dim3(256), 0, st, loss, n, n_min, stats, (OhemWork*)work, level);
+  hipLaunchKernelGGL(ohem_final_kernel, dim3(1), dim3(256), 0, st, n_min, thresh, stats, (const OhemWork*)work, value, sel);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
 // ----------------------------------------------------------------------------------------- f4: inference post-processing
 // seg18/test.py:153-158: F.interpolate(out, (H, W), bilinear, align_corners=True) -> softmax -> argmax, then Dice / IoU
 // (utils/EndoMetric.py).  One pass: interpolate the nc logits of an output pixel in registers, take the arg-max (softmax

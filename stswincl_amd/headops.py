@@ -457,14 +457,7 @@ class OhemCEFn(torch.autograd.Function):
         lg = lg.contiguous()
         lab = labels.contiguous()
         loss, stats = hip.ce_fwd(lg, lab, ignore_index, thresh)
-        n_hard, s_hard = stats[0], stats[1]
-        use_thresh = n_hard > n_min
-        top = torch.topk(loss, n_min, sorted=False)[0]
-        kth = top.min()
-        value = torch.where(use_thresh, s_hard / n_hard.clamp(min=1.0), top.mean())
-        sel = torch.stack([torch.where(use_thresh, torch.full_like(kth, thresh), kth),
-                           torch.where(use_thresh, 1.0 / n_hard.clamp(min=1.0), torch.full_like(kth, 1.0 / n_min)),
-                           torch.where(use_thresh, torch.zeros_like(kth), torch.ones_like(kth))]).float().contiguous()
+        value, sel = hip.ohem_select(loss, stats, int(n_min), float(thresh))
         ctx.ignore_index, ctx.in_dtype = ignore_index, logits.dtype
         ctx.save_for_backward(lg, lab, loss, sel)
         return value

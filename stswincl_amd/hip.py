@@ -13,12 +13,12 @@ from typing import Optional
 import torch
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_ROOT, "stswincl_amd", "lib", "libstswin_hip.so")
+LIB_PATH = os.environ.get("STSWIN_HIP_LIB") or os.path.join(_ROOT, "stswincl_amd", "lib", "libstswin_hip.so")   # override: A/B of two builds in one process pool (tools/)
 HEADER_PATH = os.path.join(_ROOT, "include", "stswin_hip.h")
 _lib: Optional[ctypes.CDLL] = None
 
 GF_GELU, GF_RESID, GF_MUL_DGELU, GF_OUT_F32, GF_ACCUM, GF_RELU, GF_WAVES4, GF_BIG, GF_NOBIG, GF_MID, GF_NOPIPE, GF_HALF, GF_NOHALF = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
-GF_MUL_R, GF_C2_DGELU = 8192, 16384
+GF_MUL_R, GF_C2_DGELU, GF_CS_PARTIAL = 8192, 16384, 32768
 GF_NOREGEPI = 1 << 22
 GF_NOSTREAM = 1 << 23
 GF_DUO = 1 << 24
@@ -50,10 +50,11 @@ def load() -> ctypes.CDLL:
                              "stswincl_amd has no CPU or eager fallback")
     lib = ctypes.CDLL(LIB_PATH)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
-    if missing:
+    if missing and not os.environ.get("STSWIN_HIP_LIB"):     # (an older build named for an A/B run may lack new entries)
         raise StswinHipError(f"libstswin_hip.so lacks declared symbols: {missing}")
     for s in declared_symbols():
-        getattr(lib, s).restype = _c_int
+        if s not in missing:
+            getattr(lib, s).restype = _c_int
     _lib = lib
     return lib
 
@@ -226,6 +227,11 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
         assert out.dtype == A.dtype
     else:
         assert out.dtype == torch.float32
+    cs_table = None
+    if colsum_out is not None and M >= _CS_PARTIAL_MIN_M and N % 4 == 0 and not (flags & (1 << 19)):
+        # >= 64 row tiles would each add into the same N addresses: per-block partial sums + one small reduce instead
+        cs_table = _cs_table(A.device, 2 * ((M + 255) // 256) * N)
+        flags |= GF_CS_PARTIAL
     name = "gemm_nt_bf16" if A.dtype == torch.bfloat16 else "gemm_nt_f32"
     if _SHAPE_NAMES:
         name += f" M={M} N={N} K={Kseg} S={S} a={int(a_rows is not None)} c={int(c_rows is not None)} fl={flags}"
@@ -234,9 +240,25 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
             _dt(A), _p(A), _c_long(_ld(A)), _p(a_rows), _p(Bw), _c_long(_ld(Bw)), _p(out), _c_long(_ld(out)),
             _p(c_rows), _p(out2), _c_long(_ld(out2) if out2 is not None else 0), _p(bias), _p(resid),
             _c_long(_ld(resid) if resid is not None else 0), _p(r_rows), M, N, Kseg, S, _c_float(scale), scale_cols,
-            flags, _p(colsum_out), _stream())
+            flags, _p(cs_table if cs_table is not None else colsum_out), _stream())
     _check(rc, "gemm_nt")
+    if cs_table is not None:
+        _check(load().stswin_cs_reduce(_p(cs_table), M, N, _p(colsum_out), _stream()), "cs_reduce")
     return out
+
+
+_CS_PARTIAL_MIN_M = int(os.environ.get("STSWIN_CS_PARTIAL_MIN_M", "8192"))
+_CS_TABLES = {}
+
+
+def _cs_table(device, floats):
+    """Caller-owned scratch of the STSWIN_GF_CS_PARTIAL column-sum table (one per device, grown on demand; every use is
+    write-then-read on the launch stream)."""
+    t = _CS_TABLES.get(device)
+    if t is None or t.numel() < floats:
+        t = torch.empty(max(floats, 1 << 20), dtype=torch.float32, device=device)
+        _CS_TABLES[device] = t
+    return t
 
 
 _TN_WS = {}
@@ -402,6 +424,19 @@ def ce_fwd(logits, labels, ignore_index, thresh):
     _check(load().stswin_ce_fwd(_dt(logits), _p(logits), _p(labels), _p(loss), _p(stats), F_, _c_long(HW), nc, ignore_index,
                                 _c_float(thresh), _stream()), "ce_fwd")
     return loss, stats
+
+
+_OHEM_WORK_BYTES = 3 * 2048 * 8 + 48
+
+
+def ohem_select(loss, stats, n_min: int, thresh: float):
+    """(value [1], sel [3]) of OhemCELoss2D's selection (losses.py:35-39) on the device: no sort, no host sync."""
+    work = torch.empty(_OHEM_WORK_BYTES // 4, dtype=torch.int32, device=loss.device)
+    value = torch.empty((), dtype=torch.float32, device=loss.device)
+    sel = torch.empty(3, dtype=torch.float32, device=loss.device)
+    _check(load().stswin_ohem_select(_p(loss), _c_long(loss.numel()), _c_long(n_min), _c_float(thresh), _p(stats), _p(work),
+                                     _c_long(_OHEM_WORK_BYTES), _p(value), _p(sel), _stream()), "ohem_select")
+    return value, sel
 
 
 def ce_bwd(logits, labels, loss, sel, gscale, ignore_index):

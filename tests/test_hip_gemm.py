@@ -86,6 +86,32 @@ def test_gemm_nt_epilogues(dtype):
     _close(out, F.relu(lin), dtype, "relu")
 
 
+@pytest.mark.parametrize("m,n,k,flags", [(8292, 512, 128, 0), (8292, 512, 128, hip.GF_NOBIG), (8292, 64, 64, 0),
+                                         (8192 + 256 + 40, 768, 64, hip.GF_BIG), (8192, 256, 128, hip.GF_MID),
+                                         (8320, 512, 64, hip.GF_BIG | hip.GF_STREAM)])
+def test_gemm_nt_colsum_partial_table(m, n, k, flags, monkeypatch):
+    """Bias-gradient column sums through the per-128-row-block table + stswin_cs_reduce (M >= 8192: default) against the
+    fp32 atomics of the same kernel and the sums of the stored values; ragged M (odd / even block counts), every tile
+    family (256x256 ring, 128x128, 256x64, 256x128, streaming)."""
+    torch.manual_seed(5)
+    a = torch.randn(m, k).bfloat16().cuda()
+    w = (torch.randn(n, k) / k ** 0.5).bfloat16().cuda()
+    out = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    seed = torch.randn(n, device="cuda")
+    cs_tab = seed.clone()
+    assert m >= hip._CS_PARTIAL_MIN_M
+    hip._cs_table(a.device, 1).fill_(float("nan"))          # stale table contents must not leak into the sums
+    hip.gemm_nt(a, w, out, M=m, flags=flags, colsum_out=cs_tab)
+    # the sums are taken in fp32 before the bf16 rounding of the stored values
+    ref = seed + F.linear(a.float(), w.float()).sum(0)
+    tol = 1e-4 * float(ref.abs().max()) + 1e-2
+    assert float((cs_tab - ref).abs().max()) <= tol, "table + reduce"
+    monkeypatch.setattr(hip, "_CS_PARTIAL_MIN_M", 1 << 30)
+    cs_at = seed.clone()
+    hip.gemm_nt(a, w, out, M=m, flags=flags, colsum_out=cs_at)
+    assert float((cs_at - ref).abs().max()) <= tol, "atomics"
+
+
 @pytest.mark.parametrize("variant", ["ring", "stream"])
 def test_gemm_nt_ring_register_epilogues(variant):
     """256x256 ring kernel (forced; also its persistent streaming variant): every mode-specialised register epilogue

@@ -185,3 +185,32 @@ def test_aspp_matches_reference_golden(mode, tol):
     net.train()
     with pytest.raises(ValueError):
         net(x[:1])
+
+
+@pytest.mark.parametrize("n,n_min,kind", [(1 << 20, 1 << 16, "random"), (1 << 20, 1 << 16, "ties"), (1 << 20, 700000, "zeros"),
+                                          (4099, 256, "random"), (4099, 4099, "random"), (1 << 18, 1, "random")])
+def test_ohem_select_matches_sorted_reference(n, n_min, kind):
+    """stswin_ohem_select (radix select over the loss bits) against the reference's sort (losses.py:35-39): both branches,
+    ties at the cut, a cut inside the ignored (zero) losses, n_min = 1 and n_min = n."""
+    from stswincl_amd import hip
+    g = torch.Generator().manual_seed(n_min + len(kind))
+    loss = torch.rand(n, generator=g) * 3
+    if kind == "ties":
+        loss = (loss * 8).round() / 8                      # ~24 distinct values: the k-th value is shared by thousands
+    if kind == "zeros":
+        loss[torch.rand(n, generator=g) < 0.5] = 0.0       # ignore_index pixels: more than n - n_min zeros
+    loss = loss.cuda()
+    srt = torch.sort(loss.double(), descending=True)[0]
+    for thresh in (0.5, 2.9, 10.0):
+        n_hard = (loss > thresh).sum().float()
+        stats = torch.stack([n_hard, loss[loss > thresh].sum()]).float()
+        value, sel = hip.ohem_select(loss, stats, n_min, thresh)
+        if int(n_hard) > n_min:                            # loss[n_min] > thresh
+            ref = srt[srt > thresh].mean()
+            assert float(sel[0]) == pytest.approx(thresh) and float(sel[2]) == 0.0
+            assert float(sel[1]) == pytest.approx(1.0 / int(n_hard), rel=1e-6)
+        else:
+            ref = srt[:n_min].mean()
+            assert float(sel[0]) == float(srt[n_min - 1]), "k-th largest loss (bit exact)"
+            assert float(sel[2]) == 1.0 and float(sel[1]) == pytest.approx(1.0 / n_min, rel=1e-6)
+        assert float(value) == pytest.approx(float(ref), rel=2e-6, abs=1e-7)

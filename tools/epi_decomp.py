@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from stswincl_amd import hip
 
-NOSTORE, NOEPI = 1 << 20, 1 << 21
+NOSTORE, NOEPI, NOWARM = 1 << 20, 1 << 21, 1 << 18
 
 
 def timeit(fn, iters=20):
@@ -25,7 +25,7 @@ def timeit(fn, iters=20):
 def main():
     dt, dev = torch.bfloat16, "cuda"
     shapes = [(65536, 2048, 512, "fc1 s1"), (16384, 4096, 1024, "fc1 s2"), (65536, 512, 2048, "fc2 s1"), (65536, 512, 512, "proj s1")]
-    print(f"{'shape':8s} {'epilogue':14s} {'full':>8s} {'nostore':>8s}   (us; 'none' = no epilogue)")
+    print(f"{'shape':8s} {'epilogue':14s} {'full':>8s} {'nostore':>8s} {'nowarm':>8s}   (us; 'none' = no epilogue; nowarm = without the R warm-up copies)")
     for M, N, K, note in shapes:
         A = torch.randn(M, K, device=dev).to(dt)
         W = (torch.randn(N, K, device=dev) / K ** 0.5).to(dt)
@@ -41,10 +41,15 @@ def main():
                  ("resid", dict(bias=bias, resid=R, flags=hip.GF_RESID)),
                  ("mul_r", dict(resid=R, flags=hip.GF_MUL_R)),
                  ("mul_r+cs", dict(resid=R, flags=hip.GF_MUL_R, colsum_out=cs)),
-                 ("cs", dict(colsum_out=cs))]
+                 ("cs", dict(colsum_out=cs)),
+                 # the same R loads served by L2 (every row aliases row 0): separates load issue cost from HBM time
+                 ("resid L2", dict(bias=bias, resid=R[:1].expand(M, N), flags=hip.GF_RESID)),
+                 ("mul_r+cs L2", dict(resid=R[:1].expand(M, N), flags=hip.GF_MUL_R, colsum_out=cs)),
+                 # half of the rows alias: half the HBM bytes
+                 ]
         for cname, kw in cases:
             cells = []
-            for extra in (0, NOSTORE):
+            for extra in (0, NOSTORE, NOWARM):
                 if cname == "none" and extra:
                     continue
                 k2 = dict(kw)
