@@ -186,10 +186,22 @@ DEVI int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
-DEVI float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// Sum over each aligned group of 16 lanes, result in every lane of the group: four DPP adds (xor 1, xor 2 inside the
+// quads, then the half-row and row mirrors) instead of four ds_bpermute round trips through the LDS crossbar.
+template <int CTRL> DEVI float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+DEVI float sum16(float v) {
+  v += dpp_f32<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);       // row_half_mirror
+  v += dpp_f32<0x140>(v);       // row_mirror
   return v;
+}
+DEVI float wave_sum(float v) {
+  v = sum16(v);
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
 }
 DEVI float wave_max(float v) {
 #pragma unroll

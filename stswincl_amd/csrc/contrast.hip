@@ -145,9 +145,7 @@ __global__ __launch_bounds__(256) void contrast_fwd_kernel(ContrastArgs p) {
   }
   // reduce over the 16 lanes that share a row, then over the two column waves
 #pragma unroll
-  for (int e = 0; e < 16; ++e)
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) { ppos[e] += __shfl_xor(ppos[e], o); pall[e] += __shfl_xor(pall[e], o); }
+  for (int e = 0; e < 16; ++e) { ppos[e] = sum16(ppos[e]); pall[e] = sum16(pall[e]); }
   __syncthreads();
   float* red = (float*)smem;                      // [2 (pos/all)][2 (wc)][128 rows]
   if (fr == 0) {

@@ -570,20 +570,36 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     // output rows of this thread's readback pieces (c_rows is a scatter map): fetched before the LDS round trip
     const int rb_row = tid / CPRW, rb_chunk = tid % CPRW;
     const bool rb_col_ok = n0 + rb_chunk * 8 < p.N;
+    // Two bodies: with a scatter map the output rows are fetched (as one batch) before the LDS round trip; without one
+    // there must be NO load in the path - hipcc puts the wait of a conditional load at the join, executed either way,
+    // and behind the stores of a first output (stores count in vmcnt) that wait sits out their whole drain.
     auto readback = [&](void* Cout, long ldo) {
-      int orow[NPASS];
+      if (p.c_rows) {
+        int orow[NPASS];
 #pragma unroll
-      for (int ps = 0; ps < NPASS; ++ps) {
-        const int gm = m0 + ps * RPP + rb_row;
-        orow[ps] = (gm < p.M && rb_col_ok) ? (p.c_rows ? p.c_rows[gm] : gm) : -1;
-      }
-      __syncthreads();
+        for (int ps = 0; ps < NPASS; ++ps) {
+          const int gm = m0 + ps * RPP + rb_row;
+          orow[ps] = (gm < p.M && rb_col_ok) ? p.c_rows[gm] : -1;
+        }
+        __syncthreads();
 #pragma unroll
-      for (int ps = 0; ps < NPASS; ++ps) {
-        const int row = ps * RPP + rb_row;
-        if (orow[ps] >= 0) {
-          const bf16x8 val = *(const bf16x8*)(img + row * PITCH + (((rb_chunk ^ (row & 15)) & (CPRW - 1)) << 4));
-          *(bf16x8*)((T*)Cout + (long)orow[ps] * ldo + n0 + rb_chunk * 8) = val;
+        for (int ps = 0; ps < NPASS; ++ps) {
+          const int row = ps * RPP + rb_row;
+          if (orow[ps] >= 0) {
+            const bf16x8 val = *(const bf16x8*)(img + row * PITCH + (((rb_chunk ^ (row & 15)) & (CPRW - 1)) << 4));
+            *(bf16x8*)((T*)Cout + (long)orow[ps] * ldo + n0 + rb_chunk * 8) = val;
+          }
+        }
+      } else {
+        __syncthreads();
+        T* cbase = (T*)Cout + (long)(m0 + rb_row) * ldo + n0 + rb_chunk * 8;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+          const int row = ps * RPP + rb_row;
+          if (m0 + row < p.M && rb_col_ok) {
+            const bf16x8 val = *(const bf16x8*)(img + row * PITCH + (((rb_chunk ^ (row & 15)) & (CPRW - 1)) << 4));
+            *(bf16x8*)(cbase + (long)(ps * RPP) * ldo) = val;
+          }
         }
       }
     };
@@ -683,7 +699,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float t = cs[j][e];
-          t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+          t = sum16(t);
           const int gn = colb + j * 16 + e;
           if (fr == 0 && gn < p.N) {                   // (register epilogue = SWAP kernels only: TM is 128 there)
             if (TM % 128 == 0) cs_emit(p, (m0 + wr * TM) / 128, TM / 128, gn, t);
@@ -1068,7 +1084,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_stream_kernel(GemmNT p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float tsum = cs[j][e];
-          tsum += __shfl_xor(tsum, 1); tsum += __shfl_xor(tsum, 2); tsum += __shfl_xor(tsum, 4); tsum += __shfl_xor(tsum, 8);
+          tsum = sum16(tsum);
           const int gn = colb + j * 16 + e;
           if (fr == 0 && gn < p.N) {
             if (TM % 128 == 0) cs_emit(p, (m0 + wr * TM) / 128, TM / 128, gn, tsum);
