@@ -153,7 +153,7 @@ class ConvTokFn(torch.autograd.Function):
                     dw[oa:oa + on, ia:ia + in_, :] = d3[ob:ob + on, :, ib:ib + in_].permute(0, 2, 1)
         db = None
         if has_bias:
-            dbp = torch.zeros(lout.width, dtype=torch.float32, device=X.device)
+            dbp = hip.zeros(lout.width, device=X.device)
             hip.colsum(g, dbp)
             db = lout.unpad_vec(dbp)
         return dx, dw.reshape(co, ci, k, k), db, None, None, None
@@ -318,8 +318,14 @@ class BNTokFn(torch.autograd.Function):
             s1, s2 = loc1, loc2
         else:
             s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training)
-        dgamma = lay.unpad_vec(s2[0] if groups == 1 else s2.sum(0))
-        dbeta = lay.unpad_vec(s1[0] if groups == 1 else s1.sum(0))
+        if groups > 1:                                   # s1 / s2 are the two halves of one [2][groups][C] buffer: one reduce
+            if s1.data_ptr() + s1.numel() * 4 == s2.data_ptr():
+                both = torch.as_strided(s1, (2, groups, s1.shape[-1]), (groups * s1.shape[-1], s1.shape[-1], 1)).sum(1)
+                s1, s2 = both[0:1], both[1:2]
+            else:
+                s1, s2 = s1.sum(0, keepdim=True), s2.sum(0, keepdim=True)
+        dgamma = lay.unpad_vec(s2[0])
+        dbeta = lay.unpad_vec(s1[0])
         return (dx.to(in_dtype), dgamma, dbeta, None, None, None, None, dres.to(in_dtype) if has_res else None,
                 None, None, None, None, None)
 

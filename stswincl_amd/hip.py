@@ -89,6 +89,48 @@ def _ld(t: torch.Tensor) -> int:
     return t.stride(0)
 
 
+# ----------------------------------------------------------------------------------------------- zero arena
+# Accumulators that the kernels add into (BatchNorm / LayerNorm statistic sums, bias gradients, CE counters) must start at
+# zero; a fill launch per buffer costs ~4.5 us of GPU time and the training step needs ~80 of them.  zeros() hands out
+# 64-byte aligned slices of one zero-filled block per device instead: ONE fill per block (1 M floats), a fresh block when
+# the current one is used up or when arena_reset() is called (model forward: once per step).  A slice is handed out
+# once and never recycled - the block is freed when its last slice dies - so nothing can observe stale contents.
+_ARENA_FLOATS = 1 << 20
+_ARENA_MAX_REQUEST = 0 if os.environ.get("STSWIN_NO_ARENA") == "1" else 1 << 16      # (switch for A/B runs)
+_ARENAS = {}
+
+
+def arena_reset(device=None) -> None:
+    """Drop the current block(s): the next zeros() starts a fresh one (called at the start of a model forward so that a
+    step's forward and backward share one fill and a long-lived slice does not pin a mostly unused block for ever)."""
+    if device is None:
+        _ARENAS.clear()
+    else:
+        _ARENAS.pop(torch.device(device), None)
+
+
+def zeros(*shape, device) -> torch.Tensor:
+    """fp32 zeros of the given shape: a slice of the device's zero arena (small requests) or torch.zeros (large ones)."""
+    if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+        shape = tuple(shape[0])
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if n > _ARENA_MAX_REQUEST or n == 0:
+        return torch.zeros(shape, dtype=torch.float32, device=device)
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    st = _ARENAS.get(device)
+    need = (n + 15) // 16 * 16
+    if st is None or st[1] + need > _ARENA_FLOATS:
+        st = [torch.zeros(_ARENA_FLOATS, dtype=torch.float32, device=device), 0]
+        _ARENAS[device] = st
+    out = st[0][st[1]:st[1] + n].view(shape)
+    st[1] += need
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- live profiling
 # bench.py brackets every launch of the dominant kernels with HIP events recorded on the launch stream (torch's
 # current stream IS the stream the kernels are launched on) and reads them back after the timed region.
@@ -354,7 +396,7 @@ def win_attn_bwd(qkv, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, s
 def colstats(x, groups=1, squares=True, M=None):
     M = x.shape[0] if M is None else M
     C = x.shape[1]
-    both = torch.zeros(2 if squares else 1, groups, C, dtype=torch.float32, device=x.device)   # one fill launch
+    both = zeros(2 if squares else 1, groups, C, device=x.device)
     s = both[0]
     ss = both[1] if squares else None
     _check(load().stswin_colstats(_dt(x), _p(x), _c_long(_ld(x)), _p(s), _p(ss), M, C, groups, _stream()), "colstats")
@@ -385,7 +427,7 @@ def bn_bwd(dy, x, y, mean, rstd, gamma, dx, dresid=None, groups=1, relu=True, tr
     M = x.shape[0] if M is None else M
     C = x.shape[1]
     if sums is None:
-        both = torch.zeros(2, groups, C, dtype=torch.float32, device=x.device)
+        both = zeros(2, groups, C, device=x.device)
         s1, s2 = both[0], both[1]
     else:
         s1, s2 = sums
@@ -420,7 +462,7 @@ def ce_fwd(logits, labels, ignore_index, thresh):
     F_, nc = logits.shape[:2]
     HW = logits[0, 0].numel()
     loss = torch.empty(F_ * HW, dtype=torch.float32, device=logits.device)
-    stats = torch.zeros(2, dtype=torch.float32, device=logits.device)
+    stats = zeros(2, device=logits.device)
     _check(load().stswin_ce_fwd(_dt(logits), _p(logits), _p(labels), _p(loss), _p(stats), F_, _c_long(HW), nc, ignore_index,
                                 _c_float(thresh), _stream()), "ce_fwd")
     return loss, stats

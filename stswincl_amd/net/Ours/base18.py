@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from ... import headops as H
+from ... import hip
 from .ASPP import ASPP
 from .resnet import ResNet18_OS8
 from .swin_512 import SwinTransformerLayerv5
@@ -59,6 +60,7 @@ class TswinPlus(nn.Module):
 
     def forward(self, x):
         hi, wi = x.shape[3:]
+        hip.arena_reset(x.device)                           # one zero-fill block per step (forward + backward accumulators)
         with H.deferred_bn_counters():
             cat, (b, h, w) = decode_tokens(self.resnet, self.swin, self.aspp, self.project1, self.project2, self.project3, x)
             y = H.conv_bn_relu(cat, self.classifier[0], self.classifier[1], (b, h, w), lin=LCAT)

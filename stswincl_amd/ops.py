@@ -109,7 +109,7 @@ def zeros_like_list(shapes, device, fill=True):
     for n in sizes:
         offs.append(tot)
         tot += (n + 15) // 16 * 16
-    flat = (torch.zeros if fill else torch.empty)(tot, dtype=torch.float32, device=device)
+    flat = hip.zeros(tot, device=device) if fill else torch.empty(tot, dtype=torch.float32, device=device)
     return [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
 
 
@@ -249,8 +249,8 @@ class PatchMergeFn(torch.autograd.Function):
         hip.gemm_tn(g, n, dred, Mk=M4, overwrite=True)
         dn = torch.empty(M4, 4 * C, dtype=dt, device=dev)
         hip.gemm_nt(g, wcast(red_w, dt, True), dn, M=M4)
-        dg = torch.zeros(4 * C, dtype=torch.float32, device=dev)
-        db = torch.zeros(4 * C, dtype=torch.float32, device=dev)
+        dg = hip.zeros(4 * C, device=dev)
+        db = hip.zeros(4 * C, device=dev)
         dx = torch.empty_like(X2)
         hip.layernorm_bwd(dn, X2, _f32(norm_w), mean, rstd, dg, db, M=M4, rows=rows, S=4, Cseg=C, dx=dx)
         return dx.view(B, T, L, C).to(ctx.in_dtype), dg, db, dred, None
@@ -343,7 +343,7 @@ class LinearFn(torch.autograd.Function):
         hip.gemm_tn(g, X2, dw, Mk=M, overwrite=True)
         db = None
         if ctx.has_b:
-            db = torch.zeros(Nn, dtype=torch.float32, device=X2.device)
+            db = hip.zeros(Nn, device=X2.device)
             hip.colsum(g, db)
         hip.gemm_nt(g, wcast(w, dt, True), dx, M=M)
         return dx.view(*dy.shape[:-1], K).to(ctx.in_dtype), dw, db, None
