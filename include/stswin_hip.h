@@ -107,7 +107,12 @@ int stswin_layernorm_fwd(int dtype, const void* x, long ldx, const int* rows, in
 int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const int* rows, int S, int Cseg,
                          const float* gamma, const float* mean, const float* rstd, void* dx, long lddx, float* dgamma,
                          float* dbeta, int M, int accumulate_dx,
-                         float* dxsum /* optional fp32 [S*Cseg]: += column sums of the dx written */, void* stream);
+                         float* dxsum /* optional fp32 [S*Cseg]: += column sums of the dx written */,
+                         float* workspace /* optional caller-owned, ZERO-FILLED fp32 [STSWIN_LN_BWD_REPLICAS][3][S*Cseg]: the
+                                             M/32 workgroups spread their dgamma / dbeta / dxsum atomics over the replicas
+                                             (same-address fp32 atomics serialise) and a fold kernel adds them up */,
+                         void* stream);
+#define STSWIN_LN_BWD_REPLICAS 32
 
 /* ---- a6: windowed attention core (swin_512.py:117-138).  qkv [nB_*T*N][3C] = q (pre-scaled) | k | v in window
  * order; biasT [heads][N][N] and maskT [nW][N][N] are the expanded relative-position bias (:122-124) and the

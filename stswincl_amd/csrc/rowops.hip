@@ -259,6 +259,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, long ldx, const
   }
 }
 
+constexpr int LN_REP = 32;       // replicas of the (dgamma | dbeta | dxsum) accumulators in the caller's workspace
+__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* ws, int C, float* dgamma, float* dbeta, float* dxsum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 3 * C) return;
+  float* out = c < C ? dgamma + c : (c < 2 * C ? dbeta + (c - C) : (dxsum ? dxsum + (c - 2 * C) : nullptr));
+  if (!out) return;
+  float t = 0.f;
+#pragma unroll
+  for (int r = 0; r < LN_REP; ++r) t += ws[(long)r * 3 * C + c];
+  *out += t;                       // one writer per address, stream-ordered behind ln_bwd_kernel
+}
+
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma += sum dy*xhat ; dbeta += sum dy.
 // Each wave walks `rows_per_wave` consecutive rows keeping its dgamma/dbeta columns in registers, the block
 // folds its 4 waves through LDS and issues one fp32 atomic per column.
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, con
                                                       int S, int Cseg, const float* gamma, const float* mean,
                                                       const float* rstd, T* dx, long lddx, float* dgamma,
                                                       float* dbeta, int M, int rows_per_wave, int accumulate_dx,
-                                                      float* dxsum) {
+                                                      float* dxsum, float* ws) {
   constexpr int PACK = TT<T>::PACK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -337,6 +349,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, con
     }
   }
   __syncthreads();
+  // M/32 blocks adding into the same C addresses serialise (~40 ns per same-address fp32 atomic: 2048 blocks = the whole
+  // kernel time at M = 65536).  With a workspace the blocks spread over LN_REP replicas [LN_REP][3][C] that
+  // ln_bwd_fold_kernel sums afterwards.
+  if (ws) {
+    float* rep = ws + (long)(blockIdx.x % LN_REP) * 3 * C;
+    dgamma = rep; dbeta = rep + C;
+    if (dxsum) dxsum = rep + 2 * C;
+  }
   for (int c = threadIdx.x; c < C; c += 256) {
     atomicAdd(dgamma + c, sg[c] + sg[C + c] + sg[2 * C + c] + sg[3 * C + c]);
     atomicAdd(dbeta + c, sb[c] + sb[C + c] + sb[2 * C + c] + sb[3 * C + c]);
@@ -519,7 +539,7 @@ extern "C" int stswin_layernorm_fwd(int dtype, const void* x, long ldx, const in
 template <typename T>
 static int ln_bwd_launch(const void* dy, long lddy, const void* x, long ldx, const int* rows, int S, int Cseg,
                          const float* g, const float* mean, const float* rstd, void* dx, long lddx, float* dg, float* db,
-                         int M, int acc, float* dxsum, hipStream_t st) {
+                         int M, int acc, float* dxsum, float* ws, hipStream_t st) {
   constexpr int PACK = TT<T>::PACK;
   const int C = S * Cseg, np = (C / PACK + 63) / 64;
   // 8 rows per wave: >= 4 waves per SIMD at M = 32768 (the serial row loop with two wave reductions per row is
@@ -527,7 +547,7 @@ static int ln_bwd_launch(const void* dy, long lddy, const void* x, long ldx, con
   const int rpw = M >= 16384 ? 8 : (M >= 4096 ? 4 : 2);
   dim3 grid((M + 4 * rpw - 1) / (4 * rpw)), blk(256);
   const size_t lds = (size_t)8 * C * sizeof(float);
-#define LN_B(NP) hipLaunchKernelGGL((ln_bwd_kernel<T, NP>), grid, blk, lds, st, (const T*)dy, lddy, (const T*)x, ldx, rows, S, Cseg, g, mean, rstd, (T*)dx, lddx, dg, db, M, rpw, acc, dxsum)
+#define LN_B(NP) hipLaunchKernelGGL((ln_bwd_kernel<T, NP>), grid, blk, lds, st, (const T*)dy, lddy, (const T*)x, ldx, rows, S, Cseg, g, mean, rstd, (T*)dx, lddx, dg, db, M, rpw, acc, dxsum, ws)
   switch (np) {
     case 1: LN_B(1); break;
     case 2: LN_B(2); break;
@@ -536,18 +556,19 @@ static int ln_bwd_launch(const void* dy, long lddy, const void* x, long ldx, con
     default: return -1104;
   }
 #undef LN_B
+  if (ws) hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((3 * C + 255) / 256), dim3(256), 0, st, ws, C, dg, db, dxsum);
   return 0;
 }
 
 extern "C" int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const int* rows, int S,
                                     int Cseg, const float* gamma, const float* mean, const float* rstd, void* dx,
                                     long lddx, float* dgamma, float* dbeta, int M, int accumulate_dx, float* dxsum,
-                                    void* stream) {
+                                    float* workspace, void* stream) {
   const int pack = dtype == 0 ? 8 : 4;
   if (Cseg % pack || ldx % pack || lddy % pack || lddx % pack) return -1105;
   if ((long)S * Cseg * 8 * 4 > 65536) return -1106;
-  int rc = dtype == 0 ? ln_bwd_launch<bf16>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, accumulate_dx, dxsum, (hipStream_t)stream)
-                      : ln_bwd_launch<float>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, accumulate_dx, dxsum, (hipStream_t)stream);
+  int rc = dtype == 0 ? ln_bwd_launch<bf16>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, accumulate_dx, dxsum, workspace, (hipStream_t)stream)
+                      : ln_bwd_launch<float>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, accumulate_dx, dxsum, workspace, (hipStream_t)stream);
   if (rc) return rc;
   STSWIN_CHECK_LAUNCH();
   return 0;

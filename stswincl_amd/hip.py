@@ -92,11 +92,11 @@ def _ld(t: torch.Tensor) -> int:
 # ----------------------------------------------------------------------------------------------- zero arena
 # Accumulators that the kernels add into (BatchNorm / LayerNorm statistic sums, bias gradients, CE counters) must start at
 # zero; a fill launch per buffer costs ~4.5 us of GPU time and the training step needs ~80 of them.  zeros() hands out
-# 64-byte aligned slices of one zero-filled block per device instead: ONE fill per block (1 M floats), a fresh block when
+# 64-byte aligned slices of one zero-filled block per device instead: ONE fill per block (4 M floats), a fresh block when
 # the current one is used up or when arena_reset() is called (model forward: once per step).  A slice is handed out
 # once and never recycled - the block is freed when its last slice dies - so nothing can observe stale contents.
-_ARENA_FLOATS = 1 << 20
-_ARENA_MAX_REQUEST = 0 if os.environ.get("STSWIN_NO_ARENA") == "1" else 1 << 16      # (switch for A/B runs)
+_ARENA_FLOATS = 1 << 22
+_ARENA_MAX_REQUEST = 0 if os.environ.get("STSWIN_NO_ARENA") == "1" else 1 << 18      # (switch for A/B runs)
 _ARENAS = {}
 
 
@@ -359,9 +359,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, *, M, rows=None, S=1,
     if dx is None:
         dx = torch.empty_like(x)
         accumulate = False
+    ws = zeros(32, 3, S * Cseg, device=x.device) if M >= 4096 and os.environ.get("STSWIN_LN_NO_WS") != "1" else None
     rc = load().stswin_layernorm_bwd(_dt(x), _p(dy), _c_long(_ld(dy)), _p(x), _c_long(_ld(x)), _p(rows), S, Cseg,
                                      _p(gamma), _p(mean), _p(rstd), _p(dx), _c_long(_ld(dx)), _p(dgamma), _p(dbeta), M,
-                                     1 if accumulate else 0, _p(dxsum), _stream())
+                                     1 if accumulate else 0, _p(dxsum), _p(ws), _stream())
     _check(rc, "layernorm_bwd")
     return dx
 
