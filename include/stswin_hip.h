@@ -114,6 +114,14 @@ int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, lo
                          void* stream);
 #define STSWIN_LN_BWD_REPLICAS 32
 
+/* ---- relative position bias (swin_512.py:122-131).  expand: out[w][h][j][i] = table[index[i*N + j]][h] (+ mask[w][i][j]),
+ * the [key][query] layout of stswin_win_attn_fwd's biasT (nW = 1, mask = NULL: plain [heads][N][N]; with the SW-MSA mask the
+ * per-window pre-summed table).  scatter: dtable[index[i*N + j]][h] += dbiasT[h][j][i] (the backward of the gather).
+ * table / dtable fp32 [(2ws-1)^2][heads], index int64 [N*N] (the module's relative_position_index buffer). */
+int stswin_bias_expand(const float* table, const long* index, const float* mask, float* out, int N, int heads, int nW,
+                       void* stream);
+int stswin_bias_scatter(const float* dbiasT, const long* index, float* dtable, int N, int heads, void* stream);
+
 /* ---- a6: windowed attention core (swin_512.py:117-138).  qkv [nB_*T*N][3C] = q (pre-scaled) | k | v in window
  * order; biasT [heads][N][N] and maskT [nW][N][N] are the expanded relative-position bias (:122-124) and the
  * SW-MSA mask (:126-131), both transposed to [key][query]; out [nB_*T*N][C] is the (B_, T*N, heads*d) layout of :136.

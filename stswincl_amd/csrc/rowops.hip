@@ -407,6 +407,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* y, long ldy, float
   }
 }
 
+// ---- relative position bias (swin_512.py:122-131): table[index] -> the attention kernels' [key][query] layout, with the
+// SW-MSA mask folded in per window, and the transposed scatter of its gradient.  One launch each instead of the
+// index / permute / contiguous / add chain (6 tiny kernels per block forward, index_add_ + permute per backward).
+__global__ __launch_bounds__(256) void bias_expand_kernel(const float* table, const long* index, const float* mask, float* out,
+                                                          int N, int heads, int nW) {
+  const long n = (long)nW * heads * N * N;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
+    const int i = (int)(t % N), j = (int)((t / N) % N);          // out[w][h][key j][query i]
+    const int h = (int)((t / ((long)N * N)) % heads), w = (int)(t / ((long)N * N * heads));
+    float v = table[index[(long)i * N + j] * heads + h];
+    if (mask) v += mask[((long)w * N + i) * N + j];
+    out[t] = v;
+  }
+}
+__global__ __launch_bounds__(256) void bias_scatter_kernel(const float* dbiasT, const long* index, float* dtable, int N, int heads) {
+  const long n = (long)heads * N * N;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
+    const int i = (int)(t % N), j = (int)((t / N) % N), h = (int)(t / ((long)N * N));
+    atomicAdd(dtable + index[(long)i * N + j] * heads + h, dbiasT[t]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" int stswin_win_rowmap(int* map, int B, int T, int H, int W, int ws, int shift, int f0, int frames_total,
                                  void* stream) {
@@ -583,6 +605,25 @@ extern "C" int stswin_colsum(int dtype, const void* y, long ldy, float* out, int
     hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)y, ldy, out, M, N, rpb);
   else
     hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, ldy, out, M, N, rpb);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_bias_expand(const float* table, const long* index, const float* mask, float* out, int N, int heads, int nW,
+                                  void* stream) {
+  if (N <= 0 || heads <= 0 || nW <= 0) return -1108;
+  const long n = (long)nW * heads * N * N;
+  hipLaunchKernelGGL(bias_expand_kernel, dim3((unsigned)min(2048L, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table,
+                     index, mask, out, N, heads, nW);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_bias_scatter(const float* dbiasT, const long* index, float* dtable, int N, int heads, void* stream) {
+  if (N <= 0 || heads <= 0) return -1109;
+  const long n = (long)heads * N * N;
+  hipLaunchKernelGGL(bias_scatter_kernel, dim3((unsigned)min(2048L, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dbiasT,
+                     index, dtable, N, heads);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

@@ -368,6 +368,22 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, *, M, rows=None, S=1,
 
 
 # ----------------------------------------------------------------------------------------------- attention
+def bias_expand(table, index, mask, N, heads):
+    """relative_position_bias_table[index] as [heads][key][query] fp32, or [nW][heads][key][query] with the mask added."""
+    nW = mask.shape[0] if mask is not None else 1
+    out = torch.empty((nW, heads, N, N) if mask is not None else (heads, N, N), dtype=torch.float32, device=table.device)
+    assert table.dtype == torch.float32 and table.is_contiguous() and index.dtype == torch.int64 and index.is_contiguous()
+    assert mask is None or (mask.dtype == torch.float32 and mask.is_contiguous())
+    _check(load().stswin_bias_expand(_p(table), _p(index), _p(mask), _p(out), N, heads, nW, _stream()), "bias_expand")
+    return out
+
+
+def bias_scatter(dbiasT, index, dtable, N, heads):
+    assert dbiasT.is_contiguous() and dtable.is_contiguous() and index.dtype == torch.int64 and index.is_contiguous()
+    _check(load().stswin_bias_scatter(_p(dbiasT), _p(index), _p(dtable), N, heads, _stream()), "bias_scatter")
+    return dtable
+
+
 def _bias_windows(biasT, maskT, nW):
     """biasT [heads][N][N] (+ optional maskT) or the pre-summed per-window table [nW][heads][N][N] (maskT None)."""
     if biasT.dim() == 4:

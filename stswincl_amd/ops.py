@@ -141,12 +141,11 @@ class SwinBlockFn(torch.autograd.Function):
         scale = d ** -0.5
         qkv = torch.empty(M, 3 * C, dtype=dt, device=dev)
         hip.gemm_nt(X2, wcast(qkv_w, dt), qkv, M=M, a_rows=rmap, bias=_f32(qkv_b), scale=scale, scale_cols=C)
-        biasT = expand_bias_T(table, index, N, heads)
+        # one [nW][heads][N][N] table = bias + SW-MSA mask (swin_512.py:122-131): the kernels then read one value per
+        # score instead of two (the separate mask read cost +60 % on the stage-1 forward kernel)
         maskT = None
-        if shift > 0 and attn_mask is not None:
-            # one [nW][heads][N][N] table = bias + SW-MSA mask (swin_512.py:122-131): the kernels then read one value per
-            # score instead of two (the separate mask read cost +60 % on the stage-1 forward kernel)
-            biasT = biasT.unsqueeze(0) + attn_mask.detach().float().transpose(1, 2).unsqueeze(1)
+        biasT = hip.bias_expand(_f32(table), index.reshape(-1).contiguous(),
+                                _f32(attn_mask) if shift > 0 and attn_mask is not None else None, N, heads)
         o = hip.win_attn_fwd(qkv, biasT, maskT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads, C=C)
         x1 = torch.empty(M, C, dtype=dt, device=dev)
         hip.gemm_nt(o, wcast(proj_w, dt), x1, M=M, c_rows=rmap, bias=_f32(proj_b), resid=X2, r_rows=rmap,
@@ -205,7 +204,7 @@ class SwinBlockFn(torch.autograd.Function):
         # attention core (also yields the dq third of the qkv bias gradient)
         dqkv = hip.win_attn_bwd(qkv, do, biasT, maskT, dbiasT, nB_=(M // (2 * N)), nW=nW, T=2, ws=ws, heads=heads,
                                 C=C, scale=d ** -0.5, colsum_out=dqkv_b)
-        dtable.index_add_(0, index.reshape(-1).long(), dbiasT.permute(2, 1, 0).reshape(N * N, heads))
+        hip.bias_scatter(dbiasT, index.reshape(-1).contiguous(), dtable, N, heads)
         # qkv
         hip.gemm_tn(dqkv, X2, dqkv_w, Mk=M, bt_rows=rmap, overwrite=True)
         dx = torch.empty(M, C, dtype=dt, device=dev)
@@ -268,7 +267,7 @@ class WindowAttentionFn(torch.autograd.Function):
         X2 = x.detach().to(dt).contiguous().view(M, C)
         qkv = torch.empty(M, 3 * C, dtype=dt, device=x.device)
         hip.gemm_nt(X2, wcast(qkv_w, dt), qkv, M=M, bias=_f32(qkv_b), scale=d ** -0.5, scale_cols=C)
-        biasT = expand_bias_T(table, index, N, heads)
+        biasT = hip.bias_expand(_f32(table), index.reshape(-1).contiguous(), None, N, heads)
         maskT = mask.detach().float().transpose(1, 2).contiguous() if mask is not None else None
         o = hip.win_attn_fwd(qkv, biasT, maskT, nB_=B_, nW=nW, T=T, ws=ws, heads=heads, C=C)
         y = torch.empty(M, C, dtype=dt, device=x.device)
@@ -297,7 +296,7 @@ class WindowAttentionFn(torch.autograd.Function):
         dqkv = hip.win_attn_bwd(qkv, do, biasT, maskT, dbiasT, nB_=M // (T * N), nW=nW, T=T, ws=ws, heads=heads, C=C,
                                 scale=d ** -0.5)
         dtable = z((2 * ws - 1) * (2 * ws - 1), heads)
-        dtable.index_add_(0, index.reshape(-1).long(), dbiasT.permute(2, 1, 0).reshape(N * N, heads))
+        hip.bias_scatter(dbiasT, index.reshape(-1).contiguous(), dtable, N, heads)
         dqkv_w, dqkv_b = z(3 * C, C), z(3 * C)
         hip.gemm_tn(dqkv, X2, dqkv_w, Mk=M)
         hip.colsum(dqkv, dqkv_b)
