@@ -103,7 +103,7 @@ DEVI void epi_piece(const GemmNT& p, float (&v)[8], const float (&bv)[8], float 
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < PACK; ++e) o.set(e, c2v[h * PACK + e]);
-        *(decltype(o.v)*)(dst + h * PACK) = o.v;
+        __builtin_nontemporal_store(o.v, (decltype(o.v)*)(dst + h * PACK));   // outputs stream past L2 (see readback)
       }
     } else {
       for (int e = 0; e < ncols; ++e) dst[e] = from_f32<T>(c2v[e]);
@@ -170,7 +170,7 @@ DEVI void epi_piece(const GemmNT& p, float (&v)[8], const float (&bv)[8], float 
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < PACK; ++e) o.set(e, v[h * PACK + e]);
-        *(decltype(o.v)*)(dst + h * PACK) = o.v;
+        __builtin_nontemporal_store(o.v, (decltype(o.v)*)(dst + h * PACK));   // outputs stream past L2 (see readback)
       }
     } else {
       for (int e = 0; e < ncols; ++e) dst[e] = from_f32<T>(v[e]);
@@ -443,6 +443,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   auto stamp = [&](int slot) {
     if (dbg_ts && tid == 0) ((unsigned long long*)p.colsum)[(long)blockIdx.x * 8 + slot] = wall_clock64();
   };
+  // Stagger (flag bit 17): the first round's workgroups start up to 7/8 of a tile time apart (8 phases among the CUs of an
+  // XCD).  All 256 CUs otherwise run in lock-step and their C stores (128 KB each: 32 MB per round, more than the L2s hold)
+  // leave as one burst; the next tile's first loads queue behind the CU's own share of that HBM write drain.
+  if ((p.flags & (1 << 17)) && blockIdx.x < 256) {
+    const unsigned long long t_go = wall_clock64() + (unsigned long long)(((blockIdx.x >> 3) & 7) * (nt + 4) * 100 / 8);
+    while (wall_clock64() < t_go) __builtin_amdgcn_s_sleep(8);
+  }
   stamp(0);
   auto epilogue = [&]() {
     if (p.flags & (1 << 21)) {        // DBG: no epilogue at all (keeps the accumulators alive)
@@ -570,6 +577,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     // output rows of this thread's readback pieces (c_rows is a scatter map): fetched before the LDS round trip
     const int rb_row = tid / CPRW, rb_chunk = tid % CPRW;
     const bool rb_col_ok = n0 + rb_chunk * 8 < p.N;
+    // The stores are non-temporal: a round of tiles writes 32 MB of C, as much as all eight L2s hold, and with ordinary
+    // stores that evicted the A / B panels the next tiles start on - their first 8 stages ran 4.3 us slower (7.2 vs
+    // 4.1 + 4.2 vs 2.95 us, tools/probes/loop_stamps.py; -15..25 % on the K = 512 shapes, tools/epi_decomp.py).
     // Two bodies: with a scatter map the output rows are fetched (as one batch) before the LDS round trip; without one
     // there must be NO load in the path - hipcc puts the wait of a conditional load at the join, executed either way,
     // and behind the stores of a first output (stores count in vmcnt) that wait sits out their whole drain.
@@ -587,18 +597,21 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
           const int row = ps * RPP + rb_row;
           if (orow[ps] >= 0) {
             const bf16x8 val = *(const bf16x8*)(img + row * PITCH + (((rb_chunk ^ (row & 15)) & (CPRW - 1)) << 4));
-            *(bf16x8*)((T*)Cout + (long)orow[ps] * ldo + n0 + rb_chunk * 8) = val;
+            __builtin_nontemporal_store(val, (bf16x8*)((T*)Cout + (long)orow[ps] * ldo + n0 + rb_chunk * 8));
           }
         }
       } else {
         __syncthreads();
+#ifdef STSWIN_DEBUG_LOOP_STAMPS                        // diagnosis build: bit 20 really drops the stores of this path
+        if (p.flags & (1 << 20)) return;
+#endif
         T* cbase = (T*)Cout + (long)(m0 + rb_row) * ldo + n0 + rb_chunk * 8;
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
           const int row = ps * RPP + rb_row;
           if (m0 + row < p.M && rb_col_ok) {
             const bf16x8 val = *(const bf16x8*)(img + row * PITCH + (((rb_chunk ^ (row & 15)) & (CPRW - 1)) << 4));
-            *(bf16x8*)(cbase + (long)(ps * RPP) * ldo) = val;
+            __builtin_nontemporal_store(val, (bf16x8*)(cbase + (long)(ps * RPP) * ldo));
           }
         }
       }
@@ -722,12 +735,14 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   };
   auto epilogue_reg = [&]() {
     if (p.flags & (1 << 21)) {        // DBG: no epilogue at all (keeps the accumulators alive)
+      stamp(3); stamp(4); stamp(5);
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < FI; ++i)
 #pragma unroll
         for (int j = 0; j < FJ; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
       if (t == 123.456f) ((T*)p.C)[tid] = from_f32<T>(t);
+      stamp(6);
       return;
     }
     const int mode = (p.bias ? E_BIAS : 0) | (p.scale_cols > 0 ? E_SCALE : 0) | ((p.flags & GF_GELU) ? E_GELU : 0) |
@@ -736,6 +751,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
                      ((p.flags & GF_C2_DGELU) ? E_C2D : 0);
     switch (mode) {                                   // the combinations the Swin / conv paths issue; anything else: generic
       case 0: epilogue_body(std::integral_constant<int, 0>{}); break;
+#ifndef STSWIN_DEBUG_ONLY_PLAIN_EPI                   // diagnosis build: a kernel with ONE epilogue body (code size experiment)
       case E_BIAS: epilogue_body(std::integral_constant<int, E_BIAS>{}); break;
       case E_BIAS | E_SCALE: epilogue_body(std::integral_constant<int, E_BIAS | E_SCALE>{}); break;
       case E_BIAS | E_GELU | E_C2: epilogue_body(std::integral_constant<int, E_BIAS | E_GELU | E_C2>{}); break;
@@ -746,6 +762,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
       case E_DGELU | E_COLSUM: epilogue_body(std::integral_constant<int, E_DGELU | E_COLSUM>{}); break;
       case E_COLSUM: epilogue_body(std::integral_constant<int, E_COLSUM>{}); break;
       default: epilogue_body(std::integral_constant<int, -1>{}); break;
+#else
+      default: epilogue_body(std::integral_constant<int, E_COLSUM>{}); break;   // (the timeline runs pass the stamp buffer as colsum)
+#endif
     }
   };
   for (int q = 0; q < NST - 1 && q < nt; ++q) issue(q);
@@ -836,6 +855,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     int kt = 0;
     if (p.S == 1) {
       for (; kt + NST - 1 < nt; ++kt) {
+#ifdef STSWIN_DEBUG_LOOP_STAMPS                        // diagnosis build only (tools/gemm_timeline.py loop): stage 4 / 8 / 12 times
+        if (kt == 4) stamp(1);
+        if (kt == 8) stamp(2);
+        if (kt == 12) stamp(7);
+#endif
         __builtin_amdgcn_s_barrier();
         issue(kt + NST - 1);
         read_frags(kt);
@@ -1005,7 +1029,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_stream_kernel(GemmNT p) {
         const int gm = m0 + wr * TM + h2 * 64 + row;
         if (gm < p.M && rb_col_ok) {
           const bf16x8 val = *(const bf16x8*)(img + row * 128 + ((rb_chunk ^ (row & 7)) << 4));
-          *(bf16x8*)((T*)Cout + (long)orow32[ps] * ldo + n0 + wc * TN + rb_chunk * 8) = val;
+          __builtin_nontemporal_store(val, (bf16x8*)((T*)Cout + (long)orow32[ps] * ldo + n0 + wc * TN + rb_chunk * 8));
         }
       }
     };

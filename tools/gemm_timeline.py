@@ -15,7 +15,8 @@ out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 nblk = (M // 256) * (N // 256)
 for _ in range(3):
     ts = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
-    hip.gemm_nt(A, W, out, M=M, flags=hip.GF_BIG | hip.GF_NOSTREAM | (1 << 19), colsum_out=ts.view(torch.float32))
+    hip.gemm_nt(A, W, out, M=M, flags=hip.GF_BIG | hip.GF_NOSTREAM | (1 << 19) | int(os.environ.get("STSWIN_TL_FLAGS", "0")),
+                colsum_out=ts.view(torch.float32))   # STSWIN_TL_FLAGS: 1048576 = no stores, 2097152 = no epilogue
 torch.cuda.synchronize()
 t = ts.view(nblk, 8).cpu().double()
 t0 = t[:, 0].min()
