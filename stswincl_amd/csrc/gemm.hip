@@ -78,7 +78,7 @@ DEVI void epi_prefetch(const GemmNT& p, Vec16<T> (&dst)[8 / TT<T>::PACK], int gm
   const long rrow = p.r_rows ? (long)p.r_rows[gm] : (long)gm;
   const T* src = (const T*)p.R + rrow * p.ldr + gn0;
 #pragma unroll
-  for (int h = 0; h < 8 / PACK; ++h) dst[h].v = *(const decltype(dst[h].v)*)(src + h * PACK);
+  for (int h = 0; h < 8 / PACK; ++h) dst[h].v = __builtin_nontemporal_load((const decltype(dst[h].v)*)(src + h * PACK));
 }
 
 template <typename T>
@@ -654,7 +654,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     int rrow[FI];
     auto load_r = [&](int i) {
 #pragma unroll
-      for (int j = 0; j < FJ; ++j) rr[i][j] = *(const bf16x4*)((const T*)p.R + (long)rrow[i] * p.ldr + min(colb + j * 16, p.N - 4));
+      for (int j = 0; j < FJ; ++j)                    // read once: streamed past L2 like the C stores
+        rr[i][j] = __builtin_nontemporal_load((const bf16x4*)((const T*)p.R + (long)rrow[i] * p.ldr + min(colb + j * 16, p.N - 4)));
     };
     if (has_r) {
 #pragma unroll
