@@ -51,6 +51,10 @@ DEVI void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+DEVI void glds16_nt(const void* gsrc, void* lds_wave_base) {        // same copy, non-temporal (read-once data)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
 // ---- buffer-addressed LDS-DMA: descriptor base (wave-uniform) + per-lane 32-bit byte offset + scalar byte offset.  The
 // descriptor claims 4 GB - 2 bytes, so an offset of 0xFFFFFFFF is out of range and the copy delivers zeros (edge rows,
 // convolution padding).  Kept inside __device__ helpers: the resource type does not exist in the host pass.

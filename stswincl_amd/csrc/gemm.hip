@@ -532,7 +532,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   // with the flags tested per fragment the 32 fragments of a wave spent 3.6 us of a 24 us tile in scalar branches
   // (tools/gemm_timeline.py).  MD >= 0: compile-time mode bits; MD < 0: generic fallback testing the runtime flags.
   enum { E_BIAS = 1, E_SCALE = 2, E_GELU = 4, E_C2 = 8, E_RESID = 16, E_DGELU = 32, E_COLSUM = 64, E_RELU = 128, E_MULR = 256, E_C2D = 512 };
-  auto epilogue_body = [&](auto tag) {
+  auto epilogue_body = [&](auto tag) __attribute__((always_inline)) {
     constexpr int MD = decltype(tag)::value;
 #define EPI_HAS(bit, rt) (MD >= 0 ? ((MD & (bit)) != 0) : (rt))
     constexpr int PITCH = BN * 2, CPRW = BN / 8, RPP = NTHR / CPRW, NPASS = BM / RPP;
@@ -644,28 +644,29 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     f32x4 cs[FJ];
 #pragma unroll
     for (int j = 0; j < FJ; ++j) cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // R (residual / GELU' factor) in the fragment layout, RAHEAD fragment rows in flight: the row indices come first as
-    // one batch (an index load next to each row's loads puts a vmcnt(0) - the join of the `r_rows ?` branch - between the
-    // rows), row i + RAHEAD is requested when row i has been consumed, into the registers its accumulators vacate.  (All
-    // FI rows at once cost 64 registers and spilled the column sums; with R in L2 the loads are free, from HBM the 32 MB
-    // that the 256 lock-stepped workgroups request per round take ~6 us whatever the depth - tools/epi_decomp.py.)
-    constexpr int RAHEAD = 4;
-    bf16x4 rr[FI][FJ];
-    int rrow[FI];
-    auto load_r = [&](int i) {
-#pragma unroll
-      for (int j = 0; j < FJ; ++j)                    // read once: streamed past L2 like the C stores
-        rr[i][j] = __builtin_nontemporal_load((const bf16x4*)((const T*)p.R + (long)rrow[i] * p.ldr + min(colb + j * 16, p.N - 4)));
-    };
+    // R (residual / GELU' factor): the whole [BM][BN] tile comes in by LDS-DMA, straight into the image positions that
+    // the results will overwrite (same row-major layout, same chunk ^ row swizzle, so a lane reads its 8-byte piece and
+    // later writes its 8-byte result to the very same address).  16 bytes per lane and whole 512-byte rows per request
+    // instead of 8-byte pieces of 16 different rows (fragment layout: 270 -> 2xx us on the fc2 input gradient), no
+    // registers, and the row map (if any) is fetched as one batch.  The launcher routes R with an unaligned pitch elsewhere.
     if (has_r) {
+      constexpr int RPW = 64 / CPRW;                   // image rows per wave request (a row = CPRW 16-byte chunks)
+      constexpr int RROWS = NTHR / 64 * RPW, RPASS = BM / RROWS;
+      int rq[RPASS];
 #pragma unroll
-      for (int i = 0; i < FI; ++i) rrow[i] = min(m0 + wr * TM + i * 16 + fr, p.M - 1);   // rows >= M / columns >= N: clamped, never stored
+      for (int q = 0; q < RPASS; ++q) rq[q] = min(m0 + q * RROWS + w * RPW + l / CPRW, p.M - 1);   // rows >= M / columns >= N: clamped, never stored
       if (p.r_rows) {
 #pragma unroll
-        for (int i = 0; i < FI; ++i) rrow[i] = p.r_rows[rrow[i]];
+        for (int q = 0; q < RPASS; ++q) rq[q] = p.r_rows[rq[q]];
       }
 #pragma unroll
-      for (int i = 0; i < RAHEAD && i < FI; ++i) load_r(i);
+      for (int q = 0; q < RPASS; ++q) {
+        const int row = q * RROWS + w * RPW + l / CPRW;
+        const int col = min(n0 + ((((l % CPRW) ^ (row & 15)) & (CPRW - 1)) << 3), p.N - 8);
+        glds16_nt((const T*)p.R + (long)rq[q] * p.ldr + col, img + (q * RROWS + w * RPW) * PITCH);
+      }
+      wait_vmcnt<0>();
+      __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < FI; ++i) {
@@ -689,7 +690,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
           v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
         }
         if (has_r) {
-          const f32x4 r = {(float)rr[i][j][0], (float)rr[i][j][1], (float)rr[i][j][2], (float)rr[i][j][3]};
+          const bf16x4 rb = *(const bf16x4*)(img + (wr * TM + i * 16 + fr) * PITCH +
+                                             (((((wc * TN + j * 16 + 4 * fq) >> 3) ^ fr) & (CPRW - 1)) << 4) + (fq & 1) * 8);
+          const f32x4 r = {(float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]};
           if (do_resid) v += r;
           else if (do_mulr) v *= r;
           else {
@@ -702,7 +705,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
         put(i, j, v);
         if (do_gelu || do_dgelu) __builtin_amdgcn_sched_barrier(0);   // one fragment's polynomial temporaries at a time
       }
-      if (has_r && i + RAHEAD < FI) load_r(i + RAHEAD);
       __builtin_amdgcn_sched_barrier(0);              // keep fragment rows apart: interleaved they spill
     }
     // Column sums leave BEFORE the C stores are issued: stores count in vmcnt, so any later wait on a load (a scratch
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     }
 #undef EPI_HAS
   };
-  auto epilogue_reg = [&]() {
+  auto epilogue_reg = [&]() __attribute__((always_inline)) {
     if (p.flags & (1 << 21)) {        // DBG: no epilogue at all (keeps the accumulators alive)
       stamp(3); stamp(4); stamp(5);
       float t = 0.f;
@@ -1688,10 +1690,10 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     static int once_big = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
                           (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)once_big;
-    // register epilogue (operand-swapped MFMA): bf16 output, every row piece 16-byte aligned, R readable in 8-byte pieces
+    // register epilogue (operand-swapped MFMA): bf16 output, every row piece 16-byte aligned, R rows copied by 16-byte LDS-DMA
     const bool regepi = !(flags & (GF_OUT_F32 | GF_ACCUM | GF_NOREGEPI)) && N % 8 == 0 && ldc % 8 == 0 && (!C2 || ldc2 % 8 == 0) &&
-                        (!R || ldr % 4 == 0) && ((uintptr_t)C % 16 == 0) && (!C2 || (uintptr_t)C2 % 16 == 0) &&
-                        (!R || (uintptr_t)R % 8 == 0) && (!bias || (uintptr_t)bias % 16 == 0);
+                        (!R || ldr % 8 == 0) && ((uintptr_t)C % 16 == 0) && (!C2 || (uintptr_t)C2 % 16 == 0) &&
+                        (!R || (uintptr_t)R % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0);
     static int once_swap = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)once_swap;
     // persistent streaming variant: plain Linear GEMMs (S = 1, no A gather) with the register epilogue
