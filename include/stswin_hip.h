@@ -128,16 +128,20 @@ int stswin_bias_scatter(const float* dbiasT, const long* index, float* dtable, i
  * bwd: dqkv gets (scale*dS k | dS^T q_s | P^T dO); dbiasT [heads][N][N] is atomically accumulated.
  * bias_windows = 1: biasT is [heads][N][N] and maskT (or NULL) is added per window as in :126-131.
  * bias_windows = nW: biasT is [nW][heads][N][N] = bias + mask already summed by the caller, maskT must be NULL
- * (one table read per score instead of two). */
+ * (one table read per score instead of two).
+ * bias_windows = U with bias_index (int [nW], values < U): biasT is [U][heads][N][N] and window w uses slot bias_index[w] - the
+ * SW-MSA mask has only 4 distinct window patterns (interior, last column, last row, corner), so the 64-window table of
+ * stage 1 (64 MB) shrinks to 4 MB and stays in L2. */
 int stswin_win_attn_fwd(int dtype, const void* qkv, long ld, void* out, long ldo, const float* biasT, const float* maskT,
-                        int nB_, int nW, int T_frames, int ws, int heads, int C, int bias_windows, void* stream);
+                        int nB_, int nW, int T_frames, int ws, int heads, int C, int bias_windows,
+                        const int* bias_index, void* stream);
 int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, long lddo, void* dqkv, long lddq,
                         const float* biasT, const float* maskT, float* dbiasT,
                         float* dqkv_q_colsum /* optional fp32 [C]: += column sums of the dq third (q bias gradient).
                            The other two thirds need no pass over dqkv: sum_rows dk = 0 exactly (rows of dS sum to
                            zero) and sum_rows dv = column sums of dout (softmax rows sum to one) */,
                         int nB_, int nW, int T_frames, int ws,
-                        int heads, int C, float scale, int bias_windows, void* stream);
+                        int heads, int C, float scale, int bias_windows, const int* bias_index, void* stream);
 
 /* ---- decode head on NHWC token matrices [M = frames*H*W][C]  (ASPP.py:33-52, base18.py:60-106) ---------------
  * Grouped BatchNorm2d: rows are `groups` equal groups with separate batch statistics (1 for the head; the number of

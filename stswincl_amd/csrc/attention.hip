@@ -24,7 +24,8 @@ struct AttnArgs {
   float* dqkv_colsum;             // bwd, optional: [C] fp32 += column sums of the dq third of dqkv (see include/stswin_hip.h)
   int nB_, nW, heads, C, N;       // nB_ = number of (clip, window) problems = B*nW
   float scale;                    // bwd: dq = scale * (dS k)
-  int bias_windows;               // 1: biasT is [heads][N][N]; nW: biasT is [nW][heads][N][N] with the mask already added
+  int bias_windows;               // 1: biasT is [heads][N][N]; > 1: biasT is [bias_windows][heads][N][N] with the mask already added
+  const int* bias_index;          // optional [nW]: table slot of each window (null: slot = window, bias_windows == nW)
 };
 
 template <int CPR> DEVI int swz_cpr(int row) {
@@ -153,7 +154,8 @@ DEVI void scores_softmax(f32x16 (&p)[NTOK / 32], const AttnArgs& a, const char* 
   // + bias + mask (transposed tables: [key n][query n], lanes contiguous in query)
   const int N = NC ? NC : a.N;
   const int qn = (q0 + lr) % N;
-  const float* bt = a.biasT + ((long)((a.bias_windows & 0xffffff) > 1 ? widx : 0) * a.heads + head) * N * N + qn;
+  const int slot = (a.bias_windows & 0xffffff) > 1 ? (a.bias_index ? a.bias_index[widx] : widx) : 0;
+  const float* bt = a.biasT + ((long)slot * a.heads + head) * N * N + qn;
   const float* mt = a.maskT ? a.maskT + (long)widx * N * N + qn : nullptr;
   // All table values are requested first and consumed afterwards.  (With the optional mask tested per element the loop
   // was load - branch - wait - add, 32 dependent L2 round trips: 11.7 of the backward kernel's 24 us per problem.)
@@ -648,19 +650,20 @@ static int attn_common(int dtype, AttnArgs& a, int T_frames, int ws, bool bwd, v
 
 extern "C" int stswin_win_attn_fwd(int dtype, const void* qkv, long ld, void* out, long ldo, const float* biasT,
                                    const float* maskT, int nB_, int nW, int T_frames, int ws, int heads, int C,
-                                   int bias_windows, void* stream) {
-  if (bias_windows != 1 && (bias_windows != nW || maskT)) return -1204;
-  AttnArgs a{qkv, ld, out, ldo, nullptr, 0, biasT, maskT, nullptr, nullptr, nB_, nW, heads, C, 0, 1.0f, bias_windows};
+                                   int bias_windows, const int* bias_index, void* stream) {
+  if (bias_windows != 1 && ((!bias_index && bias_windows != nW) || maskT)) return -1204;
+  AttnArgs a{qkv, ld, out, ldo, nullptr, 0, biasT, maskT, nullptr, nullptr, nB_, nW, heads, C, 0, 1.0f, bias_windows, bias_index};
   return attn_common(dtype, a, T_frames, ws, false, stream);
 }
 
 extern "C" int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, long lddo, void* dqkv, long lddq,
                                    const float* biasT, const float* maskT, float* dbiasT, float* dqkv_colsum, int nB_,
                                    int nW, int T_frames, int ws, int heads, int C, float scale, int bias_windows,
-                                   void* stream) {
+                                   const int* bias_index, void* stream) {
   const int dbg = bias_windows & (1 << 30);    // DBG (tools/attn_timeline.py): dqkv_colsum is a u64 [workgroups][16] timestamp buffer
   bias_windows &= ~(1 << 30);
-  if (bias_windows != 1 && (bias_windows != nW || maskT)) return -1204;
-  AttnArgs a{qkv, ld, dqkv, lddq, dout, lddo, biasT, maskT, dbiasT, dqkv_colsum, nB_, nW, heads, C, 0, scale, bias_windows | dbg};
+  if (bias_windows != 1 && ((!bias_index && bias_windows != nW) || maskT)) return -1204;
+  AttnArgs a{qkv, ld, dqkv, lddq, dout, lddo, biasT, maskT, dbiasT, dqkv_colsum, nB_, nW, heads, C, 0, scale, bias_windows | dbg,
+             bias_index};
   return attn_common(dtype, a, T_frames, ws, true, stream);
 }

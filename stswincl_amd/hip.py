@@ -384,27 +384,30 @@ def bias_scatter(dbiasT, index, dtable, N, heads):
     return dtable
 
 
-def _bias_windows(biasT, maskT, nW):
+def _bias_windows(biasT, maskT, nW, bias_index=None):
     """biasT [heads][N][N] (+ optional maskT) or the pre-summed per-window table [nW][heads][N][N] (maskT None)."""
     if biasT.dim() == 4:
-        assert maskT is None and biasT.shape[0] == nW
-        return nW
+        assert maskT is None and (biasT.shape[0] == nW or bias_index is not None)
+        return biasT.shape[0]
     return 1
 
 
-def win_attn_fwd(qkv, biasT, maskT, *, nB_, nW, T, ws, heads, C):
+def win_attn_fwd(qkv, biasT, maskT, *, nB_, nW, T, ws, heads, C, bias_index=None):
     out = torch.empty(qkv.shape[0], C, dtype=qkv.dtype, device=qkv.device)
     rc = load().stswin_win_attn_fwd(_dt(qkv), _p(qkv), _c_long(_ld(qkv)), _p(out), _c_long(_ld(out)), _p(biasT),
-                                    _p(maskT), nB_, nW, T, ws, heads, C, _bias_windows(biasT, maskT, nW), _stream())
+                                    _p(maskT), nB_, nW, T, ws, heads, C, _bias_windows(biasT, maskT, nW, bias_index), _p(bias_index),
+                                    _stream())
     _check(rc, "win_attn_fwd")
     return out
 
 
-def win_attn_bwd(qkv, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, scale, colsum_out=None, debug_ts=False):
+def win_attn_bwd(qkv, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, scale, colsum_out=None, debug_ts=False,
+                 bias_index=None):
     dqkv = torch.empty_like(qkv)
     rc = load().stswin_win_attn_bwd(_dt(qkv), _p(qkv), _c_long(_ld(qkv)), _p(dout), _c_long(_ld(dout)), _p(dqkv),
                                     _c_long(_ld(dqkv)), _p(biasT), _p(maskT), _p(dbiasT), _p(colsum_out), nB_, nW, T, ws, heads, C,
-                                    _c_float(scale), _bias_windows(biasT, maskT, nW) | ((1 << 30) if debug_ts else 0), _stream())
+                                    _c_float(scale), _bias_windows(biasT, maskT, nW, bias_index) | ((1 << 30) if debug_ts else 0),
+                                    _p(bias_index), _stream())
     _check(rc, "win_attn_bwd")
     return dqkv
 

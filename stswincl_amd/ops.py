@@ -98,6 +98,7 @@ def wcast(p: torch.Tensor, dtype: torch.dtype, transpose: bool = False) -> torch
 def clear_caches() -> None:
     _ROWMAPS.clear()
     _WCACHE.clear()
+    _UNIQ_MASKS.clear()
 
 
 def zeros_like_list(shapes, device, fill=True):
@@ -115,6 +116,25 @@ def zeros_like_list(shapes, device, fill=True):
 
 def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if p is None else p.detach().float().contiguous()
+
+
+_UNIQ_MASKS = {}
+
+
+def unique_windows(attn_mask: torch.Tensor):
+    """(distinct window masks fp32 [U][N][N], int32 [nW] slot of every window) of an SW-MSA mask buffer; cached per buffer
+    (torch.unique syncs with the host, so this runs once per module, in the first forward)."""
+    key = (attn_mask.data_ptr(), attn_mask._version, tuple(attn_mask.shape), attn_mask.device)
+    hit = _UNIQ_MASKS.get(key)
+    if hit is None:
+        nW = attn_mask.shape[0]
+        if os.environ.get("STSWIN_NO_MASK_DEDUP") == "1":      # A/B switch: one slot per window
+            u, inv = attn_mask.detach().float().reshape(nW, -1), torch.arange(nW, device=attn_mask.device)
+        else:
+            u, inv = torch.unique(attn_mask.detach().float().reshape(nW, -1), dim=0, return_inverse=True)
+        hit = (u.reshape(-1, *attn_mask.shape[1:]).contiguous(), inv.to(torch.int32).contiguous())
+        _UNIQ_MASKS[key] = hit
+    return hit
 
 
 def expand_bias_T(table: torch.Tensor, index: torch.Tensor, N: int, heads: int) -> torch.Tensor:
@@ -144,9 +164,11 @@ class SwinBlockFn(torch.autograd.Function):
         # one [nW][heads][N][N] table = bias + SW-MSA mask (swin_512.py:122-131): the kernels then read one value per
         # score instead of two (the separate mask read cost +60 % on the stage-1 forward kernel)
         maskT = None
-        biasT = hip.bias_expand(_f32(table), index.reshape(-1).contiguous(),
-                                _f32(attn_mask) if shift > 0 and attn_mask is not None else None, N, heads)
-        o = hip.win_attn_fwd(qkv, biasT, maskT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads, C=C)
+        # ... and the SW-MSA mask has only four distinct window patterns (interior / last column / last row / corner), so the
+        # table holds one slot per pattern (4 MB instead of 64 MB at stage 1: L2 resident) and a window -> slot index
+        umask, bidx = unique_windows(attn_mask) if shift > 0 and attn_mask is not None else (None, None)
+        biasT = hip.bias_expand(_f32(table), index.reshape(-1).contiguous(), umask, N, heads)
+        o = hip.win_attn_fwd(qkv, biasT, maskT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads, C=C, bias_index=bidx)
         x1 = torch.empty(M, C, dtype=dt, device=dev)
         hip.gemm_nt(o, wcast(proj_w, dt), x1, M=M, c_rows=rmap, bias=_f32(proj_b), resid=X2, r_rows=rmap,
                     flags=hip.GF_RESID)
@@ -161,6 +183,7 @@ class SwinBlockFn(torch.autograd.Function):
         ctx.geom = geom
         ctx.dt = dt
         ctx.in_dtype = x.dtype
+        ctx.bidx = bidx
         ctx.save_for_backward(X2, rmap, qkv, biasT, maskT, o, x1, mean2, rstd2, n2, h_pre, h, y2, mean1, rstd1,
                               qkv_w, proj_w, n1_w, n2_w, fc1_w, fc2_w, index)
         return out.view(Bp, T, L, C)
@@ -203,7 +226,7 @@ class SwinBlockFn(torch.autograd.Function):
         hip.gemm_nt(dx1, wcast(proj_w, dt, True), do, M=M, a_rows=rmap, colsum_out=dqkv_b[2 * C:])
         # attention core (also yields the dq third of the qkv bias gradient)
         dqkv = hip.win_attn_bwd(qkv, do, biasT, maskT, dbiasT, nB_=(M // (2 * N)), nW=nW, T=2, ws=ws, heads=heads,
-                                C=C, scale=d ** -0.5, colsum_out=dqkv_b)
+                                C=C, scale=d ** -0.5, colsum_out=dqkv_b, bias_index=ctx.bidx)
         hip.bias_scatter(dbiasT, index.reshape(-1).contiguous(), dtable, N, heads)
         # qkv
         hip.gemm_tn(dqkv, X2, dqkv_w, Mk=M, bt_rows=rmap, overwrite=True)
