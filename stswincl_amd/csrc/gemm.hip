@@ -1741,6 +1741,16 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     STSWIN_CHECK_LAUNCH();
     return 0;
   }
+  // few 128x128 tiles (ASPP's dilated 3x3 convolutions: M = 4096 -> 128 tiles on 256 CUs, K = 9216): 128x64 tiles double
+  // the workgroups; each CU can hold two of them
+  if (dtype == 0 && w8 && nblk <= 160 && N >= 128 && M >= 128 && !(flags & GF_NONARROW)) {
+    static int once_s = (int)hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16, 8, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
+    (void)once_s;
+    const int nb = ((M + 127) / 128) * ((N + 63) / 64);
+    hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8, 128, 64>), dim3(nb), dim3(512), 49152, (hipStream_t)stream, p);
+    STSWIN_CHECK_LAUNCH();
+    return 0;
+  }
   if (dtype == 0) {
     if (w8) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8>), dim3(nblk), dim3(512), 65536, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_nt_kernel<bf16, 4>), dim3(nblk), dim3(256), 65536, (hipStream_t)stream, p);

@@ -118,23 +118,26 @@ def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if p is None else p.detach().float().contiguous()
 
 
-_UNIQ_MASKS = {}
+_UNIQ_MASKS: Dict[int, tuple] = {}
 
 
 def unique_windows(attn_mask: torch.Tensor):
     """(distinct window masks fp32 [U][N][N], int32 [nW] slot of every window) of an SW-MSA mask buffer; cached per buffer
-    (torch.unique syncs with the host, so this runs once per module, in the first forward)."""
-    key = (attn_mask.data_ptr(), attn_mask._version, tuple(attn_mask.shape), attn_mask.device)
-    hit = _UNIQ_MASKS.get(key)
-    if hit is None:
+    object (id + weak reference, like wcast; torch.unique syncs with the host, so this runs once per module)."""
+    hit = _UNIQ_MASKS.get(id(attn_mask))
+    stamp = (attn_mask._version, attn_mask.data_ptr(), tuple(attn_mask.shape), attn_mask.device)
+    if hit is None or hit[0]() is not attn_mask or hit[1] != stamp:
         nW = attn_mask.shape[0]
         if os.environ.get("STSWIN_NO_MASK_DEDUP") == "1":      # A/B switch: one slot per window
             u, inv = attn_mask.detach().float().reshape(nW, -1), torch.arange(nW, device=attn_mask.device)
         else:
             u, inv = torch.unique(attn_mask.detach().float().reshape(nW, -1), dim=0, return_inverse=True)
-        hit = (u.reshape(-1, *attn_mask.shape[1:]).contiguous(), inv.to(torch.int32).contiguous())
-        _UNIQ_MASKS[key] = hit
-    return hit
+        if len(_UNIQ_MASKS) > 1024:
+            for k_ in [k_ for k_, v in _UNIQ_MASKS.items() if v[0]() is None]:
+                del _UNIQ_MASKS[k_]
+        hit = (weakref.ref(attn_mask), stamp, u.reshape(-1, *attn_mask.shape[1:]).contiguous(), inv.to(torch.int32).contiguous())
+        _UNIQ_MASKS[id(attn_mask)] = hit
+    return hit[2], hit[3]
 
 
 def expand_bias_T(table: torch.Tensor, index: torch.Tensor, N: int, heads: int) -> torch.Tensor:
