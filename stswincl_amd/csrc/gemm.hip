@@ -443,6 +443,17 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   auto stamp = [&](int slot) {
     if (dbg_ts && tid == 0) ((unsigned long long*)p.colsum)[(long)blockIdx.x * 8 + slot] = wall_clock64();
   };
+  // R tile by LDS-DMA, one 64-row block (= one ring stage buffer of the image layout) at a time; see the main loop's tail
+  constexpr bool R_EARLY_OK = SWAP && BM == 256 && BN == 256 && NST == 4 && PER_STAGE == 4 && NTHR == 512;
+  bool r_early = false;
+  auto issue_r_block = [&](int blk) {
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int row = (blk * 4 + qq) * 16 + w * 2 + (l >> 5);
+      const int col = min(n0 + (((l & 31) ^ (row & 15)) << 3), p.N - 8);
+      glds16_nt((const T*)p.R + (long)min(m0 + row, p.M - 1) * p.ldr + col, smem + ((blk * 4 + qq) * 16 + w * 2) * 512);
+    }
+  };
   // Stagger (flag bit 17): the first round's workgroups start up to 7/8 of a tile time apart (8 phases among the CUs of an
   // XCD).  All 256 CUs otherwise run in lock-step and their C stores (128 KB each: 32 MB per round, more than the L2s hold)
   // leave as one burst; the next tile's first loads queue behind the CU's own share of that HBM write drain.
@@ -649,7 +660,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     // later writes its 8-byte result to the very same address).  16 bytes per lane and whole 512-byte rows per request
     // instead of 8-byte pieces of 16 different rows (fragment layout: 270 -> 2xx us on the fc2 input gradient), no
     // registers, and the row map (if any) is fetched as one batch.  The launcher routes R with an unaligned pitch elsewhere.
-    if (has_r) {
+    if (has_r && r_early) {                            // three blocks are under way since the last stages; the fourth:
+      issue_r_block((nt - 1) % NST);
+      wait_vmcnt<0>();
+      __syncthreads();
+    } else if (has_r) {
       constexpr int RPW = 64 / CPRW;                   // image rows per wave request (a row = CPRW 16-byte chunks)
       constexpr int RROWS = NTHR / 64 * RPW, RPASS = BM / RROWS;
       int rq[RPASS];
@@ -869,6 +884,23 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
         wait_vmcnt<2 * PER_STAGE>();
         __builtin_amdgcn_s_barrier();
         mma_all();
+      }
+      // The last NST-1 iterations have no stage left to request - but the epilogue's R tile (residual / GELU' factor) lives
+      // in the same LDS as the ring, one 64-row block per stage buffer, and a block costs exactly PER_STAGE copies per
+      // wave.  So the loop keeps its steady-state form (same wait constant, no branches) and requests R block (kt-1) % NST
+      // into the buffer that stage kt-1 just vacated: three quarters of R are under way 1-3 stages before the epilogue.
+      if constexpr (R_EARLY_OK) {
+        if ((p.flags & (GF_RESID | GF_MUL_R | GF_MUL_DGELU)) && !p.r_rows && kt + NST - 1 == nt && !(p.flags & (1 << 18))) {
+          r_early = true;
+          for (; kt < nt; ++kt) {
+            __builtin_amdgcn_s_barrier();
+            issue_r_block((kt + NST - 1) % NST);
+            read_frags(kt);
+            wait_vmcnt<2 * PER_STAGE>();
+            __builtin_amdgcn_s_barrier();
+            mma_all();
+          }
+        }
       }
     }
     for (; kt < nt; ++kt) {                            // general form (tap-segmented A, and the last NST-1 stages)

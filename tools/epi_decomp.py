@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from stswincl_amd import hip
 
-NOSTORE, NOEPI, NOWARM = 1 << 20, 1 << 21, 1 << 17   # (third column: bit 17 = staggered start)
+NOSTORE, NOEPI, NOWARM = 1 << 20, 1 << 21, 1 << 18   # (third column: bit 18 = R blocks requested after the main loop instead of in its tail)
 
 
 def timeit(fn, iters=20):
@@ -25,7 +25,7 @@ def timeit(fn, iters=20):
 def main():
     dt, dev = torch.bfloat16, "cuda"
     shapes = [(65536, 2048, 512, "fc1 s1"), (16384, 4096, 1024, "fc1 s2"), (65536, 512, 2048, "fc2 s1"), (65536, 512, 512, "proj s1")]
-    print(f"{'shape':8s} {'epilogue':14s} {'full':>8s} {'nostore':>8s} {'stagger':>8s}   (us; 'none' = no epilogue; third column: staggered workgroup start)")
+    print(f"{'shape':8s} {'epilogue':14s} {'full':>8s} {'nostore':>8s} {'late R':>8s}   (us; 'none' = no epilogue; third column: R tile requested after the main loop)")
     for M, N, K, note in shapes:
         A = torch.randn(M, K, device=dev).to(dt)
         W = (torch.randn(N, K, device=dev) / K ** 0.5).to(dt)
