@@ -902,6 +902,27 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
           }
         }
       }
+      // Without R: the three draining iterations, straight-line with their own wait counts (one stage in flight, none, none)
+      // instead of the general form's ten scalar branches per stage.
+      if (kt + NST - 1 == nt && NST == 4) {
+        __builtin_amdgcn_s_barrier();
+        read_frags(kt);
+        wait_vmcnt<PER_STAGE>();
+        __builtin_amdgcn_s_barrier();
+        mma_all();
+        ++kt;
+        __builtin_amdgcn_s_barrier();
+        read_frags(kt);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        mma_all();
+        ++kt;
+        __builtin_amdgcn_s_barrier();
+        read_frags(kt);
+        __builtin_amdgcn_s_barrier();
+        mma_all();
+        ++kt;
+      }
     }
     for (; kt < nt; ++kt) {                            // general form (tap-segmented A, and the last NST-1 stages)
       __builtin_amdgcn_s_barrier();
