@@ -138,6 +138,27 @@ def contrast_main(a):
         opt.step()
         return loss
 
+    graph = None
+    if a.graph == 1 or (a.graph == -1 and world == 1 and a.no_profile):
+        # the contrastive step is ~2400 launches of 20-70 us kernels (8 encoder passes at 256x256): eager launches keep the
+        # GPU only 68 % busy (profiles/r01_v13_contrast_steady_state_kernels.txt); one hipGraph replay removes the host from
+        # the loop
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = step()
+
+        def step():  # noqa: F811
+            graph.replay()
+            return static_loss
+
     for _ in range(a.warmup):
         loss = step()
     torch.cuda.synchronize()
@@ -169,7 +190,8 @@ def contrast_main(a):
                "config": {"workload": f"BASELINE.json configs[3]: PixPro-style ConsistencyLoss, {B} x 6 clips/GPU x T=4 x 3x{S}x{S} "
                                       f"(224 is illegal for windows 8/4), per-sample label-guided loss as in the reference "
                                       f"(no bank); SGD instead of LARS", "clips_per_gpu": 6 * B, "parallelism": f"dp{world}",
-                          "input_frames_per_s": world * 6 * B * 4 * a.steps / dt, "loss": float(loss)}}
+                          "input_frames_per_s": world * 6 * B * 4 * a.steps / dt, "loss": float(loss),
+                          "launch": "hipGraph replay of the whole step" if graph is not None else "eager launches"}}
         if "contrast_fwd_bf16" in prof:
             p = prof["contrast_fwd_bf16"]
             tf = p["work"] / (p["ms_total"] * 1e-3) / 1e12

@@ -17,6 +17,9 @@ from .ops import compute_dtype, _f32
 KGRAN = 64  # channel padding granule (bf16 GEMM K tile; also valid for the f32 path)
 
 
+_INDEX_MAPS = {}
+
+
 class Layout:
     """segments (logical_start, length, padded_start); width = padded channel count."""
 
@@ -59,15 +62,17 @@ class Layout:
         return (tuple(self.segs), self.width)
 
     def index_map(self, device) -> torch.Tensor:
-        """int32 [width]: logical channel of every padded position, -1 for padding (cached per device)."""
-        cache = self.__dict__.setdefault("_imaps", {})
-        m = cache.get(device)
+        """int32 [width]: logical channel of every padded position, -1 for padding.  Cached per (layout, device) in a
+        module-level table: Layout objects are created per call (Layout.dense), and an uncached map is a host-to-device
+        copy per convolution per step (and illegal during hipGraph capture)."""
+        key = (self.key(), str(device))
+        m = _INDEX_MAPS.get(key)
         if m is None:
             m = torch.full((self.width,), -1, dtype=torch.int32)
             for a, n, b in self.segs:
                 m[b:b + n] = torch.arange(a, a + n, dtype=torch.int32)
             m = m.to(device)
-            cache[device] = m
+            _INDEX_MAPS[key] = m
         return m
 
 
