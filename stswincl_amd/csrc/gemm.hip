@@ -1503,7 +1503,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
   // below runs two iterations per trip and requests the NEXT trip's pair of sets at its top, i.e. two / three iterations
   // before their use and with no other scalar request in between.
   struct IdxSet { int4v x0, x1; };
-  IdxSet SA0, SA1, SB0, SB1;
+  IdxSet SA0, SA1, SB0, SB1, SC0, SC1;
   int ixmax = 0;                                    // largest index seen: range-checked once, after the loop
   auto load_idx = [&](IdxSet& d, int q) {            // (maps: Mk % 32 == 0, so every stage is whole and 16-byte aligned)
     d.x0 = (int4v){0, 0, 0, 0}; d.x1 = (int4v){-1, -1, -1, -1};
@@ -1511,8 +1511,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
       if (q >= nt) return;
       const int mb = (s_begin + q) * BMK + w * 4;   // wave-uniform
       const int* map = MAP_A ? p.at_rows : p.bt_rows;
+#ifdef STSWIN_DEBUG_TN_NOSMEM                          // diagnosis build: identity indices computed in SALU, no scalar loads in the loop
+      d.x0 = (int4v){mb, mb + 1, mb + 2, mb + 3};
+      if constexpr (TAPS) d.x1 = d.x0;
+      (void)map;
+#else
       d.x0 = *(cint4)(map + (TAPS ? (long)tapA0 * p.Mk : 0L) + mb);
       if constexpr (TAPS) d.x1 = *(cint4)(map + (long)tapA1 * p.Mk + mb);
+#endif
     }
   };
   auto issue = [&](int q, const IdxSet& ix) {        // stage q of this split -> ring slot q & 3
@@ -1520,7 +1526,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
     char* Ab = smem + (q & 3) * STAGE;
     char* Bb = Ab + OP_BYTES;
     const int mb = (s_begin + q) * BMK;              // first contraction row of the stage (wave-uniform)
-    const bool whole = mb + BMK <= p.Mk;             // (always true with maps)
+    const bool whole = MAPS || mb + BMK <= p.Mk;     // (maps: Mk % 32 == 0, the launcher checks it - no test in the loop)
     unsigned s0[4], s1[4];
     if constexpr (MAPS) {
       const unsigned pitch = MAP_A ? pitchA : pitchB;
@@ -1586,28 +1592,40 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
   };
   if (nt > 0) {
     for (int q = 0; q < NST - 1 && q < nt; ++q) { load_idx(SA0, q); issue(q, SA0); }   // prologue: blocking index loads
-    load_idx(SA0, NST - 1);                            // sets for iterations 0 and 1 of the steady loop
+    load_idx(SA0, NST - 1);                            // sets for iterations 0 and 1 of the steady loop ...
     load_idx(SA1, NST);
+    load_idx(SB0, NST + 1);                            // ... and for iterations 2 and 3 (maps only; no-ops otherwise)
+    load_idx(SB1, NST + 2);
     stamp(1);
     wait_tile(0);
     stamp(2);
     if (lag) __builtin_amdgcn_s_barrier();
     // steady state without data-dependent branches (see gemm_nt_ring_kernel): both rows wait for their share of stage
-    // kt+1 right behind their fragment reads, with the constant "two younger stages" count
+    // kt+1 right behind their fragment reads, with the constant "two younger stages" count.
+    // Scalar map loads: SMEM returns out of order, so hipcc turns the first use of ANY loaded set into lgkmcnt(0), a wait
+    // for everything in flight.  Requested at the top of an iteration (as before) the fresh pair was waited for at once
+    // (+0.12 us per stage).  Now a pair is requested behind an even iteration's MFMAs, four iterations before its use: the
+    // next lgkmcnt(0) - the odd iteration's fragment reads - finds it (nearly) landed, and the sets used meanwhile were
+    // covered by earlier waits.  Three pairs rotate: A in use, B next trip, C in flight.
     auto body = [&](int kt, const IdxSet& cur, IdxSet* n0, IdxSet* n1) {
       __builtin_amdgcn_s_barrier();
-      if (n0) { load_idx(*n0, kt + 2 + NST - 1); load_idx(*n1, kt + 3 + NST - 1); }   // for the iterations kt+2 and kt+3
       issue(kt + NST - 1, cur);
       read_frags(kt);
       wait_vmcnt<2 * PER_STAGE>();
       __builtin_amdgcn_s_barrier();
       mma_all();
+      if (MAPS && n0) {                                // (behind the last fragment wait: a pending scalar load turns the
+        __builtin_amdgcn_sched_barrier(0);             //  staged lgkmcnt(N) waits of the fragment reads into lgkmcnt(0))
+        load_idx(*n0, kt + 4 + NST - 1);               // for the iterations kt+4 and kt+5
+        load_idx(*n1, kt + 5 + NST - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     };
     int kt = 0;
-    for (; kt + 2 + NST - 1 <= nt; kt += 2) {          // 2 iterations per trip; the pair requested here is used in the next trip
-      body(kt, SA0, &SB0, &SB1);
+    for (; kt + 2 + NST - 1 <= nt; kt += 2) {          // 2 iterations per trip
+      body(kt, SA0, &SC0, &SC1);
       body(kt + 1, SA1, nullptr, nullptr);
-      SA0 = SB0; SA1 = SB1;                           // (requested two iterations ago: landed)
+      SA0 = SB0; SA1 = SB1; SB0 = SC0; SB1 = SC1;
     }
     // remainder (< 2 requesting iterations): SA0 / SA1 hold the sets of kt and kt+1
     for (int r = 0; kt + NST - 1 < nt; ++kt, ++r) {
