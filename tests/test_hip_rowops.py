@@ -59,7 +59,7 @@ def test_merge_and_conv_rowmaps():
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("m,c", [(37, 512), (64, 1024), (9, 2048), (130, 128), (5, 64)])
+@pytest.mark.parametrize("m,c", [(37, 512), (64, 1024), (9, 2048), (130, 128), (5, 64), (4100, 512)])   # M >= 4096: replica workspace + fold
 def test_layernorm_fwd_bwd(dtype, m, c):
     torch.manual_seed(1)
     x = (torch.randn(m, c) * 2 + 0.5).to(dtype)
@@ -109,3 +109,24 @@ def test_colsum(dtype):
     out = torch.zeros(264, device="cuda")
     hip.colsum(y.cuda(), out)
     assert torch.allclose(out.cpu(), y.float().sum(0), atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("N,heads,nW", [(64, 4, 1), (64, 16, 5), (16, 4, 3)])
+def test_relative_position_bias_expand_and_scatter(N, heads, nW):
+    """stswin_bias_expand / stswin_bias_scatter against the indexing of swin_512.py:122-131 and its autograd backward."""
+    torch.manual_seed(N + heads)
+    ws = int(N ** 0.5)
+    tsz = (2 * ws - 1) ** 2
+    table = torch.randn(tsz, heads, requires_grad=True)
+    index = torch.randint(0, tsz, (N * N,))
+    mask = torch.where(torch.rand(nW, N, N) < 0.3, torch.full((nW, N, N), -100.0), torch.zeros(nW, N, N)) if nW > 1 else None
+    ref = table[index].reshape(N, N, heads).permute(2, 0, 1)                  # [h][query i][key j]
+    ref_full = ref.unsqueeze(0) + mask.unsqueeze(1) if mask is not None else ref.unsqueeze(0)
+    out = hip.bias_expand(table.detach().cuda(), index.cuda(), mask.cuda() if mask is not None else None, N, heads)
+    out = out.reshape(nW, heads, N, N)
+    assert torch.equal(out.cpu(), ref_full.detach().transpose(2, 3).contiguous()), "[slot][h][key][query]"
+    g = torch.randn(heads, N, N)                                              # d(loss)/d(bias)[h][key j][query i]
+    (ref * g.transpose(1, 2)).sum().backward()
+    dtable = torch.zeros(tsz, heads, device="cuda")
+    hip.bias_scatter(g.cuda(), index.cuda(), dtable, N, heads)
+    assert torch.allclose(dtable.cpu(), table.grad, atol=1e-4, rtol=1e-5)
