@@ -156,8 +156,10 @@ int stswin_bn_finalize(int dtype, const void* x, long ldx, const float* sum, con
 int stswin_bn_apply(int dtype, const void* x, long ldx, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, const void* resid, long ldr, void* y, long ldy, int M, int C, int groups, int relu,
                     void* stream);
-int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const void* y, long ldy, const float* mean,
-                  const float* rstd, const float* gamma, float* s1, float* s2, void* dx, long lddx, void* dresid, long lddr,
+int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx,
+                  const void* y /* stored output (ReLU mask); NULL with relu: the mask is recomputed from x, needs beta */,
+                  long ldy, const float* mean, const float* rstd, const float* gamma, const float* beta /* may be NULL if y is given */,
+                  float* s1, float* s2, void* dx, long lddx, void* dresid, long lddr,
                   int M, int C, int groups, int relu, int training,
                   int phase /* 0 both passes, 1 reduce only, 2 dx only: SyncBatchNorm all-reduces s1/s2 in between */,
                   long rows_total /* rows per group over all ranks (0 = local) */, void* stream);

@@ -129,7 +129,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, long lddy, const T* x, long ldx, const T* y, long ldy,
                                                              const float* mean, const float* rstd, float* s1, float* s2,
                                                              int C, int group_rows, int chunks_per_group, int rows_per_chunk,
-                                                             int relu, int cpb) {
+                                                             int relu, int cpb, const float* gamma, const float* beta) {
   constexpr int PACK = TT<T>::PACK;
   __shared__ float part[2][256 * 8];
   const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
@@ -138,21 +138,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, long ld
   const long gr0 = (long)g * group_rows;
   float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c < C) {
-    float mu[8], rs[8];
+    // ReLU mask: from the stored output y, or - when there is no residual, y == NULL - recomputed from x (the sign of
+    // (x - mean) * rstd * gamma + beta): one tensor less to read in both passes
+    const bool remask = relu && y == nullptr;
+    float mu[8], rs[8], ga[8], be[8];
 #pragma unroll
-    for (int e = 0; e < PACK; ++e) { mu[e] = mean[(long)g * C + c + e]; rs[e] = rstd[(long)g * C + c + e]; }
+    for (int e = 0; e < PACK; ++e) {
+      mu[e] = mean[(long)g * C + c + e]; rs[e] = rstd[(long)g * C + c + e];
+      ga[e] = remask ? gamma[c + e] : 0.f; be[e] = remask ? beta[c + e] : 0.f;
+    }
     const int r_end = min(group_rows, (ch + 1) * rows_per_chunk);
     for (int r = ch * rows_per_chunk + rl; r < r_end; r += nrl) {
       Vec16<T> d, xi, yo;
       d.v = *(const decltype(d.v)*)(dy + (gr0 + r) * lddy + c);
       xi.v = *(const decltype(xi.v)*)(x + (gr0 + r) * ldx + c);
-      if (relu) yo.v = *(const decltype(yo.v)*)(y + (gr0 + r) * ldy + c);
+      if (relu && !remask) yo.v = *(const decltype(yo.v)*)(y + (gr0 + r) * ldy + c);
 #pragma unroll
       for (int e = 0; e < PACK; ++e) {
         float dv = d.get(e);
-        if (relu && !(yo.get(e) > 0.f)) dv = 0.f;
+        const float xh = (xi.get(e) - mu[e]) * rs[e];
+        if (relu && !((remask ? xh * ga[e] + be[e] : yo.get(e)) > 0.f)) dv = 0.f;
         a1[e] += dv;
-        a2[e] += dv * (xi.get(e) - mu[e]) * rs[e];
+        a2[e] += dv * xh;
       }
     }
   }
@@ -177,7 +184,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* dy, long lddy, 
                                                          const float* mean, const float* rstd, const float* gamma,
                                                          const float* s1, const float* s2, T* dx, long lddx, T* dres,
                                                          long lddr, int C, int group_rows, int chunks_per_group,
-                                                         int rows_per_chunk, int relu, int training, int cpb, float inv_n) {
+                                                         int rows_per_chunk, int relu, int training, int cpb, float inv_n,
+                                                         const float* beta) {
   constexpr int PACK = TT<T>::PACK;
   const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
   const int c = (blockIdx.x * cpb + cp) * PACK;
@@ -185,11 +193,13 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* dy, long lddy, 
   const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
   const long gr0 = (long)g * group_rows;
   // dx = A*dyr + B*x + D  with  A = gamma*rstd, B = -A*rstd*s2/n, D = -A*s1/n - B*mean      (training)
-  float ka[8], kb[8], kd[8];
+  const bool remask = relu && y == nullptr;              // mask recomputed exactly as in bn_bwd_reduce_kernel
+  float ka[8], kb[8], kd[8], mu[8], rs[8], ga[8], be[8];
 #pragma unroll
   for (int e = 0; e < PACK; ++e) {
     const long gc = (long)g * C + c + e;
     const float A = gamma[c + e] * rstd[gc];
+    mu[e] = mean[gc]; rs[e] = rstd[gc]; ga[e] = gamma[c + e]; be[e] = remask ? beta[c + e] : 0.f;
     ka[e] = A;
     kb[e] = training ? -A * rstd[gc] * s2[gc] * inv_n : 0.f;
     kd[e] = training ? -A * s1[gc] * inv_n - kb[e] * mean[gc] : 0.f;
@@ -199,11 +209,11 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* dy, long lddy, 
     Vec16<T> d, xi, yo, o, od;
     d.v = *(const decltype(d.v)*)(dy + (gr0 + r) * lddy + c);
     xi.v = *(const decltype(xi.v)*)(x + (gr0 + r) * ldx + c);
-    if (relu) yo.v = *(const decltype(yo.v)*)(y + (gr0 + r) * ldy + c);
+    if (relu && !remask) yo.v = *(const decltype(yo.v)*)(y + (gr0 + r) * ldy + c);
 #pragma unroll
     for (int e = 0; e < PACK; ++e) {
       float dv = d.get(e);
-      if (relu && !(yo.get(e) > 0.f)) dv = 0.f;
+      if (relu && !((remask ? (xi.get(e) - mu[e]) * rs[e] * ga[e] + be[e] : yo.get(e)) > 0.f)) dv = 0.f;
       o.set(e, ka[e] * dv + kb[e] * xi.get(e) + kd[e]);
       od.set(e, dv);
     }
@@ -467,11 +477,12 @@ extern "C" int stswin_bn_apply(int dtype, const void* x, long ldx, const float* 
 }
 
 extern "C" int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const void* y, long ldy,
-                             const float* mean, const float* rstd, const float* gamma, float* s1, float* s2, void* dx,
-                             long lddx, void* dresid, long lddr, int M, int C, int groups, int relu, int training,
+                             const float* mean, const float* rstd, const float* gamma, const float* beta, float* s1, float* s2,
+                             void* dx, long lddx, void* dresid, long lddr, int M, int C, int groups, int relu, int training,
                              int phase, long rows_total, void* stream) {
   const int pk = PACK_OF(dtype);
-  if (C % pk || ldx % pk || lddy % pk || lddx % pk || (relu && ldy % pk) || groups <= 0 || M % groups) return -1403;
+  if (C % pk || ldx % pk || lddy % pk || lddx % pk || (relu && y && ldy % pk) || groups <= 0 || M % groups) return -1403;
+  if (relu && !y && !beta) return -1404;               // no stored output: the mask is recomputed and needs beta
   const int ppr = C / pk, cpb = pick_cpb(ppr);
   const int gr = M / groups, rpc = reduce_rows_per_chunk(gr, groups * ((ppr + cpb - 1) / cpb), 256 / cpb);
   const int cpg = (gr + rpc - 1) / rpc;
@@ -481,11 +492,11 @@ extern "C" int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x
   hipStream_t st = (hipStream_t)stream;
   const float inv_n = 1.0f / (float)(rows_total > 0 ? rows_total : gr);
   if (phase != 2)
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb),
-             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb, gamma, beta),
+             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb, gamma, beta));
   if (phase != 1)
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16>, g2, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, gamma, s1, s2, (bf16*)dx, lddx, (bf16*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n),
-             hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, gamma, s1, s2, (float*)dx, lddx, (float*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16>, g2, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, gamma, s1, s2, (bf16*)dx, lddx, (bf16*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n, beta),
+             hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, gamma, s1, s2, (float*)dx, lddx, (float*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n, beta));
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

@@ -6,6 +6,7 @@ kernels of csrc/headops.hip.  `Layout` describes where logical channels sit insi
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
@@ -18,6 +19,7 @@ KGRAN = 64  # channel padding granule (bf16 GEMM K tile; also valid for the f32 
 
 
 _INDEX_MAPS = {}
+_BN_KEEP_Y = os.environ.get("STSWIN_BN_KEEP_Y") == "1"      # A/B switch: ReLU mask from the stored output everywhere
 
 
 class Layout:
@@ -302,27 +304,29 @@ class BNTokFn(torch.autograd.Function):
         R = resid.detach().to(dt) if resid is not None else None
         hip.bn_apply(X, mean, rstd, gp, bp, y, resid=R, groups=groups, relu=relu)
         ctx.cfg = (training, relu, groups, lay, dt, x.dtype, resid is not None, world, rows_total)
-        ctx.save_for_backward(X, y, mean, rstd, gp)
+        # without a residual the backward recomputes the ReLU mask from X (one tensor less to read in both of its passes)
+        keep_y = relu and (resid is not None or _BN_KEEP_Y)
+        ctx.save_for_backward(X, y if keep_y else None, mean, rstd, gp, bp if relu else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        X, y, mean, rstd, gp = ctx.saved_tensors
+        X, y, mean, rstd, gp, bp = ctx.saved_tensors
         training, relu, groups, lay, dt, in_dtype, has_res, world, rows_total = ctx.cfg
         g = dy.detach().to(dt).contiguous()
         dx = torch.empty_like(X)
         dres = torch.empty_like(X) if has_res else None
         if training and world > 1:
             import torch.distributed as dist
-            s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, phase=1)
+            s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, phase=1, beta=bp)
             loc1, loc2 = s1.clone(), s2.clone()                 # weight/bias grads stay local sums (DDP averages them)
             both = torch.stack([s1, s2])
             dist.all_reduce(both)
             hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, phase=2,
-                       sums=(both[0].contiguous(), both[1].contiguous()), rows_total=rows_total)
+                       sums=(both[0].contiguous(), both[1].contiguous()), rows_total=rows_total, beta=bp)
             s1, s2 = loc1, loc2
         else:
-            s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training)
+            s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, beta=bp)
         if groups > 1:                                   # s1 / s2 are the two halves of one [2][groups][C] buffer: one reduce
             if s1.data_ptr() + s1.numel() * 4 == s2.data_ptr():
                 both = torch.as_strided(s1, (2, groups, s1.shape[-1]), (groups * s1.shape[-1], s1.shape[-1], 1)).sum(1)

@@ -443,7 +443,7 @@ def bn_apply(x, mean, rstd, gamma, beta, out, resid=None, groups=1, relu=True, M
 
 
 def bn_bwd(dy, x, y, mean, rstd, gamma, dx, dresid=None, groups=1, relu=True, training=True, M=None, phase=0, sums=None,
-           rows_total=0):
+           rows_total=0, beta=None):
     M = x.shape[0] if M is None else M
     C = x.shape[1]
     if sums is None:
@@ -452,7 +452,7 @@ def bn_bwd(dy, x, y, mean, rstd, gamma, dx, dresid=None, groups=1, relu=True, tr
     else:
         s1, s2 = sums
     _check(load().stswin_bn_bwd(_dt(x), _p(dy), _c_long(_ld(dy)), _p(x), _c_long(_ld(x)), _p(y),
-                                _c_long(_ld(y) if y is not None else 0), _p(mean), _p(rstd), _p(gamma), _p(s1), _p(s2),
+                                _c_long(_ld(y) if y is not None else 0), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(s1), _p(s2),
                                 _p(dx), _c_long(_ld(dx)), _p(dresid), _c_long(_ld(dresid) if dresid is not None else 0), M, C,
                                 groups, 1 if relu else 0, 1 if training else 0, phase, _c_long(rows_total), _stream()), "bn_bwd")
     return s1, s2
