@@ -148,21 +148,25 @@ int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, l
  * frames when the per-frame ResNet calls of base18.py:86-89 are batched).  colstats accumulates pivot-shifted sums
  * (sumsq may be NULL: plain grouped column sums = adaptive_avg_pool numerator, ASPP.py:43); bn_finalize turns them
  * into mean / rstd and applies nn.BatchNorm2d's running-stat update group by group; bn_apply fuses affine +
- * residual + ReLU (resnet.py:42-51); bn_bwd = the two-pass backward (s1/s2 fp32 [groups][C], zeroed by the caller). */
-int stswin_colstats(int dtype, const void* x, long ldx, float* sum, float* sumsq, int M, int C, int groups, void* stream);
+ * residual + ReLU (resnet.py:42-51); bn_bwd = the two-pass backward (s1/s2 fp32 [groups][C], zeroed by the caller).
+ * unit_rows = 0: the groups are contiguous row blocks.  unit_rows > 0: group g owns the units g, g + groups, g + 2 groups, ...
+ * of unit_rows rows each - frame t of every clip when the 4-frame clips are stored clip-major, so that the per-frame
+ * statistics of base18.py:86-89 need no frame-major copy of the batch. */
+int stswin_colstats(int dtype, const void* x, long ldx, float* sum, float* sumsq, int M, int C, int groups, int unit_rows,
+                    void* stream);
 int stswin_bn_finalize(int dtype, const void* x, long ldx, const float* sum, const float* sumsq, float* mean, float* rstd,
                        float* running_mean, float* running_var, int M, int C, int groups, float eps, float momentum,
-                       void* stream);
+                       int unit_rows, void* stream);
 int stswin_bn_apply(int dtype, const void* x, long ldx, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, const void* resid, long ldr, void* y, long ldy, int M, int C, int groups, int relu,
-                    void* stream);
+                    int unit_rows, void* stream);
 int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx,
                   const void* y /* stored output (ReLU mask); NULL with relu: the mask is recomputed from x, needs beta */,
                   long ldy, const float* mean, const float* rstd, const float* gamma, const float* beta /* may be NULL if y is given */,
                   float* s1, float* s2, void* dx, long lddx, void* dresid, long lddr,
                   int M, int C, int groups, int relu, int training,
                   int phase /* 0 both passes, 1 reduce only, 2 dx only: SyncBatchNorm all-reduces s1/s2 in between */,
-                  long rows_total /* rows per group over all ranks (0 = local) */, void* stream);
+                  long rows_total /* rows per group over all ranks (0 = local) */, int unit_rows, void* stream);
 /* out[r][c] (+)= v[r / (M/groups)][c] * scale : image-pool broadcast (ASPP.py:46) and avg-pool backward */
 int stswin_rows_broadcast(int dtype, const float* v, void* out, long ldo, int M, int C, int groups, float scale,
                           int accumulate, void* stream);

@@ -17,6 +17,21 @@ static int reduce_rows_per_chunk(int group_rows, int other_blocks, int nrl) {
   return rpc;
 }
 
+// First physical row of the rows a block works on, minus its first row index inside the group: contiguous groups
+// (unit == 0) start at g * group_rows; interleaved groups (unit > 0: group g owns the units g, g + G, g + 2G, ... of `unit`
+// rows - frame t of every clip when the batch is stored clip-major) map the chunk's unit; a chunk never straddles a unit
+// (the launchers make rows_per_chunk divide unit).
+DEVI long group_row0(int g, int ch, int rows_per_chunk, int group_rows, int unit, int G) {
+  if (unit <= 0) return (long)g * group_rows;
+  return ((long)((ch * rows_per_chunk) / unit) * (G - 1) + g) * unit;
+}
+DEVI long group_first_row(int g, int group_rows, int unit) { return unit > 0 ? (long)g * unit : (long)g * group_rows; }
+static int fit_chunk(int rpc, int unit) {            // largest power-of-two shrink of rpc that divides unit; 0: impossible
+  if (unit <= 0) return rpc;
+  while (rpc > 1 && unit % rpc) rpc >>= 1;
+  return unit % rpc ? 0 : rpc;
+}
+
 static int pick_cpb(int pieces_per_row) {
   int c = 32;
   while (c > pieces_per_row) c >>= 1;
@@ -25,18 +40,18 @@ static int pick_cpb(int pieces_per_row) {
 
 template <typename T, bool SQ>
 __global__ __launch_bounds__(256) void colstats_kernel(const T* x, long ldx, float* sum, float* sumsq, int C, int group_rows,
-                                                        int chunks_per_group, int rows_per_chunk, int cpb) {
+                                                        int chunks_per_group, int rows_per_chunk, int cpb, int unit) {
   constexpr int PACK = TT<T>::PACK;
   __shared__ float part[2][256 * 8];
   const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
   const int c = (blockIdx.x * cpb + cp) * PACK;
   const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
-  const long gr0 = (long)g * group_rows;
+  const long gr0 = group_row0(g, ch, rows_per_chunk, group_rows, unit, gridDim.y / chunks_per_group);
   float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c < C) {
     if (SQ) {
       Vec16<T> p0;
-      p0.v = *(const decltype(p0.v)*)(x + gr0 * ldx + c);
+      p0.v = *(const decltype(p0.v)*)(x + group_first_row(g, group_rows, unit) * ldx + c);
 #pragma unroll
       for (int e = 0; e < PACK; ++e) pv[e] = p0.get(e);
     }
@@ -72,12 +87,12 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* x, long ldx, flo
 template <typename T>
 __global__ void bn_finalize_kernel(const T* x, long ldx, const float* sum, const float* sumsq, float* mean, float* rstd,
                                    float* running_mean, float* running_var, int C, int G, int group_rows, float eps,
-                                   float momentum) {
+                                   float momentum, int unit) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
   for (int g = 0; g < G; ++g) {
-    const float pivot = to_f32<T>(x[(long)g * group_rows * ldx + c]);
+    const float pivot = to_f32<T>(x[group_first_row(g, group_rows, unit) * ldx + c]);
     const float ms = sum[(long)g * C + c] / group_rows;
     const float var = fmaxf(sumsq[(long)g * C + c] / group_rows - ms * ms, 0.f);
     mean[(long)g * C + c] = pivot + ms;
@@ -94,13 +109,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, long ldx, const float* mean, const float* rstd,
                                                         const float* gamma, const float* beta, const T* resid, long ldr,
                                                         T* y, long ldy, int C, int group_rows, int chunks_per_group,
-                                                        int rows_per_chunk, int relu, int cpb) {
+                                                        int rows_per_chunk, int relu, int cpb, int unit) {
   constexpr int PACK = TT<T>::PACK;
   const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
   const int c = (blockIdx.x * cpb + cp) * PACK;
   if (c >= C) return;
   const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
-  const long gr0 = (long)g * group_rows;
+  const long gr0 = group_row0(g, ch, rows_per_chunk, group_rows, unit, gridDim.y / chunks_per_group);
   float sc[8], sh[8];
 #pragma unroll
   for (int e = 0; e < PACK; ++e) {
@@ -129,13 +144,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, long lddy, const T* x, long ldx, const T* y, long ldy,
                                                              const float* mean, const float* rstd, float* s1, float* s2,
                                                              int C, int group_rows, int chunks_per_group, int rows_per_chunk,
-                                                             int relu, int cpb, const float* gamma, const float* beta) {
+                                                             int relu, int cpb, const float* gamma, const float* beta, int unit) {
   constexpr int PACK = TT<T>::PACK;
   __shared__ float part[2][256 * 8];
   const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
   const int c = (blockIdx.x * cpb + cp) * PACK;
   const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
-  const long gr0 = (long)g * group_rows;
+  const long gr0 = group_row0(g, ch, rows_per_chunk, group_rows, unit, gridDim.y / chunks_per_group);
   float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c < C) {
     // ReLU mask: from the stored output y, or - when there is no residual, y == NULL - recomputed from x (the sign of
@@ -185,13 +200,13 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* dy, long lddy, 
                                                          const float* s1, const float* s2, T* dx, long lddx, T* dres,
                                                          long lddr, int C, int group_rows, int chunks_per_group,
                                                          int rows_per_chunk, int relu, int training, int cpb, float inv_n,
-                                                         const float* beta) {
+                                                         const float* beta, int unit) {
   constexpr int PACK = TT<T>::PACK;
   const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
   const int c = (blockIdx.x * cpb + cp) * PACK;
   if (c >= C) return;
   const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
-  const long gr0 = (long)g * group_rows;
+  const long gr0 = group_row0(g, ch, rows_per_chunk, group_rows, unit, gridDim.y / chunks_per_group);
   // dx = A*dyr + B*x + D  with  A = gamma*rstd, B = -A*rstd*s2/n, D = -A*s1/n - B*mean      (training)
   const bool remask = relu && y == nullptr;              // mask recomputed exactly as in bn_bwd_reduce_kernel
   float ka[8], kb[8], kd[8], mu[8], rs[8], ga[8], be[8];
@@ -432,46 +447,51 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const TL* logits, const lon
 #define DISPATCH_T(dt, CALL_BF16, CALL_F32) do { if ((dt) == 0) { CALL_BF16; } else { CALL_F32; } } while (0)
 
 extern "C" int stswin_colstats(int dtype, const void* x, long ldx, float* sum, float* sumsq, int M, int C, int groups,
-                               void* stream) {
+                               int unit_rows, void* stream) {
   if (C % PACK_OF(dtype) || ldx % PACK_OF(dtype) || groups <= 0 || M % groups) return -1401;
+  if (unit_rows > 0 && M % ((long)groups * unit_rows)) return -1405;
   const int ppr = C / PACK_OF(dtype), cpb = pick_cpb(ppr);
-  const int gr = M / groups, rpc = reduce_rows_per_chunk(gr, groups * ((ppr + cpb - 1) / cpb), 256 / cpb);
+  const int gr = M / groups, rpc = fit_chunk(reduce_rows_per_chunk(gr, groups * ((ppr + cpb - 1) / cpb), 256 / cpb), unit_rows);
+  if (rpc <= 0) return -1405;
   const int cpg = (gr + rpc - 1) / rpc;
   dim3 grid((ppr + cpb - 1) / cpb, groups * cpg);
   hipStream_t st = (hipStream_t)stream;
   if (sumsq)
-    DISPATCH_T(dtype, hipLaunchKernelGGL((colstats_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb),
-               hipLaunchKernelGGL((colstats_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colstats_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb, unit_rows),
+               hipLaunchKernelGGL((colstats_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb, unit_rows));
   else
-    DISPATCH_T(dtype, hipLaunchKernelGGL((colstats_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb),
-               hipLaunchKernelGGL((colstats_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colstats_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb, unit_rows),
+               hipLaunchKernelGGL((colstats_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb, unit_rows));
   STSWIN_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int stswin_bn_finalize(int dtype, const void* x, long ldx, const float* sum, const float* sumsq, float* mean,
                                   float* rstd, float* running_mean, float* running_var, int M, int C, int groups, float eps,
-                                  float momentum, void* stream) {
+                                  float momentum, int unit_rows, void* stream) {
   if (groups <= 0 || M % groups) return -1401;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((C + 255) / 256);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_finalize_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, ldx, sum, sumsq, mean, rstd, running_mean, running_var, C, groups, M / groups, eps, momentum),
-             hipLaunchKernelGGL(bn_finalize_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, sum, sumsq, mean, rstd, running_mean, running_var, C, groups, M / groups, eps, momentum));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_finalize_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, ldx, sum, sumsq, mean, rstd, running_mean, running_var, C, groups, M / groups, eps, momentum, unit_rows),
+             hipLaunchKernelGGL(bn_finalize_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, sum, sumsq, mean, rstd, running_mean, running_var, C, groups, M / groups, eps, momentum, unit_rows));
   STSWIN_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int stswin_bn_apply(int dtype, const void* x, long ldx, const float* mean, const float* rstd, const float* gamma,
                                const float* beta, const void* resid, long ldr, void* y, long ldy, int M, int C, int groups,
-                               int relu, void* stream) {
+                               int relu, int unit_rows, void* stream) {
   const int pk = PACK_OF(dtype);
   if (C % pk || ldx % pk || ldy % pk || (resid && ldr % pk) || groups <= 0 || M % groups) return -1402;
   const int ppr = C / pk, cpb = pick_cpb(ppr);
-  const int gr = M / groups, rpc = 8 * (256 / cpb), cpg = (gr + rpc - 1) / rpc;
+  if (unit_rows > 0 && M % ((long)groups * unit_rows)) return -1405;
+  const int gr = M / groups, rpc = fit_chunk(8 * (256 / cpb), unit_rows);
+  if (rpc <= 0) return -1405;
+  const int cpg = (gr + rpc - 1) / rpc;
   dim3 grid((ppr + cpb - 1) / cpb, groups * cpg);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, ldx, mean, rstd, gamma, beta, (const bf16*)resid, ldr, (bf16*)y, ldy, C, gr, cpg, rpc, relu, cpb),
-             hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, mean, rstd, gamma, beta, (const float*)resid, ldr, (float*)y, ldy, C, gr, cpg, rpc, relu, cpb));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, ldx, mean, rstd, gamma, beta, (const bf16*)resid, ldr, (bf16*)y, ldy, C, gr, cpg, rpc, relu, cpb, unit_rows),
+             hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, mean, rstd, gamma, beta, (const float*)resid, ldr, (float*)y, ldy, C, gr, cpg, rpc, relu, cpb, unit_rows));
   STSWIN_CHECK_LAUNCH();
   return 0;
 }
@@ -479,24 +499,27 @@ extern "C" int stswin_bn_apply(int dtype, const void* x, long ldx, const float* 
 extern "C" int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const void* y, long ldy,
                              const float* mean, const float* rstd, const float* gamma, const float* beta, float* s1, float* s2,
                              void* dx, long lddx, void* dresid, long lddr, int M, int C, int groups, int relu, int training,
-                             int phase, long rows_total, void* stream) {
+                             int phase, long rows_total, int unit_rows, void* stream) {
   const int pk = PACK_OF(dtype);
   if (C % pk || ldx % pk || lddy % pk || lddx % pk || (relu && y && ldy % pk) || groups <= 0 || M % groups) return -1403;
   if (relu && !y && !beta) return -1404;               // no stored output: the mask is recomputed and needs beta
   const int ppr = C / pk, cpb = pick_cpb(ppr);
-  const int gr = M / groups, rpc = reduce_rows_per_chunk(gr, groups * ((ppr + cpb - 1) / cpb), 256 / cpb);
+  if (unit_rows > 0 && M % ((long)groups * unit_rows)) return -1405;
+  const int gr = M / groups, rpc = fit_chunk(reduce_rows_per_chunk(gr, groups * ((ppr + cpb - 1) / cpb), 256 / cpb), unit_rows);
+  const int rpc2 = fit_chunk(8 * (256 / cpb), unit_rows);
+  if (rpc <= 0 || rpc2 <= 0) return -1405;
   const int cpg = (gr + rpc - 1) / rpc;
   dim3 g1((ppr + cpb - 1) / cpb, groups * cpg);
-  const int rpc2 = 8 * (256 / cpb), cpg2 = (gr + rpc2 - 1) / rpc2;
+  const int cpg2 = (gr + rpc2 - 1) / rpc2;
   dim3 g2((ppr + cpb - 1) / cpb, groups * cpg2);
   hipStream_t st = (hipStream_t)stream;
   const float inv_n = 1.0f / (float)(rows_total > 0 ? rows_total : gr);
   if (phase != 2)
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb, gamma, beta),
-             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb, gamma, beta));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb, gamma, beta, unit_rows),
+             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb, gamma, beta, unit_rows));
   if (phase != 1)
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16>, g2, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, gamma, s1, s2, (bf16*)dx, lddx, (bf16*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n, beta),
-             hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, gamma, s1, s2, (float*)dx, lddx, (float*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n, beta));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16>, g2, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, gamma, s1, s2, (bf16*)dx, lddx, (bf16*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n, beta, unit_rows),
+             hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, gamma, s1, s2, (float*)dx, lddx, (float*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n, beta, unit_rows));
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

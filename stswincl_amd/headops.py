@@ -256,7 +256,8 @@ class BNTokFn(torch.autograd.Function):
     """nn.BatchNorm2d (+ residual add + ReLU) on tokens with `groups` independent statistic groups."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, relu, resid, groups, lay, eps, momentum, world=1):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, relu, resid, groups, lay, eps, momentum, world=1,
+                unit=0):
         dt = compute_dtype(x)
         X = x.detach().to(dt)
         M, Cp = X.shape
@@ -268,6 +269,7 @@ class BNTokFn(torch.autograd.Function):
             # (mean, M2, count) per BN instead of the reference's per-tensor collectives.
             import torch.distributed as dist
             n_loc = M // groups
+            assert unit == 0, "SyncBatchNorm: contiguous statistic groups only"
             s, ss = hip.colstats(X, groups=groups)
             pivot = X.view(groups, n_loc, Cp)[:, 0, :].float()
             mean_l = pivot + s / n_loc
@@ -289,12 +291,12 @@ class BNTokFn(torch.autograd.Function):
             running_var.copy_(lay.unpad_vec(rv))
             mean, rstd = mean.contiguous(), rstd.contiguous()
         elif training:
-            s, ss = hip.colstats(X, groups=groups)
+            s, ss = hip.colstats(X, groups=groups, unit=unit)
             if lay.is_identity:
-                mean, rstd = hip.bn_finalize(X, s, ss, running_mean, running_var, groups, eps, momentum)
+                mean, rstd = hip.bn_finalize(X, s, ss, running_mean, running_var, groups, eps, momentum, unit=unit)
             else:
                 rm, rv = lay.pad_vec(running_mean), lay.pad_vec(running_var, 1.0)
-                mean, rstd = hip.bn_finalize(X, s, ss, rm, rv, groups, eps, momentum)
+                mean, rstd = hip.bn_finalize(X, s, ss, rm, rv, groups, eps, momentum, unit=unit)
                 running_mean.copy_(lay.unpad_vec(rm))
                 running_var.copy_(lay.unpad_vec(rv))
         else:
@@ -302,8 +304,9 @@ class BNTokFn(torch.autograd.Function):
             rstd = torch.rsqrt(lay.pad_vec(running_var, 1.0) + eps).view(1, Cp).expand(groups, Cp).contiguous()
         y = torch.empty(M, Cp, dtype=dt, device=x.device)
         R = resid.detach().to(dt) if resid is not None else None
-        hip.bn_apply(X, mean, rstd, gp, bp, y, resid=R, groups=groups, relu=relu)
+        hip.bn_apply(X, mean, rstd, gp, bp, y, resid=R, groups=groups, relu=relu, unit=unit)
         ctx.cfg = (training, relu, groups, lay, dt, x.dtype, resid is not None, world, rows_total)
+        ctx.unit = unit
         # without a residual the backward recomputes the ReLU mask from X (one tensor less to read in both of its passes)
         keep_y = relu and (resid is not None or _BN_KEEP_Y)
         ctx.save_for_backward(X, y if keep_y else None, mean, rstd, gp, bp if relu else None)
@@ -326,7 +329,7 @@ class BNTokFn(torch.autograd.Function):
                        sums=(both[0].contiguous(), both[1].contiguous()), rows_total=rows_total, beta=bp)
             s1, s2 = loc1, loc2
         else:
-            s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, beta=bp)
+            s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, beta=bp, unit=ctx.unit)
         if groups > 1:                                   # s1 / s2 are the two halves of one [2][groups][C] buffer: one reduce
             if s1.data_ptr() + s1.numel() * 4 == s2.data_ptr():
                 both = torch.as_strided(s1, (2, groups, s1.shape[-1]), (groups * s1.shape[-1], s1.shape[-1], 1)).sum(1)
@@ -336,7 +339,7 @@ class BNTokFn(torch.autograd.Function):
         dgamma = lay.unpad_vec(s2[0])
         dbeta = lay.unpad_vec(s1[0])
         return (dx.to(in_dtype), dgamma, dbeta, None, None, None, None, dres.to(in_dtype) if has_res else None,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 _NBT_PENDING = None
@@ -366,7 +369,10 @@ class deferred_bn_counters:
         return False
 
 
-def batchnorm_tokens(x, bn: torch.nn.BatchNorm2d, relu=True, resid=None, groups=1, lay: Optional[Layout] = None):
+def batchnorm_tokens(x, bn: torch.nn.BatchNorm2d, relu=True, resid=None, groups=1, lay: Optional[Layout] = None,
+                     il_frames: int = 0):
+    """il_frames = F > 0: the rows are F frames stored clip-major and statistic group g = frames g, g + groups, ... (frame t
+    of every clip); 0: `groups` contiguous row blocks."""
     lay = lay or Layout.dense(bn.num_features)
     training = bn.training or bn.running_mean is None
     if training and bn.num_batches_tracked is not None:
@@ -375,7 +381,8 @@ def batchnorm_tokens(x, bn: torch.nn.BatchNorm2d, relu=True, resid=None, groups=
         else:
             bn.num_batches_tracked += groups
     return BNTokFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, relu, resid, groups, lay,
-                         bn.eps, bn.momentum if bn.momentum is not None else 0.1, _sync_world(bn) if training else 1)
+                         bn.eps, bn.momentum if bn.momentum is not None else 0.1, _sync_world(bn) if training else 1,
+                         (x.shape[0] // il_frames) if (il_frames and groups > 1) else 0)
 
 
 class BilinearTokFn(torch.autograd.Function):

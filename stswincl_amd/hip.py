@@ -413,37 +413,37 @@ def win_attn_bwd(qkv, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, s
 
 
 # ----------------------------------------------------------------------------------------------- head ops
-def colstats(x, groups=1, squares=True, M=None):
+def colstats(x, groups=1, squares=True, M=None, unit=0):
     M = x.shape[0] if M is None else M
     C = x.shape[1]
     both = zeros(2 if squares else 1, groups, C, device=x.device)
     s = both[0]
     ss = both[1] if squares else None
-    _check(load().stswin_colstats(_dt(x), _p(x), _c_long(_ld(x)), _p(s), _p(ss), M, C, groups, _stream()), "colstats")
+    _check(load().stswin_colstats(_dt(x), _p(x), _c_long(_ld(x)), _p(s), _p(ss), M, C, groups, unit, _stream()), "colstats")
     return s, ss
 
 
-def bn_finalize(x, s, ss, running_mean, running_var, groups=1, eps=1e-5, momentum=0.1, M=None):
+def bn_finalize(x, s, ss, running_mean, running_var, groups=1, eps=1e-5, momentum=0.1, M=None, unit=0):
     M = x.shape[0] if M is None else M
     C = x.shape[1]
     mean = torch.empty(groups, C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(groups, C, dtype=torch.float32, device=x.device)
     _check(load().stswin_bn_finalize(_dt(x), _p(x), _c_long(_ld(x)), _p(s), _p(ss), _p(mean), _p(rstd), _p(running_mean),
-                                     _p(running_var), M, C, groups, _c_float(eps), _c_float(momentum), _stream()),
+                                     _p(running_var), M, C, groups, _c_float(eps), _c_float(momentum), unit, _stream()),
            "bn_finalize")
     return mean, rstd
 
 
-def bn_apply(x, mean, rstd, gamma, beta, out, resid=None, groups=1, relu=True, M=None):
+def bn_apply(x, mean, rstd, gamma, beta, out, resid=None, groups=1, relu=True, M=None, unit=0):
     M = x.shape[0] if M is None else M
     _check(load().stswin_bn_apply(_dt(x), _p(x), _c_long(_ld(x)), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(resid),
                                   _c_long(_ld(resid) if resid is not None else 0), _p(out), _c_long(_ld(out)), M,
-                                  x.shape[1], groups, 1 if relu else 0, _stream()), "bn_apply")
+                                  x.shape[1], groups, 1 if relu else 0, unit, _stream()), "bn_apply")
     return out
 
 
 def bn_bwd(dy, x, y, mean, rstd, gamma, dx, dresid=None, groups=1, relu=True, training=True, M=None, phase=0, sums=None,
-           rows_total=0, beta=None):
+           rows_total=0, beta=None, unit=0):
     M = x.shape[0] if M is None else M
     C = x.shape[1]
     if sums is None:
@@ -454,7 +454,7 @@ def bn_bwd(dy, x, y, mean, rstd, gamma, dx, dresid=None, groups=1, relu=True, tr
     _check(load().stswin_bn_bwd(_dt(x), _p(dy), _c_long(_ld(dy)), _p(x), _c_long(_ld(x)), _p(y),
                                 _c_long(_ld(y) if y is not None else 0), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(s1), _p(s2),
                                 _p(dx), _c_long(_ld(dx)), _p(dresid), _c_long(_ld(dresid) if dresid is not None else 0), M, C,
-                                groups, 1 if relu else 0, 1 if training else 0, phase, _c_long(rows_total), _stream()), "bn_bwd")
+                                groups, 1 if relu else 0, 1 if training else 0, phase, _c_long(rows_total), unit, _stream()), "bn_bwd")
     return s1, s2
 
 

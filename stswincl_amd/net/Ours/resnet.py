@@ -34,8 +34,8 @@ class _TVBasicBlock(nn.Module):
         if stride != 1 or cin != cout:
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
-    def forward_tokens(self, x, frames, h, w, groups):
-        return _block_tokens(self, x, frames, h, w, groups)
+    def forward_tokens(self, x, frames, h, w, groups, il=False):
+        return _block_tokens(self, x, frames, h, w, groups, il)
 
 
 def make_layer(block, in_channels, channels, num_blocks, stride=1, dilation=1):
@@ -44,6 +44,10 @@ def make_layer(block, in_channels, channels, num_blocks, stride=1, dilation=1):
         blocks.append(block(in_channels=in_channels, channels=channels, stride=s, dilation=dilation))
         in_channels = block.expansion * channels
     return nn.Sequential(*blocks)
+
+
+import os
+_FRAME_MAJOR = os.environ.get("STSWIN_RESNET_FRAME_MAJOR") == "1"
 
 
 class BasicBlock(nn.Module):
@@ -63,22 +67,23 @@ class BasicBlock(nn.Module):
         else:
             self.downsample = nn.Sequential()
 
-    def forward_tokens(self, x, frames, h, w, groups):
-        return _block_tokens(self, x, frames, h, w, groups)
+    def forward_tokens(self, x, frames, h, w, groups, il=False):
+        return _block_tokens(self, x, frames, h, w, groups, il)
 
 
-def _block_tokens(blk, x, frames, h, w, groups):
+def _block_tokens(blk, x, frames, h, w, groups, il=False):
     """out = relu(bn2(conv2(relu(bn1(conv1(x))))) + downsample(x))   (resnet.py:42-51)."""
     y, ho, wo = H.conv_tokens(x, blk.conv1, frames, h, w)
-    y = H.batchnorm_tokens(y, blk.bn1, relu=True, groups=groups)
+    ilf = frames if il else 0
+    y = H.batchnorm_tokens(y, blk.bn1, relu=True, groups=groups, il_frames=ilf)
     y, _, _ = H.conv_tokens(y, blk.conv2, frames, ho, wo)
     ds = blk.downsample
     if ds is not None and len(ds) > 0:
         idn, _, _ = H.conv_tokens(x, ds[0], frames, h, w)
-        idn = H.batchnorm_tokens(idn, ds[1], relu=False, groups=groups)
+        idn = H.batchnorm_tokens(idn, ds[1], relu=False, groups=groups, il_frames=ilf)
     else:
         idn = x
-    return H.batchnorm_tokens(y, blk.bn2, relu=True, resid=idn, groups=groups), ho, wo
+    return H.batchnorm_tokens(y, blk.bn2, relu=True, resid=idn, groups=groups, il_frames=ilf), ho, wo
 
 
 class ResNet_BasicBlock_OS8(nn.Module):
@@ -95,26 +100,33 @@ class ResNet_BasicBlock_OS8(nn.Module):
         self.layer4 = make_layer(BasicBlock, in_channels=128, channels=256, num_blocks=2, stride=1, dilation=2)
         self.layer5 = make_layer(BasicBlock, in_channels=256, channels=512, num_blocks=2, stride=1, dilation=4)
 
-    def forward_tokens(self, img, groups=1):
-        """img (F,3,H,W) with F = groups * (frames per statistic group), group-major -> (tokens [F*h*w][512], h, w)."""
+    def forward_tokens(self, img, groups=1, il=False):
+        """img (F,3,H,W) with F = groups * (frames per statistic group) -> (tokens [F*h*w][512], h, w).  il = False: the
+        frames are group-major (group g = frames [g*F/groups, (g+1)*F/groups)); il = True: group g = frames g, g + groups,
+        ... (clip-major clips of `groups` frames: no reordering of the batch)."""
         f, _, hh, ww = img.shape
         dt = compute_dtype(img)
         x = H.StemConvFn.apply(img, self.resnet[0].weight, dt)
         h, w = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
-        x = H.batchnorm_tokens(x, self.resnet[1], relu=True, groups=groups)
+        x = H.batchnorm_tokens(x, self.resnet[1], relu=True, groups=groups, il_frames=f if il else 0)
         x = H.MaxPoolTokFn.apply(x, (f, h, w))
         h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         for layer in (self.resnet[4], self.resnet[5], self.layer4, self.layer5):
             for blk in layer:
-                x, h, w = blk.forward_tokens(x, f, h, w, groups)
+                x, h, w = blk.forward_tokens(x, f, h, w, groups, il)
         return x, h, w
 
     def forward_frames(self, x):
         """(B,T,3,H,W) -> tokens (B, T, h*w, 512): the T sequential per-frame calls of base18.py:86-89 in one batch."""
         b, t = x.shape[:2]
-        img = x.transpose(0, 1).reshape(t * b, *x.shape[2:])          # frame-major: statistic group = frame index
-        tok, h, w = self.forward_tokens(img, groups=t)
-        return tok.view(t, b, h * w, tok.shape[1]).transpose(0, 1).contiguous(), h, w
+        # clip-major as stored; statistic group = frame index t, i.e. the frames t, t + T, t + 2T, ... of the flattened batch
+        # (interleaved groups of the BatchNorm kernels): no frame-major copy of the input, none of the tokens, none of their
+        # gradients
+        if _FRAME_MAJOR:                                   # A/B switch: the frame-major copy + contiguous groups
+            tok, h, w = self.forward_tokens(x.transpose(0, 1).reshape(t * b, *x.shape[2:]), groups=t)
+            return tok.view(t, b, h * w, tok.shape[1]).transpose(0, 1).contiguous(), h, w
+        tok, h, w = self.forward_tokens(x.reshape(b * t, *x.shape[2:]), groups=t, il=True)
+        return tok.view(b, t, h * w, tok.shape[1]), h, w
 
     def forward(self, x):
         tok, h, w = self.forward_tokens(x, groups=1)

@@ -56,6 +56,38 @@ def test_conv_tokens_fwd_bwd(mode, tol, cin, cout, k, dil, bias, stride):
 
 
 @pytest.mark.parametrize("mode,tol", MODES)
+@pytest.mark.parametrize("clips,T,h,w,relu,res", [(3, 4, 8, 8, True, True), (2, 4, 6, 5, True, False), (4, 2, 16, 4, False, False)])
+def test_batchnorm_interleaved_groups(mode, tol, clips, T, h, w, relu, res):
+    """Statistic group = frame index t of clip-major clips (group g owns frames g, g + T, ...: stswin_* unit_rows) against the
+    same data reordered frame-major with contiguous groups - outputs, all gradients and the running statistics."""
+    torch.manual_seed(clips * 10 + T)
+    c, f = 64, clips * T
+    mk = lambda: nn.BatchNorm2d(c).cuda()                                             # noqa: E731
+    bn_a, bn_b = mk(), mk()
+    bn_a.weight.data = 1 + 0.2 * torch.randn(c, device="cuda"); bn_a.bias.data = 0.2 * torch.randn(c, device="cuda")
+    bn_b.load_state_dict(bn_a.state_dict())
+    x = (torch.randn(clips, T, h * w, c, device="cuda") * 2 + 1)
+    r = torch.randn(clips, T, h * w, c, device="cuda")
+    g = torch.randn(clips, T, h * w, c, device="cuda")
+    fm = lambda t: t.transpose(0, 1).reshape(f * h * w, c).contiguous()               # noqa: E731  frame-major rows
+    xa, ra = x.reshape(-1, c).clone().requires_grad_(True), r.reshape(-1, c).clone().requires_grad_(True)
+    xb, rb = fm(x).requires_grad_(True), fm(r).requires_grad_(True)
+    with ac(mode):
+        ya = H.batchnorm_tokens(xa, bn_a, relu=relu, resid=ra if res else None, groups=T, il_frames=f)
+        yb = H.batchnorm_tokens(xb, bn_b, relu=relu, resid=rb if res else None, groups=T)
+    back = lambda t: t.view(T, clips, h * w, c).transpose(0, 1).reshape(-1, c)        # noqa: E731  frame-major -> clip-major
+    etol = 1e-5 if mode == "fp32" else tol          # same arithmetic, other summation order (chunking follows the unit size)
+    assert rel(ya, back(yb)) < etol
+    (ya.float() * g.reshape(-1, c)).sum().backward()
+    (yb.float() * fm(g)).sum().backward()
+    assert rel(xa.grad, back(xb.grad)) < 3 * etol and rel(bn_a.weight.grad, bn_b.weight.grad) < 3 * etol
+    assert rel(bn_a.bias.grad, bn_b.bias.grad) < 3 * etol
+    if res:
+        assert rel(ra.grad, back(rb.grad)) < 3 * etol
+    assert rel(bn_a.running_mean, bn_b.running_mean) < 1e-5 and rel(bn_a.running_var, bn_b.running_var) < 1e-5
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
 @pytest.mark.parametrize("groups,relu,res,training", [(1, True, False, True), (4, True, True, True), (1, False, False, True),
                                                       (1, True, False, False)])
 def test_batchnorm_tokens(mode, tol, groups, relu, res, training):
