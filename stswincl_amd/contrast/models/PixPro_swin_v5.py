@@ -218,11 +218,15 @@ class PixPro(nn.Module):
         return H.from_tokens(pred, b, h, w)
 
     def forward(self, seq_1, seq_2, seq_3, seq_4, seq_5, seq_6):
-        pred_1 = self._embed(seq_1, False)
-        pred_2 = self._embed(seq_2, False)
-        with torch.no_grad():
-            self._momentum_update_key_encoder()
-            keys = [self._embed(s, True) for s in (seq_1, seq_2, seq_3, seq_4, seq_5, seq_6)]
+        # (the num_batches_tracked increments of the 8 encoder passes - 240 one-element add kernels - are applied by one
+        # foreach add on exit; the accumulators of all passes come out of one zero-filled block)
+        hip.arena_reset(seq_1.device)
+        with H.deferred_bn_counters():
+            pred_1 = self._embed(seq_1, False)
+            pred_2 = self._embed(seq_2, False)
+            with torch.no_grad():
+                self._momentum_update_key_encoder()
+                keys = [self._embed(s, True) for s in (seq_1, seq_2, seq_3, seq_4, seq_5, seq_6)]
         return (pred_1, pred_2, *keys)
 
 

@@ -361,8 +361,12 @@ class deferred_bn_counters:
             if self.prev is not None:
                 self.prev.extend(pend)
             else:
-                by_inc = {}
+                per_t = {}                                      # a counter met several times (an encoder run twice): one entry
                 for t, inc in pend:
+                    ent = per_t.setdefault(id(t), [t, 0])
+                    ent[1] += inc
+                by_inc = {}
+                for t, inc in per_t.values():
                     by_inc.setdefault(inc, []).append(t)
                 for inc, ts in by_inc.items():
                     torch._foreach_add_(ts, inc)

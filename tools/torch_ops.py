@@ -11,21 +11,41 @@ from stswincl_amd.utils.losses import OhemCELoss2D
 from stswincl_amd.optim import FusedAdam
 
 dev = "cuda"
-S, B = 512, 4
-torch.manual_seed(0)
-model = TswinPlus(12, (S // 8, S // 8)).to(dev).train()
-opt = FusedAdam(model.parameters(), 1e-4)
-crit = OhemCELoss2D(S * S // 16)
-x = torch.randn(B, 4, 3, S, S, device=dev)
-y = torch.randint(0, 12, (B, S, S), device=dev)
+if len(sys.argv) > 1 and sys.argv[1] == "contrast":          # the contrastive pre-training step of bench.py --workload contrast
+    import types
+    from stswincl_amd.contrast.models.PixPro_swin_v5 import ConsistencyLoss
+    S, B = 256, 8
+    args = types.SimpleNamespace(pixpro_p=1.0, pixpro_momentum=0.99, pixpro_clamp_value=0.0, pixpro_transform_layer=1,
+                                 pixpro_ins_loss_weight=0.0, pixpro_pos_ratio=0.7, data="endo18", tag="1", pretrainpth=None,
+                                 num_instances=2235, batch_size=B, epochs=150, start_epoch=1)
+    torch.manual_seed(0)
+    model = ConsistencyLoss(args, input_resolution=(S // 8, S // 8)).to(dev).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, 0.05, momentum=0.9, weight_decay=1e-5)
+    ims = [torch.randn(B, 4, 3, S, S, device=dev) for _ in range(6)]
+    masks = [torch.randint(0, 12, (B, 1, S, S), device=dev).float() for _ in range(6)]
 
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = model(*ims, *masks)
+        loss.backward()
+        opt.step()
+else:
+    S, B = 512, 4
+    torch.manual_seed(0)
+    model = TswinPlus(12, (S // 8, S // 8)).to(dev).train()
+    opt = FusedAdam(model.parameters(), 1e-4)
+    crit = OhemCELoss2D(S * S // 16)
+    x = torch.randn(B, 4, 3, S, S, device=dev)
+    y = torch.randint(0, 12, (B, S, S), device=dev)
 
-def step():
-    opt.zero_grad(set_to_none=True)
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        loss = crit(model(x), y)
-    loss.backward()
-    opt.step()
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = crit(model(x), y)
+        loss.backward()
+        opt.step()
 
 
 for _ in range(2):
