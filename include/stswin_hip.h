@@ -114,6 +114,10 @@ int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, lo
                          void* stream);
 #define STSWIN_LN_BWD_REPLICAS 32
 
+/* out[i] = map[i] >= 0 ? v[map[i]] : fill, i < n: padding of per-channel parameter vectors (BatchNorm weight / bias / running
+ * statistics) to the 64-aligned channel layout of the token matrices and the gather back (base18.py:60-77 concat layout). */
+int stswin_vec_gather(const float* v, const int* map, float* out, int n, float fill, void* stream);
+
 /* ---- relative position bias (swin_512.py:122-131).  expand: out[w][h][j][i] = table[index[i*N + j]][h] (+ mask[w][i][j]),
  * the [key][query] layout of stswin_win_attn_fwd's biasT (nW = 1, mask = NULL: plain [heads][N][N]; with the SW-MSA mask the
  * per-window pre-summed table).  scatter: dtable[index[i*N + j]][h] += dbiasT[h][j][i] (the backward of the gather).

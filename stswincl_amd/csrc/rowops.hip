@@ -407,6 +407,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* y, long ldy, float
   }
 }
 
+// out[i] = map[i] >= 0 ? v[map[i]] : fill   (channel-padding / un-padding of per-channel vectors: one launch instead of a
+// fill plus one copy per layout segment)
+__global__ __launch_bounds__(256) void vec_gather_kernel(const float* v, const int* map, float* out, int n, float fill) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { const int j = map[i]; out[i] = j >= 0 ? v[j] : fill; }
+}
+
 // ---- relative position bias (swin_512.py:122-131): table[index] -> the attention kernels' [key][query] layout, with the
 // SW-MSA mask folded in per window, and the transposed scatter of its gradient.  One launch each instead of the
 // index / permute / contiguous / add chain (6 tiny kernels per block forward, index_add_ + permute per backward).
@@ -624,6 +631,13 @@ extern "C" int stswin_bias_scatter(const float* dbiasT, const long* index, float
   const long n = (long)heads * N * N;
   hipLaunchKernelGGL(bias_scatter_kernel, dim3((unsigned)min(2048L, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dbiasT,
                      index, dtable, N, heads);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_vec_gather(const float* v, const int* map, float* out, int n, float fill, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(vec_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, map, out, n, fill);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

@@ -19,6 +19,7 @@ KGRAN = 64  # channel padding granule (bf16 GEMM K tile; also valid for the f32 
 
 
 _INDEX_MAPS = {}
+_TORCH_PADVEC = os.environ.get("STSWIN_TORCH_PADVEC") == "1"   # A/B switch: fill + per-segment copies / cat
 _BN_KEEP_Y = os.environ.get("STSWIN_BN_KEEP_Y") == "1"      # A/B switch: ReLU mask from the stored output everywhere
 
 
@@ -50,6 +51,8 @@ class Layout:
     def pad_vec(self, v: torch.Tensor, fill: float = 0.0) -> torch.Tensor:
         if self.is_identity:
             return v.detach().float().contiguous()
+        if v.is_cuda and v.dim() == 1 and not _TORCH_PADVEC:
+            return hip.vec_gather(v.detach().float().contiguous(), self.index_map(v.device), fill)
         out = torch.full((self.width,), fill, dtype=torch.float32, device=v.device)
         for a, n, b in self.segs:
             out[b:b + n] = v.detach()[a:a + n]
@@ -58,7 +61,21 @@ class Layout:
     def unpad_vec(self, v: torch.Tensor) -> torch.Tensor:
         if self.is_identity:
             return v
+        if v.is_cuda and v.dim() == 1 and v.dtype == torch.float32 and not _TORCH_PADVEC:
+            return hip.vec_gather(v.contiguous(), self.position_map(v.device), 0.0)
         return torch.cat([v[..., b:b + n] for a, n, b in self.segs], dim=-1)
+
+    def position_map(self, device) -> torch.Tensor:
+        """int32 [logical]: padded position of every logical channel (the inverse of index_map), cached like it."""
+        key = ("pos", self.key(), str(device))
+        m = _INDEX_MAPS.get(key)
+        if m is None:
+            m = torch.empty(self.logical, dtype=torch.int32)
+            for a, n, b in self.segs:
+                m[a:a + n] = torch.arange(b, b + n, dtype=torch.int32)
+            m = m.to(device)
+            _INDEX_MAPS[key] = m
+        return m
 
     def key(self):
         return (tuple(self.segs), self.width)

@@ -335,6 +335,13 @@ def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: in
     return out_f32
 
 
+def vec_gather(v: torch.Tensor, imap: torch.Tensor, fill: float = 0.0) -> torch.Tensor:
+    """out[i] = v[imap[i]] (fill where imap[i] < 0); v fp32 contiguous, imap int32."""
+    out = torch.empty(imap.numel(), dtype=torch.float32, device=v.device)
+    _check(load().stswin_vec_gather(_p(v), _p(imap), _p(out), imap.numel(), _c_float(fill), _stream()), "vec_gather")
+    return out
+
+
 def colsum(y: torch.Tensor, out_f32: torch.Tensor, M: Optional[int] = None):
     M = y.shape[0] if M is None else M
     _check(load().stswin_colsum(_dt(y), _p(y), _c_long(_ld(y)), _p(out_f32), M, y.shape[1], _stream()), "colsum")
