@@ -130,3 +130,17 @@ def test_relative_position_bias_expand_and_scatter(N, heads, nW):
     dtable = torch.zeros(tsz, heads, device="cuda")
     hip.bias_scatter(g.cuda(), index.cuda(), dtable, N, heads)
     assert torch.allclose(dtable.cpu(), table.grad, atol=1e-4, rtol=1e-5)
+
+
+def test_vec_gather_pads_and_unpads_channel_vectors():
+    """stswin_vec_gather through Layout.pad_vec / unpad_vec: the 400-channel decode concat inside 448 columns."""
+    from stswincl_amd import headops as H
+    lay = H.Layout.concat([H.Layout.dense(48), H.Layout.dense(48), H.Layout.dense(48), H.Layout.dense(256)])
+    v = torch.randn(lay.logical, device="cuda")
+    p = lay.pad_vec(v, 1.5)
+    assert p.shape == (lay.width,)
+    ref = torch.full((lay.width,), 1.5)
+    for a, n, b in lay.segs:
+        ref[b:b + n] = v.cpu()[a:a + n]
+    assert torch.equal(p.cpu(), ref)
+    assert torch.equal(lay.unpad_vec(p).cpu(), v.cpu())
