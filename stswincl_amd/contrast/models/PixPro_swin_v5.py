@@ -136,6 +136,17 @@ def Pred_Head(in_dim=256, inner_dim=4096, out_dim=256):
 LCAT = H.Layout.concat([H.Layout.dense(48)] * 3 + [H.Layout.dense(256)])
 
 
+def _batched_views_ok(model) -> bool:
+    """View batching needs the interleaved-group BatchNorm kernels: local statistics only (SyncBatchNorm across ranks keeps
+    the sequential passes), train mode, and not switched off (STSWIN_SEQUENTIAL_VIEWS=1: A/B runs)."""
+    if os.environ.get("STSWIN_SEQUENTIAL_VIEWS") == "1" or not model.training:
+        return False
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return not any(isinstance(m, nn.SyncBatchNorm) for m in model.modules())
+    return True
+
+
 class PixPro(nn.Module):
     """Query / momentum-key encoders (PixPro_swin_v5.py:140-561)."""
 
@@ -221,12 +232,29 @@ class PixPro(nn.Module):
         # (the num_batches_tracked increments of the 8 encoder passes - 240 one-element add kernels - are applied by one
         # foreach add on exit; the accumulators of all passes come out of one zero-filled block)
         hip.arena_reset(seq_1.device)
+        seqs = (seq_1, seq_2, seq_3, seq_4, seq_5, seq_6)
         with H.deferred_bn_counters():
-            pred_1 = self._embed(seq_1, False)
-            pred_2 = self._embed(seq_2, False)
-            with torch.no_grad():
-                self._momentum_update_key_encoder()
-                keys = [self._embed(s, True) for s in (seq_1, seq_2, seq_3, seq_4, seq_5, seq_6)]
+            if _batched_views_ok(self):
+                # The 2 query and the 6 key passes as ONE batch each (view-interleaved clips, per-view BatchNorm statistics -
+                # see headops.bn_views): 2x / 6x the rows per kernel, a quarter of the launches, and the query encoder's
+                # parameters receive one gradient instead of two that autograd has to add up (255 add kernels per step)
+                b = seq_1.shape[0]
+                xq = torch.stack(seqs[:2], 1).reshape(2 * b, *seq_1.shape[1:])
+                with H.bn_views(2, 2 * b):
+                    pq = self._embed(xq, False)
+                pred_1, pred_2 = pq[0::2], pq[1::2]
+                with torch.no_grad():
+                    self._momentum_update_key_encoder()
+                    xk = torch.stack(seqs, 1).reshape(6 * b, *seq_1.shape[1:])
+                    with H.bn_views(6, 6 * b):
+                        pk = self._embed(xk, True)
+                    keys = [pk[i::6] for i in range(6)]
+            else:
+                pred_1 = self._embed(seq_1, False)
+                pred_2 = self._embed(seq_2, False)
+                with torch.no_grad():
+                    self._momentum_update_key_encoder()
+                    keys = [self._embed(s, True) for s in seqs]
         return (pred_1, pred_2, *keys)
 
 

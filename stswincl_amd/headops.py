@@ -360,6 +360,29 @@ class BNTokFn(torch.autograd.Function):
 
 
 _NBT_PENDING = None
+_BN_VIEWS = None
+
+
+class bn_views:
+    """with bn_views(V, clips): the batch is `clips` clips = V augmented views x clips/V clips each, ordered view-interleaved
+    (clip c of view v at index c * V + v).  Every train-mode BatchNorm inside then keeps separate statistics per view (and
+    per frame in the ResNet), and updates its running statistics view by view: numerically the V sequential encoder calls
+    of the reference (PixPro_swin_v5.py:331-362), in one pass with V times the rows per kernel."""
+
+    def __init__(self, views: int, clips: int):
+        assert clips % views == 0
+        self.v = (views, clips) if views > 1 else None
+
+    def __enter__(self):
+        global _BN_VIEWS
+        self.prev, _BN_VIEWS = _BN_VIEWS, self.v
+        return self
+
+    def __exit__(self, *exc):
+        global _BN_VIEWS
+        _BN_VIEWS = self.prev
+        return False
+
 
 
 class deferred_bn_counters:
@@ -396,6 +419,15 @@ def batchnorm_tokens(x, bn: torch.nn.BatchNorm2d, relu=True, resid=None, groups=
     of every clip); 0: `groups` contiguous row blocks."""
     lay = lay or Layout.dense(bn.num_features)
     training = bn.training or bn.running_mean is None
+    if _BN_VIEWS is not None and training:
+        # several augmented views run as one batch (clips ordered view-interleaved): every view keeps its own batch statistics,
+        # exactly as when the encoder is called once per view
+        views, clips = _BN_VIEWS
+        if il_frames:
+            groups = groups * views                        # frame u -> group u % (views * T) = (view, t)
+        else:
+            assert groups == 1, "view batching: contiguous multi-group BatchNorm inside an encoder is not supported"
+            groups, il_frames = views, clips               # clip c -> group c % views
     if training and bn.num_batches_tracked is not None:
         if _NBT_PENDING is not None:
             _NBT_PENDING.append((bn.num_batches_tracked, groups))
