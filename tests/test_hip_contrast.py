@@ -51,7 +51,10 @@ def _args():
                                  pretrainpth="none", num_instances=2235, batch_size=2, epochs=150, start_epoch=1)
 
 
-def test_consistency_loss_step_matches_reference():
+@pytest.mark.parametrize("views", ["batched", "sequential"])
+def test_consistency_loss_step_matches_reference(views, monkeypatch):
+    # batched: the 2 query / 6 key passes as one batch each with per-view BatchNorm statistics; sequential: one pass per view
+    monkeypatch.setenv("STSWIN_SEQUENTIAL_VIEWS", "1" if views == "sequential" else "0")
     g = gu.load("consistency.npz")
     hh, ww = [int(v) for v in g["hw"]]
     net = P.ConsistencyLoss(_args(), input_resolution=(hh // 8, ww // 8))
