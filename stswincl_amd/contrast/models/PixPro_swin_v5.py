@@ -214,7 +214,7 @@ class PixPro(nn.Module):
         for q_mod, k_mod in self._pairs():
             for pq, pk in zip(q_mod.parameters(), k_mod.parameters()):
                 qs.append(pq.data)
-                ks.append(pk.data)
+                ks.append(pk)                              # the parameter itself: ema_update bumps its version counter
         from ...optim import ema_update
         ema_update(ks, qs, m)
 

@@ -15,6 +15,19 @@ import torch
 from . import hip
 
 
+def _mark_updated(params: Sequence[torch.Tensor]) -> None:
+    """The multi-tensor kernel writes through raw pointers, which autograd's version counters do not see - and the bf16
+    weight cache of the GEMM path (ops.wcast) is keyed on `_version`, exactly like anything else that memoises on a
+    parameter.  Bump the counters of the tensors just written (no kernel launch)."""
+    if not params:
+        return
+    setter = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
+    if setter is not None:
+        setter(list(params), [int(p._version) + 1 for p in params])
+    else:                                  # older torch: an in-place no-op through the dispatcher
+        torch._foreach_add_(list(params), 0)
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
@@ -23,7 +36,7 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
-            ps, gs, ms, vs = [], [], [], []
+            ps, gs, ms, vs, touched = [], [], [], [], []
             b1, b2 = group["betas"]
             step = None
             for p in group["params"]:
@@ -37,12 +50,14 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 step = st["step"]
                 ps.append(p.data)
+                touched.append(p)
                 gs.append(p.grad.contiguous() if not p.grad.is_contiguous() else p.grad)
                 ms.append(st["exp_avg"])
                 vs.append(st["exp_avg_sq"])
             if ps:
                 hip.multi_tensor(0, ps, gs, ms, vs, lr=group["lr"], b1=b1, b2=b2, eps=group["eps"], wd=group["weight_decay"],
                                  c1=1.0 - b1 ** step, c2=math.sqrt(1.0 - b2 ** step))
+                _mark_updated(touched)
         return loss
 
 
@@ -54,7 +69,7 @@ class FusedSGD(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
-            first, later = ([], [], []), ([], [], [])
+            first, later, touched = ([], [], []), ([], [], []), []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -66,15 +81,19 @@ class FusedSGD(torch.optim.Optimizer):
                 else:
                     tgt = later
                 tgt[0].append(p.data)
+                touched.append(p)
                 tgt[1].append(g)
                 tgt[2].append(st["momentum_buffer"])
             for (ps, gs, ms), c1 in ((first, 1.0), (later, 0.0)):
                 if ps:
                     hip.multi_tensor(1, ps, gs, ms, None, lr=group["lr"], b1=group["momentum"], wd=group["weight_decay"], c1=c1)
+            _mark_updated(touched)
         return loss
 
 
 @torch.no_grad()
 def ema_update(keys: Sequence[torch.Tensor], queries: Sequence[torch.Tensor], momentum: float) -> None:
-    """key <- key * momentum + query * (1 - momentum) for every pair."""
+    """key <- key * momentum + query * (1 - momentum) for every pair.  Pass the key PARAMETERS (not their .data aliases):
+    their version counters are bumped so that caches keyed on them see the update."""
     hip.multi_tensor(2, [k.data for k in keys], [q.data for q in queries], b1=momentum)
+    _mark_updated(list(keys))

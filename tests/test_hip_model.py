@@ -96,3 +96,30 @@ def test_resnet_frames_batched_equals_per_frame_oracle(mode, tol):
         net2.load_state_dict(sd)
         y = net2.cuda().train()(xg[:, 0])
         assert rel(y, ref[:, 0]) < tol
+
+
+def test_fused_adam_steps_reach_the_gemm_weight_cache():
+    """Three training steps with FusedAdam against the same steps with torch.optim.Adam (fp32 path): the fused kernel writes
+    the parameters through raw pointers, so it must bump their version counters or the cached GEMM operands (ops.wcast,
+    keyed on `_version`) would keep multiplying the initial weights."""
+    from stswincl_amd.optim import FusedAdam
+    losses = {}
+    for name in ("fused", "torch"):
+        g, m = _model()
+        m.train()
+        opt = FusedAdam(m.parameters(), 1e-3) if name == "fused" else torch.optim.Adam(m.parameters(), 1e-3)
+        x = gu.det_tensor("tswinplus/x", (2, 4, 3, 128, 128)).cuda()
+        labels = torch.from_numpy(g["labels"]).long().cuda()
+        v0 = next(m.swin.parameters())._version
+        ls = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = OhemCELoss2D(128 * 128 // 16)(m(x), labels)
+            loss.backward()
+            opt.step()
+            ls.append(float(loss))
+        assert next(m.swin.parameters())._version > v0
+        losses[name] = ls
+    assert losses["fused"][1] != losses["fused"][0], "the second step must see the updated weights"
+    for a, b in zip(losses["fused"], losses["torch"]):
+        assert abs(a - b) < 2e-3 * abs(b), (losses["fused"], losses["torch"])
