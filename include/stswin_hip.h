@@ -72,6 +72,9 @@ int stswin_stem_im2col(int dtype, const float* img, void* patches, long ld, int 
  * channel of each padded channel position or -1 (zero).  (ASPP.py:37-50, base18.py:60-77, resnet.py convolutions) */
 int stswin_conv_pack(int dtype, const float* w, void* fwd, void* dgrad, const int* omap, const int* imap, int co, int ci, int S,
                      int cop, int cip, void* stream);
+/* nn.Linear weight [n][k] fp32 -> fwd [n][k] and (if not NULL) tr [k][n] in the compute dtype, one launch (n, k multiples of 4):
+ * the B operands of y = x W^T and of dx = dy W (swin_512.py:18-21,115,139,275), re-made after every optimizer step. */
+int stswin_linear_pack(int dtype, const float* w, void* fwd, void* tr, int n, int k, void* stream);
 int stswin_maxpool3x3s2(int dtype, const void* in, long ldi, void* out, long ldo, unsigned char* arg, int frames, int H,
                         int W, int Ho, int Wo, int C, int backward, void* stream);
 

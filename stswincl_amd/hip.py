@@ -240,6 +240,16 @@ def conv_pack(w: torch.Tensor, dt: torch.dtype, omap: torch.Tensor, imap: torch.
     return fwd, dg
 
 
+def linear_pack(w: torch.Tensor, dt: torch.dtype, want_tr: bool = True):
+    """nn.Linear weight [n][k] fp32 -> (W, W^T or None) in dtype dt, one launch."""
+    n, k = w.shape
+    wf = w.detach().float().contiguous()
+    fwd = torch.empty(n, k, dtype=dt, device=w.device)
+    tr = torch.empty(k, n, dtype=dt, device=w.device) if want_tr else None
+    _check(load().stswin_linear_pack(0 if dt == torch.bfloat16 else 1, _p(wf), _p(fwd), _p(tr), n, k, _stream()), "linear_pack")
+    return fwd, tr
+
+
 def stem_im2col(img: torch.Tensor, dtype: torch.dtype, Ho: int, Wo: int, ld: int = 192) -> torch.Tensor:
     """img fp32 NCHW [F][3][H][W] -> patches [F*Ho*Wo][ld] (7x7 / stride 2 / pad 3)."""
     F_, c, H, W = img.shape

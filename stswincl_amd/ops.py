@@ -80,7 +80,10 @@ def wcast(p: torch.Tensor, dtype: torch.dtype, transpose: bool = False) -> torch
         if (w.dim() == 2 and w.is_cuda and w.dtype == torch.float32 and dtype in (torch.bfloat16, torch.float32)
                 and os.environ.get("STSWIN_TORCH_PACK") != "1"):   # (env switch: A/B against the torch formulation)
             n, k = w.shape
-            fwd, tr = hip.conv_pack(w.view(n, k, 1, 1), dtype, _identity_map(n, w.device), _identity_map(k, w.device))
+            if n % 4 == 0 and k % 4 == 0:
+                fwd, tr = hip.linear_pack(w, dtype)
+            else:
+                fwd, tr = hip.conv_pack(w.view(n, k, 1, 1), dtype, _identity_map(n, w.device), _identity_map(k, w.device))
         else:
             fwd, tr = w.to(dtype).contiguous(), None
         if len(_WCACHE) > 4096:          # drop entries whose parameter died (ids get recycled)
