@@ -335,7 +335,7 @@ def main():
             res["roofline"] = {"kernel": k, "bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": tf / PEAK_BF16_TFLOPS, "traffic": traffic,
                                "traffic_note": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc "
-                                               "passes over this command (profiles/r01_v14_pmc_*.txt)",
+                                               "passes over this command (profiles/r01_v16_pmc_*.txt)",
                                "algorithmic_flops_per_launch": p["work"] / p["sampled"],
                                "launches_per_step": p["launches"] / a.steps,
                                "launches_timed": p["sampled"],
