@@ -145,15 +145,19 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* w, T* fwd, 
   {
     const int ip = i0 + tx;
     const int si = ip < cip ? imap[ip] : -1;
-#pragma unroll 4
+    // three phases, each with its 16 requests in flight together (map entries, weights, stores): as one loop it was 16
+    // dependent map -> weight round trips per thread
+    int so[16];
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int op = o0 + k * 4 + ty; so[k] = op < cop ? omap[op] : -1; }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (so[k] >= 0 && si >= 0) ? w[((long)so[k] * ci + si) * S + s] : 0.f;
+#pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int ol = k * 4 + ty, op = o0 + ol;
-      T o = from_f32<T>(0.f);
-      if (op < cop && ip < cip) {
-        const int so = omap[op];
-        if (so >= 0 && si >= 0) o = from_f32<T>(w[((long)so * ci + si) * S + s]);
-        fwd[((long)op * S + s) * cip + ip] = o;
-      }
+      const T o = from_f32<T>(v[k]);
+      if (op < cop && ip < cip) fwd[((long)op * S + s) * cip + ip] = o;
       tile[ol][tx] = o;
     }
   }
