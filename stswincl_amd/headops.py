@@ -348,7 +348,7 @@ class BNTokFn(torch.autograd.Function):
         else:
             s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, beta=bp, unit=ctx.unit)
         if groups > 1:                                   # s1 / s2 are the two halves of one [2][groups][C] buffer: one reduce
-            if s1.data_ptr() + s1.numel() * 4 == s2.data_ptr():
+            if s1._base is not None and s2._base is s1._base and s2.storage_offset() == s1.storage_offset() + s1.numel():
                 both = torch.as_strided(s1, (2, groups, s1.shape[-1]), (groups * s1.shape[-1], s1.shape[-1], 1)).sum(1)
                 s1, s2 = both[0:1], both[1:2]
             else:
