@@ -144,3 +144,14 @@ def test_vec_gather_pads_and_unpads_channel_vectors():
         ref[b:b + n] = v.cpu()[a:a + n]
     assert torch.equal(p.cpu(), ref)
     assert torch.equal(lay.unpad_vec(p).cpu(), v.cpu())
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("n,k", [(512, 2048), (132, 68), (64, 64), (4, 260)])
+def test_linear_pack_cast_and_transpose(dt, n, k):
+    """stswin_linear_pack: W and W^T of an nn.Linear weight in the compute dtype (tile edges, both dtypes)."""
+    w = torch.randn(n, k, device="cuda")
+    fwd, tr = hip.linear_pack(w, dt)
+    assert torch.equal(fwd, w.to(dt)) and torch.equal(tr, w.t().to(dt).contiguous())
+    fwd2, none = hip.linear_pack(w, dt, want_tr=False)
+    assert none is None and torch.equal(fwd2, fwd)
