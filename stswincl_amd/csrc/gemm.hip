@@ -1365,6 +1365,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(GemmTN p) {
     for (int j = 0; j < JN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fr = l & 15, fq = l >> 4;
+  const bool row_active = i0 + wr * 64 < p.Ni;
   fetch_rows(t_begin);
   stage(0);
   if (t_begin + 1 < t_end) fetch_rows(t_begin + 1);
@@ -1372,13 +1373,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(GemmTN p) {
     const int buf = (tk - t_begin) & 1;
     wait_vm0();
     __syncthreads();
-    if (tk + 1 < t_end) {
-      stage(buf ^ 1);
-      if (tk + 2 < t_end) fetch_rows(tk + 2);
-    }
+    if (tk + 1 < t_end) stage(buf ^ 1);
     const char* Ab = smem + buf * 32768;
     const char* Bb = Ab + 16384;
-    if constexpr (TT<T>::IS_BF16) {
+    // (wave rows whose 64 output rows lie beyond Ni - the second row of a tile when Ni <= 64, ResNet layer 1 - only copy)
+    if (!row_active) {
+    } else if constexpr (TT<T>::IS_BF16) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8 a[4], b[JN];
@@ -1416,6 +1416,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(GemmTN p) {
           for (int j = 0; j < JN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
+    // the scalar map loads of the tile after next go out BEHIND the fragment reads: requested in front of them they turned
+    // the staged lgkmcnt waits of the reads into one wait for everything (see gemm_tn_ring_kernel)
+    if (tk + 2 < t_end) fetch_rows(tk + 2);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
