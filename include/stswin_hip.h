@@ -92,6 +92,8 @@ int stswin_cs_reduce(const float* partials, int M, int N, float* out, void* stre
 /* weight gradients: C[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]   (fp32 atomics; splits<=0: auto).
  * bseg > 0 (convolution wgrad in one launch): column j of the B operand is column j % bseg of row
  * bt_rows[(j / bseg) * Mk + m], i.e. tap t = j / bseg uses its own row map.
+ * With bf16 operands and a workspace the split-K partials are kept as bf16 (each an fp32 sum of Mk / splits products, rounded
+ * once; the combine pass adds them in fp32): half the slab traffic.  Environment STSWIN_TN_F32_SLABS=1 keeps fp32 partials.
  * Bits of a positive `splits`: STSWIN_TN_OVERWRITE (1<<27) stores C = result instead of accumulating (C may be
  * uninitialised; saves the caller's zero fill); bits 28-30 are tuning overrides (forbid / force the 256x256 ring kernel,
  * 4-wave 128x128 variant) used by tools/tn_sweep.py; the low bits are the split count, 0 = automatic. */

@@ -1254,6 +1254,7 @@ struct GemmTN {
   int splits;                                     // grid.y
   int bseg;                                       // >0: Bt column j reads source column j % bseg of row bt_rows[(j / bseg)*Mk + m]
   float* slabs;                                   // optional [splits][Ni][Nj] partial results (plain stores) instead of atomics
+  int slab_bf16;                                  // the partials are stored as bf16 (half the slab traffic; see stswin_gemm_tn)
 };
 
 template <typename T, int NW>
@@ -1429,7 +1430,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(GemmTN p) {
         const int gi = i0 + wr * 64 + i * 16 + 4 * fq + r;
         const int gj = j0 + wc * (16 * JN) + j * 16 + fr;
         if (gi < p.Ni && gj < p.Nj) {
-          if (p.slabs) p.slabs[((long)split_id * p.Ni + gi) * p.Nj + gj] = acc[i][j][r];
+          if (p.slabs) {
+            const long so = ((long)split_id * p.Ni + gi) * p.Nj + gj;
+            if (p.slab_bf16) ((bf16*)p.slabs)[so] = (bf16)acc[i][j][r];
+            else p.slabs[so] = acc[i][j][r];
+          }
           else atomicAdd(p.C + (long)gi * p.ldc + gj, acc[i][j][r]);
         }
       }
@@ -1662,7 +1667,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
         const int gi = i0 + wr * 128 + i * 16 + 4 * fq + r;
         const int gj = j0 + wc * 64 + j * 16 + fr;
         if (gi < p.Ni && gj < p.Nj) {
-          if (p.slabs) p.slabs[((long)split_id * p.Ni + gi) * p.Nj + gj] = acc[i][j][r];
+          if (p.slabs) {
+            const long so = ((long)split_id * p.Ni + gi) * p.Nj + gj;
+            if (p.slab_bf16) ((bf16*)p.slabs)[so] = (bf16)acc[i][j][r];
+            else p.slabs[so] = acc[i][j][r];
+          }
           else atomicAdd(p.C + (long)gi * p.ldc + gj, acc[i][j][r]);
         }
       }
@@ -1670,12 +1679,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
 
 // C[i][j] += sum_s slabs[s][i][j]   (the split-K combine: plain stores + this pass cost ~half of 32 MB of fp32 atomics)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, float* C, long ldc, int Ni, int Nj, int splits,
-                                                        int overwrite) {
+                                                        int overwrite, int slab_bf16) {
   const long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (idx >= (long)Ni * Nj) return;
   const int i = idx / Nj, j = idx % Nj;           // Nj % 4 == 0
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < splits; ++s) a += *(const f32x4*)(slabs + (long)s * Ni * Nj + idx);
+  if (slab_bf16) {
+    for (int s = 0; s < splits; ++s) {
+      const bf16x4 v = *(const bf16x4*)((const bf16*)slabs + (long)s * Ni * Nj + idx);
+      a += (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+  } else {
+    for (int s = 0; s < splits; ++s) a += *(const f32x4*)(slabs + (long)s * Ni * Nj + idx);
+  }
   float* dst = C + (long)i * ldc + j;
   if (overwrite) {
     if ((ldc & 3) == 0) *(f32x4*)dst = a;
@@ -1841,6 +1857,11 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
                               float* workspace, long workspace_floats, void* stream) {
   if (Mk <= 0 || Ni <= 0 || Nj <= 0) return 0;
   const int overwrite = (splits > 0 && (splits & (1 << 27))) ? 1 : 0;         // C = result instead of C += result
+  // bf16 operands: the split-K partials are stored as bf16 (each the fp32 sum of Mk / splits products, rounded once; the
+  // combine pass adds them in fp32) - half the slab traffic of the weight gradients, the relative rounding error of a
+  // gradient is 2^-9 / sqrt(splits) (a bf16 autocast GEMM rounds its whole result once, 2^-9).  STSWIN_TN_F32_SLABS=1: fp32.
+  static const int f32_slabs = getenv("STSWIN_TN_F32_SLABS") && atoi(getenv("STSWIN_TN_F32_SLABS")) ? 1 : 0;
+  const int slab_bf16 = (dtype == 0 && !f32_slabs) ? 1 : 0;
   if (splits > 0) splits &= ~(1 << 27);
   const int splits_flags_w4 = (splits > 0 && (splits & (1 << 30))) ? 1 : 0;   // tuning: bit 30 selects the 4-wave variant
   if (splits > 0) splits &= ~(1 << 30);
@@ -1879,7 +1900,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
     if (ring) {
       const bool slabs = workspace && rs > 1 && (long)rs * Ni * Nj <= workspace_floats;
       if (overwrite && !slabs) (void)hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)Nj * sizeof(float), (size_t)Ni, (hipStream_t)stream);
-      GemmTN q{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, rs, bseg, slabs ? workspace : nullptr};
+      GemmTN q{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, rs, bseg, slabs ? workspace : nullptr, slab_bf16};
       static int once_r = (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
                           (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
                           (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
@@ -1893,7 +1914,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
       if (slabs) {
         const long n4 = ((long)Ni * Nj + 3) / 4;
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, C, ldc,
-                           Ni, Nj, rs, overwrite);
+                           Ni, Nj, rs, overwrite, slab_bf16);
       }
       STSWIN_CHECK_LAUNCH();
       return 0;
@@ -1917,7 +1938,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   if (splits > ntile) splits = ntile;
   const bool use_slabs = workspace && splits > 1 && (long)splits * Ni * Nj <= workspace_floats;
   if (overwrite && !use_slabs) (void)hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)Nj * sizeof(float), (size_t)Ni, (hipStream_t)stream);
-  GemmTN p{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, splits, bseg, use_slabs ? workspace : nullptr};
+  GemmTN p{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, splits, bseg, use_slabs ? workspace : nullptr, slab_bf16};
   dim3 grid(((Ni + 127) / 128) * ((Nj + 127) / 128) * splits);
   static int once = set_lds_once((const void*)gemm_tn_kernel<bf16, 4>) | set_lds_once((const void*)gemm_tn_kernel<float, 4>) |
                     set_lds_once((const void*)gemm_tn_kernel<bf16, 8>) | set_lds_once((const void*)gemm_tn_kernel<float, 8>);
@@ -1933,7 +1954,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   if (use_slabs) {
     const long n4 = ((long)Ni * Nj + 3) / 4;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, C, ldc,
-                       Ni, Nj, splits, overwrite);
+                       Ni, Nj, splits, overwrite, slab_bf16);
   }
   STSWIN_CHECK_LAUNCH();
   return 0;
