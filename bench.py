@@ -122,7 +122,8 @@ def contrast_main(a):
     torch.manual_seed(0)
     model = ConsistencyLoss(args, input_resolution=(S // 8, S // 8)).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.SGD(params, 0.05, momentum=0.9, weight_decay=1e-5)
+    from stswincl_amd.optim import FusedSGD
+    opt = FusedSGD(params, 0.05, momentum=0.9, weight_decay=1e-5)   # == torch.optim.SGD (tests/test_hip_optim.py), one multi-tensor launch
     reducer = GradBucketReducer(params, bucket_mb=64.0) if world > 1 else None
     torch.manual_seed(1234 + rank)
     ims = [torch.randn(B, 4, 3, S, S, device=dev) for _ in range(6)]
