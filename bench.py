@@ -6,16 +6,23 @@ B = 4 clips/GPU of T = 4 frames (the reference asserts T == 4), 3x512x512, bf16 
 OHEM cross-entropy (n_min = 512*512/16), Adam lr 1e-4 (seg18/train_swin.py:122), synthetic frames and labels
 resident in HBM, random-init weights.  One step = model fwd + loss + bwd (+ gradient all-reduce) + optimizer.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without WORLD_SIZE in the environment: this process starts N ranks itself (a child `python -m torch.distributed.run
+--nproc-per-node N ... bench.py <same flags>`, BEFORE anything here touches the GPU) and exits with the child's code;
+under torch.distributed.run (WORLD_SIZE set) it is one rank of the job.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, live HIP
-events) and `cpu_baseline` (the CPU oracle timed on this host, N = 1 only).
+events), `secondary` (BASELINE's second metric, contrastive pairs/s, from a short run of the configs[3] step) and
+`cpu_baseline` (the CPU oracle timed on this host, N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,7 +46,10 @@ def parse():
     ap.add_argument("--cpu-size", type=int, default=512)
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-stride", type=int, default=9,
-                    help="bracket every n-th launch of each kernel family with HIP events (1 = all; the records cost host time)")
+                    help="bracket one launch in n of each kernel family (seeded random choice) with HIP events (1 = all; the "
+                         "records cost host time)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short contrastive run that fills `secondary`")
+    ap.add_argument("--secondary-steps", type=int, default=4)
     ap.add_argument("--dump-prof", default=None,
                     help="write the per-span timing table here (with STSWIN_SHAPE_PROFILE=1: one row per GEMM shape)")
     ap.add_argument("--workload", default="seg", choices=["seg", "contrast"],
@@ -52,11 +62,12 @@ def parse():
 def cpu_baseline(size: int, budget_s: float = 25.0):
     """The oracle (a port of the reference graph) doing the same training step on the host cores.
 
-    Bounded sample: one fwd+bwd+Adam step of B = 2 clips (B = 1 cannot train: ASPP's BatchNorm on a 1x1 map) in fp32.
+    Bounded sample: fwd+bwd+Adam steps of B = 2 clips (B = 1 cannot train: ASPP's BatchNorm on a 1x1 map) in fp32.
     A 128x128 calibration step predicts the cost of the full-resolution step (work scales with pixels); if that would
     exceed the budget the largest of {size, size/2, size/4} that fits is timed and the rate is scaled by the pixel
-    ratio (stated in `sample`).  Threads are capped at 32: oversubscribing a shared 256-thread host made the same
-    step 20x slower."""
+    ratio (stated in `sample`).  As many repeats as fit the budget (at most 3) are run and the best is reported.
+    Threads are capped at 32: oversubscribing a shared 256-thread host made the same step 20x slower (so this is NOT the
+    "all physical cores, best of 3" baseline SURVEY 8(d) sketches; `cores` and `sample` say what was run)."""
     from oracle import stswin_oracle as O
     from stswincl_amd.net.Ours.base18 import TswinPlus
     try:
@@ -88,42 +99,120 @@ def cpu_baseline(size: int, budget_s: float = 25.0):
     sz = size
     while sz > 128 and t_cal * (sz / 128.0) ** 2 > budget_s:
         sz //= 2
-    dt = t_cal if sz == 128 else one_step(sz)
+    t_pred = t_cal * (sz / 128.0) ** 2
+    times = [t_cal] if sz == 128 else []
+    while len(times) < 3 and (not times or sum(times) + t_pred <= budget_s):
+        times.append(one_step(sz))
+    dt = min(times)
     scale = (sz / float(size)) ** 2    # pixel-count ratio: a smaller frame is proportionally less work
     return {"value": 2 * 4 / dt * scale, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"1 fwd+bwd+Adam step of the CPU oracle, B=2 clips x 4 frames at {sz}x{sz} fp32 took {dt:.1f} s on "
-                      f"{threads} threads ({avail} visible); rate scaled by ({sz}/{size})^2 to {size}x{size} frames; "
-                      f"calibration step at 128x128: {t_cal:.1f} s"}
+            "sample": f"best of {len(times)} fwd+bwd+Adam step(s) of the CPU oracle, B=2 clips x 4 frames at {sz}x{sz} fp32: "
+                      f"{dt:.1f} s on {threads} threads ({avail} visible; capped at 32, more made it slower); rate scaled by "
+                      f"({sz}/{size})^2 to {size}x{size} frames; calibration step at 128x128: {t_cal:.1f} s"}
 
 
-def contrast_main(a):
-    """BASELINE.json configs[3] as far as the reference can run it: ConsistencyLoss (PixPro-style, 2 query + 6 momentum-key
-    encoder passes) at 256x256 (224 is illegal for the window sizes), B clips/GPU, SGD momentum (LARS is a next row).
-    Reports contrastive pairs/s = 2 directions x B x HW x 5 HW per step, and input frames/s."""
-    import types
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("STSWIN_BENCH_SHARE_GPU") == "1":     # functional test of the N > 1 path on a 1-GPU box (gloo backend)
-        local = local % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("STSWIN_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
-                                **({"device_id": dev} if os.environ.get("STSWIN_DIST_BACKEND", "nccl") == "nccl" else {}))
+class Ctx:
+    """Rank / device / process group of this process (one process per GPU)."""
+
+    def __init__(self):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.share = os.environ.get("STSWIN_BENCH_SHARE_GPU") == "1"   # functional test of the N > 1 path on a 1-GPU box
+        ndev = torch.cuda.device_count()
+        if self.share:
+            local = local % max(1, ndev)
+        elif self.world > ndev:
+            raise SystemExit(f"bench.py: {self.world} ranks but {ndev} GPUs visible (STSWIN_BENCH_SHARE_GPU=1 + gloo shares one "
+                             f"GPU for a functional test)")
+        torch.cuda.set_device(local)
+        self.dev = torch.device("cuda", local)
+        self.backend = os.environ.get("STSWIN_DIST_BACKEND", "gloo" if self.share else "nccl")
+        self.ranks_seen = 1
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(self.backend, rank=self.rank, world_size=self.world,
+                                    **({"device_id": self.dev} if self.backend == "nccl" else {}))
+            one = torch.ones(1, device=self.dev if self.backend == "nccl" else "cpu")
+            dist.all_reduce(one)                       # every rank really is in the collective
+            self.ranks_seen = int(one.item())
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt: float) -> float:
+        if self.world == 1:
+            return dt
+        tt = torch.tensor([dt], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def dist_info(self, reducer):
+        return {"backend": ("rccl (torch.distributed 'nccl')" if self.backend == "nccl" else self.backend),
+                "rccl_ranks": self.ranks_seen,
+                "allreduce_bytes_per_step_per_rank": reducer.bytes_per_step() if reducer is not None else 0,
+                "shared_gpu_functional_test": self.share}
+
+
+def timed_steps(ctx, step, steps, warmup, profile_stride):
+    """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
     from stswincl_amd import hip
+    loss = None
+    for _ in range(warmup):
+        loss = step()
+    ctx.barrier()
+    if profile_stride and ctx.rank == 0:
+        hip.profile_begin(profile_stride)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    prof = hip.profile_end() if (profile_stride and ctx.rank == 0) else {}
+    return ctx.max_over_ranks(dt), prof, loss
+
+
+def capture(step_fn, zero_grad):
+    """hipGraph capture of a whole training step: every kernel of libstswin_hip is launched on the current stream with
+    caller-owned workspaces and no host sync, so the step replays as one graph launch."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step_fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    zero_grad()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_loss = step_fn()
+
+    def replay():
+        graph.replay()
+        return static_loss
+    return replay
+
+
+def contrast_run(a, ctx, steps, warmup, profile_stride, batch=8):
+    """BASELINE.json configs[3] as far as the reference can run it: ConsistencyLoss (PixPro-style, 2 query + 6 momentum-key
+    encoder passes) at 256x256 (224 is illegal for the window sizes), B clips/GPU, LARS over SGD-momentum as in
+    main_pretrain_swinv5.py:37-47.  Reports contrastive pairs/s = 2 directions x B x HW x 5 HW per step."""
+    import types
     from stswincl_amd.contrast.models.PixPro_swin_v5 import ConsistencyLoss
     from stswincl_amd.dp import GradBucketReducer
-    S, B = 256, (a.batch if a.batch != 4 else 8)
+    from stswincl_amd.optim import make_contrast_optimizer
+    world, rank, dev = ctx.world, ctx.rank, ctx.dev
+    S, B = 256, batch
     args = types.SimpleNamespace(pixpro_p=1.0, pixpro_momentum=0.99, pixpro_clamp_value=0.0, pixpro_transform_layer=1,
                                  pixpro_ins_loss_weight=0.0, pixpro_pos_ratio=0.7, data="endo18", tag="1", pretrainpth=None,
                                  num_instances=2235, batch_size=B, epochs=150, start_epoch=1)
     torch.manual_seed(0)
     model = ConsistencyLoss(args, input_resolution=(S // 8, S // 8)).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
-    from stswincl_amd.optim import FusedSGD
-    opt = FusedSGD(params, 0.05, momentum=0.9, weight_decay=1e-5)   # == torch.optim.SGD (tests/test_hip_optim.py), one multi-tensor launch
+    opt, opt_name = make_contrast_optimizer(params, batch_size=B * world)
     reducer = GradBucketReducer(params, bucket_mb=64.0) if world > 1 else None
     torch.manual_seed(1234 + rank)
     ims = [torch.randn(B, 4, 3, S, S, device=dev) for _ in range(6)]
@@ -139,107 +228,56 @@ def contrast_main(a):
         opt.step()
         return loss
 
-    graph = None
-    if a.graph == 1 or (a.graph == -1 and world == 1 and a.no_profile):
+    graphed = a.graph == 1 or (a.graph == -1 and world == 1 and not profile_stride)
+    if graphed:
         # the contrastive step is ~2400 launches of 20-70 us kernels (8 encoder passes at 256x256): eager launches keep the
-        # GPU only 68 % busy (profiles/r01_v13_contrast_steady_state_kernels.txt); one hipGraph replay removes the host from
-        # the loop
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        opt.zero_grad(set_to_none=True)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = step()
-
-        def step():  # noqa: F811
-            graph.replay()
-            return static_loss
-
-    for _ in range(a.warmup):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    if rank == 0 and not a.no_profile:
-        hip.profile_begin(a.profile_stride)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof = hip.profile_end() if (rank == 0 and not a.no_profile) else {}
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    if rank == 0:
-        hw = (S // 8) ** 2
-        pairs = world * 2 * B * hw * 5 * hw * a.steps
-        res = {"metric": "contrastive pairs/s, ConsistencyLoss fwd+bwd+SGD (2 query + 6 key encoder passes), 256x256",
-               "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"BASELINE.json configs[3]: PixPro-style ConsistencyLoss, {B} x 6 clips/GPU x T=4 x 3x{S}x{S} "
-                                      f"(224 is illegal for windows 8/4), per-sample label-guided loss as in the reference "
-                                      f"(no bank); SGD instead of LARS", "clips_per_gpu": 6 * B, "parallelism": f"dp{world}",
-                          "input_frames_per_s": world * 6 * B * 4 * a.steps / dt, "loss": float(loss),
-                          "launch": "hipGraph replay of the whole step" if graph is not None else "eager launches"}}
-        if "contrast_fwd_bf16" in prof:
-            p = prof["contrast_fwd_bf16"]
-            tf = p["work"] / (p["ms_total"] * 1e-3) / 1e12
-            res["roofline"] = {"kernel": "contrast_fwd_bf16", "bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS,
+        # GPU only 68 % busy (profiles/r01_v13_contrast_steady_state_kernels.txt); one hipGraph replay removes the host
+        step = capture(step, lambda: opt.zero_grad(set_to_none=True))
+    dt, prof, loss = timed_steps(ctx, step, steps, warmup, profile_stride)
+    hw = (S // 8) ** 2
+    pairs = world * 2 * B * hw * 5 * hw * steps
+    res = {"metric": f"contrastive pairs/s, ConsistencyLoss fwd+bwd+{opt_name} (2 query + 6 key encoder passes), 256x256",
+           "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"BASELINE.json configs[3]: PixPro-style ConsistencyLoss, {B} x 6 clips/GPU x T=4 x 3x{S}x{S} "
+                                  f"(224 is illegal for windows 8/4), per-sample label-guided loss as in the reference; {opt_name}",
+                      "clips_per_gpu": 6 * B, "parallelism": f"dp{world}",
+                      "input_frames_per_s": world * 6 * B * 4 * steps / dt, "loss": float(loss),
+                      "launch": "hipGraph replay of the whole step" if graphed else "eager launches"},
+           "dist": ctx.dist_info(reducer)}
+    for name in ("contrast_fwd_bf16", "contrast_bank_fwd_bf16"):
+        if name in prof:
+            q = prof[name]
+            tf = q["work"] / (q["ms_total"] * 1e-3) / 1e12
+            res["roofline"] = {"kernel": name, "bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS,
                                "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "traffic": None,
-                               "avg_launch_ms": p["ms_avg"], "pairs_per_s_in_kernel": p["work"] / 512.0 / (p["ms_total"] * 1e-3)}
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+                               "avg_launch_ms": q["ms_avg"], "pairs_per_s_in_kernel": q["work"] / 512.0 / (q["ms_total"] * 1e-3)}
+    del model, opt, reducer, ims, masks, step
+    return res
 
 
-def main():
-    a = parse()
-    if a.workload == "contrast":
-        return contrast_main(a)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("STSWIN_BENCH_SHARE_GPU") == "1":     # functional test of the N > 1 path on a 1-GPU box (gloo backend)
-        local = local % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("STSWIN_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
-                                **({"device_id": dev} if os.environ.get("STSWIN_DIST_BACKEND", "nccl") == "nccl" else {}))
-
-    import __graft_entry__ as ge
-    if rank == 0 and not os.path.exists(ge.LIB):
-        ge.build(verbose=False)
-    if world > 1:
-        dist.barrier()
+def seg_run(a, ctx):
     from stswincl_amd import hip
     from stswincl_amd.dp import GradBucketReducer
     from stswincl_amd.net.Ours.base18 import TswinPlus
+    from stswincl_amd.optim import FusedAdam
     from stswincl_amd.utils.losses import OhemCELoss2D
-    hip.load()
-
+    world, rank, dev = ctx.world, ctx.rank, ctx.dev
     S, B = a.size, a.batch
     torch.manual_seed(0)
     model = TswinPlus(12, (S // 8, S // 8)).to(dev)
     model.train()
     if world > 1:   # identical initial weights on every rank
         for p in model.parameters():
-            dist.broadcast(p.data, 0)
-    use_graph = a.graph == 1 or (a.graph == -1 and world == 1 and a.no_profile)
-    from stswincl_amd.optim import FusedAdam
+            if ctx.backend == "nccl":
+                dist.broadcast(p.data, 0)
+            else:
+                t = p.data.cpu()
+                dist.broadcast(t, 0)
+                p.data.copy_(t)
+    profile_stride = 0 if a.no_profile else a.profile_stride
+    use_graph = a.graph == 1 or (a.graph == -1 and world == 1 and not profile_stride)
     opt = FusedAdam(model.parameters(), 1e-4)          # == torch.optim.Adam (tests/test_hip_optim.py), 8 launches per step
     crit = OhemCELoss2D(S * S // 16)
     reducer = GradBucketReducer(model.parameters(), bucket_mb=64.0) if world > 1 else None
@@ -258,98 +296,107 @@ def main():
         opt.step()
         return loss
 
-    graph = None
     if use_graph:
-        # hipGraph capture of the whole step (fwd + loss + bwd + Adam): every kernel of libstswin_hip is launched on the
-        # current stream with caller-owned workspaces and no host sync, so the step replays as one graph launch.
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        opt.zero_grad(set_to_none=True)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = step()
-        eager_step = step
-
-        def step():  # noqa: F811
-            graph.replay()
-            return static_loss
-
-    for _ in range(a.warmup):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    if not a.no_profile and rank == 0:
-        hip.profile_begin(a.profile_stride)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof = hip.profile_end() if (not a.no_profile and rank == 0) else {}
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    if rank == 0:
-        frames = world * B * 4 * a.steps
-        res = {
-            "metric": "input frames/s, TswinPlus fwd+bwd+Adam, 4-frame 512x512 clips", "value": frames / dt,
-            "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: TswinPlus(12) seg train step, {B} clips/GPU x T=4 frames "
-                                   f"x 3x{S}x{S}, swin res ({S // 8},{S // 8}), OHEM-CE, Adam; T=4 because the reference "
-                                   f"asserts it (swin_512.py:313)",
-                       "clips_per_gpu": B, "frames_per_clip": 4, "parallelism": f"dp{world}",
-                       "launch": "hipGraph replay of the whole step" if graph is not None else "eager launches",
-                       "loss": float(loss)},
-        }
-        if prof and a.dump_prof:
-            with open(a.dump_prof, "w") as f:
-                f.write(f"# {a.steps} steps; ms are totals over those steps\n")
-                for n in sorted(prof, key=lambda n: -prof[n]["ms_total"]):
-                    q = prof[n]
-                    f.write(f"{q['ms_avg'] * q['launches'] / a.steps:9.3f} ms/step {q['launches'] // a.steps:4d} x {1e3 * q['ms_avg']:8.1f} us "
-                            f"{q['work'] / max(q['ms_total'], 1e-9) / 1e9:8.1f} TF/s  {n}\n")
-        if prof:
-            k = max(prof, key=lambda n: prof[n]["ms_avg"] * prof[n]["launches"])
-            p = prof[k]
-            tf = p["work"] / (p["ms_total"] * 1e-3) / 1e12
-            traffic = None      # HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/)
+        step = capture(step, lambda: opt.zero_grad(set_to_none=True))
+    dt, prof, loss = timed_steps(ctx, step, a.steps, a.warmup, profile_stride)
+    frames = world * B * 4 * a.steps
+    res = {
+        "metric": "input frames/s, TswinPlus fwd+bwd+Adam, 4-frame 512x512 clips", "value": frames / dt,
+        "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[1]: TswinPlus(12) seg train step, {B} clips/GPU x T=4 frames "
+                               f"x 3x{S}x{S}, swin res ({S // 8},{S // 8}), OHEM-CE, Adam; T=4 because the reference "
+                               f"asserts it (swin_512.py:313)",
+                   "clips_per_gpu": B, "frames_per_clip": 4, "parallelism": f"dp{world}",
+                   "launch": "hipGraph replay of the whole step" if use_graph else "eager launches",
+                   "loss": float(loss)},
+        "dist": ctx.dist_info(reducer),
+    }
+    if prof and a.dump_prof and rank == 0:
+        with open(a.dump_prof, "w") as f:
+            f.write(f"# {a.steps} steps; ms are totals over those steps\n")
+            for n in sorted(prof, key=lambda n: -prof[n]["ms_total"]):
+                q = prof[n]
+                f.write(f"{q['ms_avg'] * q['launches'] / a.steps:9.3f} ms/step {q['launches'] // a.steps:4d} x {1e3 * q['ms_avg']:8.1f} us "
+                        f"{q['work'] / max(q['ms_total'], 1e-9) / 1e9:8.1f} TF/s  {n}\n")
+    if prof:
+        k = max(prof, key=lambda n: prof[n]["ms_avg"] * prof[n]["launches"])
+        q = prof[k]
+        tf = q["work"] / (q["ms_total"] * 1e-3) / 1e12
+        traffic, traffic_src = None, None      # HBM bytes per launch: NOT measured in this run, read from the committed PMC summary
+        for name in ("r02_pmc_dominant_kernel.json", "r01_pmc_dominant_kernel.json"):
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")) as f:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
                     pmc = json.load(f)
                 if pmc.get("kernel") == k:
-                    traffic = pmc["hbm_bytes_per_launch"]
+                    traffic, traffic_src = pmc["hbm_bytes_per_launch"], name
+                    break
             except Exception:
                 pass
-            res["roofline"] = {"kernel": k, "bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tf / PEAK_BF16_TFLOPS, "traffic": traffic,
-                               "traffic_note": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc "
-                                               "passes over this command (profiles/r01_v16_pmc_*.txt)",
-                               "algorithmic_flops_per_launch": p["work"] / p["sampled"],
-                               "launches_per_step": p["launches"] / a.steps,
-                               "launches_timed": p["sampled"],
-                               "timing": f"HIP events on the launch stream around every {a.profile_stride}-th launch inside the "
-                                         f"timed region; averages are over the timed launches",
-                               "avg_launch_ms": p["ms_avg"], "ms_per_step": p["ms_avg"] * p["launches"] / a.steps,
-                               "other_kernels": {n: {"ms_per_step": v["ms_avg"] * v["launches"] / a.steps,
-                                                     "tflops": v["work"] / (v["ms_total"] * 1e-3) / 1e12}
-                                                 for n, v in prof.items() if n != k}}
-        if world == 1 and not a.no_cpu_baseline:
+        res["roofline"] = {"kernel": k, "bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": tf / PEAK_BF16_TFLOPS, "traffic": traffic,
+                           "traffic_static_source": f"profiles/{traffic_src}: bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from "
+                                                    f"separate rocprofv3 --pmc passes over this command; a committed number, "
+                                                    f"not collected during this run" if traffic_src else None,
+                           "algorithmic_flops_per_launch": q["work"] / q["sampled"],
+                           "launches_per_step": q["launches"] / a.steps,
+                           "launches_timed": q["sampled"],
+                           "timing": f"HIP events on the launch stream around one launch in {a.profile_stride} (seeded random "
+                                     f"choice per launch) inside the timed region; averages are over the timed launches",
+                           "avg_launch_ms": q["ms_avg"], "ms_per_step": q["ms_avg"] * q["launches"] / a.steps,
+                           "other_kernels": {n: {"ms_per_step": v["ms_avg"] * v["launches"] / a.steps,
+                                                 "tflops": v["work"] / (v["ms_total"] * 1e-3) / 1e12}
+                                             for n, v in prof.items() if n != k}}
+    del model, opt, reducer, x, y, step
+    return res
+
+
+def launch_ranks(a) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run job.  Nothing in this
+    process has touched the GPU (only `import torch`), and nothing is exec'ed: the parent waits and returns the child's code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
+    ctx = Ctx()
+    if a.gpus != ctx.world and ctx.rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={ctx.world}; reporting n_gpus = {ctx.world}", file=sys.stderr)
+    import __graft_entry__ as ge
+    if ctx.rank == 0 and not os.path.exists(ge.LIB):
+        ge.build(verbose=False)
+    if ctx.world > 1:
+        dist.barrier()
+    from stswincl_amd import hip
+    hip.load()
+    if a.workload == "contrast":
+        res = contrast_run(a, ctx, a.steps, a.warmup, 0 if a.no_profile else a.profile_stride, batch=(a.batch if a.batch != 4 else 8))
+    else:
+        res = seg_run(a, ctx)
+        if not a.no_secondary:
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            hip.arena_reset()
+            sec = contrast_run(a, ctx, a.secondary_steps, 2, 0)
+            res["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype")}
+            res["secondary"]["config"] = sec["config"]
+        if ctx.world == 1 and not a.no_cpu_baseline and ctx.rank == 0:
             res["cpu_baseline"] = cpu_baseline(a.cpu_size)
+    if ctx.rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if ctx.world > 1:
         dist.destroy_process_group()
 
 

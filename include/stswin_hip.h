@@ -102,6 +102,32 @@ int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, cons
                    float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg,
                    float* workspace /* optional caller-owned scratch: split-K partials are stored there and combined by a
                                        second kernel instead of fp32 atomics */, long workspace_floats, void* stream);
+/* Which kernel the launcher chose for the calling thread's most recent stswin_gemm_nt (family 0) / stswin_gemm_tn
+ * (family 1) call: one of the codes below (family 1: | slab bits | split count << 16).  Test instrumentation only - the
+ * parity suite asserts that the production shapes of the training step run the production kernels
+ * (swin_512.py:109-141 qkv/proj, :7-23 Mlp, resnet.py:31-34 3x3 convolutions and their weight gradients). */
+#define STSWIN_VAR_F32 100                 /* added to a 128x128-family code when the exact-fp32 instantiation ran */
+#define STSWIN_VAR_NT_RING256_REGEPI 1     /* 256x256 ping-pong ring, operand-swapped MFMA + register epilogue (production) */
+#define STSWIN_VAR_NT_RING256_LDSEPI 2     /* 256x256 ping-pong ring, fp32 LDS epilogue (fp32 outputs, unaligned operands) */
+#define STSWIN_VAR_NT_RING256_NOPIPE 3
+#define STSWIN_VAR_NT_STREAM 4
+#define STSWIN_VAR_NT_DUO 5
+#define STSWIN_VAR_NT_RING256x128_PP 6
+#define STSWIN_VAR_NT_MID 7
+#define STSWIN_VAR_NT_256x64 8
+#define STSWIN_VAR_NT_128x64 9
+#define STSWIN_VAR_NT_128x128 10
+#define STSWIN_VAR_NT_128x128_W4 11
+#define STSWIN_VAR_TN_RING_PLAIN 20        /* gemm_tn_ring_kernel<0> */
+#define STSWIN_VAR_TN_RING_ATROWS 21       /* <1> */
+#define STSWIN_VAR_TN_RING_BTROWS 22       /* <2> */
+#define STSWIN_VAR_TN_RING_BSEG 23         /* <3>: tap-segmented convolution weight gradient */
+#define STSWIN_VAR_TN_128x128 30
+#define STSWIN_VAR_TN_128x128_W4 31
+#define STSWIN_VAR_TN_SLABS_F32 0x1000     /* split-K partial slabs + tn_reduce, fp32 partials */
+#define STSWIN_VAR_TN_SLABS_BF16 0x2000    /* ... bf16 partials */
+int stswin_last_variant(int family);
+
 /* out[n] += sum_m Y[m][n]  (bias gradients) */
 int stswin_colsum(int dtype, const void* y, long ldy, float* out, int M, int N, void* stream);
 
@@ -209,6 +235,35 @@ int stswin_ce_bwd(int dtype, const void* logits, const long* labels, const float
 int stswin_contrast_fwd(int dtype, const void* Q, long ldq, const void* const* K5, long ldk, const int* lq,
                         const int* const* lk5, float* pos, float* all, int N, int HW, int C, void* stream);
 
+/* Bank mode of the same loss: every query pixel against a bank of key embeddings, ONE launch for both loss directions and all
+ * key maps (PixPro_swin_v5.py:594-595 = two regression_loss calls, :71-129), and the inter-video bank that the reference
+ * sketches in its unused dist_collect (pixcontrast_18/contrast/util.py:47-58).
+ *   Q [M][C] + lq[M]: the M query rows are q_sets (1 or 2: the loss directions) equal sets of nblk = M / (q_sets q_block) blocks of
+ *     q_block rows (a block = one sample's HW pixels in the reference's per-sample mode; q_block = M / q_sets: one block, every
+ *     query sees the whole segment);
+ *   bank [maps][seg][C] + lb[maps][seg]: query set s uses map gmap[s*groups + g] as its group g; a query of block b sees rows
+ *     [b bank_block, (b+1) bank_block) of that map (bank_block = seg / nblk, or = seg when nblk = 1).
+ * Writes pos[m][g] = sum_p S[m][p] [lq[m] == lb[p]], all[m][g] = sum_p S[m][p] over the visible rows of group g (fp32 [M][groups]) and,
+ * if not NULL, rowmax[m] / lse[m] = max / log-sum-exp of inv_tau * S[m][p] over the visible rows of ALL groups (the InfoNCE
+ * denominator; monitoring and hard-negative statistics - the reference loss itself is linear in S).  C <= 256, a multiple of 64
+ * (bf16) / 32 (fp32).  workspace: caller-owned fp32 scratch, >= 4 M groups floats (more lets the launcher split long bank segments
+ * over workgroups; the partials are combined in a fixed order, so results are deterministic). */
+int stswin_contrast_bank_fwd(int dtype, const void* Q, long ldq, const int* lq, int M, int C, int q_sets, int q_block,
+                             const void* bank, long ldb, const int* lb, int maps, int seg, int bank_block, int groups,
+                             const int* gmap /* host memory, [q_sets][groups] */, float inv_tau, float* pos, float* all,
+                             float* rowmax, float* lse, float* workspace, long workspace_floats, void* stream);
+/* Backward to the queries (keys are no-grad, PixPro_swin_v5.py:366): the masked sums are linear in the scores, so
+ * dq[m] = sum_g dpos[m][g] Kcls[map(g)][blk][lq[m]] + dneg[m][g] (Ktot[map(g)][blk] - Kcls[..][lq[m]]), where dpos / dneg are the
+ * gradients of pos and of neg = all - pos.  class_sums writes ksum [maps][seg / bank_block][ncls + 1][C] fp32 (slot ncls = all
+ * rows; zeroed by the call; labels outside [0, ncls) only count in the total); bank_dq combines them per query row into dq
+ * fp32 [M][C].  cnt[m][g] (fp32) = number of visible rows of group g with label lq[m]: where it equals bank_block the negative
+ * set is empty and its term is skipped, so the gradient is exactly zero like the reference's masked products (:103-113). */
+int stswin_contrast_class_sums(int dtype, const void* bank, long ldb, const int* lb, int maps, int seg, int bank_block, int C,
+                               int ncls, float* ksum, void* stream);
+int stswin_contrast_bank_dq(const float* dpos, const float* dneg, const float* cnt, const int* lq, const float* ksum, float* dq,
+                            long lddq, int M, int C, int q_sets, int q_block, int seg, int bank_block, int ncls, int groups, const int* gmap,
+                            void* stream);
+
 /* ---- f4: inference post-processing (seg18/test.py:153-158 + utils/EndoMetric.py): labels[f][y][x] = argmax_c of the
  * bilinear (align_corners = True) resize of NCHW logits [F][nc][h][w] to (H, W); with gt (int64 [F][H][W]) also
  * counts[f][0|1|2][c] = |gt == c|, |pred == c|, |gt == c and pred == c|  (int32, zeroed by the caller). */
@@ -221,6 +276,14 @@ int stswin_upsample_argmax(int dtype, const void* logits, unsigned char* labels,
  * p = p*b1 + g*(1-b1) with g = the query parameter (PixPro_swin_v5.py:258-289). */
 int stswin_multi_tensor(int mode, int count, void* const* p, const void* const* g, void* const* m, void* const* v,
                         const int* n, float lr, float b1, float b2, float eps, float wd, float c1, float c2, void* stream);
+
+/* LARS over SGD-momentum (pixcontrast_18/contrast/lars.py:109-152 wrapping torch.optim.SGD, main_pretrain_swinv5.py:37-47) for up
+ * to 48 fp32 tensors of ONE parameter group, two launches: per-tensor ||p||^2 and ||g + wd p||^2 into `norms` (caller-owned
+ * fp32 [count][2], zeroed by the call), then g' = (g + wd p) * (adaptive && both norms > 0 ? trust_coef ||p|| / (||g'|| + eps) : 1),
+ * buf = first ? g' : momentum * buf + g', p -= lr * buf.  adaptive = 0: the 'ignore' group of add_weight_decay (biases, norms). */
+int stswin_multi_tensor_lars(int count, void* const* p, const void* const* g, void* const* m, const int* n, float* norms,
+                             float lr, float momentum, float wd, float trust_coef, float eps, int first, int adaptive,
+                             void* stream);
 
 /* ---- device self-test of the MFMA / LDS primitives the kernels are built on; writes a report into `out`
  * (fp32, >= 64 KiB) and returns the number of failed checks (0 = all good). Used by tests only. */

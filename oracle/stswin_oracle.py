@@ -509,3 +509,83 @@ def consistency_loss(ims: Sequence[Tensor], masks: Sequence[Tensor], sd: SD, par
         + regression_loss(pred2, keys[0], keys[2], keys[3], keys[4], keys[5],
                           lm[1], lm[0], lm[2], lm[3], lm[4], lm[5], class_num)
     return loss, k + 1
+
+
+# --------------------------------------------------------------------------------------
+# f2: LARS over SGD-momentum (the contrastive stage's optimizer)
+# --------------------------------------------------------------------------------------
+
+
+def lars_sgd_step(params: Sequence[Tensor], grads: Sequence[Tensor], bufs: List[Optional[Tensor]], lr: float, momentum: float,
+                  weight_decay: float, adaptive: bool, trust_coef: float = 0.001, eps: float = 1e-8) -> None:
+    """One step of pixcontrast_18/contrast/lars.py:109-152 around torch.optim.SGD (momentum, dampening 0) for ONE parameter
+    group, in place on `params` / `bufs`: weight decay joins the gradient first (:124-125), the trust ratio
+    trust_coef * |p| / (|g| + eps) scales it only in groups with ignore == False and only when both norms are > 0 (:129-142),
+    then the inner SGD runs with weight decay 0 (:147-150): buf = g on a parameter's first step, momentum * buf + g after."""
+    for i, (p, g) in enumerate(zip(params, grads)):
+        if weight_decay > 0:
+            g = g + weight_decay * p
+        if adaptive:
+            pn, gn = p.norm(), g.norm()
+            if pn > 0 and gn > 0:
+                g = g * (trust_coef * pn / (gn + eps))
+        bufs[i] = g.clone() if bufs[i] is None else bufs[i] * momentum + g
+        p.sub_(lr * bufs[i])
+
+
+# --------------------------------------------------------------------------------------
+# N1: bank mode of the pixel-contrastive loss (dense restatement)
+# --------------------------------------------------------------------------------------
+
+
+def bank_scores(q: Tensor, lq: Tensor, bank: Tensor, lb: Tensor, gmap: Sequence[Sequence[int]], q_block: int, bank_block: int,
+                inv_tau: float = 1.0) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """q [M][C] with labels lq [M]: `len(gmap)` equal query sets of blocks of q_block rows; bank [maps][seg][C] with labels lb;
+    query set s uses map gmap[s][g] as group g, block b sees bank rows [b*bank_block, (b+1)*bank_block) (every row if the
+    bank has a single block).  Materialises the logits like PixPro_swin_v5.py:82-113 does per sample (logit = bmm(q^T, key),
+    posMask = label equality, negMask = 1 - posMask) and returns pos, neg [M][G] (the two masked row sums), rowmax, lse [M] (of
+    inv_tau * logit over all groups).  With gmap = [[0..4]] and blocks = samples this is exactly the five bmm + mask
+    products of the reference (an empty negative set contributes an exactly-zero sum AND gradient, as there)."""
+    M, _ = q.shape
+    groups = len(gmap[0])
+    per_set = M // len(gmap)
+    nb = bank.shape[1] // bank_block
+    pos_rows: List[Tensor] = []
+    neg_rows: List[Tensor] = []
+    rows_logits: List[Tensor] = []
+    for s, maps in enumerate(gmap):
+        for b in range(per_set // q_block):
+            r0 = s * per_set + b * q_block
+            sl = slice(r0, r0 + q_block)
+            bb = b if nb > 1 else 0
+            chunks, pg, ng = [], [], []
+            for g, mp in enumerate(maps):
+                keys = bank[mp, bb * bank_block:(bb + 1) * bank_block]
+                logit = q[sl] @ keys.t()
+                mask = (lq[sl, None] == lb[mp, None, bb * bank_block:(bb + 1) * bank_block]).to(logit.dtype)
+                pg.append((logit * mask).sum(1))
+                ng.append((logit * (1.0 - mask)).sum(1))
+                chunks.append(logit)
+            pos_rows.append(torch.stack(pg, 1))
+            neg_rows.append(torch.stack(ng, 1))
+            rows_logits.append(torch.cat(chunks, 1) * inv_tau)
+    allv = torch.cat(rows_logits, 0)
+    return torch.cat(pos_rows, 0), torch.cat(neg_rows, 0), allv.max(1).values, torch.logsumexp(allv, 1)
+
+
+def bank_contrast_loss(q: Tensor, lq: Tensor, bank: Tensor, lb: Tensor, gmap, q_block: int, bank_block: int) -> Tensor:
+    """PixPro_swin_v5.py:114-129 on bank_scores: P = sum_g pos / (sum_g |pos| + 1e-6), N = sum_g neg_g / (|neg_g| + 1e-6),
+    loss = sum over query sets of -mean(log(e^P / (e^P + e^N) + 1e-6))."""
+    pos, neg, _, _ = bank_scores(q, lq, bank, lb, gmap, q_block, bank_block)
+    M = q.shape[0]
+    per_set = M // len(gmap)
+    nb = bank.shape[1] // bank_block
+    cnt = torch.zeros_like(pos)
+    for m in range(M):
+        s, b = m // per_set, ((m % per_set) // q_block if nb > 1 else 0)
+        for g, mp in enumerate(gmap[s]):
+            cnt[m, g] = float((lb[mp, b * bank_block:(b + 1) * bank_block] == lq[m]).sum())
+    P = pos.sum(1) / (cnt.sum(1) + 1e-6)
+    N = (neg / ((bank_block - cnt) + 1e-6)).sum(1)
+    term = -torch.log(torch.exp(P) / (torch.exp(P) + torch.exp(N)) + 1e-6)
+    return term.view(len(gmap), -1).mean(1).sum()

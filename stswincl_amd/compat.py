@@ -20,6 +20,7 @@ _ALIASES = {
     "utils.LoadModel": "stswincl_amd.utils.LoadModel",
     "utils.EndoMetric": "stswincl_amd.utils.EndoMetric",
     "contrast.models.PixPro_swin_v5": "stswincl_amd.contrast.models.PixPro_swin_v5",
+    "contrast.lars": "stswincl_amd.contrast.lars",
     "contrast.models.Ours.base": "stswincl_amd.contrast.models.Ours.base",
     "contrast.models.Ours.swin_tem": "stswincl_amd.net.Ours.swin_512",
     "contrast.models.Ours.ASPPv5": "stswincl_amd.net.Ours.ASPP",

@@ -73,37 +73,71 @@ def negMask(pred1, pred2, class_num):
     return 1 - posMask(pred1, pred2, class_num)
 
 
-class ContrastSumsFn(torch.autograd.Function):
-    """(q, 5 key maps, labels) -> pos[N,HW,5], neg[N,HW,5]: masked similarity sums over label-equal / label-different
-    key pixels (see csrc/contrast.hip).  Keys are no-grad in the reference (PixPro_swin_v5.py:366).  Backward to q uses
-    sum_p [l_i == l_p] k_p = Kpos[l_i] and sum_p [l_i != l_p] k_p = Kneg[l_i] (per-class sums of the keys, built with
-    exact 0/1 masks so an empty set gives an exactly-zero gradient like the reference's masked products):
-    dq_i = sum_j dpos_ij Kpos_j[l_i] + dneg_ij Kneg_j[l_i] - the gradient of the dense products at O(HW C) cost."""
+class ContrastBankFn(torch.autograd.Function):
+    """(queries, labels, key bank, bank labels) -> pos, neg fp32 [M][groups] (+ rowmax, lse [M]): the masked similarity sums over
+    label-equal / label-different visible bank rows, one launch for every key map and both loss directions
+    (csrc/contrast.hip, stswin_contrast_bank_fwd).  The bank is no-grad (keys come from the momentum encoders,
+    PixPro_swin_v5.py:366).  Backward to the queries, all HIP: per-class sums of the bank rows (exact fp32 adds, so an empty set
+    gives an exactly-zero gradient like the reference's masked products) and one combination pass:
+    dq_m = sum_g dpos_mg Kcls_g[l_m] + dneg_mg (Ktot_g - Kcls_g[l_m])."""
 
     @staticmethod
-    def forward(ctx, q, k0, k1, k2, k3, k4, lq, lk, N, HW, class_num):
-        dt = compute_dtype(q)
-        Q = q.detach().to(dt).contiguous()
-        keys = [k.detach().to(dt).contiguous() for k in (k0, k1, k2, k3, k4)]
-        pos, tot = hip.contrast_fwd(Q, keys, lq, [lk[j] for j in range(5)], N, HW)
-        ctx.cfg = (N, HW, class_num, q.dtype)
-        ctx.save_for_backward(lq, lk, *keys)
-        return pos, tot - pos
+    def forward(ctx, q, lq, bank, lb, cnt, cfg):
+        q_sets, q_block, bank_block, gmap, ncls, inv_tau, want_lse = cfg
+        Q = q.detach().to(bank.dtype).contiguous()
+        pos, tot, rmax, lse = hip.contrast_bank_fwd(Q, lq, bank, lb, q_sets=q_sets, q_block=q_block, bank_block=bank_block,
+                                                    gmap=gmap, inv_tau=inv_tau, want_lse=want_lse)
+        ctx.cfg = (q_sets, q_block, bank_block, gmap, ncls, q.dtype)
+        ctx.save_for_backward(lq, bank, lb, cnt)
+        if not want_lse:
+            rmax = lse = pos.new_zeros(())
+        ctx.mark_non_differentiable(rmax, lse)
+        return pos, tot - pos, rmax, lse
 
     @staticmethod
-    def backward(ctx, dpos, dneg):
-        lq, lk, *keys = ctx.saved_tensors
-        N, HW, ncls, in_dtype = ctx.cfg
-        C = keys[0].shape[1]
-        dq = torch.zeros(N, HW, C, dtype=torch.float32, device=keys[0].device)
-        idx = lq.long().unsqueeze(-1).expand(N, HW, C)
-        for j, k in enumerate(keys):
-            kf = k.float().view(N, HW, C)
-            oh = F.one_hot(lk[j].long(), ncls).float()                      # [N][HW][cls], exact 0/1
-            kpos = torch.bmm(oh.transpose(1, 2), kf)                        # [N][cls][C]
-            kneg = torch.bmm((1.0 - oh).transpose(1, 2), kf)
-            dq += dpos[:, :, j:j + 1] * torch.gather(kpos, 1, idx) + dneg[:, :, j:j + 1] * torch.gather(kneg, 1, idx)
-        return (dq.view(N * HW, C).to(in_dtype),) + (None,) * 10
+    def backward(ctx, dpos, dneg, _dm, _dl):
+        lq, bank, lb, cnt = ctx.saved_tensors
+        q_sets, q_block, bank_block, gmap, ncls, in_dtype = ctx.cfg
+        ksum = hip.contrast_class_sums(bank, lb, bank_block, ncls)
+        dq = hip.contrast_bank_dq(dpos.float(), dneg.float(), cnt, lq, ksum, q_sets=q_sets, q_block=q_block, seg=bank.shape[1],
+                                  bank_block=bank_block, gmap=gmap)
+        return dq.to(in_dtype), None, None, None, None, None
+
+
+def _label_counts(lq, lb, gmap, q_sets, q_block, bank_block, class_num):
+    """cnt[m][g] = number of visible bank rows of group g whose label equals lq[m] (the |posMask| row sums of
+    PixPro_swin_v5.py:116-118), from per-block label histograms: O(rows) integer work instead of HW x HW masks."""
+    maps, seg = lb.shape
+    nb = seg // bank_block
+    hist = F.one_hot(lb.long().clamp(0, class_num - 1), class_num).view(maps, nb, bank_block, class_num).sum(2)   # [maps][nb][cls]
+    M = lq.shape[0]
+    rows = torch.arange(M, device=lq.device)
+    per_set = M // q_sets
+    blk = ((rows % per_set) // q_block) if nb > 1 else torch.zeros_like(rows)
+    gm = torch.tensor(gmap, device=lq.device)[rows // per_set]                          # [M][groups] map index
+    return hist[gm, blk[:, None], lq.long().clamp(0, class_num - 1)[:, None]].float()   # [M][groups]
+
+
+def bank_contrast_loss(q_tok, lq, bank, lb, gmap, q_block, bank_block, class_num, inv_tau=1.0, want_lse=False):
+    """The loss of PixPro_swin_v5.py:71-129 for `len(gmap)` query sets against a key bank (see stswin_contrast_bank_fwd):
+    P = sum_g pos / (sum_g |pos| + 1e-6), N = sum_g neg_g / (|neg_g| + 1e-6), loss = sum over the query sets of
+    -mean(log(e^P / (e^P + e^N) + 1e-6)).  -> (loss, rowmax, lse)."""
+    q_sets = len(gmap)
+    cnt = _label_counts(lq, lb, gmap, q_sets, q_block, bank_block, class_num)
+    pos, neg, rmax, lse = ContrastBankFn.apply(q_tok, lq, bank, lb, cnt, (q_sets, q_block, bank_block, tuple(map(tuple, gmap)),
+                                                                          class_num, float(inv_tau), bool(want_lse)))
+    P = pos.sum(-1) / (cnt.sum(-1) + 1e-6)
+    Nn = (neg / ((bank_block - cnt) + 1e-6)).sum(-1)
+    pe, ne = torch.exp(P), torch.exp(Nn)
+    term = -torch.log(pe / (pe + ne) + 1e-6)
+    return term.view(q_sets, -1).mean(1).sum(), rmax, lse
+
+
+def _tokens_and_labels(feats, labels, dt):
+    n, c, h, w = feats[0].shape
+    toks = torch.stack([H.to_tokens(t).detach().to(dt) for t in feats], 0).contiguous()          # [maps][N*HW][C]
+    labs = torch.stack([l.reshape(n * h * w).to(torch.int32) for l in labels], 0).contiguous()   # [maps][N*HW]
+    return toks, labs
 
 
 def regression_loss(q, k, adj1, adj2, adj3, neg3, label_patch1, label_patch2, label_adj1, label_adj2, label_adj3,
@@ -112,17 +146,50 @@ def regression_loss(q, k, adj1, adj2, adj3, neg3, label_patch1, label_patch2, la
     loss = -mean(log(e^P / (e^P + e^N) + 1e-6)).  No temperature, no softmax over keys."""
     n, c, h, w = q.shape
     HW = h * w
-    labs = [l.reshape(n, HW).to(torch.int32).contiguous() for l in
-            (label_patch1, label_patch2, label_adj1, label_adj2, label_adj3, label_neg3)]
-    lq, lk = labs[0], torch.stack(labs[1:], 0)
-    toks = [H.to_tokens(t) for t in (q, k, adj1, adj2, adj3, neg3)]
-    pos, neg = ContrastSumsFn.apply(toks[0], *toks[1:], lq, lk, n, HW, class_num)
-    hist = F.one_hot(lk.long(), class_num).sum(2).float()                       # [5][N][cls]
-    cnt = torch.gather(hist, 2, lq.long().unsqueeze(0).expand(5, n, HW)).permute(1, 2, 0)   # [N][HW][5]
-    P = pos.sum(-1) / (cnt.sum(-1) + 1e-6)
-    Nn = (neg / ((HW - cnt) + 1e-6)).sum(-1)
-    pe, ne = torch.exp(P), torch.exp(Nn)
-    return -torch.mean(torch.log(pe / (pe + ne) + 1e-6))
+    dt = compute_dtype(q)
+    bank, lb = _tokens_and_labels((k, adj1, adj2, adj3, neg3), (label_patch2, label_adj1, label_adj2, label_adj3, label_neg3), dt)
+    lq = label_patch1.reshape(n * HW).to(torch.int32).contiguous()
+    loss, _, _ = bank_contrast_loss(H.to_tokens(q), lq, bank, lb, [[0, 1, 2, 3, 4]], HW, HW, class_num)
+    return loss
+
+
+def gather_bank(bank: torch.Tensor, lb: torch.Tensor, group=None):
+    """Inter-video key bank: all-gather every key map (and its labels) over the ranks into [maps][world * rows][C] - one
+    RCCL all-gather per map straight into its slice (no re-layout copy); keys are no-grad, so there is no backward collective.
+    The reference's (unused) dist_collect, pixcontrast_18/contrast/util.py:47-58."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bank, lb
+    world = dist.get_world_size(group)
+    maps, rows, C = bank.shape
+    out = torch.empty(maps, world * rows, C, dtype=bank.dtype, device=bank.device)
+    lo = torch.empty(maps, world * rows, dtype=lb.dtype, device=lb.device)
+    for m in range(maps):
+        dist.all_gather_into_tensor(out[m], bank[m].contiguous(), group=group)
+        dist.all_gather_into_tensor(lo[m], lb[m].contiguous(), group=group)
+    return out, lo
+
+
+def consistency_pair_loss(pred_1, pred_2, k1, k2, a1, a2, a3, n3, m, class_num, bank_mode="sample", inv_tau=1.0, want_lse=False):
+    """Both regression_loss calls of ConsistencyLoss.forward (PixPro_swin_v5.py:594-595) as ONE similarity launch.
+    bank_mode 'sample': the reference - a query pixel sees the five key maps of its own sample; 'batch': the key maps of every
+    sample of this rank (inter-video); 'world': of every sample of every rank (RCCL all-gather of the keys, gather_bank)."""
+    n, c, h, w = pred_1.shape
+    HW = h * w
+    dt = compute_dtype(pred_1)
+    bank, lb = _tokens_and_labels((k1, k2, a1, a2, a3, n3), m, dt)
+    q_tok = torch.cat([H.to_tokens(pred_1), H.to_tokens(pred_2)], 0)
+    lq = torch.cat([lb[0], lb[1]], 0)
+    gmap = [[1, 2, 3, 4, 5], [0, 2, 3, 4, 5]]
+    if bank_mode == "sample":
+        q_block = bank_block = HW
+    else:
+        if bank_mode == "world":
+            bank, lb = gather_bank(bank, lb)
+        elif bank_mode != "batch":
+            raise ValueError(f"bank_mode {bank_mode!r}")
+        q_block, bank_block = n * HW, bank.shape[1]
+    return bank_contrast_loss(q_tok, lq, bank, lb, gmap, q_block, bank_block, class_num, inv_tau, want_lse)
 
 
 def Proj_Head(in_dim=400, inner_dim=512, out_dim=256):
@@ -168,7 +235,8 @@ class PixPro(nn.Module):
         seg_q, seg_k = TswinPlusv5(class_num, input_resolution), TswinPlusv5(class_num, input_resolution)
         pre = getattr(args, "pretrainpth", None)
         if pre and os.path.exists(pre):          # the reference reads 'xx/results/' + pretrainpth (:155-166)
-            sd = torch.load(pre, map_location="cpu")
+            from ...utils.LoadModel import _torch_load
+            sd = _torch_load(pre, "cpu")
             sd = {k[7:] if k.startswith("module.") else k: v for k, v in sd.items()}
             seg_q.load_state_dict(sd, strict=False)
             seg_k.load_state_dict(sd, strict=False)
@@ -269,10 +337,18 @@ class ConsistencyLoss(nn.Module):
             self.class_num = 12
         elif args.data == 'cata':
             self.class_num = int(num_class_table[args.tag])
+        # extension (not in the reference's option list; default = the reference): 'sample' | 'batch' | 'world' key bank,
+        # see consistency_pair_loss.  pixpro_bank_stats additionally returns the row-max / log-sum-exp of the scores / tau.
+        self.bank_mode = getattr(args, "pixpro_bank", "sample")
+        self.bank_inv_tau = 1.0 / float(getattr(args, "pixpro_bank_tau", 1.0))
+        self.bank_stats = bool(getattr(args, "pixpro_bank_stats", False))
+        self.last_rowmax = self.last_lse = None
 
     def forward(self, im_1, im_2, im_3, im_4, im_5, im_6, mask_1, mask_2, mask_3, mask_4, mask_5, mask_6):
         pred_1, pred_2, k1, k2, a1, a2, a3, n3 = self.pixpro(im_1, im_2, im_3, im_4, im_5, im_6)
         hh, ww = pred_1.shape[2:]
         m = [F.interpolate(x, size=[hh, ww], mode='nearest') for x in (mask_1, mask_2, mask_3, mask_4, mask_5, mask_6)]
-        return regression_loss(pred_1, k2, a1, a2, a3, n3, m[0], m[1], m[2], m[3], m[4], m[5], self.class_num) \
-            + regression_loss(pred_2, k1, a1, a2, a3, n3, m[1], m[0], m[2], m[3], m[4], m[5], self.class_num)
+        # regression_loss(pred_1 | k2, a1, a2, a3, n3) + regression_loss(pred_2 | k1, a1, a2, a3, n3)  (:594-595), one launch
+        loss, self.last_rowmax, self.last_lse = consistency_pair_loss(pred_1, pred_2, k1, k2, a1, a2, a3, n3, m, self.class_num,
+                                                                      self.bank_mode, self.bank_inv_tau, self.bank_stats)
+        return loss

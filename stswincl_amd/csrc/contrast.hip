@@ -7,6 +7,7 @@
 // looping over all key tiles, so only 2 floats per (query, key map) ever reach HBM.  The masked means, exp/log and
 // the class-count denominators are O(HW) work done by the caller.
 #include "common.h"
+#include <type_traits>
 
 struct ContrastArgs {
   const void* Q; long ldq;
@@ -179,6 +180,437 @@ extern "C" int stswin_contrast_fwd(int dtype, const void* Q, long ldq, const voi
   (void)once;
   if (dtype == 0) hipLaunchKernelGGL(contrast_fwd_kernel<bf16>, grid, dim3(256), 65536, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(contrast_fwd_kernel<float>, grid, dim3(256), 65536, (hipStream_t)stream, a);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+// =====================================================================================================================
+// Bank mode: every query pixel against a bank of key embeddings (all-gathered over samples and ranks), as ONE launch for
+// both loss directions and all key maps.
+//
+//   queries  Q  [M][C], labels lq[M]; the M rows are `q_sets` equal sets (the two loss directions) of `nblk` blocks of
+//            q_block rows (a block = one sample in the reference's per-sample mode; nblk = 1 = every query sees the whole
+//            bank segment in inter-video mode)
+//   bank     Kb [maps][seg][C], labels lb[maps][seg]; query set s uses, as its group g (g < groups), map gmap[s][g]; a query
+//            of block b sees rows [b*bank_block, (b+1)*bank_block) of that map's segment
+//   outputs  pos[m][g] = sum_p S[m][p] [lq[m] == lb[p]],  all[m][g] = sum_p S[m][p]   over the visible rows p of group g,
+//            and (optional) rowmax[m], lse[m] = max / log-sum-exp of inv_tau * S[m][p] over ALL visible rows of all groups.
+//
+// With q_sets = 2, gmap = {{1,2,3,4,5},{0,2,3,4,5}}, q_block = bank_block = HW this is exactly the reference's two
+// regression_loss calls (PixPro_swin_v5.py:594-595, :71-129); with nblk = 1 it is the inter-video bank the reference
+// sketches in its unused dist_collect (contrast/util.py:47-58).
+//
+// Kernel: one workgroup (8 waves as 4 row x 2 column waves of 32 x 64) = 128 query rows x one (group, bank split).  The query
+// fragments stay in REGISTERS for the whole kernel (C <= 256: 2 row fragments x 8 k-steps x 4 VGPRs), so only bank rows
+// stream through LDS: 128 rows x 64 columns
+// (128 bytes per row, chunk ^ row&7 swizzle on the LDS-DMA source address) per stage, 3-stage ring, counted vmcnt + raw
+// s_barrier (the copies of the next two stages stay in flight across the barrier).  The bank labels of a tile ride in the
+// same ring as a 4-byte LDS-DMA per stage (an ordinary global load inside the loop would make hipcc drain the ring with
+// vmcnt(0)).  After the C/64 stages of a bank tile the 64x64 accumulators of a wave are folded: label compare + masked add
+// (pos), add (all) and an online max / sum-exp per row.  Partials per (row, group, split) go to a workspace; a small
+// combine kernel adds the splits (fixed order: deterministic) and merges the max / sum-exp pairs.
+// =====================================================================================================================
+#define CB_MAX_GROUPS 8
+struct BankArgs {
+  const void* Q; long ldq; const int* lq;
+  const void* Kb; long ldk; const int* lb;
+  int M, C, q_sets, nblk, q_block, seg, bank_block, groups, splits, chunk;   // chunk = bank rows per split (multiple of 128)
+  int gmap[2][CB_MAX_GROUPS];
+  float inv_tau;
+  float* part;      // [4][M][groups*splits]: pos, all, max, sumexp partials
+  int want_lse;
+};
+
+template <typename T, int KCH>      // KCH = C / 64 (bf16) resp. C / 32 (f32): stages per bank tile
+__global__ __launch_bounds__(512, 2) void contrast_bank_kernel(BankArgs p) {
+  constexpr bool BF = TT<T>::IS_BF16;
+  constexpr int PACK = TT<T>::PACK;
+  constexpr int BK = 8 * PACK;                      // 64 (bf16) / 32 (f32) columns = 128 bytes per bank row and stage
+  constexpr int KST = KCH;                          // stages per bank tile = C / BK
+  constexpr int FI = 2;                             // 16-row fragments per wave: wave tile 32 x 64, workgroup tile 128 x 128
+  constexpr int TM = 4 * 16 * FI;
+  constexpr int SUB = BF ? 2 : 8;                   // MFMA k-steps per stage (32 resp. 4 columns each)
+  constexpr int NST = 3, STAGE = 16384 + 2048;      // bank tile slice + per-wave label slots [8][64] ints
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63, w = wave_id();
+  const int wr = w >> 1, wc = w & 1;
+  const int fr = l & 15, fq = l >> 4;
+
+  // ---- which rows / which bank range
+  const int tiles_per_blk = (p.q_block + TM - 1) / TM;
+  int rt = blockIdx.x;
+  const int qset = rt / (p.nblk * tiles_per_blk);
+  rt -= qset * p.nblk * tiles_per_blk;
+  const int blk = rt / tiles_per_blk, t_in = rt - blk * tiles_per_blk;
+  const int row_lo = (qset * p.nblk + blk) * p.q_block + t_in * TM;            // first query row of this workgroup
+  const int row_hi = (qset * p.nblk + blk + 1) * p.q_block;                    // end of its block
+  const int g = blockIdx.y / p.splits, sp = blockIdx.y - g * p.splits;
+  const long bank0 = (long)p.gmap[qset][g] * p.seg + (long)blk * p.bank_block;  // first visible bank row of group g
+  const int k_lo = sp * p.chunk, k_hi = min(p.bank_block, k_lo + p.chunk);     // this split's rows within the visible range
+  const int nkt = k_hi > k_lo ? (k_hi - k_lo + 127) >> 7 : 0;
+  const int nst = nkt * KST;
+
+  // ---- query fragments (registers, loaded once) and their labels
+  typedef typename std::conditional<BF, bf16x8, float>::type AFrag;
+  AFrag a[FI][KST * SUB];
+  int lrow[FI * 4];
+#pragma unroll
+  for (int i = 0; i < FI; ++i) {
+    const int gm = row_lo + wr * 16 * FI + i * 16 + fr;
+    const bool ok = gm < row_hi;
+    const T* src = (const T*)p.Q + (long)(ok ? gm : row_lo) * p.ldq;
+#pragma unroll
+    for (int kk = 0; kk < KST * SUB; ++kk) {
+      if constexpr (BF) {
+        a[i][kk] = ok ? *(const bf16x8*)(src + kk * 32 + fq * 8) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      } else {
+        a[i][kk] = ok ? src[kk * 4 + fq] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gr = row_lo + wr * 16 * FI + i * 16 + 4 * fq + r;
+      lrow[i * 4 + r] = gr < row_hi ? p.lq[gr] : -2147483647;
+    }
+  }
+  // every ordinary load above must be complete before the first LDS-DMA is issued: from here on vmcnt counts ring copies only
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const char* zero = (const char*)g_stswin_zero;
+  const int rsub = l >> 3, cphys = l & 7, csrc = cphys ^ rsub;
+  auto issue = [&](int s) {
+    const int kt = s / KST, sk = s - kt * KST;
+    char* Bb = smem + (s % NST) * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int gk = k_lo + kt * 128 + (w * 2 + i) * 8 + rsub;
+      const char* src = gk < k_hi ? (const char*)((const T*)p.Kb + (bank0 + gk) * p.ldk) + csrc * 16 + (long)sk * BK * sizeof(T)
+                                  : zero + cphys * 16;
+      glds16(src, Bb + (w * 2 + i) * 1024);
+    }
+    // labels of the 64 bank rows this wave's column half covers (rows beyond the range: any valid address, masked later)
+    const int gl = min(k_lo + kt * 128 + wc * 64 + l, k_hi - 1);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.lb + bank0 + gl),
+                                     (__attribute__((address_space(3))) void*)(Bb + 16384 + w * 256), 4, 0, 0);
+  };
+
+  float ppos[FI * 4], pall[FI * 4], pmax[FI * 4], pse[FI * 4];
+#pragma unroll
+  for (int e = 0; e < FI * 4; ++e) { ppos[e] = 0.f; pall[e] = 0.f; pmax[e] = -3.0e38f; pse[e] = 0.f; }
+  f32x4 acc[FI][4];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int s = 0; s < NST - 1 && s < nst; ++s) issue(s);
+  for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+    for (int sk = 0; sk < KST; ++sk) {
+      const int s = kt * KST + sk;
+      if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // 2 copies + 1 label copy per wave and stage: the next stage may stay in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s + NST - 1 < nst) issue(s + NST - 1);
+      const char* Bb = smem + (s % NST) * STAGE;
+#pragma unroll
+      for (int kk = 0; kk < SUB; ++kk) {
+        if constexpr (BF) {
+          bf16x8 b[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int row = wc * 64 + jj * 16 + fr;
+            b[jj] = *(const bf16x8*)(Bb + row * 128 + (((kk * 4 + fq) ^ (row & 7)) << 4));
+          }
+#pragma unroll
+          for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][sk * SUB + kk], b[jj], acc[i][jj], 0, 0, 0);
+        } else {
+          float b[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int row = wc * 64 + jj * 16 + fr;
+            b[jj] = *(const float*)(Bb + row * 128 + ((kk ^ (row & 7)) << 4) + fq * 4);
+          }
+#pragma unroll
+          for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][sk * SUB + kk], b[jj], acc[i][jj], 0, 0, 0);
+        }
+      }
+      if (sk == KST - 1) {                          // bank tile finished: fold the 16 FI x 64 scores of this wave
+        int lcol[4]; bool cok[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int c = wc * 64 + jj * 16 + fr;
+          cok[jj] = k_lo + kt * 128 + c < k_hi;
+          const int lab = *(const int*)(Bb + 16384 + w * 256 + (jj * 16 + fr) * 4);
+          lcol[jj] = cok[jj] ? lab : -2147483646;
+        }
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = i * 4 + r;
+            float v0 = acc[i][0][r], v1 = acc[i][1][r], v2 = acc[i][2][r], v3 = acc[i][3][r];
+            pall[e] += (v0 + v1) + (v2 + v3);
+            ppos[e] += ((lrow[e] == lcol[0] ? v0 : 0.f) + (lrow[e] == lcol[1] ? v1 : 0.f)) +
+                       ((lrow[e] == lcol[2] ? v2 : 0.f) + (lrow[e] == lcol[3] ? v3 : 0.f));
+            if (p.want_lse) {
+              v0 = cok[0] ? v0 * p.inv_tau : -3.0e38f; v1 = cok[1] ? v1 * p.inv_tau : -3.0e38f;
+              v2 = cok[2] ? v2 * p.inv_tau : -3.0e38f; v3 = cok[3] ? v3 * p.inv_tau : -3.0e38f;
+              const float mx = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), pmax[e]);
+              pse[e] = pse[e] * __expf(pmax[e] - mx) + ((__expf(v0 - mx) + __expf(v1 - mx)) + (__expf(v2 - mx) + __expf(v3 - mx)));
+              pmax[e] = mx;
+            }
+          }
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+  }
+  // ---- fold over the 16 lanes of a row (columns), then over the two column waves through LDS
+  __syncthreads();
+  float* red = (float*)smem;                        // [4][2 (wc)][TM]  (8 KB)
+#pragma unroll
+  for (int e = 0; e < FI * 4; ++e) {
+    ppos[e] = sum16(ppos[e]);
+    pall[e] = sum16(pall[e]);
+    if (p.want_lse) {                               // merge (max, sumexp) pairs over the 16 lanes: butterflies inside the row group
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const float om = __shfl_xor(pmax[e], o), os = __shfl_xor(pse[e], o);
+        const float mx = fmaxf(pmax[e], om);
+        pse[e] = pse[e] * __expf(pmax[e] - mx) + os * __expf(om - mx);
+        pmax[e] = mx;
+      }
+    }
+  }
+  if (fr == 0) {
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr * 16 * FI + i * 16 + 4 * fq + r, e = i * 4 + r;
+        red[(0 * 2 + wc) * TM + row] = ppos[e];
+        red[(1 * 2 + wc) * TM + row] = pall[e];
+        red[(2 * 2 + wc) * TM + row] = pmax[e];
+        red[(3 * 2 + wc) * TM + row] = pse[e];
+      }
+  }
+  __syncthreads();
+  if (tid < TM && row_lo + tid < row_hi) {
+    const int gs = p.groups * p.splits;
+    const long o = (long)(row_lo + tid) * gs + blockIdx.y, plane = (long)p.M * gs;
+    p.part[o] = red[tid] + red[TM + tid];
+    p.part[plane + o] = red[2 * TM + tid] + red[3 * TM + tid];
+    if (p.want_lse) {
+      const float m0 = red[4 * TM + tid], m1 = red[5 * TM + tid], mx = fmaxf(m0, m1);
+      p.part[2 * plane + o] = mx;
+      p.part[3 * plane + o] = red[6 * TM + tid] * __expf(m0 - mx) + red[7 * TM + tid] * __expf(m1 - mx);
+    }
+  }
+}
+
+// pos / all [M][groups] = sum over splits (fixed order); rowmax / lse [M] over all groups and splits.
+__global__ __launch_bounds__(256) void contrast_bank_combine_kernel(const float* part, int M, int groups, int splits, float* pos,
+                                                                    float* all, float* rowmax, float* lse) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const int gs = groups * splits;
+  const long plane = (long)M * gs;
+  const float* pp = part + (long)m * gs;
+  for (int g = 0; g < groups; ++g) {
+    float a = 0.f, b = 0.f;
+    for (int s = 0; s < splits; ++s) { a += pp[g * splits + s]; b += pp[plane + g * splits + s]; }
+    pos[(long)m * groups + g] = a;
+    all[(long)m * groups + g] = b;
+  }
+  if (rowmax || lse) {
+    float mx = -3.0e38f;
+    for (int k = 0; k < gs; ++k) mx = fmaxf(mx, pp[2 * plane + k]);
+    float se = 0.f;
+    for (int k = 0; k < gs; ++k) se += pp[3 * plane + k] * __expf(pp[2 * plane + k] - mx);
+    if (rowmax) rowmax[m] = mx;
+    if (lse) lse[m] = mx + __logf(se);
+  }
+}
+
+extern "C" int stswin_contrast_bank_fwd(int dtype, const void* Q, long ldq, const int* lq, int M, int C, int q_sets, int q_block,
+                                        const void* bank, long ldb, const int* lb, int maps, int seg, int bank_block, int groups,
+                                        const int* gmap /* host, [q_sets][groups] */, float inv_tau, float* pos, float* all,
+                                        float* rowmax, float* lse, float* workspace, long workspace_floats, void* stream) {
+  const int bk = dtype == 0 ? 64 : 32;
+  if (M <= 0 || groups <= 0 || seg <= 0) return 0;
+  if (C % bk || C > 256 || groups > CB_MAX_GROUPS || q_sets < 1 || q_sets > 2 || q_block <= 0 || bank_block <= 0) return -1511;
+  if (M % (q_sets * q_block) || seg % bank_block) return -1512;
+  const int nblk = M / (q_sets * q_block);
+  if (nblk != seg / bank_block && !(nblk == 1 && bank_block == seg)) return -1513;
+  for (int i = 0; i < q_sets * groups; ++i)
+    if (gmap[i] < 0 || gmap[i] >= maps) return -1514;
+  BankArgs a;
+  a.Q = Q; a.ldq = ldq; a.lq = lq; a.Kb = bank; a.ldk = ldb; a.lb = lb;
+  a.M = M; a.C = C; a.q_sets = q_sets; a.nblk = nblk; a.q_block = q_block; a.seg = seg; a.bank_block = bank_block; a.groups = groups;
+  for (int s = 0; s < 2; ++s)
+    for (int g = 0; g < CB_MAX_GROUPS; ++g) a.gmap[s][g] = (s < q_sets && g < groups) ? gmap[s * groups + g] : 0;
+  a.inv_tau = inv_tau;
+  a.want_lse = (rowmax || lse) ? 1 : 0;
+  const int TM = 128;
+  const long row_tiles = (long)q_sets * nblk * ((q_block + TM - 1) / TM);
+  // bank splits: at least two rounds of workgroups over the 256 CUs (one 8-wave workgroup per CU), but at least 4 bank tiles
+  // of 128 rows per split
+  int splits = (int)((512 + row_tiles * groups - 1) / (row_tiles * groups));
+  const int max_by_rows = (bank_block + 511) / 512;
+  if (splits > max_by_rows) splits = max_by_rows;
+  if (splits < 1) splits = 1;
+  while (splits > 1 && 4L * M * groups * splits > workspace_floats) --splits;
+  if (4L * M * groups * splits > workspace_floats || !workspace) return -1515;
+  a.splits = splits;
+  a.chunk = ((bank_block + splits - 1) / splits + 127) / 128 * 128;
+  a.part = workspace;
+  const dim3 grid((unsigned)row_tiles, (unsigned)(groups * splits));
+  const int lds = 3 * (16384 + 2048);
+#define CB_LAUNCH(TT_, KCH_)                                                                                                  \
+  do {                                                                                                                        \
+    static int once = (int)hipFuncSetAttribute((const void*)contrast_bank_kernel<TT_, KCH_>,                                   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);                              \
+    (void)once;                                                                                                               \
+    hipLaunchKernelGGL((contrast_bank_kernel<TT_, KCH_>), grid, dim3(512), lds, (hipStream_t)stream, a);                      \
+  } while (0)
+  const int kch = C / bk;
+  if (dtype == 0) {
+    if (kch == 1) CB_LAUNCH(bf16, 1); else if (kch == 2) CB_LAUNCH(bf16, 2); else if (kch == 3) CB_LAUNCH(bf16, 3); else CB_LAUNCH(bf16, 4);
+  } else {
+    if (kch == 1) CB_LAUNCH(float, 1); else if (kch == 2) CB_LAUNCH(float, 2); else if (kch == 4) CB_LAUNCH(float, 4);
+    else if (kch == 8) CB_LAUNCH(float, 8); else return -1516;
+  }
+#undef CB_LAUNCH
+  hipLaunchKernelGGL(contrast_bank_combine_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, M, groups, splits, pos, all, rowmax, lse);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the masked sums with respect to the queries (the keys are no-grad: PixPro_swin_v5.py:366).  The sums are
+// linear in the scores, so  d q_m = sum_g  dpos[m][g] * Kcls[g][l_m] + dneg[m][g] * (Ktot[g] - Kcls[g][l_m])   with the per-class
+// key sums Kcls[c] = sum_{p visible, l_p = c} k_p and Ktot = sum_p k_p: O(rows x C) instead of a second dense GEMM.  Two
+// kernels: class sums of the bank, then the per-row combination.  Empty sets must give EXACTLY zero like the reference's
+// masked products (their denominators are 0 + 1e-6, so a 1e-7 residual would become a 0.1 gradient): an empty positive set
+// has an untouched (zero) class row; an empty negative set (cnt == visible rows) is skipped by its count.
+// ---------------------------------------------------------------------------------------------------------------------
+// ksum [maps][nb][ncls + 1][C] fp32 (zeroed by the caller), nb = seg / bank_block; slot ncls = sum over all rows.
+template <typename T>
+__global__ __launch_bounds__(256) void contrast_class_sums_kernel(const T* bank, long ldk, const int* lb, int seg, int bank_block,
+                                                                  int C, int ncls, int rows_per_wg, float* ksum) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tab = (float*)smem;                         // [ncls + 1][C]
+  const int nb = seg / bank_block;
+  const int map = blockIdx.y / nb, b = blockIdx.y - map * nb;
+  const int r0 = blockIdx.x * rows_per_wg, r1 = min(bank_block, r0 + rows_per_wg);
+  if (r0 >= r1) return;
+  for (int i = threadIdx.x; i < (ncls + 1) * C; i += 256) tab[i] = 0.f;
+  __syncthreads();
+  const long base = (long)map * seg + (long)b * bank_block;
+  // thread = (column pair cp, row lane rl): C / 2 column pairs, 512 / C row lanes; a thread's LDS cells are its own columns of
+  // every class row, but two row lanes may hit the same cell: LDS float atomics
+  const int cpairs = C >> 1, rlanes = max(1, 256 / cpairs);
+  const int cp = threadIdx.x % cpairs, rl = threadIdx.x / cpairs;
+  if (rl < rlanes) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int r = r0 + rl; r < r1; r += rlanes) {
+      const int lab = lb[base + r];
+      const T* src = bank + (base + r) * ldk + 2 * cp;
+      const float v0 = to_f32<T>(src[0]), v1 = to_f32<T>(src[1]);
+      t0 += v0; t1 += v1;
+      if (lab >= 0 && lab < ncls) {
+        atomicAdd(tab + lab * C + 2 * cp, v0);
+        atomicAdd(tab + lab * C + 2 * cp + 1, v1);
+      }
+    }
+    atomicAdd(tab + ncls * C + 2 * cp, t0);
+    atomicAdd(tab + ncls * C + 2 * cp + 1, t1);
+  }
+  __syncthreads();
+  float* out = ksum + ((long)map * nb + b) * (ncls + 1) * C;
+  for (int i = threadIdx.x; i < (ncls + 1) * C; i += 256) {
+    const float v = tab[i];
+    if (v != 0.f) atomicAdd(out + i, v);
+  }
+}
+
+struct BankDqArgs {
+  const float* dpos; const float* dneg;      // [M][groups]
+  const float* cnt; int visible;             // cnt[m][g] = visible rows of group g with label lq[m]; visible = rows per group
+  const int* lq; const float* ksum; float* dq; long lddq;
+  int M, C, q_sets, nblk, q_block, nb, ncls, groups;
+  int gmap[2][CB_MAX_GROUPS];
+};
+
+__global__ __launch_bounds__(256) void contrast_bank_dq_kernel(BankDqArgs p) {
+  const int c4 = p.C >> 2;                          // float4 column groups per row
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int m = (int)(idx / c4), c = (int)(idx - (long)m * c4) * 4;
+  if (m >= p.M) return;
+  const int qset = m / (p.nblk * p.q_block);
+  const int blk = p.nb == 1 ? 0 : (m - qset * p.nblk * p.q_block) / p.q_block;
+  const int lab = p.lq[m];
+  const bool lab_ok = lab >= 0 && lab < p.ncls;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int g = 0; g < p.groups; ++g) {
+    const float* tabs = p.ksum + ((long)p.gmap[qset][g] * p.nb + blk) * (p.ncls + 1) * p.C;
+    const float dp = p.dpos[(long)m * p.groups + g], dn = p.dneg[(long)m * p.groups + g];
+    const f32x4 kc = lab_ok ? *(const f32x4*)(tabs + (long)lab * p.C + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc += dp * kc;
+    if (p.cnt[(long)m * p.groups + g] < (float)p.visible) acc += dn * (*(const f32x4*)(tabs + (long)p.ncls * p.C + c) - kc);
+  }
+  *(f32x4*)(p.dq + (long)m * p.lddq + c) = acc;
+}
+
+extern "C" int stswin_contrast_class_sums(int dtype, const void* bank, long ldb, const int* lb, int maps, int seg, int bank_block,
+                                          int C, int ncls, float* ksum, void* stream) {
+  if (maps <= 0 || seg <= 0) return 0;
+  if (C % 2 || C > 512 || ncls <= 0 || ncls > 63 || bank_block <= 0 || seg % bank_block) return -1521;
+  const int nb = seg / bank_block;
+  (void)hipMemsetAsync(ksum, 0, sizeof(float) * (size_t)maps * nb * (ncls + 1) * C, (hipStream_t)stream);
+  int rows_per_wg = 512;
+  while (rows_per_wg > 64 && (long)((bank_block + rows_per_wg - 1) / rows_per_wg) * maps * nb < 512) rows_per_wg >>= 1;
+  const dim3 grid((unsigned)((bank_block + rows_per_wg - 1) / rows_per_wg), (unsigned)(maps * nb));
+  const int lds = (ncls + 1) * C * 4;
+  if (dtype == 0) {
+    static int once = (int)hipFuncSetAttribute((const void*)contrast_class_sums_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)once;
+    hipLaunchKernelGGL(contrast_class_sums_kernel<bf16>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16*)bank, ldb, lb, seg,
+                       bank_block, C, ncls, rows_per_wg, ksum);
+  } else {
+    static int once = (int)hipFuncSetAttribute((const void*)contrast_class_sums_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)once;
+    hipLaunchKernelGGL(contrast_class_sums_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)bank, ldb, lb, seg,
+                       bank_block, C, ncls, rows_per_wg, ksum);
+  }
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_contrast_bank_dq(const float* dpos, const float* dneg, const float* cnt, const int* lq, const float* ksum,
+                                       float* dq, long lddq, int M, int C, int q_sets, int q_block, int seg, int bank_block, int ncls, int groups,
+                                       const int* gmap, void* stream) {
+  if (M <= 0) return 0;
+  if (C % 4 || groups <= 0 || groups > CB_MAX_GROUPS || q_sets < 1 || q_sets > 2 || M % (q_sets * q_block) || seg % bank_block || lddq % 4)
+    return -1531;
+  BankDqArgs a;
+  a.dpos = dpos; a.dneg = dneg; a.cnt = cnt; a.visible = bank_block; a.lq = lq; a.ksum = ksum; a.dq = dq; a.lddq = lddq;
+  a.M = M; a.C = C; a.q_sets = q_sets; a.nblk = M / (q_sets * q_block); a.q_block = q_block; a.nb = seg / bank_block; a.ncls = ncls;
+  a.groups = groups;
+  if (a.nb != a.nblk && a.nb != 1) return -1532;
+  for (int s = 0; s < 2; ++s)
+    for (int g = 0; g < CB_MAX_GROUPS; ++g) a.gmap[s][g] = (s < q_sets && g < groups) ? gmap[s * groups + g] : 0;
+  const long threads = (long)M * (C >> 2);
+  hipLaunchKernelGGL(contrast_bank_dq_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

@@ -14,6 +14,7 @@
 // per K tile.  Epilogue goes through an fp32 LDS image so that stores / residual reads are whole 16-byte
 // row pieces (and so that scatter maps cost nothing).
 #include "common.h"
+#include "stswin_hip.h"
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
@@ -1701,6 +1702,11 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, floa
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
+// Which kernel the launcher picked for the calling thread's most recent stswin_gemm_nt / stswin_gemm_tn call (codes in
+// include/stswin_hip.h): the parity tests assert that the production shapes really run the production kernels.
+static thread_local int g_last_variant[2] = {0, 0};
+extern "C" int stswin_last_variant(int family) { return family >= 0 && family < 2 ? g_last_variant[family] : -1; }
+
 static int set_lds_once(const void* fn) {
   return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
 }
@@ -1757,9 +1763,12 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
   const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
   const long rounds = (big_tiles + 255) / 256;
   const bool fills = big_tiles * 10 >= rounds * 256 * 9;          // >= 90 % of the last round's slots used
-  bool big = dtype == 0 && Kseg % 32 == 0 && N >= 256 && M >= 256 && fills && !(flags & (GF_NOBIG | GF_WAVES4));
-  if ((flags & GF_BIG) && dtype == 0 && Kseg % 32 == 0) big = true;
-  const bool mid_ok = dtype == 0 && Kseg % 32 == 0 && !(flags & (GF_NOBIG | GF_WAVES4));
+  // The ring kernels address their operands with 32-bit byte offsets (buffer descriptors): a plain operand beyond 4 GB goes
+  // to the 64-bit-addressed 128x128 family instead (gathered rows are only known on the device: those trap in the kernel).
+  const bool fits32 = (a_rows || (long)M * lda * 2 <= 0xFFFF0000L) && (long)N * ldb * 2 <= 0xFFFF0000L;
+  bool big = dtype == 0 && Kseg % 32 == 0 && N >= 256 && M >= 256 && fills && fits32 && !(flags & (GF_NOBIG | GF_WAVES4));
+  if ((flags & GF_BIG) && dtype == 0 && Kseg % 32 == 0 && fits32) big = true;
+  const bool mid_ok = dtype == 0 && Kseg % 32 == 0 && fits32 && !(flags & (GF_NOBIG | GF_WAVES4));
   const bool mid = (flags & GF_MID) && mid_ok;
   // 256x128 ping-pong ring (twice the tiles of the 256x256 one): for shapes whose 256x256 grid leaves CUs idle
   const long half_tiles = (long)((M + 255) / 256) * ((N + 127) / 128);
@@ -1772,6 +1781,7 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
   if (half && !(flags & GF_BIG)) {
     static int once_half = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 128, 2, 4, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
     (void)once_half;
+    g_last_variant[0] = STSWIN_VAR_NT_RING256x128_PP;
     hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 128, 2, 4, 4, 2, true>), dim3((unsigned)half_tiles), dim3(512), 98304, (hipStream_t)stream, p);
     STSWIN_CHECK_LAUNCH();
     return 0;
@@ -1792,6 +1802,7 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
       static int once_stream = (int)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
       (void)once_stream;
       const unsigned grid = (unsigned)(big_tiles < 256 ? big_tiles : 256);
+      g_last_variant[0] = STSWIN_VAR_NT_STREAM;
       hipLaunchKernelGGL(gemm_nt_stream_kernel, dim3(grid), dim3(512), 163840, (hipStream_t)stream, p);
       STSWIN_CHECK_LAUNCH();
       return 0;
@@ -1802,10 +1813,12 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
       static int once_duo = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<128, 256, 1, 4, 3, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
       (void)once_duo;
       const long duo_tiles = (long)((M + 127) / 128) * ((N + 255) / 256);
+      g_last_variant[0] = STSWIN_VAR_NT_DUO;
       hipLaunchKernelGGL((gemm_nt_ring_kernel<128, 256, 1, 4, 3, 2, false, true>), dim3((unsigned)duo_tiles), dim3(256), 73728, (hipStream_t)stream, p);
       STSWIN_CHECK_LAUNCH();
       return 0;
     }
+    g_last_variant[0] = (flags & GF_NOPIPE) ? STSWIN_VAR_NT_RING256_NOPIPE : regepi ? STSWIN_VAR_NT_RING256_REGEPI : STSWIN_VAR_NT_RING256_LDSEPI;
     if (flags & GF_NOPIPE) hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, false>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
     else if (regepi) hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
@@ -1816,6 +1829,7 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     static int once_mid = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 128, 4, 2, 3, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
     (void)once_mid;
     const long mid_tiles = (long)((M + 255) / 256) * ((N + 127) / 128);
+    g_last_variant[0] = STSWIN_VAR_NT_MID;
     hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 128, 4, 2, 3, 4, false>), dim3((unsigned)mid_tiles), dim3(512), 73728, (hipStream_t)stream, p);
     STSWIN_CHECK_LAUNCH();
     return 0;
@@ -1826,6 +1840,7 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
                         (int)hipFuncSetAttribute((const void*)gemm_nt_kernel<float, 8, 256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     (void)once_n;
     const int nb = ((M + 255) / 256) * ((N + 63) / 64);
+    g_last_variant[0] = STSWIN_VAR_NT_256x64 + (dtype ? STSWIN_VAR_F32 : 0);
     if (dtype == 0) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8, 256, 64>), dim3(nb), dim3(512), 81920, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_nt_kernel<float, 8, 256, 64>), dim3(nb), dim3(512), 81920, (hipStream_t)stream, p);
     STSWIN_CHECK_LAUNCH();
@@ -1837,10 +1852,12 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     static int once_s = (int)hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16, 8, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
     (void)once_s;
     const int nb = ((M + 127) / 128) * ((N + 63) / 64);
+    g_last_variant[0] = STSWIN_VAR_NT_128x64;
     hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8, 128, 64>), dim3(nb), dim3(512), 49152, (hipStream_t)stream, p);
     STSWIN_CHECK_LAUNCH();
     return 0;
   }
+  g_last_variant[0] = (w8 ? STSWIN_VAR_NT_128x128 : STSWIN_VAR_NT_128x128_W4) + (dtype ? STSWIN_VAR_F32 : 0);
   if (dtype == 0) {
     if (w8) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8>), dim3(nblk), dim3(512), 65536, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_nt_kernel<bf16, 4>), dim3(nblk), dim3(256), 65536, (hipStream_t)stream, p);
@@ -1860,7 +1877,8 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   // bf16 operands: the split-K partials are stored as bf16 (each the fp32 sum of Mk / splits products, rounded once; the
   // combine pass adds them in fp32) - half the slab traffic of the weight gradients, the relative rounding error of a
   // gradient is 2^-9 / sqrt(splits) (a bf16 autocast GEMM rounds its whole result once, 2^-9).  STSWIN_TN_F32_SLABS=1: fp32.
-  static const int f32_slabs = getenv("STSWIN_TN_F32_SLABS") && atoi(getenv("STSWIN_TN_F32_SLABS")) ? 1 : 0;
+  const char* f32_env = getenv("STSWIN_TN_F32_SLABS");        // read per call: the parity tests flip it inside one process
+  const int f32_slabs = f32_env && atoi(f32_env) ? 1 : 0;
   const int slab_bf16 = (dtype == 0 && !f32_slabs) ? 1 : 0;
   if (splits > 0) splits &= ~(1 << 27);
   const int splits_flags_w4 = (splits > 0 && (splits & (1 << 30))) ? 1 : 0;   // tuning: bit 30 selects the 4-wave variant
@@ -1881,6 +1899,8 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   if (splits > 0) splits &= ~((1 << 29) | (1 << 28));
   bool ring = dtype == 0 && !splits_flags_w4 && !no_ring && (force_ring || (splits <= 0 && Ni >= 256 && Nj >= 256));
   if (ring && (at_rows || bt_rows) && ((at_rows && bt_rows) || Mk % 32 != 0)) ring = false;   // map modes of the ring kernel
+  if (ring && ((!at_rows && (long)Mk * lda * 2 > 0xFFFF0000L) || (!bt_rows && (long)Mk * ldb * 2 > 0xFFFF0000L)))
+    ring = false;                                          // 32-bit buffer offsets: plain operands beyond 4 GB take the 128x128 kernel
   if (ring && bseg > 0)
     for (int j0 = 0; j0 < Nj; j0 += 256)
       if ((j0 + 255 < Nj ? j0 + 255 : Nj - 1) / bseg - j0 / bseg > 1) ring = false;
@@ -1907,6 +1927,8 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
                           (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       (void)once_r;
       const dim3 grid((unsigned)(t256 * rs));
+      g_last_variant[1] = (at_rows ? STSWIN_VAR_TN_RING_ATROWS : (bt_rows && bseg > 0) ? STSWIN_VAR_TN_RING_BSEG : bt_rows ? STSWIN_VAR_TN_RING_BTROWS : STSWIN_VAR_TN_RING_PLAIN) |
+                          (slabs ? (slab_bf16 ? STSWIN_VAR_TN_SLABS_BF16 : STSWIN_VAR_TN_SLABS_F32) : 0) | (rs << 16);
       if (at_rows) hipLaunchKernelGGL(gemm_tn_ring_kernel<1>, grid, dim3(512), 131072, (hipStream_t)stream, q);
       else if (bt_rows && bseg > 0) hipLaunchKernelGGL(gemm_tn_ring_kernel<3>, grid, dim3(512), 131072, (hipStream_t)stream, q);
       else if (bt_rows) hipLaunchKernelGGL(gemm_tn_ring_kernel<2>, grid, dim3(512), 131072, (hipStream_t)stream, q);
@@ -1944,6 +1966,8 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
                     set_lds_once((const void*)gemm_tn_kernel<bf16, 8>) | set_lds_once((const void*)gemm_tn_kernel<float, 8>);
   (void)once;
   const bool w8 = splits_flags_w4 == 0;
+  g_last_variant[1] = ((w8 ? STSWIN_VAR_TN_128x128 : STSWIN_VAR_TN_128x128_W4) + (dtype ? STSWIN_VAR_F32 : 0)) |
+                      (use_slabs ? (slab_bf16 ? STSWIN_VAR_TN_SLABS_BF16 : STSWIN_VAR_TN_SLABS_F32) : 0) | (splits << 16);
   if (dtype == 0) {
     if (w8) hipLaunchKernelGGL((gemm_tn_kernel<bf16, 8>), grid, dim3(512), 65536, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_tn_kernel<bf16, 4>), grid, dim3(256), 65536, (hipStream_t)stream, p);

@@ -16,8 +16,48 @@ struct MTArgs {
   int n[MT_MAX];               // elements
   int count;
   float lr, b1, b2, eps, wd, c1, c2;   // c1 = 1 - b1^t, c2 = sqrt(1 - b2^t) (Adam); EMA: b1 = momentum
-  int mode;                    // 0 Adam, 1 SGD (momentum b1, dampening 0, nesterov off; first = c1 != 0), 2 EMA
+  int mode;                    // 0 Adam, 1 SGD (momentum b1, dampening 0, nesterov off; first = c1 != 0), 2 EMA,
+                               // 3 LARS-scaled SGD: mode 1 with the gradient (after weight decay) times the tensor's trust ratio
+  const float* norms;          // mode 3: fp32 [count][2] = sum p^2, sum (g + wd p)^2 per tensor (mt_norms_kernel), or NULL = ratio 1
+  float trust;                 // mode 3: trust coefficient (b2 is unused there; eps = LARS eps)
 };
+
+// LARS needs ||p|| and ||g + wd p|| of every tensor before any element moves (contrast/lars.py:131-139): one pass over the
+// same (tensor, chunk) grid as the update kernel, a wave-level fold and one fp32 atomic pair per block (<= a few hundred
+// adds per address, spread over the launch).
+__global__ __launch_bounds__(256) void mt_norms_kernel(MTArgs a, float* __restrict__ norms) {
+  int b = blockIdx.x, t = 0;
+  for (; t < a.count; ++t) {
+    const int nb = (a.n[t] + MT_CHUNK - 1) / MT_CHUNK;
+    if (b < nb) break;
+    b -= nb;
+  }
+  if (t >= a.count) return;
+  const int n = a.n[t];
+  const float* __restrict__ p = a.p[t];
+  const float* __restrict__ g = a.g[t];
+  const int base = b * MT_CHUNK, end = min(n, base + MT_CHUNK);
+  float sp = 0.f, sg = 0.f;
+  for (int i = base + threadIdx.x * 4; i < end; i += 256 * 4) {
+    const int cnt = min(4, end - i);
+    if (cnt == 4 && ((((uintptr_t)(p + i)) | ((uintptr_t)(g + i))) & 15) == 0) {
+      const f32x4 pv = *(const f32x4*)(p + i), gv = *(const f32x4*)(g + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float gr = gv[e] + a.wd * pv[e]; sp += pv[e] * pv[e]; sg += gr * gr; }
+    } else {
+      for (int e = 0; e < cnt; ++e) { const float pv = p[i + e], gr = g[i + e] + a.wd * pv; sp += pv * pv; sg += gr * gr; }
+    }
+  }
+  sp = wave_sum(sp);
+  sg = wave_sum(sg);
+  __shared__ float fold[4][2];
+  if ((threadIdx.x & 63) == 0) { fold[threadIdx.x >> 6][0] = sp; fold[threadIdx.x >> 6][1] = sg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(norms + 2 * t, fold[0][0] + fold[1][0] + fold[2][0] + fold[3][0]);
+    atomicAdd(norms + 2 * t + 1, fold[0][1] + fold[1][1] + fold[2][1] + fold[3][1]);
+  }
+}
 
 __global__ __launch_bounds__(256) void multi_tensor_kernel(MTArgs a) {
   int b = blockIdx.x, t = 0;
@@ -34,11 +74,16 @@ __global__ __launch_bounds__(256) void multi_tensor_kernel(MTArgs a) {
   float* __restrict__ v = a.v[t];
   const int base = b * MT_CHUNK;
   const int end = min(n, base + MT_CHUNK);
+  float ratio = 1.f;                           // LARS trust ratio of this tensor (lars.py:136-139)
+  if (a.mode == 3 && a.norms) {
+    const float pn = sqrtf(a.norms[2 * t]), gn = sqrtf(a.norms[2 * t + 1]);
+    if (pn > 0.f && gn > 0.f) ratio = a.trust * pn / (gn + a.eps);
+  }
   for (int i = base + threadIdx.x * 4; i < end; i += 256 * 4) {
     const int cnt = min(4, end - i);
     float pv[4], gv[4], mv[4], vv[4];
     const bool vec = cnt == 4 && ((((uintptr_t)(p + i)) | ((uintptr_t)(g + i))) & 15) == 0 &&
-                     (a.mode == 2 || ((((uintptr_t)(m + i)) & 15) == 0 && (a.mode == 1 || (((uintptr_t)(v + i)) & 15) == 0)));
+                     (a.mode == 2 || ((((uintptr_t)(m + i)) & 15) == 0 && (a.mode != 0 || (((uintptr_t)(v + i)) & 15) == 0)));
     if (vec) {
       *(f32x4*)pv = *(const f32x4*)(p + i);
       *(f32x4*)gv = *(const f32x4*)(g + i);
@@ -60,8 +105,8 @@ __global__ __launch_bounds__(256) void multi_tensor_kernel(MTArgs a) {
         vv[e] = a.b2 * vv[e] + (1.f - a.b2) * gr * gr;
         const float denom = sqrtf(vv[e]) / a.c2 + a.eps;
         pv[e] -= (a.lr / a.c1) * (mv[e] / denom);
-      } else if (a.mode == 1) {                // torch.optim.SGD with momentum
-        float gr = gv[e] + a.wd * pv[e];
+      } else if (a.mode == 1 || a.mode == 3) { // torch.optim.SGD with momentum (mode 3: gradient scaled by the trust ratio)
+        float gr = (gv[e] + a.wd * pv[e]) * ratio;
         mv[e] = (a.c1 != 0.f) ? gr : a.b1 * mv[e] + gr;     // first step: buf = grad
         pv[e] -= a.lr * (a.b1 != 0.f ? mv[e] : gr);
       } else {                                 // EMA: key = key * m + query * (1 - m)
@@ -97,6 +142,32 @@ extern "C" int stswin_multi_tensor(int mode, int count, void* const* p, const vo
     blocks += (n[i] + MT_CHUNK - 1) / MT_CHUNK;
   }
   a.count = count; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = wd; a.c1 = c1; a.c2 = c2; a.mode = mode;
+  a.norms = nullptr; a.trust = 0.f;
+  hipLaunchKernelGGL(multi_tensor_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+// LARS over SGD-momentum (contrast/lars.py:109-152 around torch.optim.SGD, main_pretrain_swinv5.py:37-47) for up to 48 tensors
+// of ONE parameter group: g' = g + wd p; adaptive: g' *= trust_coef ||p|| / (||g'|| + eps) when both norms are > 0;
+// buf = first ? g' : momentum buf + g'; p -= lr buf.  `norms` = caller-owned fp32 [count][2] scratch (zeroed here).
+extern "C" int stswin_multi_tensor_lars(int count, void* const* p, const void* const* g, void* const* m, const int* n,
+                                        float* norms, float lr, float momentum, float wd, float trust_coef, float eps,
+                                        int first, int adaptive, void* stream) {
+  if (count <= 0) return 0;
+  if (count > MT_MAX || (adaptive && !norms)) return -1602;
+  MTArgs a;
+  long blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    a.p[i] = (float*)p[i]; a.g[i] = (const float*)g[i]; a.m[i] = (float*)m[i]; a.v[i] = nullptr; a.n[i] = n[i];
+    blocks += (n[i] + MT_CHUNK - 1) / MT_CHUNK;
+  }
+  a.count = count; a.lr = lr; a.b1 = momentum; a.b2 = 0.f; a.eps = eps; a.wd = wd; a.c1 = first ? 1.f : 0.f; a.c2 = 0.f; a.mode = 3;
+  a.norms = adaptive ? norms : nullptr; a.trust = trust_coef;
+  if (adaptive) {
+    (void)hipMemsetAsync(norms, 0, sizeof(float) * 2 * count, (hipStream_t)stream);
+    hipLaunchKernelGGL(mt_norms_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, norms);
+  }
   hipLaunchKernelGGL(multi_tensor_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   STSWIN_CHECK_LAUNCH();
   return 0;

@@ -9,6 +9,7 @@ stream as soon as the bucket's last gradient is produced so they overlap the res
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Iterable, List, Optional
 
 import torch
@@ -61,6 +62,9 @@ class GradBucketReducer:
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._hooks = []
+        self._accumulate_only = 0
+        backend = dist.get_backend(group) if dist.is_initialized() else ""
+        self._avg_op = dist.ReduceOp.AVG if backend == "nccl" else None
         if self.world > 1 and overlap:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -72,32 +76,54 @@ class GradBucketReducer:
         self._flat = [None] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward() calls inside this context only accumulate into p.grad (no bucket is counted
+        or launched); the first backward() outside it reduces the accumulated gradients.  Without it a second backward()
+        before finish() raises instead of silently dropping the later micro-batches."""
+        self._accumulate_only += 1
+        try:
+            yield
+        finally:
+            self._accumulate_only -= 1
+
     def _on_grad(self, p):
+        if self._accumulate_only:
+            return
         i = self._bucket_of[id(p)]
         self._pending[i] -= 1
+        if self._pending[i] < 0:
+            raise RuntimeError("GradBucketReducer: a parameter received a second gradient before finish() - one backward() "
+                               "per finish(); wrap the earlier micro-batches of a gradient-accumulation step in no_sync()")
         if self._pending[i] == 0:
             self._launch(i)
 
     def _launch(self, i):
-        bucket = [p for p in self.buckets[i] if p.grad is not None]
+        bucket = self.buckets[i]
         self._launched[i] = True
         if not bucket:
             return
-        dt = self.comm_dtype or bucket[0].grad.dtype
+        dt = self.comm_dtype or torch.float32
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             ctx = torch.cuda.stream(self.comm_stream)
         else:
-            import contextlib
             ctx = contextlib.nullcontext()
         with ctx:
-            flat = torch.cat([p.grad.reshape(-1).to(dt) for p in bucket])
-            flat.div_(self.world)
+            # every parameter of the bucket takes part, zeros where this rank produced no gradient: the message size is
+            # the same on all ranks whatever their grad-is-None pattern (a mismatch would hang or corrupt the collective)
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dt) for p in bucket])
+            if self._avg_op is not None:                   # RCCL: the division rides in the collective (one pass less)
+                op = self._avg_op
+            else:
+                flat.div_(self.world)
+                op = dist.ReduceOp.SUM
             self._flat[i] = (flat, bucket)
-            self._work[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._work[i] = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
 
     def finish(self):
-        """Call after backward(): launches any bucket not yet reduced, waits, writes averaged grads back."""
+        """Call after backward(): launches any bucket not yet reduced, waits, and points every p.grad at its averaged
+        slice of the bucket buffer (a pointer swap: no copy back)."""
         if self.world == 1:
             return
         for i in range(len(self.buckets)):
@@ -108,14 +134,11 @@ class GradBucketReducer:
                 continue
             flat, bucket = item
             if self.comm_stream is not None:
-                # the collective was enqueued from comm_stream: make THAT stream wait for it, scatter the averages back
-                # there, and let the compute stream join once at the end
-                with torch.cuda.stream(self.comm_stream):
+                with torch.cuda.stream(self.comm_stream):   # the collective was enqueued from comm_stream: wait there
                     self._work[i].wait()
-                    self._unflatten(flat, bucket)
             else:
                 self._work[i].wait()
-                self._unflatten(flat, bucket)
+            self._unflatten(flat, bucket)
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.reset()
@@ -125,8 +148,14 @@ class GradBucketReducer:
         off = 0
         for p in bucket:
             n = p.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            g = flat[off:off + n].view(p.shape)
+            p.grad = g if g.dtype == p.dtype else g.to(p.dtype)
             off += n
+
+    def bytes_per_step(self) -> int:
+        """Bytes each rank contributes to the gradient all-reduce per step."""
+        esz = torch.empty((), dtype=self.comm_dtype or torch.float32).element_size()
+        return sum(p.numel() for p in self.params) * esz
 
 
 def all_gather_embeddings(x: torch.Tensor, group=None) -> torch.Tensor:

@@ -135,16 +135,19 @@ def zeros(*shape, device) -> torch.Tensor:
 # bench.py brackets every launch of the dominant kernels with HIP events recorded on the launch stream (torch's
 # current stream IS the stream the kernels are launched on) and reads them back after the timed region.
 # Two event records per launch cost ~1.7 ms of host time per training step (480 spans), which would make the timed
-# region launch-bound; `stride` > 1 brackets only every stride-th launch of each kernel family (a stride coprime with
-# the launches per step visits every launch site over `stride` steps), the others are only counted.
+# region launch-bound; `stride` > 1 brackets each launch with probability 1 / stride (a seeded generator: every launch
+# site is equally likely whatever the number of launches per step - a fixed stride that divides the launches per step
+# would time the same sites every step), the others are only counted.
 _PROFILE = None
 _PROFILE_STRIDE = 1
 _PROFILE_COUNT = {}
+_PROFILE_RNG = None
 
 
 def profile_begin(stride: int = 1):
-    global _PROFILE, _PROFILE_STRIDE, _PROFILE_COUNT
-    _PROFILE, _PROFILE_STRIDE, _PROFILE_COUNT = {}, max(1, int(stride)), {}
+    global _PROFILE, _PROFILE_STRIDE, _PROFILE_COUNT, _PROFILE_RNG
+    import random
+    _PROFILE, _PROFILE_STRIDE, _PROFILE_COUNT, _PROFILE_RNG = {}, max(1, int(stride)), {}, random.Random(12345)
 
 
 def profile_end():
@@ -173,7 +176,7 @@ class _Span:
         if _PROFILE is not None:
             n = _PROFILE_COUNT.get(self.name, 0)
             _PROFILE_COUNT[self.name] = n + 1
-            if n % _PROFILE_STRIDE == 0:
+            if _PROFILE_STRIDE == 1 or _PROFILE_RNG.random() * _PROFILE_STRIDE < 1.0:
                 self.a = torch.cuda.Event(enable_timing=True)
                 self.a.record()
         return self
@@ -343,6 +346,23 @@ def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: in
                                    _c_long(ws.numel() if ws is not None else 0), _stream())
     _check(rc, "gemm_tn")
     return out_f32
+
+
+# kernel-variant codes of stswin_last_variant (include/stswin_hip.h)
+VAR_F32 = 100
+(VAR_NT_RING256_REGEPI, VAR_NT_RING256_LDSEPI, VAR_NT_RING256_NOPIPE, VAR_NT_STREAM, VAR_NT_DUO, VAR_NT_RING256x128_PP,
+ VAR_NT_MID, VAR_NT_256x64, VAR_NT_128x64, VAR_NT_128x128, VAR_NT_128x128_W4) = range(1, 12)
+VAR_TN_RING_PLAIN, VAR_TN_RING_ATROWS, VAR_TN_RING_BTROWS, VAR_TN_RING_BSEG = 20, 21, 22, 23
+VAR_TN_128x128, VAR_TN_128x128_W4 = 30, 31
+VAR_TN_SLABS_F32, VAR_TN_SLABS_BF16 = 0x1000, 0x2000
+
+
+def last_variant(family: int) -> dict:
+    """Which kernel the most recent gemm_nt (family 0) / gemm_tn (family 1) call of this thread launched:
+    {kernel, slabs ('' / 'f32' / 'bf16'), splits}.  Test instrumentation (asserts the production dispatch)."""
+    v = load().stswin_last_variant(family)
+    return {"kernel": v & 0xFFF, "slabs": "bf16" if v & VAR_TN_SLABS_BF16 else ("f32" if v & VAR_TN_SLABS_F32 else ""),
+            "splits": v >> 16}
 
 
 def vec_gather(v: torch.Tensor, imap: torch.Tensor, fill: float = 0.0) -> torch.Tensor:
@@ -542,6 +562,59 @@ def contrast_fwd(q, keys, lq, lks, N, HW):
     return pos, tot
 
 
+_BANK_WS = {}
+
+
+def _bank_workspace(device, floats):
+    ws = _BANK_WS.get(device)
+    if ws is None or ws.numel() < floats:
+        ws = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)
+        _BANK_WS[device] = ws
+    return ws
+
+
+def contrast_bank_fwd(Q, lq, bank, lb, *, q_sets, q_block, bank_block, gmap, inv_tau=1.0, want_lse=False):
+    """Q [M][C], lq int32 [M]; bank [maps][seg][C], lb int32 [maps][seg]; gmap: q_sets lists of map indices (one per group).
+    -> pos, all fp32 [M][groups] (+ rowmax, lse fp32 [M] or None, None); see include/stswin_hip.h."""
+    M, C = Q.shape
+    maps, seg = bank.shape[0], bank.shape[1]
+    groups = len(gmap[0])
+    assert Q.dtype == bank.dtype and bank.is_contiguous() and lb.is_contiguous() and lq.is_contiguous()
+    assert lq.dtype == torch.int32 and lb.dtype == torch.int32 and len(gmap) == q_sets and all(len(g) == groups for g in gmap)
+    pos = torch.empty(M, groups, dtype=torch.float32, device=Q.device)
+    tot = torch.empty(M, groups, dtype=torch.float32, device=Q.device)
+    rowmax = torch.empty(M, dtype=torch.float32, device=Q.device) if want_lse else None
+    lse = torch.empty(M, dtype=torch.float32, device=Q.device) if want_lse else None
+    ws = _bank_workspace(Q.device, 4 * M * groups * 8)
+    gm = (_c_int * (q_sets * groups))(*[int(v) for row in gmap for v in row])
+    name = "contrast_bank_fwd_bf16" if Q.dtype == torch.bfloat16 else "contrast_bank_fwd_f32"
+    with _Span(name, 2.0 * M * groups * bank_block * C):
+        rc = load().stswin_contrast_bank_fwd(_dt(Q), _p(Q), _c_long(_ld(Q)), _p(lq), M, C, q_sets, q_block, _p(bank),
+                                             _c_long(bank.stride(1)), _p(lb), maps, seg, bank_block, groups, gm, _c_float(inv_tau),
+                                             _p(pos), _p(tot), _p(rowmax), _p(lse), _p(ws), _c_long(ws.numel()), _stream())
+    _check(rc, "contrast_bank_fwd")
+    return pos, tot, rowmax, lse
+
+
+def contrast_class_sums(bank, lb, bank_block, ncls):
+    """-> ksum fp32 [maps][seg / bank_block][ncls + 1][C]: per-class sums of the bank rows (slot ncls: all rows)."""
+    maps, seg, C = bank.shape
+    ksum = torch.empty(maps, seg // bank_block, ncls + 1, C, dtype=torch.float32, device=bank.device)
+    _check(load().stswin_contrast_class_sums(_dt(bank), _p(bank), _c_long(bank.stride(1)), _p(lb), maps, seg, bank_block, C, ncls,
+                                             _p(ksum), _stream()), "contrast_class_sums")
+    return ksum
+
+
+def contrast_bank_dq(dpos, dneg, cnt, lq, ksum, *, q_sets, q_block, seg, bank_block, gmap):
+    M, groups = dpos.shape
+    C, ncls = ksum.shape[3], ksum.shape[2] - 1
+    dq = torch.empty(M, C, dtype=torch.float32, device=dpos.device)
+    gm = (_c_int * (q_sets * groups))(*[int(v) for row in gmap for v in row])
+    _check(load().stswin_contrast_bank_dq(_p(dpos.contiguous()), _p(dneg.contiguous()), _p(cnt.contiguous()), _p(lq), _p(ksum), _p(dq), _c_long(C), M, C,
+                                          q_sets, q_block, seg, bank_block, ncls, groups, gm, _stream()), "contrast_bank_dq")
+    return dq
+
+
 def upsample_argmax(logits, H, W, gt=None):
     """NCHW logits [F][nc][h][w] -> uint8 labels [F][H][W] (+ int32 counts [F][3][nc] when gt int64 [F][H][W] is given)."""
     F_, nc, h, w = logits.shape
@@ -568,6 +641,24 @@ def multi_tensor(mode, ps, gs, ms=None, vs=None, lr=0.0, b1=0.0, b2=0.0, eps=0.0
         _check(lib.stswin_multi_tensor(mode, k, arr(ps), arr(gs), arr(ms), arr(vs), ns, _c_float(lr), _c_float(b1),
                                        _c_float(b2), _c_float(eps), _c_float(wd), _c_float(c1), _c_float(c2), st),
                "multi_tensor")
+
+
+def multi_tensor_lars(ps, gs, ms, norms, *, lr, momentum, wd, trust_coef, eps, first, adaptive):
+    """LARS-scaled SGD-momentum step of one parameter group (lists of contiguous fp32 GPU tensors; chunks of 48 tensors,
+    two launches each: norms, update).  norms: fp32 scratch of >= 96 floats."""
+    lib = load()
+    st = _stream()
+    for t in list(ps) + list(gs) + list(ms):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise StswinHipError("multi_tensor_lars needs contiguous fp32 GPU tensors")
+    for lo in range(0, len(ps), 48):
+        hi = min(len(ps), lo + 48)
+        k = hi - lo
+        arr = lambda ts: (_c_void_p * k)(*[t.data_ptr() for t in ts[lo:hi]])  # noqa: E731
+        ns = (_c_int * k)(*[t.numel() for t in ps[lo:hi]])
+        _check(lib.stswin_multi_tensor_lars(k, arr(ps), arr(gs), arr(ms), ns, _p(norms), _c_float(lr), _c_float(momentum),
+                                            _c_float(wd), _c_float(trust_coef), _c_float(eps), 1 if first else 0,
+                                            1 if adaptive else 0, st), "multi_tensor_lars")
 
 
 def selftest(which: int) -> torch.Tensor:

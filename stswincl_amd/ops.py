@@ -102,6 +102,23 @@ def clear_caches() -> None:
     _ROWMAPS.clear()
     _WCACHE.clear()
     _UNIQ_MASKS.clear()
+    from . import headops
+    headops._CW.clear()
+
+
+def invalidate_weights(module: Optional[torch.nn.Module] = None) -> None:
+    """Drop the cached compute-dtype GEMM operands (W, W^T, packed convolution matrices) of `module`'s parameters, or all of
+    them.  The caches are keyed on a parameter's autograd version counter, which in-place writes through ``p.data`` (a
+    hand-written optimizer, DDP's ``_sync_module_states`` broadcast, ``p.data.copy_``) do NOT bump: call this after any such
+    write that happens once the model has run.  stswincl_amd's own optimizers / EMA / checkpoint loaders do it themselves."""
+    if module is None:
+        _WCACHE.clear()
+    else:
+        ids = {id(p) for p in module.parameters()}
+        for k in [k for k in _WCACHE if k[0] in ids]:
+            del _WCACHE[k]
+    from . import headops
+    headops._CW.clear()
 
 
 def zeros_like_list(shapes, device, fill=True):

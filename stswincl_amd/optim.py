@@ -2,7 +2,8 @@
 
 ``FusedAdam`` == torch.optim.Adam(params, lr, betas, eps, weight_decay) as used by seg18/train_swin.py:122;
 ``FusedSGD``  == torch.optim.SGD(params, lr, momentum, weight_decay) with per-group lr / weight_decay
-                 (train_CL_ft_mswin_sgd_minput.py:147-162; the LARS wrapper of the contrastive stage is still torch);
+                 (train_CL_ft_mswin_sgd_minput.py:147-162); the LARS wrapper of the contrastive stage is
+                 stswincl_amd/contrast/lars.py (``make_contrast_optimizer`` builds main_pretrain_swinv5.py:37-47's stack);
 ``ema_update``== PixPro._momentum_update_key_encoder (PixPro_swin_v5.py:258-289) in ~8 launches instead of ~370x2.
 """
 from __future__ import annotations
@@ -36,9 +37,9 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
-            ps, gs, ms, vs, touched = [], [], [], [], []
             b1, b2 = group["betas"]
-            step = None
+            by_step = {}          # torch.optim.Adam keeps the step count PER PARAMETER (bias corrections differ when a branch
+            touched = []          # had no gradient on some steps, or a parameter was unfrozen later): one launch per count
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -47,17 +48,17 @@ class FusedAdam(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["step"] += 1
-                step = st["step"]
+                st["step"] = int(st["step"]) + 1
+                ps, gs, ms, vs = by_step.setdefault(st["step"], ([], [], [], []))
                 ps.append(p.data)
                 touched.append(p)
                 gs.append(p.grad.contiguous() if not p.grad.is_contiguous() else p.grad)
                 ms.append(st["exp_avg"])
                 vs.append(st["exp_avg_sq"])
-            if ps:
+            for step, (ps, gs, ms, vs) in by_step.items():
                 hip.multi_tensor(0, ps, gs, ms, vs, lr=group["lr"], b1=b1, b2=b2, eps=group["eps"], wd=group["weight_decay"],
                                  c1=1.0 - b1 ** step, c2=math.sqrt(1.0 - b2 ** step))
-                _mark_updated(touched)
+            _mark_updated(touched)
         return loss
 
 
@@ -75,7 +76,7 @@ class FusedSGD(torch.optim.Optimizer):
                     continue
                 st = self.state[p]
                 g = p.grad.contiguous() if not p.grad.is_contiguous() else p.grad
-                if "momentum_buffer" not in st:
+                if st.get("momentum_buffer") is None:      # (a loaded state may hold None: first step)
                     st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     tgt = first
                 else:
@@ -97,3 +98,18 @@ def ema_update(keys: Sequence[torch.Tensor], queries: Sequence[torch.Tensor], mo
     their version counters are bumped so that caches keyed on them see the update."""
     hip.multi_tensor(2, [k.data for k in keys], [q.data for q in queries], b1=momentum)
     _mark_updated(list(keys))
+
+
+def make_contrast_optimizer(params, batch_size: int, base_learning_rate: float = 1.0, momentum: float = 0.9,
+                            weight_decay: float = 1e-5, optimizer: str = "lars"):
+    """The optimizer stack of main_pretrain_swinv5.py:32-47 on the fused kernels: lr = global batch / 256 * base lr;
+    'lars': add_weight_decay groups (1-D parameters: no decay, no trust ratio) + SGD momentum under LARS; 'sgd': plain
+    SGD momentum with weight decay.  -> (optimizer, short name for reports)."""
+    from .contrast.lars import LARS
+    params = list(params)
+    lr = batch_size / 256.0 * base_learning_rate
+    if optimizer == "sgd":
+        return FusedSGD(params, lr, momentum=momentum, weight_decay=weight_decay), "SGD"
+    groups = [{"params": [p for p in params if p.dim() == 1], "weight_decay": 0, "ignore": True},
+              {"params": [p for p in params if p.dim() != 1], "weight_decay": weight_decay, "ignore": False}]
+    return LARS(FusedSGD(groups, lr, momentum=momentum)), "LARS(SGD)"

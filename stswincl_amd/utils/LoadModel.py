@@ -7,7 +7,16 @@
 * ``load_model_mswin_CL`` (seg18/utils/LoadModel.py:6-49) maps the latter onto ``TswinPlus`` and silently keeps the
   model's own tensor wherever shapes differ (e.g. ``attn_mask`` when the resolution changed).
 
-Same function names and behaviour; ``map_location`` defaults to the model's device instead of a hard-coded 'cuda:0'.
+Same function names and key handling as seg18/utils/LoadModel.py: ``load_model`` strips ``module.`` only from
+``module.resnet*`` keys (:55-59), ``load_model_full`` strips nothing (:96-100), ``load_model_full_fortest`` strips it from
+every ``module*`` key (:128-132), ``load_model_mswin_CL`` remaps the contrastive prefixes (:14-28); all four keep the model's
+own tensor where shapes differ.  Deviations: ``map_location`` is the model's device instead of a hard-coded 'cuda:0'; a
+``{'model': state_dict, ...}`` wrapper is unwrapped by the three raw loaders as well; the GEMM operand caches are dropped
+after a load (ops.clear_caches).
+
+The reference's contrastive checkpoints hold ``{'opt': argparse.Namespace, 'model', 'optimizer', 'scheduler', 'epoch'}``
+(main_pretrain_swinv5.py:91-102); torch >= 2.6 refuses the Namespace under its default ``weights_only=True``, so
+``_torch_load`` allow-lists it and, for other trusted reference pickles, falls back to ``weights_only=False``.
 """
 from __future__ import annotations
 
@@ -17,6 +26,16 @@ import torch
 
 _CL_PREFIXES = (("pixpro.encoder_1", "resnet"), ("pixpro.encoder_2", "swin"), ("pixpro.encoder_3", "aspp"),
                 ("pixpro.proj1", "project1"), ("pixpro.proj2", "project2"), ("pixpro.proj3", "project3"))
+
+
+def _torch_load(path, map_location):
+    import argparse
+    import pickle
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(path, map_location=map_location, weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError, AttributeError):
+        return torch.load(path, map_location=map_location, weights_only=False)   # trusted checkpoints of the reference's own scripts
 
 
 def _device_of(model):
@@ -66,19 +85,40 @@ def _merge_into(model, state_dict, log=True):
     return model
 
 
-def load_model_mswin_CL(model, pretrain_dir, log=True):
-    ckpt = torch.load(pretrain_dir, map_location=_device_of(model))
+def _after_load(model):
+    from .. import ops
+    ops.clear_caches()            # cached bf16 / transposed GEMM operands of the overwritten parameters
+    return model
+
+
+def _raw_state_dict(pretrain_dir, model):
+    ckpt = _torch_load(pretrain_dir, _device_of(model))
     print('loaded pretrained weights form %s !' % pretrain_dir)
-    return _merge_into(model, remap_contrastive_keys(ckpt['model']), log)
+    if isinstance(ckpt, dict) and 'model' in ckpt and not any(str(k).endswith('.weight') for k in ckpt):
+        ckpt = ckpt['model']
+    return ckpt
+
+
+def load_model_mswin_CL(model, pretrain_dir, log=True):
+    ckpt = _torch_load(pretrain_dir, _device_of(model))
+    print('loaded pretrained weights form %s !' % pretrain_dir)
+    return _after_load(_merge_into(model, remap_contrastive_keys(ckpt['model']), log))
 
 
 def load_model(model, pretrain_dir, log=True):
-    """Raw seg checkpoint (optionally ``module.``-prefixed), shape-checked."""
-    ckpt = torch.load(pretrain_dir, map_location=_device_of(model))
-    print('loaded pretrained weights form %s !' % pretrain_dir)
-    if isinstance(ckpt, dict) and 'model' in ckpt and not any(k.endswith('.weight') for k in ckpt):
-        ckpt = ckpt['model']
-    return _merge_into(model, strip_module_prefix(ckpt), log)
+    """Raw seg checkpoint; only ``module.resnet*`` keys lose their DataParallel prefix (LoadModel.py:55-59)."""
+    sd = _raw_state_dict(pretrain_dir, model)
+    sd = OrderedDict((k[7:] if (k.startswith('module.resnet') and not k.startswith('module_list')) else k, v) for k, v in sd.items())
+    return _after_load(_merge_into(model, sd, log))
 
 
-load_model_full = load_model
+def load_model_full(model, pretrain_dir, log=True):
+    """Raw checkpoint, keys taken as they are (LoadModel.py:96-100)."""
+    return _after_load(_merge_into(model, OrderedDict(_raw_state_dict(pretrain_dir, model)), log))
+
+
+def load_model_full_fortest(model, pretrain_dir, log=True):
+    """Raw checkpoint saved from nn.DataParallel: every ``module*`` key loses its first 7 characters (LoadModel.py:128-132)."""
+    sd = _raw_state_dict(pretrain_dir, model)
+    sd = OrderedDict((k[7:] if (k.startswith('module') and not k.startswith('module_list')) else k, v) for k, v in sd.items())
+    return _after_load(_merge_into(model, sd, log))

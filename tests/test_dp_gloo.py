@@ -71,6 +71,113 @@ def test_bucketed_allreduce_world2(overlap):
         assert mine == [rank, rank + 2, rank + 4, rank + 6]
 
 
+def _worker_accum(rank, world, port, q):
+    """Gradient accumulation (two micro-batches, the first under no_sync), a parameter whose gradient is None on ONE rank
+    only (bucket sizes must still agree), and the loud failure of a second backward() without no_sync."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        a, b = torch.nn.Linear(8, 8), torch.nn.Linear(8, 8)        # b is used by rank 0 only
+        params = list(a.parameters()) + list(b.parameters())
+        red = GradBucketReducer(params, bucket_mb=1.0)
+        x = torch.arange(4 * 8, dtype=torch.float32).reshape(4, 8) / 10 + rank
+
+        def loss_of(xx):
+            y = a(xx)
+            return (b(y) if rank == 0 else y).pow(2).mean()
+
+        with red.no_sync():
+            loss_of(x[:2]).backward()
+        loss_of(x[2:]).backward()
+        red.finish()
+        ga = a.weight.grad.clone()
+        gb = b.weight.grad.clone()
+        # reference: mean over ranks of (sum of the two micro-batch gradients); rank 1 contributes zeros to b
+        refs_a, refs_b = [], []
+        for r in range(world):
+            a2, b2 = torch.nn.Linear(8, 8), torch.nn.Linear(8, 8)
+            a2.load_state_dict(a.state_dict()), b2.load_state_dict(b.state_dict())
+            xr = torch.arange(4 * 8, dtype=torch.float32).reshape(4, 8) / 10 + r
+            for part in (xr[:2], xr[2:]):
+                y = a2(part)
+                (b2(y) if r == 0 else y).pow(2).mean().backward()
+            refs_a.append(a2.weight.grad)
+            refs_b.append(b2.weight.grad if b2.weight.grad is not None else torch.zeros(8, 8))
+        err = max(float((ga - sum(refs_a) / world).abs().max()), float((gb - sum(refs_b) / world).abs().max()))
+        raised = False
+        c = torch.nn.Linear(8, 8)
+        red2 = GradBucketReducer(list(c.parameters()), bucket_mb=1.0)
+        c(x[:2]).pow(2).mean().backward()
+        try:
+            c(x[2:]).pow(2).mean().backward()
+        except RuntimeError as e:
+            raised = "no_sync" in str(e)
+        red2.finish()                                   # (drains the collective the first backward launched)
+        q.put((rank, err, raised))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_accumulation_none_grads_and_double_backward_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_accum, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, err, raised in res:
+        assert err < 1e-6, (rank, err)
+        assert raised, "a second backward() before finish() must raise"
+
+
+def _worker_bank(rank, world, port, q):
+    """Inter-video key bank: gather_bank's layout ([maps][world * rows][C], rank-major inside a map) and the bank loss of one
+    rank's queries against the gathered bank == the dense oracle on the concatenated keys."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import stswin_oracle as O
+        from stswincl_amd.contrast.models.PixPro_swin_v5 import gather_bank
+        maps, rows, c = 6, 40, 32
+        gen = [torch.Generator().manual_seed(100 + r) for r in range(world)]
+        banks = [torch.nn.functional.normalize(torch.randn(maps, rows, c, generator=g), dim=2) for g in gen]
+        labels = [torch.randint(0, 12, (maps, rows), generator=g, dtype=torch.int32) for g in gen]
+        bank, lb = gather_bank(banks[rank], labels[rank])
+        ref_bank, ref_lb = torch.cat(banks, 1), torch.cat(labels, 1)
+        ok_layout = torch.equal(bank, ref_bank) and torch.equal(lb, ref_lb)
+        qg = torch.Generator().manual_seed(7 + rank)
+        qq = torch.nn.functional.normalize(torch.randn(2 * rows, c, generator=qg), dim=1)
+        lq = torch.cat([labels[rank][0], labels[rank][1]]).long()
+        gmap = [[1, 2, 3, 4, 5], [0, 2, 3, 4, 5]]
+        a = O.bank_contrast_loss(qq, lq, bank, lb.long(), gmap, rows, world * rows)
+        b = O.bank_contrast_loss(qq, lq, ref_bank, ref_lb.long(), gmap, rows, world * rows)
+        q.put((rank, ok_layout, float(a), float(b), tuple(bank.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_bank_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok_layout, a, b, shape in res:
+        assert ok_layout and shape == (6, 80, 32), (rank, shape)
+        assert a == b
+
+
 def test_shard_indices_padding_and_shuffle():
     assert shard_indices(5, 0, 2) == [0, 2, 4] and shard_indices(5, 1, 2) == [1, 3, 0]
     a, b = shard_indices(10, 0, 2, epoch=3, shuffle=True), shard_indices(10, 1, 2, epoch=3, shuffle=True)

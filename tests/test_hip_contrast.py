@@ -51,8 +51,9 @@ def _args():
                                  pretrainpth="none", num_instances=2235, batch_size=2, epochs=150, start_epoch=1)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("views", ["batched", "sequential"])
-def test_consistency_loss_step_matches_reference(views, monkeypatch):
+def test_consistency_loss_step_matches_reference(views, mode, monkeypatch):
     # batched: the 2 query / 6 key passes as one batch each with per-view BatchNorm statistics; sequential: one pass per view
     monkeypatch.setenv("STSWIN_SEQUENTIAL_VIEWS", "1" if views == "sequential" else "0")
     g = gu.load("consistency.npz")
@@ -67,13 +68,21 @@ def test_consistency_loss_step_matches_reference(views, monkeypatch):
     ims = [gu.det_tensor(f"consistency/im{i}", (2, 4, 3, hh, ww)).cuda() for i in range(6)]
     masks = [torch.floor(gu.det_tensor(f"consistency/mask{i}", (2, 1, hh // 8, ww // 8), "uniform", 12.0))
              .clamp(0, 11).repeat_interleave(8, 2).repeat_interleave(8, 3).cuda() for i in range(6)]
-    loss = net(*ims, *masks)
+    # bf16 (what bench.py --workload contrast runs): the loss is a mean over 2 x 2 x 256 pixel terms of O(1) log-ratios of
+    # normalised-embedding similarities, so the bf16 storage error of the embeddings (2^-9 relative per element, 256-d dot
+    # products) averages down: 1e-2 on the loss; the projector gradient sees the whole bf16 encoder: 0.15 rel-L2.
+    tol_loss, tol_grad = (1e-3, 1e-2) if mode == "fp32" else (1e-2, 0.15)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(mode == "bf16")):
+        loss = net(*ims, *masks)
     assert net.pixpro.k == int(g["k1"])
-    assert abs(float(loss) - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))
+    print(f"consistency {views} {mode}: loss {float(loss):.6f} vs {float(g['loss']):.6f}")
+    assert abs(float(loss) - float(g["loss"])) < tol_loss * abs(float(g["loss"]))
     loss.backward()
-    assert rel(net.pixpro.projector.linear2.weight.grad, g["d_projector_linear2"]) < 1e-2
+    r_g = rel(net.pixpro.projector.linear2.weight.grad, g["d_projector_linear2"])
+    print(f"  d projector.linear2 rel-L2 {r_g:.4f}")
+    assert r_g < tol_grad
     sd_after = net.state_dict()
-    for key in [f for f in g.files if f.startswith("probe/")]:
+    for key in [f for f in g.files if f.startswith("probe/")]:      # EMA'd key weights / running statistics (fp32 master copies)
         t = sd_after[key[len("probe/"):]].double()
-        assert abs(float(t.abs().sum()) - float(g[key][1])) < 1e-3 * float(g[key][1]) + 1e-9, key
+        assert abs(float(t.abs().sum()) - float(g[key][1])) < (1e-3 if mode == "fp32" or "running" not in key else 2e-2) * float(g[key][1]) + 1e-9, key
     assert all(p.grad is None for p in net.pixpro.encoder_k_2.parameters())

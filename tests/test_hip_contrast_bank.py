@@ -1,0 +1,138 @@
+"""N1: bank mode of the pixel-contrastive similarity (stswin_contrast_bank_fwd / class_sums / bank_dq) against the dense CPU
+oracle (oracle.bank_scores: logits + one-hot style masks like PixPro_swin_v5.py:82-113) and the reference goldens."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_util as gu
+from oracle import stswin_oracle as O
+from stswincl_amd import hip
+from stswincl_amd.contrast.models import PixPro_swin_v5 as P
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _case(seed, M, C, maps, seg, ncls=12):
+    torch.manual_seed(seed)
+    q = F.normalize(torch.randn(M, C), dim=1)
+    bank = F.normalize(torch.randn(maps, seg, C), dim=2)
+    lq = torch.randint(0, ncls, (M,), dtype=torch.int32)
+    lb = torch.randint(0, ncls, (maps, seg), dtype=torch.int32)
+    return q, lq, bank, lb
+
+
+# (M, C, maps, seg, gmap, q_block, bank_block): per-sample blocks with ragged HW (63 = 7x9, 240 = 12x20), both directions in one
+# launch, one block seeing a long segment (bank splits > 1), C = 64 / 128 / 256
+CASES = [
+    (2 * 64, 256, 5, 2 * 64, [[0, 1, 2, 3, 4]], 64, 64),
+    (2 * 3 * 63, 256, 6, 3 * 63, [[1, 2, 3, 4, 5], [0, 2, 3, 4, 5]], 63, 63),
+    (3 * 240, 64, 5, 3 * 240, [[0, 1, 2, 3, 4]], 240, 240),
+    (2 * 256, 128, 6, 4096, [[1, 2, 3, 4, 5], [0, 2, 3, 4, 5]], 256, 4096),
+    (300, 256, 2, 5000, [[0, 1]], 300, 5000),
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_bank_fwd_matches_dense_oracle(case, dtype, tol):
+    M, C, maps, seg, gmap, qb, bb = CASES[case]
+    q, lq, bank, lb = _case(case, M, C, maps, seg)
+    lb[0, :bb] = lq[0]                                # a query whose negative set in group 0 may be small / empty
+    qd, bd = q.to(dtype), bank.to(dtype)
+    pos, tot, rmax, lse = hip.contrast_bank_fwd(qd.cuda(), lq.cuda(), bd.cuda(), lb.cuda(), q_sets=len(gmap), q_block=qb,
+                                                bank_block=bb, gmap=gmap, inv_tau=5.0, want_lse=True)
+    rp, rn, rm, rl = O.bank_scores(qd.float(), lq.long(), bd.float(), lb.long(), gmap, qb, bb, inv_tau=5.0)
+    scale = float((rp + rn).abs().max()) + 1e-6
+    assert float((pos.cpu() - rp).abs().max()) <= tol * scale, "pos"
+    assert float(((tot - pos).cpu() - rn).abs().max()) <= tol * scale, "neg = all - pos"
+    assert float((rmax.cpu() - rm).abs().max()) <= tol * 5.0, "row max"
+    assert float((lse.cpu() - rl).abs().max()) <= tol * 5.0 + 1e-4, "log-sum-exp"
+
+
+def test_empty_negative_set_is_exactly_zero():
+    """All visible keys share the query's label: neg = all - pos must be bitwise 0 (its denominator is 0 + 1e-6) and its
+    gradient exactly zero, as with the reference's masked products (PixPro_swin_v5.py:103-113)."""
+    M, C, maps, seg, gmap, qb, bb = 128, 256, 5, 128, [[0, 1, 2, 3, 4]], 64, 64
+    q, lq, bank, lb = _case(7, M, C, maps, seg)
+    lq[:64] = 3
+    lb[2, :64] = 3                                   # group 2 of block 0: no negatives at all
+    for dtype in (torch.float32, torch.bfloat16):
+        pos, tot, _, _ = hip.contrast_bank_fwd(q.to(dtype).cuda(), lq.cuda(), bank.to(dtype).cuda(), lb.cuda(), q_sets=1, q_block=qb,
+                                               bank_block=bb, gmap=gmap)
+        assert torch.equal(pos[:64, 2], tot[:64, 2])
+    qg = q.clone().cuda().requires_grad_(True)
+    loss, _, _ = P.bank_contrast_loss(qg, lq.cuda(), bank.cuda(), lb.cuda(), gmap, qb, bb, 12)
+    loss.backward()
+    qo = q.clone().requires_grad_(True)
+    lo = O.bank_contrast_loss(qo, lq.long(), bank, lb.long(), gmap, qb, bb)
+    lo.backward()
+    assert abs(float(loss) - float(lo)) < 1e-5 * abs(float(lo))
+    assert rel(qg.grad, qo.grad) < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["sample", "batch"])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 2e-2)])
+def test_pair_loss_and_gradient_vs_oracle(mode, dtype, tol):
+    """consistency_pair_loss (both directions, one launch) in the reference's per-sample mode and with the rank's whole batch as
+    the bank, value and d/d(pred_1), d/d(pred_2) against the dense oracle."""
+    torch.manual_seed(11)
+    n, c, h, w = 3, 256, 8, 12
+    feats = [F.normalize(torch.randn(n, c, h, w), dim=1) for _ in range(8)]
+    m = [torch.randint(0, 12, (n, 1, h, w)).float() for _ in range(6)]
+    p1, p2 = feats[0].clone().cuda().requires_grad_(True), feats[1].clone().cuda().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(dtype == "bf16")):
+        loss, _, _ = P.consistency_pair_loss(p1, p2, *[f.cuda() for f in feats[2:]], [x.cuda() for x in m], 12, bank_mode=mode)
+    loss.backward()
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(n * h * w, c)      # noqa: E731
+    q = torch.cat([tok(feats[0]), tok(feats[1])], 0).clone().requires_grad_(True)
+    bank = torch.stack([tok(f) for f in feats[2:]], 0)
+    lb = torch.stack([x.reshape(-1).long() for x in m], 0)
+    lq = torch.cat([lb[0], lb[1]])
+    qb, bb = (h * w, h * w) if mode == "sample" else (n * h * w, n * h * w)
+    lo = O.bank_contrast_loss(q, lq, bank, lb, [[1, 2, 3, 4, 5], [0, 2, 3, 4, 5]], qb, bb)
+    lo.backward()
+    assert abs(float(loss) - float(lo)) < tol * abs(float(lo))
+    g = q.grad.view(2, n, h, w, c).permute(0, 1, 4, 2, 3)
+    assert rel(p1.grad, g[0]) < 50 * tol and rel(p2.grad, g[1]) < 50 * tol
+
+
+def test_legacy_per_map_kernel_agrees_with_bank_kernel():
+    """stswin_contrast_fwd (round-1 entry point, one launch per direction) and the bank kernel on the same problem."""
+    torch.manual_seed(3)
+    n, hw, c = 2, 240, 256
+    q = F.normalize(torch.randn(n * hw, c), dim=1).cuda()
+    keys = [F.normalize(torch.randn(n * hw, c), dim=1).cuda() for _ in range(5)]
+    lq = torch.randint(0, 12, (n, hw), dtype=torch.int32).cuda()
+    lks = [torch.randint(0, 12, (n, hw), dtype=torch.int32).cuda() for _ in range(5)]
+    p0, t0 = hip.contrast_fwd(q, keys, lq, lks, n, hw)
+    p1, t1, _, _ = hip.contrast_bank_fwd(q, lq.reshape(-1), torch.stack(keys, 0), torch.stack([x.reshape(-1) for x in lks], 0),
+                                         q_sets=1, q_block=hw, bank_block=hw, gmap=[[0, 1, 2, 3, 4]])
+    assert torch.allclose(p0.view(n * hw, 5), p1, atol=2e-4) and torch.allclose(t0.view(n * hw, 5), t1, atol=2e-4)
+
+
+def test_production_size_bank_of_65k_entries():
+    """BASELINE configs[3] bank size: 8192 query pixels x 2 directions against a 65536-entry bank per key map (8 ranks x 8 clips x
+    32x32 pixels), bf16.  Dense CPU reference on a sample of the rows (the whole problem is 1.4 TFLOP)."""
+    M, C, maps, seg = 2 * 8192, 256, 6, 65536
+    q, lq, bank, lb = _case(5, M, C, maps, seg)
+    gmap = [[1, 2, 3, 4, 5], [0, 2, 3, 4, 5]]
+    qd, bd = q.bfloat16(), bank.bfloat16()
+    pos, tot, rmax, lse = hip.contrast_bank_fwd(qd.cuda(), lq.cuda(), bd.cuda(), lb.cuda(), q_sets=2, q_block=8192, bank_block=seg,
+                                                gmap=gmap, inv_tau=10.0, want_lse=True)
+    rows = torch.cat([torch.arange(0, 8192, 257), torch.arange(8192, 16384, 263)])
+    bf = bd.float()
+    for r in rows.tolist():
+        s = r // 8192
+        logits = torch.stack([bf[mp] @ qd[r].float() for mp in gmap[s]], 0)                  # [5][65536]
+        match = torch.stack([lb[mp] == lq[r] for mp in gmap[s]], 0)
+        rp = (logits * match).sum(1)
+        ra = logits.sum(1)
+        assert float((pos[r].cpu() - rp).abs().max()) < 2e-2 * float(logits.abs().sum(1).max()) ** 0.5 + 0.05, r
+        assert float((tot[r].cpu() - ra).abs().max()) < 2e-2 * float(logits.abs().sum(1).max()) ** 0.5 + 0.05, r
+        assert abs(float(rmax[r]) - 10.0 * float(logits.max())) < 2e-2
+        assert abs(float(lse[r]) - float(torch.logsumexp(10.0 * logits.reshape(-1), 0))) < 2e-2

@@ -50,11 +50,44 @@ def test_tswinplus_bf16_autocast():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = m(x)
         loss = OhemCELoss2D(128 * 128 // 16)(y, labels)
-    # bf16 tolerance, measured with tools/diag_bf16.py on these untrained fixture weights: Swin stack alone 0.8 %,
-    # library bf16 ResNet feeder 4 %, train-mode BN on the 16x16 / B=2 head maps amplifies to ~9 % on the logits.
-    assert rel(y.float()[:, :, ::2, ::2], g["y_train_sub"]) < 0.12
-    assert abs(float(loss) - float(g["loss_train"])) < 3e-2 * float(g["loss_train"])
+    # Yardstick: the REFERENCE graph itself under CPU bf16 autocast on this fixture deviates by rel_logits_128 (7.8 %) from its
+    # own fp32 run (tests/golden/bf16_yardstick.npz, tools/gen_golden.py --only bf16_yardstick): untrained weights and
+    # train-mode BN on 16x16 / B = 2 maps amplify bf16 rounding.  The HIP bf16 path keeps more in bf16 than autocast does
+    # (BatchNorm / LayerNorm outputs, residual streams), so it is held to 1.3 x the yardstick on the logits.
+    yard = gu.load("bf16_yardstick.npz")
+    r_log = rel(y.float()[:, :, ::2, ::2], g["y_train_sub"])
+    r_loss = abs(float(loss) - float(g["loss_train"])) / float(g["loss_train"])
+    print(f"bf16 128x128: logits {r_log:.4f} (reference autocast {float(yard['rel_logits_128']):.4f}) loss {r_loss:.2e}")
+    assert r_log < 1.3 * float(yard["rel_logits_128"])
+    assert r_loss < 1e-2
     loss.backward()
+
+
+def test_tswinplus_256_fp32_gate_and_bf16_vs_reference_autocast_yardstick():
+    """256x256, B = 4 (decode-head BatchNorm on 32x32 maps): the fp32 path against the reference's fp32 logits (1e-3 gate of
+    BASELINE.json north_star) and the bf16 path against what the reference's own bf16 autocast run loses (9.6 %)."""
+    yard = gu.load("bf16_yardstick.npz")
+    g = gu.load("tswinplus.npz")
+    m = TswinPlus(12, (32, 32))
+    sd = gu.det_fill(gu.skeleton_sd(g["keys"], g["shapes"], g["dtypes"]))
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda().train()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    x = gu.det_tensor("tswinplus/x256", (4, 4, 3, 256, 256)).cuda()
+    labels = torch.from_numpy(yard["labels_256"]).long().cuda()
+    crit = OhemCELoss2D(256 * 256 // 16)
+    with torch.no_grad():
+        y = m(x)
+    assert rel(y[:, :, ::4, ::4], yard["y_sub_256"]) < 1e-3
+    assert abs(float(crit(y, labels)) - float(yard["loss_256"])) < 1e-3 * float(yard["loss_256"])
+    m.load_state_dict(sd0)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        yb = m(x).float()
+    r_log = rel(yb[:, :, ::4, ::4], yard["y_sub_256"])
+    r_loss = abs(float(crit(yb, labels)) - float(yard["loss_256"])) / float(yard["loss_256"])
+    print(f"bf16 256x256: logits {r_log:.4f} (reference autocast {float(yard['rel_logits_256']):.4f}) loss {r_loss:.2e}")
+    assert r_log < 1.3 * float(yard["rel_logits_256"])
+    assert r_loss < 1e-2
 
 
 @pytest.mark.parametrize("tag", ["thresh_branch", "topk_branch"])

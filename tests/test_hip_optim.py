@@ -50,3 +50,77 @@ def test_ema_update():
     ema_update(k, q, 0.99)
     for x, y in zip(k, ref):
         assert torch.allclose(x, y, atol=1e-7, rtol=1e-6)
+
+
+def test_fused_adam_keeps_a_step_count_per_parameter():
+    """A parameter that gets no gradient on the first step (an unused branch, a parameter unfrozen later) has its own bias
+    correction in torch.optim.Adam."""
+    a = [p.clone().requires_grad_(True) for p in _params(4)[:6]]
+    b = [p.clone().requires_grad_(True) for p in _params(4)[:6]]
+    oa, ob = torch.optim.Adam(a, 1e-2), FusedAdam(b, 1e-2)
+    for step in range(3):
+        for i, (x, y) in enumerate(zip(a, b)):
+            if step == 0 and i % 2:
+                x.grad = y.grad = None
+                continue
+            g = torch.randn_like(x)
+            x.grad, y.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, atol=1e-6, rtol=1e-5)
+
+
+def test_fused_sgd_accepts_a_loaded_state_without_buffers():
+    b = [p.clone().requires_grad_(True) for p in _params(5)[:3]]
+    ob = FusedSGD(b, 0.1, momentum=0.9)
+    for p in b:
+        ob.state[p]["momentum_buffer"] = None        # what torch.optim.SGD.state_dict() holds before the first step
+        p.grad = torch.ones_like(p)
+    before = [p.detach().clone() for p in b]
+    ob.step()
+    for p, q in zip(b, before):
+        assert torch.allclose(p, q - 0.1, atol=1e-6)
+
+
+def test_lars_matches_reference_golden():
+    """contrast/lars.py (add_weight_decay + LARS around SGD momentum, main_pretrain_swinv5.py:37-47) against three steps of the
+    reference itself (tests/golden/lars.npz): the zero-norm branch, a zero gradient (norm from the decay term only), 1-D
+    parameters without trust ratio, momentum-buffer state of the wrapped optimizer."""
+    import golden_util as gu
+    from stswincl_amd.contrast.lars import LARS, add_weight_decay
+    g = gu.load("lars.npz")
+    names = [str(n) for n in g["names"]]
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = torch.nn.Linear(24, 16)
+            self.bn = torch.nn.BatchNorm1d(16)
+            self.conv = torch.nn.Conv2d(4, 8, 3)
+            self.zero = torch.nn.Linear(16, 8, bias=False)
+
+    for inner in ("fused", "torch"):
+        net = Net().cuda()
+        params = dict(net.named_parameters())
+        assert list(params) == names
+        with torch.no_grad():
+            for n in names:
+                params[n].copy_(torch.from_numpy(g[f"p0/{n}"]))
+        groups = add_weight_decay(net, float(g["wd"]))
+        base = (FusedSGD if inner == "fused" else torch.optim.SGD)(groups, lr=float(g["lr"]), momentum=float(g["momentum"]))
+        opt = LARS(base)
+        assert opt.eps == float(g["eps"]) and opt.trust_coef == float(g["trust_coef"])
+        for step in range(3):
+            for n in names:
+                params[n].grad = torch.from_numpy(g[f"g{step}/{n}"]).cuda()
+            v0 = params["fc.weight"]._version
+            opt.step()
+            assert params["fc.weight"]._version > v0              # GEMM weight caches must see the update
+            for n in names:
+                ref = torch.from_numpy(g[f"p{step + 1}/{n}"])
+                assert torch.allclose(params[n].detach().cpu(), ref, rtol=2e-5, atol=1e-7), (inner, step, n)
+        for n in names:
+            assert torch.allclose(opt.state[params[n]]["momentum_buffer"].cpu(), torch.from_numpy(g[f"buf/{n}"]), rtol=2e-5, atol=1e-7)
+        sd = opt.state_dict()
+        assert len(sd["param_groups"]) == 2 and sd["param_groups"][1]["ignore"] is False

@@ -26,12 +26,44 @@ def test_contrastive_checkpoint_remaps_onto_tswinplus(tmp_path):
     assert torch.equal(after["classifier.0.weight"], before["classifier.0.weight"])                 # not in the checkpoint
 
 
-def test_dataparallel_prefix_is_stripped(tmp_path):
+def test_dataparallel_prefix_handling_of_the_three_raw_loaders(tmp_path):
+    """seg18/utils/LoadModel.py: load_model strips 'module.' from module.resnet* only (:55-59), load_model_full from nothing
+    (:96-100), load_model_full_fortest from every module* key (:128-132)."""
+    torch.manual_seed(1)
     m = TswinPlus(12, (8, 8))
-    sd = {"module." + k: v.clone() for k, v in m.state_dict().items()}
+    sd = {"module." + k: (v.clone() + 1.0 if v.is_floating_point() else v.clone()) for k, v in m.state_dict().items()}
     path = tmp_path / "checkpoint.t7"
     torch.save(sd, path)
-    m2 = TswinPlus(12, (8, 8))
-    L.load_model(m2, str(path), log=False)
-    for k, v in m.state_dict().items():
-        assert torch.equal(v, m2.state_dict()[k])
+    probe_r, probe_s = "resnet.layer5.1.conv2.weight", "swin.layers.0.0.attn.qkv.weight"
+    for fn, resnet_loaded, swin_loaded in ((L.load_model, True, False), (L.load_model_full, False, False),
+                                           (L.load_model_full_fortest, True, True)):
+        m2 = TswinPlus(12, (8, 8))
+        before = {k: v.clone() for k, v in m2.state_dict().items()}
+        fn(m2, str(path), log=False)
+        after = m2.state_dict()
+        assert torch.equal(after[probe_r], sd["module." + probe_r] if resnet_loaded else before[probe_r]), fn.__name__
+        assert torch.equal(after[probe_s], sd["module." + probe_s] if swin_loaded else before[probe_s]), fn.__name__
+    plain = tmp_path / "plain.t7"
+    torch.save({k[7:]: v for k, v in sd.items()}, plain)
+    m3 = TswinPlus(12, (8, 8))
+    L.load_model_full(m3, str(plain), log=False)
+    assert torch.equal(m3.state_dict()[probe_s], sd["module." + probe_s])
+
+
+def test_reference_shaped_contrastive_checkpoint_loads_under_weights_only_default(tmp_path):
+    """main_pretrain_swinv5.py:91-102 saves {'opt': argparse.Namespace, 'model', 'optimizer', 'scheduler', 'epoch'}: torch >= 2.6
+    refuses the Namespace with its default weights_only=True."""
+    import argparse
+    src = TswinPlus(12, (8, 8))
+    cl = {"module.pixpro.encoder_1" + k[len("resnet"):]: v.clone() + 2.0 for k, v in src.state_dict().items()
+          if k.startswith("resnet.") and v.is_floating_point()}
+    lin = torch.nn.Linear(2, 2)
+    opt = torch.optim.SGD(lin.parameters(), 0.1, momentum=0.9)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 3)
+    path = tmp_path / "ckpt_epoch_3.pth"
+    torch.save({"opt": argparse.Namespace(batch_size=8, data="endo18", lr=0.5), "model": cl, "optimizer": opt.state_dict(),
+                "scheduler": sched.state_dict(), "epoch": 3}, path)
+    dst = TswinPlus(12, (8, 8))
+    L.load_model_mswin_CL(dst, str(path), log=False)
+    k = "resnet.layer5.1.conv2.weight"
+    assert torch.equal(dst.state_dict()[k], src.state_dict()[k] + 2.0)

@@ -212,3 +212,60 @@ def test_consistency_loss_one_step():
         t = sd[key[len("probe/"):]].detach().double()
         ref = g[key]
         assert abs(float(t.abs().sum()) - float(ref[1])) < 1e-5 * float(ref[1]) + 1e-9, key
+
+
+# ---------------------------------------------------------------- f2 LARS
+def lars_fixture():
+    g = gu.load("lars.npz")
+    names = [str(n) for n in g["names"]]
+    hyper = dict(lr=float(g["lr"]), momentum=float(g["momentum"]), trust_coef=float(g["trust_coef"]), eps=float(g["eps"]))
+    return g, names, hyper, float(g["wd"])
+
+
+def test_lars_three_steps():
+    g, names, hyper, wd = lars_fixture()
+    params = {n: torch.from_numpy(g[f"p0/{n}"]).clone() for n in names}
+    groups = {True: [n for n in names if params[n].dim() != 1], False: [n for n in names if params[n].dim() == 1]}
+    bufs = {n: None for n in names}
+    for step in range(3):
+        for adaptive, ns in groups.items():
+            bl = [bufs[n] for n in ns]
+            O.lars_sgd_step([params[n] for n in ns], [torch.from_numpy(g[f"g{step}/{n}"]) for n in ns], bl,
+                            weight_decay=wd if adaptive else 0.0, adaptive=adaptive, **hyper)
+            bufs.update(zip(ns, bl))
+        for n in names:
+            assert rel(params[n], g[f"p{step + 1}/{n}"]) < 1e-6 or float(np.abs(g[f"p{step + 1}/{n}"]).max()) == 0, (step, n)
+    for n in names:
+        assert torch.allclose(bufs[n], torch.from_numpy(g[f"buf/{n}"]), rtol=1e-5, atol=1e-7), n
+    assert float(np.abs(g["p3/zero.weight"]).max()) > 0          # param_norm == 0 took the un-scaled branch and moved
+
+
+# ---------------------------------------------------------------- N1 bank mode
+def _tok(t):
+    n, c, h, w = t.shape
+    return t.permute(0, 2, 3, 1).reshape(n * h * w, c)
+
+
+def test_bank_loss_with_own_key_maps_is_the_reference_regression_loss():
+    """World size 1, bank = the sample's own five key maps: the bank formulation must give the reference's golden value and
+    gradient (regression_loss.npz, generated by the reference itself)."""
+    g = gu.load("regression_loss.npz")
+    n, c, h, w = [int(v) for v in g["shape"]]
+    feats = [torch.nn.functional.normalize(gu.det_tensor(f"regression/f{i}", (n, c, h, w)), dim=1) for i in range(6)]
+    labs = [torch.from_numpy(g[f"l{i}"]).reshape(n * h * w).long() for i in range(6)]
+    q = _tok(feats[0]).clone().requires_grad_(True)
+    bank = torch.stack([_tok(f) for f in feats[1:]], 0)
+    loss = O.bank_contrast_loss(q, labs[0], bank, torch.stack(labs[1:], 0), [[0, 1, 2, 3, 4]], h * w, h * w)
+    assert rel(loss, g["loss"]) < 1e-6
+    loss.backward()
+    dq = q.grad.view(n, h, w, c).permute(0, 3, 1, 2)
+    assert rel(dq, g["dq"]) < 1e-5
+    # both directions at once = the sum of the two calls of ConsistencyLoss.forward (PixPro_swin_v5.py:594-595)
+    six = torch.stack([_tok(f) for f in feats], 0)
+    six_l = torch.stack(labs, 0)
+    q2 = torch.cat([_tok(feats[0]), _tok(feats[1])], 0)
+    both = O.bank_contrast_loss(q2, torch.cat([labs[0], labs[1]]), six, six_l, [[1, 2, 3, 4, 5], [0, 2, 3, 4, 5]], h * w, h * w)
+    a = O.regression_loss(feats[0], feats[1], *feats[2:], *[l.view(n, 1, h, w).float() for l in labs], 12)
+    b = O.regression_loss(feats[1], feats[0], *feats[2:], labs[1].view(n, 1, h, w).float(), labs[0].view(n, 1, h, w).float(),
+                          *[l.view(n, 1, h, w).float() for l in labs[2:]], 12)
+    assert rel(both, a + b) < 1e-6

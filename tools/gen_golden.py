@@ -425,6 +425,77 @@ def gen_consistency(pix):
          **sd_meta(sd))
 
 
+class _LarsNet(nn.Module):
+    """Small parameter set for the LARS fixture: 2-D / 4-D weights (decay group: trust ratio), 1-D biases and norm scales
+    (no-decay group: plain SGD), and one all-zero weight (param_norm == 0 -> adaptive lr 1, lars.py:138-139)."""
+
+    def __init__(self):
+        super().__init__()
+        self.fc = nn.Linear(24, 16)
+        self.bn = nn.BatchNorm1d(16)
+        self.conv = nn.Conv2d(4, 8, 3)
+        self.zero = nn.Linear(16, 8, bias=False)
+
+
+def gen_lars():
+    """pixcontrast_18/contrast/lars.py as main_pretrain_swinv5.py:37-47 uses it: add_weight_decay groups + SGD momentum
+    wrapped in LARS; three steps with fixed gradients."""
+    lars = importlib.import_module("contrast.lars")
+    net = _LarsNet()
+    sd = gu.det_fill(net.state_dict())
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        net.zero.weight.zero_()
+    wd, lr, mom = 1e-2, 0.3, 0.9
+    opt = lars.LARS(torch.optim.SGD(lars.add_weight_decay(net, wd), lr=lr, momentum=mom))
+    names = [n for n, _ in net.named_parameters()]
+    out = {"names": np.array(names), "wd": np.array(wd), "lr": np.array(lr), "momentum": np.array(mom),
+           "eps": np.array(opt.eps), "trust_coef": np.array(opt.trust_coef)}
+    for n, p in net.named_parameters():
+        out[f"p0/{n}"] = p.detach().clone()
+    for step in range(3):
+        for n, p in net.named_parameters():
+            g = gu.det_tensor(f"lars/g{step}/{n}", tuple(p.shape), scale=0.05 * (step + 1))
+            if n == "conv.weight" and step == 1:
+                g = torch.zeros_like(g)            # grad_norm > 0 only through the weight decay term
+            out[f"g{step}/{n}"] = g
+            p.grad = g.clone()
+        opt.step()
+        for n, p in net.named_parameters():
+            out[f"p{step + 1}/{n}"] = p.detach().clone()
+    for n, p in net.named_parameters():
+        out[f"buf/{n}"] = opt.state[p]["momentum_buffer"].clone()
+    save("lars.npz", **out)
+
+
+def gen_bf16_yardstick(swin, base, losses):
+    """What bf16 autocast costs on the REFERENCE graph itself (CPU autocast, the same untrained fixture weights): the
+    yardstick the HIP bf16 path is held to (tests/test_hip_model.py).  Also stores fp32 reference logits at 256x256 / B = 4,
+    a size at which the decode head's BatchNorm maps are 32x32 rather than 16x16."""
+    res = {}
+    for tag, hh, bsz in (("128", 128, 2), ("256", 256, 4)):
+        torch.manual_seed(8)
+        x = gu.det_tensor("tswinplus/x" if tag == "128" else "tswinplus/x256", (bsz, 4, 3, hh, hh))
+        labels = torch.randint(0, 12, (bsz, hh, hh))
+        crit = losses.OhemCELoss2D(hh * hh // 16)
+        outs = {}
+        for mode in ("fp32", "bf16"):
+            net = _make_tswin(base, swin, 12, (hh // 8, hh // 8))
+            gu.det_fill(net.state_dict())
+            net.train()
+            with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16, enabled=(mode == "bf16")):
+                y = net(x).float()
+                outs[mode] = (y, float(crit(y, labels)))
+        (yf, lf), (yb, lb) = outs["fp32"], outs["bf16"]
+        res[f"rel_logits_{tag}"] = np.array(float((yb.double() - yf.double()).norm() / yf.double().norm()))
+        res[f"rel_loss_{tag}"] = np.array(abs(lb - lf) / abs(lf))
+        res[f"loss_{tag}"] = np.array(lf)
+        res[f"labels_{tag}"] = labels.to(torch.int8)
+        res[f"y_sub_{tag}"] = yf[:, :, ::4, ::4]
+        print(f"  bf16 autocast yardstick {tag}: logits rel-L2 {float(res[f'rel_logits_{tag}']):.4f} loss rel {float(res[f'rel_loss_{tag}']):.4f}")
+    save("bf16_yardstick.npz", **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -455,8 +526,12 @@ def main():
         gen_ohem(losses)
     if want("tswinplus"):
         gen_tswinplus(swin, base, losses)
-    if want("regression_loss") or want("consistency"):
+    if want("bf16_yardstick"):
+        gen_bf16_yardstick(swin, base, losses)
+    if want("regression_loss") or want("consistency") or want("lars") or want("regression_bank"):
         pix = import_contrast()
+        if want("lars"):
+            gen_lars()
         if want("regression_loss"):
             gen_regression(pix)
         if want("consistency"):
