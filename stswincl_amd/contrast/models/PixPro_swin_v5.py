@@ -104,18 +104,32 @@ class ContrastBankFn(torch.autograd.Function):
         return dq.to(in_dtype), None, None, None, None, None
 
 
+_COUNT_INDEX: dict = {}
+
+
+def _count_index(M, q_sets, q_block, nb, gmap, device):
+    """(map index [M][groups], bank block [M][1]) of every query row; cached per geometry (built on the host once: an
+    H2D copy per step would also be illegal inside a hipGraph capture)."""
+    key = (M, q_sets, q_block, nb, tuple(map(tuple, gmap)), str(device))
+    hit = _COUNT_INDEX.get(key)
+    if hit is None:
+        rows = torch.arange(M)
+        per_set = M // q_sets
+        blk = ((rows % per_set) // q_block) if nb > 1 else torch.zeros_like(rows)
+        gm = torch.tensor(gmap)[rows // per_set]
+        hit = (gm.to(device), blk[:, None].to(device))
+        _COUNT_INDEX[key] = hit
+    return hit
+
+
 def _label_counts(lq, lb, gmap, q_sets, q_block, bank_block, class_num):
     """cnt[m][g] = number of visible bank rows of group g whose label equals lq[m] (the |posMask| row sums of
     PixPro_swin_v5.py:116-118), from per-block label histograms: O(rows) integer work instead of HW x HW masks."""
     maps, seg = lb.shape
     nb = seg // bank_block
     hist = F.one_hot(lb.long().clamp(0, class_num - 1), class_num).view(maps, nb, bank_block, class_num).sum(2)   # [maps][nb][cls]
-    M = lq.shape[0]
-    rows = torch.arange(M, device=lq.device)
-    per_set = M // q_sets
-    blk = ((rows % per_set) // q_block) if nb > 1 else torch.zeros_like(rows)
-    gm = torch.tensor(gmap, device=lq.device)[rows // per_set]                          # [M][groups] map index
-    return hist[gm, blk[:, None], lq.long().clamp(0, class_num - 1)[:, None]].float()   # [M][groups]
+    gm, blk = _count_index(lq.shape[0], q_sets, q_block, nb, gmap, lq.device)
+    return hist[gm, blk, lq.long().clamp(0, class_num - 1)[:, None]].float()             # [M][groups]
 
 
 def bank_contrast_loss(q_tok, lq, bank, lb, gmap, q_block, bank_block, class_num, inv_tau=1.0, want_lse=False):

@@ -142,6 +142,7 @@ _PROFILE = None
 _PROFILE_STRIDE = 1
 _PROFILE_COUNT = {}
 _PROFILE_RNG = None
+_PROFILE_ALWAYS = ("contrast_",)      # kernels launched once per step: every launch is timed
 
 
 def profile_begin(stride: int = 1):
@@ -176,7 +177,7 @@ class _Span:
         if _PROFILE is not None:
             n = _PROFILE_COUNT.get(self.name, 0)
             _PROFILE_COUNT[self.name] = n + 1
-            if _PROFILE_STRIDE == 1 or _PROFILE_RNG.random() * _PROFILE_STRIDE < 1.0:
+            if _PROFILE_STRIDE == 1 or self.name.startswith(_PROFILE_ALWAYS) or _PROFILE_RNG.random() * _PROFILE_STRIDE < 1.0:
                 self.a = torch.cuda.Event(enable_timing=True)
                 self.a.record()
         return self

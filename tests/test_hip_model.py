@@ -63,6 +63,31 @@ def test_tswinplus_bf16_autocast():
     loss.backward()
 
 
+def test_tswinplus_bf16_weight_gradients_vs_reference_autocast_yardstick():
+    """Weight gradients of the bf16 path against the fp32 path on the golden fixture (128x128, B = 2), each held to 1.3 x what
+    the reference's own bf16-autocast backward loses on the same fixture (bf16_yardstick.npz: 0.14 classifier ... 0.79 stem)."""
+    yard = gu.load("bf16_yardstick.npz")
+    names = [k[len("rel_grad/"):] for k in yard.files if k.startswith("rel_grad/")]
+    g, m = _model()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    x = gu.det_tensor("tswinplus/x", (2, 4, 3, 128, 128)).cuda()
+    labels = torch.from_numpy(yard["labels_128"]).long().cuda()
+    grads = {}
+    for mode in ("fp32", "bf16"):
+        m.load_state_dict(sd0)
+        m.zero_grad(set_to_none=True)
+        m.train()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(mode == "bf16")):
+            loss = OhemCELoss2D(128 * 128 // 16)(m(x), labels)
+        loss.backward()
+        params = dict(m.named_parameters())
+        grads[mode] = {n: params[n].grad.detach().double().cpu() for n in names}
+    for n in names:
+        r = float((grads["bf16"][n] - grads["fp32"][n]).norm() / grads["fp32"][n].norm())
+        print(f"grad {n}: bf16 vs fp32 {r:.4f} (reference autocast {float(yard['rel_grad/' + n]):.4f})")
+        assert r < 1.3 * float(yard["rel_grad/" + n]), (n, r)
+
+
 def test_tswinplus_256_fp32_gate_and_bf16_vs_reference_autocast_yardstick():
     """256x256, B = 4 (decode-head BatchNorm on 32x32 maps): the fp32 path against the reference's fp32 logits (1e-3 gate of
     BASELINE.json north_star) and the bf16 path against what the reference's own bf16 autocast run loses (9.6 %)."""

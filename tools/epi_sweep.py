@@ -23,8 +23,9 @@ def timeit(fn, iters=20):
 
 def main():
     dt, dev = torch.bfloat16, "cuda"
-    shapes = [(65536, 2048, 512, "fc1 s1"), (16384, 4096, 1024, "fc1 s2"), (65536, 512, 2048, "fc2 s1"), (65536, 512, 512, "proj s1")]
-    variants = (("auto", 0), ("8w", hip.GF_NOBIG), ("stream", hip.GF_BIG | hip.GF_STREAM), ("duo", hip.GF_BIG | hip.GF_DUO), ("ring", hip.GF_BIG | hip.GF_NOSTREAM), ("ring-lds", hip.GF_BIG | hip.GF_NOREGEPI))
+    shapes = [(65536, 2048, 512, "fc1 s1"), (16384, 4096, 1024, "fc1 s2"), (65536, 512, 2048, "fc2 s1"), (65536, 512, 512, "proj s1"),
+              (65536, 1536, 512, "qkv s1")]
+    variants = (("auto", 0), ("8w", hip.GF_NOBIG), ("stream", hip.GF_BIG | hip.GF_STREAM), ("duo", hip.GF_BIG | hip.GF_DUO), ("ring", hip.GF_BIG | hip.GF_NOSTREAM), ("mid", hip.GF_MID))
     print(f"{'shape':10s} {'epilogue':10s} " + " ".join(f"{n:>8s}" for n, _ in variants) + "   (us)")
     for M, N, K, note in shapes:
         A = torch.randn(M, K, device=dev).to(dt)
@@ -34,9 +35,9 @@ def main():
         R = torch.randn(M, N, device=dev).to(dt)
         bias = torch.randn(N, device=dev)
         cs = torch.zeros(N, device=dev)
-        cases = [("plain", dict()), ("gelu+pre", dict(bias=bias, out2=out2, flags=hip.GF_GELU)),
+        cases = [("plain", dict()), ("bias", dict(bias=bias)), ("gelu+dgelu", dict(bias=bias, out2=out2, flags=hip.GF_GELU | hip.GF_C2_DGELU)),
                  ("resid", dict(bias=bias, resid=R, flags=hip.GF_RESID)),
-                 ("dgelu+cs", dict(resid=R, flags=hip.GF_MUL_DGELU, colsum_out=cs))]
+                 ("mul_r+cs", dict(resid=R, flags=hip.GF_MUL_R, colsum_out=cs))]
         for cname, kw in cases:
             cells = []
             for vname, vf in variants:

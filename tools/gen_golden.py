@@ -468,6 +468,11 @@ def gen_lars():
     save("lars.npz", **out)
 
 
+YARD_GRADS = ["swin.layers.0.0.attn.qkv.weight", "swin.layers.1.1.mlp.fc1.weight", "swin.layers.5.1.mlp.fc2.weight",
+              "swin.downsample.reduction.weight", "resnet.layer5.1.conv2.weight", "aspp.conv_3x3_2.weight",
+              "classifier.0.weight", "swin.layers.3.1.attn.relative_position_bias_table", "resnet.resnet.0.weight"]
+
+
 def gen_bf16_yardstick(swin, base, losses):
     """What bf16 autocast costs on the REFERENCE graph itself (CPU autocast, the same untrained fixture weights): the
     yardstick the HIP bf16 path is held to (tests/test_hip_model.py).  Also stores fp32 reference logits at 256x256 / B = 4,
@@ -479,13 +484,23 @@ def gen_bf16_yardstick(swin, base, losses):
         labels = torch.randint(0, 12, (bsz, hh, hh))
         crit = losses.OhemCELoss2D(hh * hh // 16)
         outs = {}
+        grads = {}
         for mode in ("fp32", "bf16"):
             net = _make_tswin(base, swin, 12, (hh // 8, hh // 8))
             gu.det_fill(net.state_dict())
             net.train()
-            with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16, enabled=(mode == "bf16")):
+            with torch.set_grad_enabled(tag == "128"), torch.autocast("cpu", dtype=torch.bfloat16, enabled=(mode == "bf16")):
                 y = net(x).float()
-                outs[mode] = (y, float(crit(y, labels)))
+                loss = crit(y, labels)
+                outs[mode] = (y.detach(), float(loss))
+            if tag == "128":            # gradient yardstick: what the reference's own bf16 autocast backward loses
+                loss.backward()
+                params = dict(net.named_parameters())
+                grads[mode] = {n: params[n].grad.detach().double() for n in YARD_GRADS}
+        if tag == "128":
+            for n in YARD_GRADS:
+                res["rel_grad/" + n] = np.array(float((grads["bf16"][n] - grads["fp32"][n]).norm() / grads["fp32"][n].norm()))
+                print(f"    grad {n}: {float(res['rel_grad/' + n]):.4f}")
         (yf, lf), (yb, lb) = outs["fp32"], outs["bf16"]
         res[f"rel_logits_{tag}"] = np.array(float((yb.double() - yf.double()).norm() / yf.double().norm()))
         res[f"rel_loss_{tag}"] = np.array(abs(lb - lf) / abs(lf))
