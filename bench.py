@@ -389,9 +389,12 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             hip.arena_reset()
-            sec = contrast_run(a, ctx, a.secondary_steps, 2, 0)
-            res["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype")}
-            res["secondary"]["config"] = sec["config"]
+            try:                       # the primary line must survive whatever happens in the second workload
+                sec = contrast_run(a, ctx, a.secondary_steps, 2, 0)
+                res["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype")}
+                res["secondary"]["config"] = sec["config"]
+            except Exception as e:     # noqa: BLE001
+                res["secondary"] = {"error": f"{type(e).__name__}: {e}"[:400]}
         if ctx.world == 1 and not a.no_cpu_baseline and ctx.rank == 0:
             res["cpu_baseline"] = cpu_baseline(a.cpu_size)
     if ctx.rank == 0:

@@ -218,14 +218,9 @@ LCAT = H.Layout.concat([H.Layout.dense(48)] * 3 + [H.Layout.dense(256)])
 
 
 def _batched_views_ok(model) -> bool:
-    """View batching needs the interleaved-group BatchNorm kernels: local statistics only (SyncBatchNorm across ranks keeps
-    the sequential passes), train mode, and not switched off (STSWIN_SEQUENTIAL_VIEWS=1: A/B runs)."""
-    if os.environ.get("STSWIN_SEQUENTIAL_VIEWS") == "1" or not model.training:
-        return False
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return not any(isinstance(m, nn.SyncBatchNorm) for m in model.modules())
-    return True
+    """View batching (interleaved-group BatchNorm kernels; SyncBatchNorm gathers the per-view statistics over the ranks in the same
+    one collective per layer): train mode, and not switched off (STSWIN_SEQUENTIAL_VIEWS=1: A/B runs)."""
+    return os.environ.get("STSWIN_SEQUENTIAL_VIEWS") != "1" and model.training
 
 
 class PixPro(nn.Module):

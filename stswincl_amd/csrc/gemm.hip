@@ -1678,21 +1678,50 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
       }
 }
 
-// C[i][j] += sum_s slabs[s][i][j]   (the split-K combine: plain stores + this pass cost ~half of 32 MB of fp32 atomics)
+// C[i][j] += sum_s slabs[s][i][j]   (the split-K combine: plain stores + this pass cost ~half of 32 MB of fp32 atomics).
+// bf16 partials: 8 outputs per thread (16-byte loads) and eight splits requested before the first is consumed - the pass is a
+// pure HBM stream (splits x Ni x Nj x 2 bytes in, 4 bytes per output out); with 8-byte loads issued one split at a time it
+// ran at 2.5 TB/s (14.5 us for the 16-split 512 x 2048 weight gradients, 1.4 ms per training step over its 80 launches).
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, float* C, long ldc, int Ni, int Nj, int splits,
                                                         int overwrite, int slab_bf16) {
+  if (slab_bf16) {
+    const long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    const long total = (long)Ni * Nj;
+    if (idx >= total) return;
+    const int i = idx / Nj, j = idx % Nj;         // Nj % 8 == 0 (checked by the launcher)
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16* src = (const bf16*)slabs + idx;
+    int s = 0;
+    for (; s + 8 <= splits; s += 8) {
+      bf16x8 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load((const bf16x8*)(src + (long)(s + u) * total));
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += (float)v[u][e];
+    }
+    for (; s < splits; ++s) {
+      const bf16x8 v = __builtin_nontemporal_load((const bf16x8*)(src + (long)s * total));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+    }
+    float* dst = C + (long)i * ldc + j;
+    if ((ldc & 3) == 0) {
+      f32x4 lo = {a[0], a[1], a[2], a[3]}, hi = {a[4], a[5], a[6], a[7]};
+      if (!overwrite) { lo += *(const f32x4*)dst; hi += *(const f32x4*)(dst + 4); }
+      *(f32x4*)dst = lo;
+      *(f32x4*)(dst + 4) = hi;
+    } else {
+      for (int e = 0; e < 8; ++e) dst[e] = overwrite ? a[e] : dst[e] + a[e];
+    }
+    return;
+  }
   const long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (idx >= (long)Ni * Nj) return;
   const int i = idx / Nj, j = idx % Nj;           // Nj % 4 == 0
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
-  if (slab_bf16) {
-    for (int s = 0; s < splits; ++s) {
-      const bf16x4 v = *(const bf16x4*)((const bf16*)slabs + (long)s * Ni * Nj + idx);
-      a += (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-    }
-  } else {
-    for (int s = 0; s < splits; ++s) a += *(const f32x4*)(slabs + (long)s * Ni * Nj + idx);
-  }
+  for (int s = 0; s < splits; ++s) a += *(const f32x4*)(slabs + (long)s * Ni * Nj + idx);
   float* dst = C + (long)i * ldc + j;
   if (overwrite) {
     if ((ldc & 3) == 0) *(f32x4*)dst = a;
@@ -1934,7 +1963,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
       else if (bt_rows) hipLaunchKernelGGL(gemm_tn_ring_kernel<2>, grid, dim3(512), 131072, (hipStream_t)stream, q);
       else hipLaunchKernelGGL(gemm_tn_ring_kernel<0>, grid, dim3(512), 131072, (hipStream_t)stream, q);
       if (slabs) {
-        const long n4 = ((long)Ni * Nj + 3) / 4;
+        const long n4 = slab_bf16 ? ((long)Ni * Nj + 7) / 8 : ((long)Ni * Nj + 3) / 4;
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, C, ldc,
                            Ni, Nj, rs, overwrite, slab_bf16);
       }
@@ -1976,7 +2005,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
     else hipLaunchKernelGGL((gemm_tn_kernel<float, 4>), grid, dim3(256), 65536, (hipStream_t)stream, p);
   }
   if (use_slabs) {
-    const long n4 = ((long)Ni * Nj + 3) / 4;
+    const long n4 = slab_bf16 ? ((long)Ni * Nj + 7) / 8 : ((long)Ni * Nj + 3) / 4;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, C, ldc,
                        Ni, Nj, splits, overwrite, slab_bf16);
   }

@@ -282,24 +282,23 @@ class BNTokFn(torch.autograd.Function):
         gp, bp = lay.pad_vec(gamma), lay.pad_vec(beta)
         rows_total = 0
         if training and world > 1:
-            # nn.SyncBatchNorm (PixPro_swin_v5.py:215-228): batch statistics over ALL ranks.  One all-gather of
-            # (mean, M2, count) per BN instead of the reference's per-tensor collectives.
+            # nn.SyncBatchNorm (PixPro_swin_v5.py:215-228): batch statistics over ALL ranks.  ONE all-gather of the per-group
+            # (mean, M2) of every statistic group of this BatchNorm (per-view and per-frame groups of a batched pass included:
+            # interleaved groups work like local BatchNorm, so view batching and the clip-major layout stay on under SyncBN)
+            # instead of the reference's per-tensor collectives; no host synchronisation: every rank holds the same number of
+            # rows per group (DistributedSampler pads the shards to equal length, contrast/data/__init__.py:21-25).
             import torch.distributed as dist
             n_loc = M // groups
-            assert unit == 0, "SyncBatchNorm: contiguous statistic groups only"
-            s, ss = hip.colstats(X, groups=groups)
-            pivot = X.view(groups, n_loc, Cp)[:, 0, :].float()
+            s, ss = hip.colstats(X, groups=groups, unit=unit)
+            pivot = (X.view(-1, unit, Cp)[:groups, 0, :] if unit > 0 else X.view(groups, n_loc, Cp)[:, 0, :]).float()
             mean_l = pivot + s / n_loc
             m2_l = ss - s * s / n_loc
-            pack = torch.cat([mean_l.reshape(-1), m2_l.reshape(-1), mean_l.new_tensor([float(n_loc)])])
-            allp = [torch.empty_like(pack) for _ in range(world)]
-            dist.all_gather(allp, pack)
-            allp = torch.stack(allp)
-            gc = groups * Cp
-            mean, var, n_tot = combine_bn_stats(allp[:, :gc].view(world, groups, Cp), allp[:, gc:2 * gc].view(world, groups, Cp),
-                                                allp[:, -1])
+            pack = torch.stack([mean_l, m2_l])                                  # [2][groups][C]
+            allp = torch.empty(world, *pack.shape, dtype=pack.dtype, device=pack.device)
+            dist.all_gather_into_tensor(allp, pack)
+            rows_total = world * n_loc
+            mean, var, _ = combine_bn_stats(allp[:, 0], allp[:, 1], torch.full((world,), float(n_loc), device=pack.device))
             rstd = torch.rsqrt(var + eps)
-            rows_total = int(n_tot.item())
             rm, rv = lay.pad_vec(running_mean), lay.pad_vec(running_var, 1.0)
             for g in range(groups):
                 rm = (1 - momentum) * rm + momentum * mean[g]
@@ -338,12 +337,13 @@ class BNTokFn(torch.autograd.Function):
         dres = torch.empty_like(X) if has_res else None
         if training and world > 1:
             import torch.distributed as dist
-            s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, phase=1, beta=bp)
+            s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, phase=1, beta=bp,
+                                unit=ctx.unit)
             loc1, loc2 = s1.clone(), s2.clone()                 # weight/bias grads stay local sums (DDP averages them)
             both = torch.stack([s1, s2])
             dist.all_reduce(both)
             hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, phase=2,
-                       sums=(both[0].contiguous(), both[1].contiguous()), rows_total=rows_total, beta=bp)
+                       sums=(both[0].contiguous(), both[1].contiguous()), rows_total=rows_total, beta=bp, unit=ctx.unit)
             s1, s2 = loc1, loc2
         else:
             s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, beta=bp, unit=ctx.unit)

@@ -122,8 +122,8 @@ class ResNet_BasicBlock_OS8(nn.Module):
         # clip-major as stored; statistic group = frame index t, i.e. the frames t, t + T, t + 2T, ... of the flattened batch
         # (interleaved groups of the BatchNorm kernels): no frame-major copy of the input, none of the tokens, none of their
         # gradients
-        # SyncBatchNorm across ranks combines per-group statistics of CONTIGUOUS groups only: frame-major copy as before
-        if _FRAME_MAJOR or (self.training and H._sync_world(self.resnet[1]) > 1):   # (_FRAME_MAJOR: A/B switch)
+        # (SyncBatchNorm across ranks gathers the per-group statistics of interleaved groups just the same)
+        if _FRAME_MAJOR:                                                            # (A/B switch)
             tok, h, w = self.forward_tokens(x.transpose(0, 1).reshape(t * b, *x.shape[2:]), groups=t)
             return tok.view(t, b, h * w, tok.shape[1]).transpose(0, 1).contiguous(), h, w
         tok, h, w = self.forward_tokens(x.reshape(b * t, *x.shape[2:]), groups=t, il=True)
