@@ -13,6 +13,7 @@
 // row-wise (ds_read_b128) or transposed (ds_read_b64_tr_b16).
 // f32 : fragments are single elements, so K/V/Q/dO are read from global directly; only P/dS use LDS.
 #include "common.h"
+#include <cstdlib>
 
 struct AttnArgs {
   const void* qkv; long ld;       // [rows][3C]: q (pre-scaled) | k | v, window-ordered rows
@@ -592,6 +593,331 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   }
 }
 
+// ====================================================================================================
+// Backward for the stage-1 shape (bf16, 128 tokens, head dim 128) with EIGHT waves per workgroup.
+// The 160 KB of LDS a problem needs (K, V/Q, dO tiles + P + dS) allow one workgroup per CU, and with four waves (one per
+// SIMD) every phase of the kernel above exposes its full latency: 2.2 us of MFMA work took 15 us per problem
+// (profiles/r01_v9_attn_bwd_timeline.txt), 3.2 TB/s = 40 % of the HBM rate.  Here two waves share every query tile:
+//   scores / softmax / dP / dS : wave (qt, hw) owns the keys 64 hw .. 64 hw + 63 of query tile qt; the softmax statistics
+//     (max, sum) and the row sums of P o dP are exchanged with the partner wave through 3 KB of LDS
+//     (online-softmax merge: one exchange for max + sum);
+//   dV / dK / dQ : waves 0-3 multiply dV (4 key tiles) and the first half of dQ's columns, waves 4-7 the second half of dQ
+//     and dK - 1.5 tile products per wave instead of 3;
+//   every LDS-DMA tile copy is issued by all eight waves.
+// Same persistent schedule, buffer rotation (K | V -> Q | dO -> next K) and register-accumulated bias / q-bias gradients.
+// Two waves per SIMD leave 256 registers per lane: LDS addresses are lane constants + instruction immediates (16 registers
+// instead of one per unrolled read), the 64 two-byte row stores of a product and the bias-table reads are buffer
+// instructions with ONE per-lane offset and scalar row offsets.
+DEVI void buf_store_b16(void* base, bf16 v, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)0xFFFFFFFE, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, v), rs, voff, soff, 0);
+}
+DEVI float buf_load_f32(const void* base, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)0xFFFFFFFE, 0x00020000);
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+DEVI bf16x8 lds_tr_pair(const char* tile, int off0, int off1, int imm) {
+  const short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(tile + off0 + imm));
+  const short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(tile + off1 + imm));
+  return cat4(__builtin_bit_cast(bf16x4, t0), __builtin_bit_cast(bf16x4, t1));
+}
+
+template <int NC>
+__global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
+  using T = bf16;
+  constexpr int NTOK = 128, HD = 128, ROWB = 256;          // K / V / Q / dO tiles and the P / dS tiles all have 256-byte rows
+  using Cfg = AttnCfg<T, NTOK, HD>;
+  constexpr int KV = Cfg::KV_BYTES;
+  static_assert(Cfg::RB == ROWB && Cfg::PRB == ROWB, "tile geometry");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int l = threadIdx.x & 63, lr = l & 31, half = l >> 5, w = wave_id();
+  const int qt = w & 3, hw = w >> 2;
+  const long ngroups = (long)a.nB_ * a.heads;
+  const int head = (int)(blockIdx.x % a.heads);
+  f32x16 dbacc[2];
+  float csacc[2] = {0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dbacc[kk][r] = 0.f;
+  int kbuf = 0, xbuf = 2;
+  char* Pt = smem + 3 * KV;
+  char* St = Pt + Cfg::P_BYTES;
+  float2* ex1 = (float2*)St;                       // [2 key halves][128 queries]: (max, sum of exp) of the wave's 64 keys
+  float* ex2 = (float*)(St + 2048);                // [2][128]: sum over the wave's keys of P o dP
+  const int N = NC ? NC : a.N;
+  const int q0 = qt * 32, qn = (q0 + lr) % N;
+  // ---- lane constants of the LDS images (tile_off<256>: byte = row * 256 + ((chunk ^ swz256(row)) & 15) * 16)
+  // row fragments of rows X + lr (X a multiple of 32: swz256 sees lr only): rowc[ks] + X * 256 = offset of k-step ks
+  int rowc[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) rowc[ks] = lr * ROWB + ((((2 * ks + half) ^ swz256(lr)) & 15) << 4);
+  // transposed fragments (frag_tr): rows 16 ks + 8 (l >> 5) + 4 e + q, columns 32 ct + 16 ((l >> 4) & 1) + 4 p
+  int troff[4][2];
+  {
+    const int q = (l & 15) >> 2, pp = l & 3;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int row = 8 * half + 4 * e + q;
+        const int chunk = 4 * ct + 2 * ((l >> 4) & 1) + (pp >> 1);
+        troff[ct][e] = row * ROWB + (((chunk ^ swz256(row)) & 15) << 4) + (pp & 1) * 8;
+      }
+  }
+  auto ld_row = [&](const char* tile, int X, int ks) -> bf16x8 { return *(const bf16x8*)(tile + X * ROWB + rowc[ks]); };
+  auto ld_tr = [&](const char* tile, int ks, int ct) -> bf16x8 { return lds_tr_pair(tile, troff[ct][0], troff[ct][1], ks * 16 * ROWB); };
+  {
+    const long rb0 = (long)(blockIdx.x / a.heads) * NTOK;
+    const T* q0b = (const T*)a.qkv + rb0 * a.ld + head * HD;
+    stage_tile<NTOK, ROWB>(smem, (const char*)(q0b + a.C), a.ld * sizeof(T), w, 8);
+    stage_tile<NTOK, ROWB>(smem + KV, (const char*)(q0b + 2 * a.C), a.ld * sizeof(T), w, 8);
+  }
+  const int out_voff = (4 * half * (int)a.ldo + lr) * 2;                 // per-lane part of every dqkv store address
+  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int b_ = (int)(grp / a.heads);
+    const long rowbase = (long)b_ * NTOK;
+    const T* qbase = (const T*)a.qkv + rowbase * a.ld + head * HD;
+    const T* dobase = (const T*)a.dout + rowbase * a.lddo + head * HD;
+    char* Kt = smem + kbuf * KV;
+    char* Vt = smem + KV;                          // V, later Q
+    char* Xt = smem + xbuf * KV;                   // dO, later the next problem's K
+    bf16x8 qf[HD / 16];
+    load_row_frags<T, HD>(qf, qbase, a.ld, q0 + lr);
+    wait_vm0();
+    __syncthreads();                               // K, V (requested during the previous problem) have landed
+    stage_tile<NTOK, ROWB>(Xt, (const char*)dobase, a.lddo * sizeof(T), w, 8);
+    // ---- bias (+ mask) values of this wave's 2 x 16 (key, query) entries per lane: requested first
+    const int widx = b_ % a.nW;
+    const int slot = (a.bias_windows & 0xffffff) > 1 ? (a.bias_index ? a.bias_index[widx] : widx) : 0;
+    float tb[2][16];
+    if constexpr (NC == 64) {                      // key n = (kt & 1) * 32 + crow32(r, half): no wrap inside a 32-key tile
+      const int tvoff = (4 * half * NC + qn) * 4;
+      const int tsoff = (slot * a.heads + head) * NC * NC * 4;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tb[kk][r] = buf_load_f32(a.biasT, tvoff, tsoff + (kk * 32 + crow32(r, 0)) * NC * 4);
+    } else {
+      const float* bt = a.biasT + ((long)slot * a.heads + head) * N * N + qn;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tb[kk][r] = bt[(((2 * hw + kk) * 32 + crow32(r, half)) % N) * N];
+    }
+    if (a.maskT) {
+      const float* mt = a.maskT + (long)widx * N * N + qn;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tb[kk][r] += mt[(((2 * hw + kk) * 32 + crow32(r, half)) % N) * N];
+    }
+    // ---- S^T for this wave's two key tiles: lane = query column, registers = keys
+    f32x16 p[2], dp[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[kk][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks)
+        p[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Kt, (2 * hw + kk) * 32, ks), qf[ks], p[kk], 0, 0, 0);
+    }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[kk][r] += tb[kk][r];
+        mx = fmaxf(mx, p[kk][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(p[kk][r] - mx);
+        p[kk][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32);
+    if (half == 0) ex1[hw * NTOK + q0 + lr] = make_float2(mx, sum);
+    wait_vm0();                                    // this wave's pieces of the dO tile
+    __syncthreads();                               // partner statistics + dO tile visible
+    {
+      const float2 o = ex1[(hw ^ 1) * NTOK + q0 + lr];
+      const float m = fmaxf(mx, o.x);
+      const float mine = __expf(mx - m);
+      const float inv = mine / (sum * mine + o.y * __expf(o.x - m));
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[kk][r] *= inv;
+    }
+    // ---- dP^T = V dO^T on the same key tiles (the dO row pieces replace Q's in qf)
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) qf[ks] = ld_row(Xt, q0, ks);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[kk][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks)
+        dp[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Vt, (2 * hw + kk) * 32, ks), qf[ks], dp[kk], 0, 0, 0);
+    }
+    float delta = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) delta += p[kk][r] * dp[kk][r];
+    delta += __shfl_xor(delta, 32);
+    if (half == 0) ex2[hw * NTOK + q0 + lr] = delta;
+    __syncthreads();
+    delta += ex2[(hw ^ 1) * NTOK + q0 + lr];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dp[kk][r] = p[kk][r] * (dp[kk][r] - delta);          // dS^T
+        dbacc[kk][r] += dp[kk][r];
+      }
+    __syncthreads();                               // every wave has read the exchange area: P / dS may overwrite it
+    // P and dS tiles [query row][key] (bf16): this wave's 32 query rows x 64 keys
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 vp, vs;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vp[e] = (bf16)p[kk][4 * g + e]; vs[e] = (bf16)dp[kk][4 * g + e]; }
+        const int off = (q0 + lr) * ROWB + (((((2 * hw + kk) * 4 + g) ^ swz256(lr)) & 15) << 4) + half * 8;
+        *(bf16x4*)(Pt + off) = vp;
+        *(bf16x4*)(St + off) = vs;
+      }
+    __syncthreads();                               // P, dS complete; every wave is done with V
+    stage_tile<NTOK, ROWB>(Vt, (const char*)qbase, a.ld * sizeof(T), w, 8);      // V is dead: Q (for dK)
+    // dqkv row rowbase + .., columns head * HD + ..: scalar byte offsets of the three thirds
+    const int so_q = (int)((rowbase * a.ldo + head * HD) * 2), so_k = so_q + a.C * 2, so_v = so_k + a.C * 2;
+    const int k0 = qt * 32;
+    f32x16 acc[4];
+    auto zero4 = [&]() {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    };
+    auto store4 = [&](int sbase, int row0) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          buf_store_b16(a.out, (bf16)acc[dt][r], out_voff, sbase + ((row0 + crow32(r, 0)) * (int)a.ldo + dt * 32) * 2);
+    };
+    // acc[0..3] += A^T(tile at, column tile qt) x B(tile bt) over the 128 contraction rows: dV (P, dO) and dK (dS, Q).
+    // (the operands of step ks + 1 are requested before the MFMAs of step ks; the scheduling barrier keeps hipcc from
+    // hoisting every step's LDS reads to the top)
+    auto tr_product = [&](const char* at, const char* btile) {
+      bf16x8 pa = ld_tr(at, 0, qt), xb[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) xb[dt] = ld_tr(btile, 0, dt);
+#pragma unroll
+      for (int ks = 0; ks < NTOK / 16; ++ks) {
+        bf16x8 pa_n = pa, xb_n[4] = {xb[0], xb[1], xb[2], xb[3]};
+        if (ks + 1 < NTOK / 16) {
+          pa_n = ld_tr(at, ks + 1, qt);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) xb_n[dt] = ld_tr(btile, ks + 1, dt);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, xb[dt], acc[dt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        pa = pa_n;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) xb[dt] = xb_n[dt];
+      }
+    };
+    // dQ[q][d] = scale * sum_key dS[q][key] K[key][d] for the two head-dim tiles 2 hw, 2 hw + 1 (acc[0], acc[1])
+    auto dq_half = [&]() {
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dd][r] = 0.f;
+      bf16x8 sa = ld_row(St, q0, 0), kb[2];
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) kb[dd] = ld_tr(Kt, 0, 2 * hw + dd);
+#pragma unroll
+      for (int ks = 0; ks < NTOK / 16; ++ks) {
+        bf16x8 sa_n = sa, kb_n[2] = {kb[0], kb[1]};
+        if (ks + 1 < NTOK / 16) {
+          sa_n = ld_row(St, q0, ks + 1);
+#pragma unroll
+          for (int dd = 0; dd < 2; ++dd) kb_n[dd] = ld_tr(Kt, ks + 1, 2 * hw + dd);
+        }
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) acc[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa, kb[dd], acc[dd], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        sa = sa_n; kb[0] = kb_n[0]; kb[1] = kb_n[1];
+      }
+    };
+    auto dq_store = [&]() {
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) {
+        float csum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const T o = (bf16)(acc[dd][r] * a.scale);
+          buf_store_b16(a.out, o, out_voff, so_q + ((q0 + crow32(r, 0)) * (int)a.ldo + (2 * hw + dd) * 32) * 2);
+          csum += (float)o;
+        }
+        csacc[dd] += csum;
+      }
+    };
+    if (hw == 0) {                                 // dV[key][d] = sum_q P[q][key] dO[q][d]
+      zero4();
+      tr_product(Pt, Xt);
+    } else {
+      dq_half();
+    }
+    wait_vm0();                                    // Q has landed (waited for BEFORE this phase's stores are issued)
+    __syncthreads();                               // ... and every wave is done with the dO tile
+    if (hw == 0) store4(so_v, k0);
+    else dq_store();
+    if (grp + gridDim.x < ngroups) {               // the next problem's K into the buffer dO just left
+      const T* nq = (const T*)a.qkv + (long)((grp + gridDim.x) / a.heads) * NTOK * a.ld + head * HD;
+      stage_tile<NTOK, ROWB>(Xt, (const char*)(nq + a.C), a.ld * sizeof(T), w, 8);
+    }
+    if (hw == 0) {
+      dq_half();
+      dq_store();
+    } else {                                       // dK[key][d] = sum_q dS[q][key] q_s[q][d]
+      zero4();
+      tr_product(St, Vt);
+      store4(so_k, k0);
+    }
+    __syncthreads();                               // the next problem's tiles overwrite Q / K / dS
+    if (grp + gridDim.x < ngroups) {
+      const T* nq = (const T*)a.qkv + (long)((grp + gridDim.x) / a.heads) * NTOK * a.ld + head * HD;
+      stage_tile<NTOK, ROWB>(smem + KV, (const char*)(nq + 2 * a.C), a.ld * sizeof(T), w, 8);
+    }
+    const int tbuf = kbuf; kbuf = xbuf; xbuf = tbuf;
+  }
+  if (a.dbiasT) {
+    float* db = a.dbiasT + (long)head * N * N + qn;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) atomicAdd(db + (((2 * hw + kk) * 32 + crow32(r, half)) % N) * N, dbacc[kk][r]);
+  }
+  if (a.dqkv_colsum) {
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) {
+      float csum = csacc[dd];
+      csum += __shfl_xor(csum, 32);
+      if (half == 0) atomicAdd(a.dqkv_colsum + head * HD + (2 * hw + dd) * 32 + lr, csum);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 template <typename T, int NTOK, int HD, int NC>
 static int launch_attn(const AttnArgs& a, bool bwd, hipStream_t st) {
@@ -606,6 +932,25 @@ static int launch_attn(const AttnArgs& a, bool bwd, hipStream_t st) {
   static const int attr_bwd = (int)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NTOK, HD, NC>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::BWD_LDS);
   if (attr_fwd != 0 || attr_bwd != 0) return -(attr_fwd ? attr_fwd : attr_bwd);
+  if constexpr (TT<T>::IS_BF16 && NTOK == 128 && HD == 128 && NC == 64) {      // (window size known: table offsets are scalar)
+    const char* e4 = getenv("STSWIN_ATTN_BWD4");                             // A/B switch (read per call): the 4-wave kernel
+    const int no8 = e4 && atoi(e4) ? 1 : 0;
+    const bool fits = (long)a.nB_ * NTOK * a.ldo * 2 < 0x7FFF0000L;          // 32-bit buffer offsets of the dqkv stores
+    if (bwd && !no8 && fits && !(a.bias_windows & (1 << 30))) {
+      static const int attr8 = (int)hipFuncSetAttribute((const void*)attn_bwd8_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        Cfg::BWD_LDS);
+      if (attr8 != 0) return -attr8;
+      int g = 256;
+      if (g > grid) g = grid;
+      g = (g / a.heads) * a.heads;
+      if (g < a.heads) g = a.heads;
+      if (grid % a.heads == 0 && g >= a.heads) {
+        hipLaunchKernelGGL((attn_bwd8_kernel<NC>), dim3(g), dim3(512), Cfg::BWD_LDS, st, a);
+        STSWIN_CHECK_LAUNCH();
+        return 0;
+      }
+    }
+  }
   if (bwd) {
     // persistent: as many workgroups as fit the chip at once (LDS bound), rounded so that grid * PPB is a multiple of heads
     const int per_cu = (160 * 1024) / Cfg::BWD_LDS > 0 ? (160 * 1024) / Cfg::BWD_LDS : 1;

@@ -57,3 +57,44 @@ def test_attention_fwd_bwd(dtype, ws, C, heads, masked):
         assert e <= 2 * tol * float(g[:, sl].abs().max()), f"{name} err {e} scale {float(g[:, sl].abs().max())}"
     e = float((dbT.transpose(1, 2).cpu() - br.grad).abs().max())
     assert e <= 2 * tol * float(br.grad.abs().max()), f"dbias err {e}"
+
+
+def test_attention_bwd_stage1_persistent_eight_wave_kernel(monkeypatch):
+    """Stage-1 production geometry (ws 8, C 512, 4 heads, 2 frames) with more problems than workgroups (3 per workgroup: the
+    persistent loop, the K | V/Q | dO buffer rotation), the pre-summed 4-slot bias+mask table with a window -> slot index and the
+    q-bias column sums: the 8-wave backward kernel against the fp32 CPU reference on a sample of windows and against the 4-wave
+    kernel (STSWIN_ATTN_BWD4=1) everywhere."""
+    torch.manual_seed(0)
+    ws, C, heads, T = 8, 512, 4, 2
+    N, nW, B = ws * ws, 64, 3
+    nB_ = B * nW                                          # 192 windows x 4 heads = 768 problems on <= 256 workgroups
+    rows = nB_ * T * N
+    qkv = (torch.randn(rows, 3 * C) * 0.5).bfloat16()
+    qkv[:, :C] *= (C // heads) ** -0.5
+    dout = torch.randn(rows, C).bfloat16()
+    bias = torch.randn(heads, N, N) * 0.5
+    masks = torch.where(torch.rand(4, N, N) < 0.2, -100.0, 0.0)
+    masks[0] = 0
+    bidx = torch.randint(0, 4, (nW,), dtype=torch.int32)
+    table = (bias[None] + masks[:, None]).transpose(2, 3).contiguous().cuda()      # [slot][heads][key][query]
+    res = {}
+    for mode in ("8", "4"):
+        monkeypatch.setenv("STSWIN_ATTN_BWD4", "1" if mode == "4" else "0")
+        dbT = torch.zeros(heads, N, N, device="cuda")
+        cs = torch.zeros(3 * C, device="cuda")
+        dqkv = hip.win_attn_bwd(qkv.cuda(), dout.cuda(), table, None, dbT, nB_=nB_, nW=nW, T=T, ws=ws, heads=heads, C=C, scale=0.7,
+                                colsum_out=cs, bias_index=bidx.cuda())
+        res[mode] = (dqkv.float().cpu(), dbT.cpu(), cs.cpu())
+    for a, b, what in zip(res["8"], res["4"], ("dqkv", "dbias", "q colsum")):
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-3, what
+    # fp32 reference for three windows (first, middle, last: different workgroups / loop iterations)
+    for wi in (0, 97, nB_ - 1):
+        sl = slice(wi * T * N, (wi + 1) * T * N)
+        qr = qkv[sl].float().requires_grad_(True)
+        m = masks[bidx[wi % nW]]
+        ref = _ref(qr, bias, m[None], 1, 1, T, N, heads, C)
+        (ref * dout[sl].float()).sum().backward()
+        g = qr.grad.clone()
+        g[:, :C] *= 0.7                                   # dq carries the kernel's `scale`
+        got = res["8"][0][sl]
+        assert float((got - g).abs().max()) <= 3e-2 * float(g.abs().max()), wi
