@@ -75,6 +75,13 @@ int stswin_conv_pack(int dtype, const float* w, void* fwd, void* dgrad, const in
 /* nn.Linear weight [n][k] fp32 -> fwd [n][k] and (if not NULL) tr [k][n] in the compute dtype, one launch (n, k multiples of 4):
  * the B operands of y = x W^T and of dx = dy W (swin_512.py:18-21,115,139,275), re-made after every optimizer step. */
 int stswin_linear_pack(int dtype, const float* w, void* fwd, void* tr, int n, int k, void* stream);
+/* The same two packings for up to 64 Linear / 32 convolution weights in ONE launch each (host arrays of device pointers and
+ * sizes): the re-cast of every GEMM operand after an optimizer step (train_swin.py:170-173 steps ~125 M parameters) was ~90
+ * launches of 6-15 us; see stswincl_amd.ops.repack. */
+int stswin_linear_pack_multi(int dtype, int count, const float* const* w, void* const* fwd, void* const* tr, const int* n, const int* k,
+                             void* stream);
+int stswin_conv_pack_multi(int dtype, int count, const float* const* w, void* const* fwd, void* const* dgrad, const int* const* omap,
+                           const int* const* imap, const int* ci, const int* S, const int* cop, const int* cip, void* stream);
 int stswin_maxpool3x3s2(int dtype, const void* in, long ldi, void* out, long ldo, unsigned char* arg, int frames, int H,
                         int W, int Ho, int Wo, int C, int backward, void* stream);
 

@@ -606,11 +606,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
 //   every LDS-DMA tile copy is issued by all eight waves.
 // Same persistent schedule, buffer rotation (K | V -> Q | dO -> next K) and register-accumulated bias / q-bias gradients.
 // Two waves per SIMD leave 256 registers per lane: LDS addresses are lane constants + instruction immediates (16 registers
-// instead of one per unrolled read), the 64 two-byte row stores of a product and the bias-table reads are buffer
-// instructions with ONE per-lane offset and scalar row offsets.
+// instead of one per unrolled read) and the bias-table reads are buffer instructions with ONE per-lane offset and scalar row
+// offsets.
+// Output stores stay two-byte row stores (64 per lane and product, as buffer instructions with scalar row offsets): routing them
+// through a private 4 KB of the dead P tile as whole 16-byte row pieces (4 store instructions of 1 KB instead of 32 of 128 B)
+// measured only 3 % faster (145.7 -> 141.1 us) - the kernel is bound by exposed load latency, not by its stores - and the P
+// tile's buffer is better spent on the next problem's V (below).
 DEVI void buf_store_b16(void* base, bf16 v, int voff, int soff) {
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)0xFFFFFFFE, 0x00020000);
   __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, v), rs, voff, soff, 0);
+}
+typedef int v4i32_t __attribute__((ext_vector_type(4)));
+DEVI void buf_store_b128(void* base, bf16x8 v, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)0xFFFFFFFE, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32_t, v), rs, voff, soff, 0);
 }
 DEVI float buf_load_f32(const void* base, int voff, int soff) {
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)0xFFFFFFFE, 0x00020000);
@@ -640,9 +649,10 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
   for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dbacc[kk][r] = 0.f;
-  int kbuf = 0, xbuf = 2;
-  char* Pt = smem + 3 * KV;
-  char* St = Pt + Cfg::P_BYTES;
+  // five 32 KB buffers; roles of a problem: K | V, later Q | dO, later the NEXT K | P, later the NEXT V | dS (fixed).
+  // Both tiles of the next problem are requested right after the barrier that ends dV, half a problem ahead.
+  int kb = 0, vb = 1, xb = 2, pb = 3;
+  char* St = smem + 4 * KV;
   float2* ex1 = (float2*)St;                       // [2 key halves][128 queries]: (max, sum of exp) of the wave's 64 keys
   float* ex2 = (float*)(St + 2048);                // [2][128]: sum over the wave's keys of P o dP
   const int N = NC ? NC : a.N;
@@ -674,20 +684,25 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
     stage_tile<NTOK, ROWB>(smem + KV, (const char*)(q0b + 2 * a.C), a.ld * sizeof(T), w, 8);
   }
   const int out_voff = (4 * half * (int)a.ldo + lr) * 2;                 // per-lane part of every dqkv store address
+  const bool dbg_ts = (a.bias_windows & (1 << 30)) != 0;   // DBG (tools/attn_timeline.py): dqkv_colsum = u64 [workgroups][32] stamps
+  auto stamp = [&](int slot) {
+    if (dbg_ts && (threadIdx.x & 255) == 0) ((unsigned long long*)a.dqkv_colsum)[(long)blockIdx.x * 32 + hw * 16 + slot] = wall_clock64();
+  };
   for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int b_ = (int)(grp / a.heads);
     const long rowbase = (long)b_ * NTOK;
     const T* qbase = (const T*)a.qkv + rowbase * a.ld + head * HD;
     const T* dobase = (const T*)a.dout + rowbase * a.lddo + head * HD;
-    char* Kt = smem + kbuf * KV;
-    char* Vt = smem + KV;                          // V, later Q
-    char* Xt = smem + xbuf * KV;                   // dO, later the next problem's K
+    char* Kt = smem + kb * KV;
+    char* Vt = smem + vb * KV;                     // V, later Q
+    char* Xt = smem + xb * KV;                     // dO, later the next problem's K
+    char* Pt = smem + pb * KV;                     // P, later the next problem's V
+    const bool has_next = grp + gridDim.x < ngroups;
+    const T* nqbase = (const T*)a.qkv + (long)((grp + gridDim.x) / a.heads) * NTOK * a.ld + head * HD;
+    stamp(0);
     bf16x8 qf[HD / 16];
     load_row_frags<T, HD>(qf, qbase, a.ld, q0 + lr);
-    wait_vm0();
-    __syncthreads();                               // K, V (requested during the previous problem) have landed
-    stage_tile<NTOK, ROWB>(Xt, (const char*)dobase, a.lddo * sizeof(T), w, 8);
-    // ---- bias (+ mask) values of this wave's 2 x 16 (key, query) entries per lane: requested first
+    // ---- bias (+ mask) values of this wave's 2 x 16 (key, query) entries per lane: requested BEFORE the tile wait
     const int widx = b_ % a.nW;
     const int slot = (a.bias_windows & 0xffffff) > 1 ? (a.bias_index ? a.bias_index[widx] : widx) : 0;
     float tb[2][16];
@@ -712,6 +727,10 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) tb[kk][r] += mt[(((2 * hw + kk) * 32 + crow32(r, half)) % N) * N];
     }
+    wait_vm0();
+    __syncthreads();                               // K, V (requested half a problem ago) and the Q row pieces have landed
+    stamp(1);
+    stage_tile<NTOK, ROWB>(Xt, (const char*)dobase, a.lddo * sizeof(T), w, 8);
     // ---- S^T for this wave's two key tiles: lane = query column, registers = keys
     f32x16 p[2], dp[2];
 #pragma unroll
@@ -742,8 +761,10 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
       }
     sum += __shfl_xor(sum, 32);
     if (half == 0) ex1[hw * NTOK + q0 + lr] = make_float2(mx, sum);
+    stamp(2);
     wait_vm0();                                    // this wave's pieces of the dO tile
     __syncthreads();                               // partner statistics + dO tile visible
+    stamp(3);
     {
       const float2 o = ex1[(hw ^ 1) * NTOK + q0 + lr];
       const float m = fmaxf(mx, o.x);
@@ -772,6 +793,7 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
       for (int r = 0; r < 16; ++r) delta += p[kk][r] * dp[kk][r];
     delta += __shfl_xor(delta, 32);
     if (half == 0) ex2[hw * NTOK + q0 + lr] = delta;
+    stamp(4);
     __syncthreads();
     delta += ex2[(hw ^ 1) * NTOK + q0 + lr];
 #pragma unroll
@@ -781,6 +803,7 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
         dp[kk][r] = p[kk][r] * (dp[kk][r] - delta);          // dS^T
         dbacc[kk][r] += dp[kk][r];
       }
+    stamp(5);
     __syncthreads();                               // every wave has read the exchange area: P / dS may overwrite it
     // P and dS tiles [query row][key] (bf16): this wave's 32 query rows x 64 keys
 #pragma unroll
@@ -795,6 +818,7 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
         *(bf16x4*)(St + off) = vs;
       }
     __syncthreads();                               // P, dS complete; every wave is done with V
+    stamp(6);
     stage_tile<NTOK, ROWB>(Vt, (const char*)qbase, a.ld * sizeof(T), w, 8);      // V is dead: Q (for dK)
     // dqkv row rowbase + .., columns head * HD + ..: scalar byte offsets of the three thirds
     const int so_q = (int)((rowbase * a.ldo + head * HD) * 2), so_k = so_q + a.C * 2, so_v = so_k + a.C * 2;
@@ -878,14 +902,17 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
     } else {
       dq_half();
     }
+    stamp(7);
     wait_vm0();                                    // Q has landed (waited for BEFORE this phase's stores are issued)
     __syncthreads();                               // ... and every wave is done with the dO tile
+    stamp(8);
     if (hw == 0) store4(so_v, k0);
     else dq_store();
-    if (grp + gridDim.x < ngroups) {               // the next problem's K into the buffer dO just left
-      const T* nq = (const T*)a.qkv + (long)((grp + gridDim.x) / a.heads) * NTOK * a.ld + head * HD;
-      stage_tile<NTOK, ROWB>(Xt, (const char*)(nq + a.C), a.ld * sizeof(T), w, 8);
+    if (has_next) {                                // the next problem's K and V into the buffers dO and P just left
+      stage_tile<NTOK, ROWB>(Xt, (const char*)(nqbase + a.C), a.ld * sizeof(T), w, 8);
+      stage_tile<NTOK, ROWB>(Pt, (const char*)(nqbase + 2 * a.C), a.ld * sizeof(T), w, 8);
     }
+    stamp(9);
     if (hw == 0) {
       dq_half();
       dq_store();
@@ -894,12 +921,10 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
       tr_product(St, Vt);
       store4(so_k, k0);
     }
+    stamp(10);
     __syncthreads();                               // the next problem's tiles overwrite Q / K / dS
-    if (grp + gridDim.x < ngroups) {
-      const T* nq = (const T*)a.qkv + (long)((grp + gridDim.x) / a.heads) * NTOK * a.ld + head * HD;
-      stage_tile<NTOK, ROWB>(smem + KV, (const char*)(nq + 2 * a.C), a.ld * sizeof(T), w, 8);
-    }
-    const int tbuf = kbuf; kbuf = xbuf; xbuf = tbuf;
+    stamp(11);
+    { const int t0 = kb, t1 = vb; kb = xb; vb = pb; xb = t0; pb = t1; }     // next K sits in xb, next V in pb
   }
   if (a.dbiasT) {
     float* db = a.dbiasT + (long)head * N * N + qn;
@@ -908,7 +933,7 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) atomicAdd(db + (((2 * hw + kk) * 32 + crow32(r, half)) % N) * N, dbacc[kk][r]);
   }
-  if (a.dqkv_colsum) {
+  if (a.dqkv_colsum && !dbg_ts) {
 #pragma unroll
     for (int dd = 0; dd < 2; ++dd) {
       float csum = csacc[dd];
@@ -936,7 +961,7 @@ static int launch_attn(const AttnArgs& a, bool bwd, hipStream_t st) {
     const char* e4 = getenv("STSWIN_ATTN_BWD4");                             // A/B switch (read per call): the 4-wave kernel
     const int no8 = e4 && atoi(e4) ? 1 : 0;
     const bool fits = (long)a.nB_ * NTOK * a.ldo * 2 < 0x7FFF0000L;          // 32-bit buffer offsets of the dqkv stores
-    if (bwd && !no8 && fits && !(a.bias_windows & (1 << 30))) {
+    if (bwd && !no8 && fits) {
       static const int attr8 = (int)hipFuncSetAttribute((const void*)attn_bwd8_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         Cfg::BWD_LDS);
       if (attr8 != 0) return -attr8;

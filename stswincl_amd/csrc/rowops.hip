@@ -137,10 +137,8 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* img, T* p
 // output channels.  (One element per thread with a cop-strided 2-byte store for the transposed copy took 1.1 ms per
 // training step for the 110 M parameters of TswinPlus - the re-cast happens after every optimizer step.)
 template <typename T>
-__global__ __launch_bounds__(256) void conv_pack_kernel(const float* w, T* fwd, T* dg, const int* omap, const int* imap,
-                                                         int co, int ci, int S, int cop, int cip) {
-  __shared__ T tile[64][66];
-  const int i0 = blockIdx.x * 64, o0 = blockIdx.y * 64, s = blockIdx.z;
+DEVI void conv_pack_tile(T (&tile)[64][66], const float* w, T* fwd, T* dg, const int* omap, const int* imap, int ci, int S, int cop,
+                         int cip, int i0, int o0, int s) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   {
     const int ip = i0 + tx;
@@ -171,12 +169,41 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* w, T* fwd, 
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float* w, T* fwd, T* dg, const int* omap, const int* imap,
+                                                         int co, int ci, int S, int cop, int cip) {
+  __shared__ T tile[64][66];
+  conv_pack_tile<T>(tile, w, fwd, dg, omap, imap, ci, S, cop, cip, blockIdx.x * 64, blockIdx.y * 64, blockIdx.z);
+}
+
+// Every convolution weight of a model in ONE launch: the re-cast after an optimizer step was 36 launches of ~15 us for the 36
+// convolutions of TswinPlus (and 55 of ~6 us for its Linear weights, below) - kernels far too small to fill the chip, plus a
+// launch boundary each.  A workgroup finds its (weight, tile) by scanning the <= 32 tile counts.
+#define CPM_MAX 32
+struct ConvPackMulti {
+  const float* w[CPM_MAX]; void* fwd[CPM_MAX]; void* dg[CPM_MAX]; const int* omap[CPM_MAX]; const int* imap[CPM_MAX];
+  int ci[CPM_MAX], S[CPM_MAX], cop[CPM_MAX], cip[CPM_MAX], tiles[CPM_MAX];
+  int count;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void conv_pack_multi_kernel(ConvPackMulti a) {
+  __shared__ T tile[64][66];
+  int b = blockIdx.x, e = 0;
+  for (; e < a.count; ++e) {
+    if (b < a.tiles[e]) break;
+    b -= a.tiles[e];
+  }
+  if (e >= a.count) return;
+  const int ti = (a.cip[e] + 63) / 64, to = (a.cop[e] + 63) / 64;
+  const int s = b / (ti * to), r = b - s * ti * to;
+  conv_pack_tile<T>(tile, a.w[e], (T*)a.fwd[e], (T*)a.dg[e], a.omap[e], a.imap[e], a.ci[e], a.S[e], a.cop[e], a.cip[e], (r % ti) * 64,
+                    (r / ti) * 64, s);
+}
+
 // nn.Linear weight [n][k] fp32 -> W (cast) and W^T (cast + transpose) in one launch, 16-byte reads, 8-byte writes: a
 // 64 x 64 tile per workgroup, four consecutive elements per thread and pass, the transposed copy through an LDS tile.
 template <typename T>
-__global__ __launch_bounds__(256) void linear_pack_kernel(const float* w, T* fwd, T* tr, int n, int k) {
-  __shared__ float tile[64][65];
-  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+DEVI void linear_pack_tile(float (&tile)[64][65], const float* w, T* fwd, T* tr, int n, int k, int k0, int n0) {
   const int g = threadIdx.x & 15, r = threadIdx.x >> 4;          // 16 groups of 4 columns x 16 rows per pass
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
@@ -201,6 +228,31 @@ __global__ __launch_bounds__(256) void linear_pack_kernel(const float* w, T* fwd
                                              from_f32<T>(tile[g * 4 + 2][row]), from_f32<T>(tile[g * 4 + 3][row])};
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void linear_pack_kernel(const float* w, T* fwd, T* tr, int n, int k) {
+  __shared__ float tile[64][65];
+  linear_pack_tile<T>(tile, w, fwd, tr, n, k, blockIdx.x * 64, blockIdx.y * 64);
+}
+
+#define LPM_MAX 64
+struct LinearPackMulti {
+  const float* w[LPM_MAX]; void* fwd[LPM_MAX]; void* tr[LPM_MAX];
+  int n[LPM_MAX], k[LPM_MAX], tiles[LPM_MAX];
+  int count;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void linear_pack_multi_kernel(LinearPackMulti a) {
+  __shared__ float tile[64][65];
+  int b = blockIdx.x, e = 0;
+  for (; e < a.count; ++e) {
+    if (b < a.tiles[e]) break;
+    b -= a.tiles[e];
+  }
+  if (e >= a.count) return;
+  const int tk = (a.k[e] + 63) / 64;
+  linear_pack_tile<T>(tile, a.w[e], (T*)a.fwd[e], (T*)a.tr[e], a.n[e], a.k[e], (b % tk) * 64, (b / tk) * 64);
 }
 
 // maxpool 3x3 stride 2 pad 1 on tokens
@@ -695,6 +747,46 @@ extern "C" int stswin_bias_scatter(const float* dbiasT, const long* index, float
 extern "C" int stswin_vec_gather(const float* v, const int* map, float* out, int n, float fill, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(vec_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, map, out, n, fill);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_linear_pack_multi(int dtype, int count, const float* const* w, void* const* fwd, void* const* tr, const int* n,
+                                        const int* k, void* stream) {
+  if (count <= 0) return 0;
+  if (count > LPM_MAX) return -1113;
+  LinearPackMulti a;
+  long blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    if (n[i] <= 0 || k[i] <= 0 || n[i] % 4 || k[i] % 4) return -1112;
+    a.w[i] = w[i]; a.fwd[i] = fwd[i]; a.tr[i] = tr ? tr[i] : nullptr; a.n[i] = n[i]; a.k[i] = k[i];
+    a.tiles[i] = ((k[i] + 63) / 64) * ((n[i] + 63) / 64);
+    blocks += a.tiles[i];
+  }
+  a.count = count;
+  if (dtype == 0) hipLaunchKernelGGL(linear_pack_multi_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(linear_pack_multi_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_conv_pack_multi(int dtype, int count, const float* const* w, void* const* fwd, void* const* dgrad,
+                                      const int* const* omap, const int* const* imap, const int* ci, const int* S, const int* cop,
+                                      const int* cip, void* stream) {
+  if (count <= 0) return 0;
+  if (count > CPM_MAX) return -1113;
+  ConvPackMulti a;
+  long blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    if (ci[i] <= 0 || S[i] <= 0 || cop[i] <= 0 || cip[i] <= 0) return -1111;
+    a.w[i] = w[i]; a.fwd[i] = fwd[i]; a.dg[i] = dgrad ? dgrad[i] : nullptr; a.omap[i] = omap[i]; a.imap[i] = imap[i];
+    a.ci[i] = ci[i]; a.S[i] = S[i]; a.cop[i] = cop[i]; a.cip[i] = cip[i];
+    a.tiles[i] = ((cip[i] + 63) / 64) * ((cop[i] + 63) / 64) * S[i];
+    blocks += a.tiles[i];
+  }
+  a.count = count;
+  if (dtype == 0) hipLaunchKernelGGL(conv_pack_multi_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(conv_pack_multi_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

@@ -106,11 +106,12 @@ def _conv_mats(w: torch.Tensor, dt, lin: Layout, lout: Layout, dgrad: bool) -> t
     stamp = (w._version, w.data_ptr(), tuple(w.shape))
     hit = _CW.get(key)
     if hit is None or hit[0]() is not w or hit[1] != stamp:
-        fwd, dg = hip.conv_pack(w, dt, lout.index_map(w.device), lin.index_map(w.device))
+        omap, imap = lout.index_map(w.device), lin.index_map(w.device)
+        fwd, dg = hip.conv_pack(w, dt, omap, imap)
         if len(_CW) > 2048:
             for kk in [kk for kk, v in _CW.items() if v[0]() is None]:
                 del _CW[kk]
-        hit = (weakref.ref(w), stamp, fwd, dg)
+        hit = (weakref.ref(w), stamp, fwd, dg, omap, imap)       # (the maps are kept for ops.repack's batched re-packing)
         _CW[key] = hit
     return hit[3] if dgrad else hit[2]
 
@@ -294,8 +295,9 @@ class BNTokFn(torch.autograd.Function):
             mean_l = pivot + s / n_loc
             m2_l = ss - s * s / n_loc
             pack = torch.stack([mean_l, m2_l])                                  # [2][groups][C]
-            allp = torch.empty(world, *pack.shape, dtype=pack.dtype, device=pack.device)
+            allp = torch.empty(world * 2, *pack.shape[1:], dtype=pack.dtype, device=pack.device)   # (gloo wants the dim-0 concat form)
             dist.all_gather_into_tensor(allp, pack)
+            allp = allp.view(world, 2, *pack.shape[1:])
             rows_total = world * n_loc
             mean, var, _ = combine_bn_stats(allp[:, 0], allp[:, 1], torch.full((world,), float(n_loc), device=pack.device))
             rstd = torch.rsqrt(var + eps)

@@ -254,6 +254,33 @@ def linear_pack(w: torch.Tensor, dt: torch.dtype, want_tr: bool = True):
     return fwd, tr
 
 
+def linear_pack_multi(entries, dt: torch.dtype):
+    """entries: [(w fp32 [n][k], fwd [n][k], tr [k][n] or None)] -> re-pack all of them in place, 64 weights per launch."""
+    lib, st = load(), _stream()
+    for lo in range(0, len(entries), 64):
+        ch = entries[lo:lo + 64]
+        c = len(ch)
+        ws = (_c_void_p * c)(*[e[0].data_ptr() for e in ch])
+        fs = (_c_void_p * c)(*[e[1].data_ptr() for e in ch])
+        ts = (_c_void_p * c)(*[(e[2].data_ptr() if e[2] is not None else 0) for e in ch])
+        ns = (_c_int * c)(*[e[0].shape[0] for e in ch])
+        ks = (_c_int * c)(*[e[0].shape[1] for e in ch])
+        _check(lib.stswin_linear_pack_multi(0 if dt == torch.bfloat16 else 1, c, ws, fs, ts, ns, ks, st), "linear_pack_multi")
+
+
+def conv_pack_multi(entries, dt: torch.dtype):
+    """entries: [(w fp32 (co,ci,k,k), fwd, dgrad or None, omap, imap)] -> re-pack in place, 32 weights per launch."""
+    lib, st = load(), _stream()
+    for lo in range(0, len(entries), 32):
+        ch = entries[lo:lo + 32]
+        c = len(ch)
+        arr = lambda i: (_c_void_p * c)(*[(e[i].data_ptr() if e[i] is not None else 0) for e in ch])  # noqa: E731
+        ints = lambda f: (_c_int * c)(*[f(e) for e in ch])  # noqa: E731
+        _check(lib.stswin_conv_pack_multi(0 if dt == torch.bfloat16 else 1, c, arr(0), arr(1), arr(2), arr(3), arr(4),
+                                          ints(lambda e: e[0].shape[1]), ints(lambda e: e[0].shape[2] * e[0].shape[3]),
+                                          ints(lambda e: e[3].numel()), ints(lambda e: e[4].numel()), st), "conv_pack_multi")
+
+
 def stem_im2col(img: torch.Tensor, dtype: torch.dtype, Ho: int, Wo: int, ld: int = 192) -> torch.Tensor:
     """img fp32 NCHW [F][3][H][W] -> patches [F*Ho*Wo][ld] (7x7 / stride 2 / pad 3)."""
     F_, c, H, W = img.shape

@@ -98,6 +98,45 @@ def wcast(p: torch.Tensor, dtype: torch.dtype, transpose: bool = False) -> torch
     return hit[3]
 
 
+def repack(params) -> int:
+    """Re-make, in place and in TWO launches, every cached GEMM operand (W / W^T of the Linear layers, the tap-major matrices of
+    the convolutions) of the given parameters after they were updated - called by the fused optimizers / EMA right after they
+    bump the version counters.  Without it each weight is re-packed lazily at its next use: ~90 launches of 6-15 us per
+    training step (0.9 ms of 30).  Returns the number of operands rewritten; entries it cannot batch are left to the lazy path."""
+    from . import headops
+    ids = {id(p): p for p in params}
+    if not ids:
+        return 0
+    lin, conv = {}, {}
+    for key, hit in _WCACHE.items():
+        p = ids.get(key[0])
+        if p is None or hit[0]() is not p:
+            continue
+        w = p.detach()
+        if not (w.dim() == 2 and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.shape[0] % 4 == 0
+                and w.shape[1] % 4 == 0 and hit[2].shape == w.shape and hit[2].device == w.device):
+            continue                                    # (odd sizes take the conv_pack path of wcast: lazily, as before)
+        if hit[3] is not None and hit[3].shape != (w.shape[1], w.shape[0]):
+            continue
+        lin.setdefault(key[1], []).append((w, hit[2], hit[3]))
+        hit[1] = (p._version, p.data_ptr(), tuple(p.shape), p.device)
+    for key, hit in list(headops._CW.items()):
+        p = ids.get(key[0])
+        if p is None or hit[0]() is not p or not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+            continue
+        ref, _, fwd, dg, omap, imap = hit
+        conv.setdefault(key[1], []).append((p.detach(), fwd, dg, omap, imap))
+        headops._CW[key] = (ref, (p._version, p.data_ptr(), tuple(p.shape)), fwd, dg, omap, imap)
+    n = 0
+    for dt, entries in lin.items():
+        hip.linear_pack_multi(entries, dt)
+        n += len(entries)
+    for dt, entries in conv.items():
+        hip.conv_pack_multi(entries, dt)
+        n += len(entries)
+    return n
+
+
 def clear_caches() -> None:
     _ROWMAPS.clear()
     _WCACHE.clear()

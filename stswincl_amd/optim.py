@@ -13,7 +13,11 @@ from typing import Iterable, Sequence
 
 import torch
 
+import os
+
 from . import hip
+
+_EAGER_REPACK = os.environ.get("STSWIN_LAZY_REPACK") != "1"       # (A/B switch: per-weight re-packing at the next use)
 
 
 def _mark_updated(params: Sequence[torch.Tensor]) -> None:
@@ -27,6 +31,9 @@ def _mark_updated(params: Sequence[torch.Tensor]) -> None:
         setter(list(params), [int(p._version) + 1 for p in params])
     else:                                  # older torch: an in-place no-op through the dispatcher
         torch._foreach_add_(list(params), 0)
+    if _EAGER_REPACK:                      # ... and re-make their cached GEMM operands now, batched (two launches instead of ~90)
+        from . import ops
+        ops.repack(params)
 
 
 class FusedAdam(torch.optim.Optimizer):

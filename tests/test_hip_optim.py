@@ -124,3 +124,42 @@ def test_lars_matches_reference_golden():
             assert torch.allclose(opt.state[params[n]]["momentum_buffer"].cpu(), torch.from_numpy(g[f"buf/{n}"]), rtol=2e-5, atol=1e-7)
         sd = opt.state_dict()
         assert len(sd["param_groups"]) == 2 and sd["param_groups"][1]["ignore"] is False
+
+
+def test_batched_repack_after_optimizer_step_matches_lazy_packing():
+    """ops.repack (two launches for every cached GEMM operand of the stepped parameters) must leave exactly what the lazy
+    per-weight packing produces: W / W^T of Linear weights, tap-major forward / dgrad matrices of convolutions (incl. a padded
+    channel layout), and stamps that keep the cache from re-packing again."""
+    from stswincl_amd import headops as H, hip, ops
+    torch.manual_seed(0)
+    lin = [torch.nn.Parameter(torch.randn(n, k, device="cuda")) for n, k in ((512, 512), (1536, 512), (2048, 512), (64, 192), (12, 256))]
+    convs = [torch.nn.Parameter(torch.randn(co, ci, k, k, device="cuda")) for co, ci, k in ((64, 64, 3), (512, 256, 3), (48, 512, 1), (256, 400, 3))]
+    lays = [(H.Layout.dense(64), H.Layout.dense(64)), (H.Layout.dense(256), H.Layout.dense(512)), (H.Layout.dense(512), H.Layout.dense(48)),
+            (H.Layout.concat([H.Layout.dense(48)] * 3 + [H.Layout.dense(256)]), H.Layout.dense(256))]
+    ops.clear_caches()
+    for dt in (torch.bfloat16, torch.float32):
+        for p in lin:
+            ops.wcast(p, dt), ops.wcast(p, dt, True)
+        for p, (li, lo) in zip(convs, lays):
+            H._conv_mats(p, dt, li, lo, False)
+    opt = FusedSGD(lin + convs, 0.5)
+    for p in lin + convs:
+        p.grad = torch.randn_like(p)
+    opt.step()                                             # -> _mark_updated -> ops.repack
+    calls = {"lin": 0, "conv": 0}
+    real_lin, real_conv = hip.linear_pack, hip.conv_pack
+    hip.linear_pack = lambda *a, **k: (calls.__setitem__("lin", calls["lin"] + 1), real_lin(*a, **k))[1]
+    hip.conv_pack = lambda *a, **k: (calls.__setitem__("conv", calls["conv"] + 1), real_conv(*a, **k))[1]
+    try:
+        for dt in (torch.bfloat16, torch.float32):
+            for p in lin:
+                w, wt = ops.wcast(p, dt), ops.wcast(p, dt, True)
+                assert torch.equal(w, p.detach().to(dt)) and torch.equal(wt, p.detach().t().to(dt))
+            for p, (li, lo) in zip(convs, lays):
+                fwd, dg = H._conv_mats(p, dt, li, lo, False), H._conv_mats(p, dt, li, lo, True)
+                rf, rd = real_conv(p, dt, lo.index_map(p.device), li.index_map(p.device))
+                assert torch.equal(fwd, rf) and torch.equal(dg, rd)
+    finally:
+        hip.linear_pack, hip.conv_pack = real_lin, real_conv
+    # the (12, 256) weight has n % 4 == 0 too; nothing may have been re-packed lazily after the batched pass
+    assert calls == {"lin": 0, "conv": 0}, calls
