@@ -177,6 +177,12 @@ int stswin_bias_scatter(const float* dbiasT, const long* index, float* dtable, i
 int stswin_win_attn_fwd(int dtype, const void* qkv, long ld, void* out, long ldo, const float* biasT, const float* maskT,
                         int nB_, int nW, int T_frames, int ws, int heads, int C, int bias_windows,
                         const int* bias_index, void* stream);
+/* BASELINE.json configs[4] "fp8 MFMA attention": the forward above with q, k, v and the probabilities quantised to OCP e4m3 in
+ * registers (per (window, head) amax scales, P x 128) and both products on v_mfma_f32_32x32x16_fp8_fp8; qkv / out stay bf16 in
+ * memory (same arguments, dtype fixed to bf16 storage).  A numerics mode (the non-scaled fp8 MFMA has the bf16 rate on gfx950);
+ * the backward is stswin_win_attn_bwd on the unquantised qkv (straight-through). */
+int stswin_win_attn_fwd_fp8(const void* qkv, long ld, void* out, long ldo, const float* biasT, const float* maskT, int nB_, int nW,
+                            int T_frames, int ws, int heads, int C, int bias_windows, const int* bias_index, void* stream);
 int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, long lddo, void* dqkv, long lddq,
                         const float* biasT, const float* maskT, float* dbiasT,
                         float* dqkv_q_colsum /* optional fp32 [C]: += column sums of the dq third (q bias gradient).

@@ -298,6 +298,142 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // ====================================================================================================
+// fp8 (OCP e4m3) forward for BASELINE.json configs[4] ("fp8 MFMA attention"): the same kernel with q, k, v and the
+// probabilities quantised in registers and both products on v_mfma_f32_32x32x16_fp8_fp8.  q / k / v stay bf16 in HBM (the
+// QKV GEMM writes them, the backward reads them), so this mode changes the arithmetic, not the traffic: per (window, head)
+// problem amax scales (amax / 448) for q, k and v, P scaled by 128 (softmax outputs below 2^-6 would otherwise fall into the
+// e4m3 subnormals), fp32 accumulation, fp32 softmax.  The non-scaled fp8 MFMA has the bf16 rate on gfx950
+// (MI355X_MICROARCH.md, Matrix cores), so this is a numerics mode, not a speed-up; the backward is the bf16 kernel on the
+// unquantised q / k / v (straight-through).
+DEVI long pack_fp8x8(const bf16x8 v, float mul) {
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[0] * mul, (float)v[1] * mul, lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[2] * mul, (float)v[3] * mul, lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[4] * mul, (float)v[5] * mul, hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[6] * mul, (float)v[7] * mul, hi, true);
+  return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+}
+DEVI float amax8(const bf16x8 v, float m) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)v[e]));
+  return m;
+}
+
+template <int NTOK, int HD, int NC>
+__global__ __launch_bounds__(256) void attn_fwd_fp8_kernel(AttnArgs a) {
+  using T = bf16;
+  using Cfg = AttnCfg<T, NTOK, HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int l = threadIdx.x & 63, lr = l & 31, half = l >> 5, w = wave_id();
+  const int sp = w / Cfg::QW, qt = w % Cfg::QW;
+  const long prob = (long)blockIdx.x * Cfg::PPB + sp;
+  const int b_ = min((int)(prob / a.heads), a.nB_ - 1), head = prob % a.heads;
+  const bool live = prob / a.heads < a.nB_;
+  const long rowbase = (long)b_ * NTOK;
+  const T* qbase = (const T*)a.qkv + rowbase * a.ld + head * HD;
+  char* Kt = smem + sp * 2 * Cfg::KV_BYTES;
+  char* Vt = Kt + Cfg::KV_BYTES;
+  float* ex = (float*)(smem + Cfg::PPB * 2 * Cfg::KV_BYTES);       // [4 waves][3]: |q|, |k|, |v| maxima of each wave's share
+  const int q0 = qt * 32;
+  bf16x8 qf[HD / 16];
+  stage_tile<NTOK, Cfg::RB>(Kt, (const char*)(qbase + a.C), a.ld * sizeof(T), qt, Cfg::QW);
+  stage_tile<NTOK, Cfg::RB>(Vt, (const char*)(qbase + 2 * a.C), a.ld * sizeof(T), qt, Cfg::QW);
+  load_row_frags<T, HD>(qf, qbase, a.ld, q0 + lr);
+  wait_vm0();
+  __syncthreads();
+  // ---- per-problem amax: this wave's 32 query rows, and its 32 rows of the K and V tiles
+  float mq = 0.f, mk = 0.f, mv = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < HD / 16; ++ks) {
+    mq = amax8(qf[ks], mq);
+    mk = amax8(frag_row<Cfg::RB>(Kt, q0 + lr, ks, half), mk);
+    mv = amax8(frag_row<Cfg::RB>(Vt, q0 + lr, ks, half), mv);
+  }
+  mq = wave_max(mq); mk = wave_max(mk); mv = wave_max(mv);
+  if (l == 0) { ex[w * 3 + 0] = mq; ex[w * 3 + 1] = mk; ex[w * 3 + 2] = mv; }
+  __syncthreads();
+#pragma unroll
+  for (int o = 0; o < Cfg::QW; ++o) {
+    mq = fmaxf(mq, ex[(sp * Cfg::QW + o) * 3 + 0]);
+    mk = fmaxf(mk, ex[(sp * Cfg::QW + o) * 3 + 1]);
+    mv = fmaxf(mv, ex[(sp * Cfg::QW + o) * 3 + 2]);
+  }
+  const float sq = mq > 0.f ? mq * (1.0f / 448.0f) : 1.0f, sk = mk > 0.f ? mk * (1.0f / 448.0f) : 1.0f,
+              sv = mv > 0.f ? mv * (1.0f / 448.0f) : 1.0f;
+  long q8[HD / 16];
+#pragma unroll
+  for (int ks = 0; ks < HD / 16; ++ks) q8[ks] = pack_fp8x8(qf[ks], 1.0f / sq);
+  // ---- S^T = K Q^T on the fp8 MFMA, rescaled; + bias (+ mask); softmax in fp32
+  f32x16 p[Cfg::KT];
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[kt][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks)
+      p[kt] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(pack_fp8x8(frag_row<Cfg::RB>(Kt, kt * 32 + lr, ks, half), 1.0f / sk), q8[ks],
+                                                        p[kt], 0, 0, 0);
+  }
+  const int N = NC ? NC : a.N;
+  const int qn = (q0 + lr) % N, widx = b_ % a.nW;
+  const int slot = (a.bias_windows & 0xffffff) > 1 ? (a.bias_index ? a.bias_index[widx] : widx) : 0;
+  const float* bt = a.biasT + ((long)slot * a.heads + head) * N * N + qn;
+  const float* mt = a.maskT ? a.maskT + (long)widx * N * N + qn : nullptr;
+  const float ssc = sq * sk;
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kn = ((kt * 32 + crow32(r, half)) % N) * N;
+      float sc = p[kt][r] * ssc + bt[kn];
+      if (mt) sc += mt[kn];
+      p[kt][r] = sc;
+      mx = fmaxf(mx, sc);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __expf(p[kt][r] - mx);
+      p[kt][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32);
+  const float pscale = 128.0f / sum;               // P * 128 in e4m3
+  // ---- O = P V: P from the score accumulators (k-slots in accumulator order), V read transposed in the same order
+  f32x16 o[Cfg::DT];
+#pragma unroll
+  for (int dt = 0; dt < Cfg::DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(p[kt][8 * m + 0] * pscale, p[kt][8 * m + 1] * pscale, lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(p[kt][8 * m + 2] * pscale, p[kt][8 * m + 3] * pscale, lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(p[kt][8 * m + 4] * pscale, p[kt][8 * m + 5] * pscale, hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(p[kt][8 * m + 6] * pscale, p[kt][8 * m + 7] * pscale, hi, true);
+      const long pa = (long)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+#pragma unroll
+      for (int dt = 0; dt < Cfg::DT; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(pa, pack_fp8x8(frag_tr_perm<Cfg::RB>(Vt, kt * 32 + 16 * m, dt), 1.0f / sv), o[dt],
+                                                          0, 0, 0);
+    }
+  if (!live) return;
+  const float osc = sv * (1.0f / 128.0f);
+  T* ob = (T*)a.out + (rowbase + q0) * a.ldo + head * HD;
+#pragma unroll
+  for (int dt = 0; dt < Cfg::DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ob[(long)crow32(r, half) * a.ldo + dt * 32 + lr] = (bf16)(o[dt][r] * osc);
+}
+
+// ====================================================================================================
 // Backward: dq = scale * dS k ; dk = dS^T q_s ; dv = P^T dO ; dbias += fold(dS) ;  dS = P o (dP - rowsum(P o dP)).
 // Persistent over problems: a workgroup walks problem groups blockIdx.x, blockIdx.x + gridDim.x, ... and the launcher
 // makes gridDim.x * PPB a multiple of `heads`, so a lane meets the same (head, query n, key n) and the same dqkv columns
@@ -1036,4 +1172,35 @@ extern "C" int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const vo
   AttnArgs a{qkv, ld, dqkv, lddq, dout, lddo, biasT, maskT, dbiasT, dqkv_colsum, nB_, nW, heads, C, 0, scale, bias_windows | dbg,
              bias_index};
   return attn_common(dtype, a, T_frames, ws, true, stream);
+}
+
+template <int NTOK, int HD, int NC>
+static int launch_attn_fp8(const AttnArgs& a, hipStream_t st) {
+  using Cfg = AttnCfg<bf16, NTOK, HD>;
+  const long probs = (long)a.nB_ * a.heads;
+  const int grid = (int)((probs + Cfg::PPB - 1) / Cfg::PPB);
+  const int lds = Cfg::FWD_LDS + 64;
+  static const int attr = (int)hipFuncSetAttribute((const void*)attn_fwd_fp8_kernel<NTOK, HD, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (attr != 0) return -attr;
+  hipLaunchKernelGGL((attn_fwd_fp8_kernel<NTOK, HD, NC>), dim3(grid), dim3(256), lds, st, a);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_win_attn_fwd_fp8(const void* qkv, long ld, void* out, long ldo, const float* biasT, const float* maskT, int nB_,
+                                       int nW, int T_frames, int ws, int heads, int C, int bias_windows, const int* bias_index,
+                                       void* stream) {
+  if (bias_windows != 1 && ((!bias_index && bias_windows != nW) || maskT)) return -1204;
+  AttnArgs a{qkv, ld, out, ldo, nullptr, 0, biasT, maskT, nullptr, nullptr, nB_, nW, heads, C, ws * ws, 1.0f, bias_windows, bias_index};
+  const int ntok = T_frames * ws * ws;
+  if (C % heads || nW <= 0 || nB_ % nW) return -1203;
+  const int hd = C / heads;
+  hipStream_t st = (hipStream_t)stream;
+  if (ntok == 128 && hd == 128 && a.N == 64) return launch_attn_fp8<128, 128, 64>(a, st);
+  if (ntok == 32 && hd == 256 && a.N == 16) return launch_attn_fp8<32, 256, 16>(a, st);
+  if (ntok == 128 && hd == 128) return launch_attn_fp8<128, 128, 0>(a, st);
+  if (ntok == 32 && hd == 256) return launch_attn_fp8<32, 256, 0>(a, st);
+  if (ntok == 128 && hd == 32) return launch_attn_fp8<128, 32, 0>(a, st);
+  if (ntok == 32 && hd == 64) return launch_attn_fp8<32, 64, 0>(a, st);
+  return -1201;
 }

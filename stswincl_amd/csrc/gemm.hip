@@ -1682,6 +1682,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
 // bf16 partials: 8 outputs per thread (16-byte loads) and eight splits requested before the first is consumed - the pass is a
 // pure HBM stream (splits x Ni x Nj x 2 bytes in, 4 bytes per output out); with 8-byte loads issued one split at a time it
 // ran at 2.5 TB/s (14.5 us for the 16-split 512 x 2048 weight gradients, 1.4 ms per training step over its 80 launches).
+// The loads are ORDINARY loads: non-temporal ones returned stale slab contents (weight gradients off by 100 %, different from run
+// to run) - the partials were written with plain stores by the kernel just before, possibly through another XCD's L2.
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, float* C, long ldc, int Ni, int Nj, int splits,
                                                         int overwrite, int slab_bf16) {
   if (slab_bf16) {
@@ -1695,14 +1697,14 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, floa
     for (; s + 8 <= splits; s += 8) {
       bf16x8 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load((const bf16x8*)(src + (long)(s + u) * total));
+      for (int u = 0; u < 8; ++u) v[u] = *(const bf16x8*)(src + (long)(s + u) * total);
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] += (float)v[u][e];
     }
     for (; s < splits; ++s) {
-      const bf16x8 v = __builtin_nontemporal_load((const bf16x8*)(src + (long)s * total));
+      const bf16x8 v = *(const bf16x8*)(src + (long)s * total);
 #pragma unroll
       for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
     }

@@ -457,8 +457,15 @@ def _bias_windows(biasT, maskT, nW, bias_index=None):
     return 1
 
 
-def win_attn_fwd(qkv, biasT, maskT, *, nB_, nW, T, ws, heads, C, bias_index=None):
+def win_attn_fwd(qkv, biasT, maskT, *, nB_, nW, T, ws, heads, C, bias_index=None, fp8=False):
     out = torch.empty(qkv.shape[0], C, dtype=qkv.dtype, device=qkv.device)
+    if fp8:
+        if qkv.dtype != torch.bfloat16:
+            raise StswinHipError("fp8 attention quantises bf16 q / k / v")
+        rc = load().stswin_win_attn_fwd_fp8(_p(qkv), _c_long(_ld(qkv)), _p(out), _c_long(_ld(out)), _p(biasT), _p(maskT), nB_, nW, T, ws,
+                                            heads, C, _bias_windows(biasT, maskT, nW, bias_index), _p(bias_index), _stream())
+        _check(rc, "win_attn_fwd_fp8")
+        return out
     rc = load().stswin_win_attn_fwd(_dt(qkv), _p(qkv), _c_long(_ld(qkv)), _p(out), _c_long(_ld(out)), _p(biasT),
                                     _p(maskT), nB_, nW, T, ws, heads, C, _bias_windows(biasT, maskT, nW, bias_index), _p(bias_index),
                                     _stream())

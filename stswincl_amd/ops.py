@@ -230,7 +230,9 @@ class SwinBlockFn(torch.autograd.Function):
         # table holds one slot per pattern (4 MB instead of 64 MB at stage 1: L2 resident) and a window -> slot index
         umask, bidx = unique_windows(attn_mask) if shift > 0 and attn_mask is not None else (None, None)
         biasT = hip.bias_expand(_f32(table), index.reshape(-1).contiguous(), umask, N, heads)
-        o = hip.win_attn_fwd(qkv, biasT, maskT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads, C=C, bias_index=bidx)
+        # STSWIN_FP8_ATTN=1 (BASELINE configs[4]): e4m3 q / k / v / P on the fp8 MFMA in the forward; the backward stays bf16
+        o = hip.win_attn_fwd(qkv, biasT, maskT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads, C=C, bias_index=bidx,
+                             fp8=(dt == torch.bfloat16 and os.environ.get("STSWIN_FP8_ATTN") == "1"))
         x1 = torch.empty(M, C, dtype=dt, device=dev)
         hip.gemm_nt(o, wcast(proj_w, dt), x1, M=M, c_rows=rmap, bias=_f32(proj_b), resid=X2, r_rows=rmap,
                     flags=hip.GF_RESID)

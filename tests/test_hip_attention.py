@@ -98,3 +98,30 @@ def test_attention_bwd_stage1_persistent_eight_wave_kernel(monkeypatch):
         g[:, :C] *= 0.7                                   # dq carries the kernel's `scale`
         got = res["8"][0][sl]
         assert float((got - g).abs().max()) <= 3e-2 * float(g.abs().max()), wi
+
+
+@pytest.mark.parametrize("ws,C,heads", [(8, 512, 4), (4, 1024, 4), (8, 128, 4)])
+def test_attention_fwd_fp8_mode(ws, C, heads):
+    """BASELINE configs[4]: e4m3 q / k / v / P on the fp8 MFMA (per-problem amax scales), fp32 softmax and accumulation.
+    Tolerance = what 3-bit mantissas cost: every product q_i k_i carries ~4 % rms relative error, a 128..256-term score ~4 % of its
+    spread; measured on MI355X: rel-L2 4.3-5.0e-2 of the output, max error 4-7 % of the output scale (bf16 path: 2e-3)."""
+    torch.manual_seed(ws + C)
+    T, N, nW, B = 2, ws * ws, 4, 2
+    nB_ = B * nW
+    rows = nB_ * T * N
+    qkv = (torch.randn(rows, 3 * C) * 0.5).bfloat16()
+    qkv[:, :C] *= (C // heads) ** -0.5
+    qkv[5, :] *= 6.0                                         # an outlier row: the per-problem amax must absorb it
+    bias = torch.randn(heads, N, N) * 0.5
+    mask = O.shift_attn_mask(2 * ws, 2 * ws, ws, ws // 2)
+    ref = _ref(qkv.float(), bias, mask, nB_, nW, T, N, heads, C)
+    biasT = bias.transpose(1, 2).contiguous().cuda()
+    maskT = mask.transpose(1, 2).contiguous().cuda()
+    out8 = hip.win_attn_fwd(qkv.cuda(), biasT, maskT, nB_=nB_, nW=nW, T=T, ws=ws, heads=heads, C=C, fp8=True).float().cpu()
+    out16 = hip.win_attn_fwd(qkv.cuda(), biasT, maskT, nB_=nB_, nW=nW, T=T, ws=ws, heads=heads, C=C).float().cpu()
+    rel8 = float((out8 - ref).norm() / ref.norm())
+    rel16 = float((out16 - ref).norm() / ref.norm())
+    print(f"fp8 attention ws={ws} C={C}: rel-L2 {rel8:.4f} (bf16 {rel16:.4f}), max err {float((out8 - ref).abs().max()):.4f} of {float(ref.abs().max()):.3f}")
+    assert torch.isfinite(out8).all()
+    assert rel16 < rel8 < 6e-2                               # really a different (coarser) arithmetic, and a bounded one
+    assert float((out8 - ref).abs().max()) < 0.12 * float(ref.abs().max())
