@@ -211,6 +211,8 @@ extern "C" int stswin_contrast_fwd(int dtype, const void* Q, long ldq, const voi
 // combine kernel adds the splits (fixed order: deterministic) and merges the max / sum-exp pairs.
 // =====================================================================================================================
 #define CB_MAX_GROUPS 8
+#define CB_NST 8              // ring depth: 8 x 18 KB = 144 KB.  With 3 stages (one stage of 0.25 us of MFMA work in flight beyond the
+                              // one being multiplied) every stage waited ~0.7 us for its copy: 0.95 us per stage, 468 TFLOP/s
 struct BankArgs {
   const void* Q; long ldq; const int* lq;
   const void* Kb; long ldk; const int* lb;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void contrast_bank_kernel(BankArgs p) {
   constexpr int FI = 2;                             // 16-row fragments per wave: wave tile 32 x 64, workgroup tile 128 x 128
   constexpr int TM = 4 * 16 * FI;
   constexpr int SUB = BF ? 2 : 8;                   // MFMA k-steps per stage (32 resp. 4 columns each)
-  constexpr int NST = 3, STAGE = 16384 + 2048;      // bank tile slice + per-wave label slots [8][64] ints
+  constexpr int NST = CB_NST, STAGE = 16384 + 2048; // bank tile slice + per-wave label slots [8][64] ints
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, l = tid & 63, w = wave_id();
   const int wr = w >> 1, wc = w & 1;
@@ -308,8 +310,16 @@ __global__ __launch_bounds__(512, 2) void contrast_bank_kernel(BankArgs p) {
 #pragma unroll
     for (int sk = 0; sk < KST; ++sk) {
       const int s = kt * KST + sk;
-      if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // 2 copies + 1 label copy per wave and stage: the next stage may stay in flight
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // 2 copies + 1 label copy per wave and stage; the NST - 2 younger stages (fewer at the tail) may stay in flight
+      switch (min(NST - 2, nst - 1 - s)) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+      }
       __builtin_amdgcn_s_barrier();
       if (s + NST - 1 < nst) issue(s + NST - 1);
       const char* Bb = smem + (s % NST) * STAGE;
@@ -461,19 +471,24 @@ extern "C" int stswin_contrast_bank_fwd(int dtype, const void* Q, long ldq, cons
   a.want_lse = (rowmax || lse) ? 1 : 0;
   const int TM = 128;
   const long row_tiles = (long)q_sets * nblk * ((q_block + TM - 1) / TM);
-  // bank splits: at least two rounds of workgroups over the 256 CUs (one 8-wave workgroup per CU), but at least 4 bank tiles
-  // of 128 rows per split
-  int splits = (int)((512 + row_tiles * groups - 1) / (row_tiles * groups));
-  const int max_by_rows = (bank_block + 511) / 512;
-  if (splits > max_by_rows) splits = max_by_rows;
-  if (splits < 1) splits = 1;
+  // bank splits (one 8-wave workgroup per CU): the split count that minimises rounds x (bank tiles per workgroup + ~2 tiles of
+  // fixed cost: query fragments, pipeline fill, partial stores), with at least 2 bank tiles of 128 rows per split
+  const int tiles_total = (bank_block + 127) / 128;
+  const int max_by_rows = tiles_total / 2 > 0 ? tiles_total / 2 : 1;
+  int splits = 1;
+  long best = -1;
+  for (int sp = 1; sp <= max_by_rows && sp <= 64; ++sp) {
+    const long wgs = row_tiles * groups * sp, rounds = (wgs + 255) / 256;
+    const long cost = rounds * ((tiles_total + sp - 1) / sp + 2);
+    if (best < 0 || cost < best) { best = cost; splits = sp; }
+  }
   while (splits > 1 && 4L * M * groups * splits > workspace_floats) --splits;
   if (4L * M * groups * splits > workspace_floats || !workspace) return -1515;
   a.splits = splits;
   a.chunk = ((bank_block + splits - 1) / splits + 127) / 128 * 128;
   a.part = workspace;
   const dim3 grid((unsigned)row_tiles, (unsigned)(groups * splits));
-  const int lds = 3 * (16384 + 2048);
+  const int lds = CB_NST * (16384 + 2048);
 #define CB_LAUNCH(TT_, KCH_)                                                                                                  \
   do {                                                                                                                        \
     static int once = (int)hipFuncSetAttribute((const void*)contrast_bank_kernel<TT_, KCH_>,                                   \
