@@ -99,32 +99,41 @@ __global__ void conv_rowmap_kernel(int* map, int frames, int Hin, int Win, int H
 template <typename T>
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* img, T* patches, long ld, int frames, int H, int W,
                                                            int Ho, int Wo) {
+  // One workgroup = TP consecutive output pixels of one output row.  The 7 input rows x (2 TP + 5) columns x 3 channels they
+  // read are staged in LDS with coalesced loads (zeros outside the image), then every thread assembles 16-byte pieces of
+  // patch rows from LDS.  (Reading the taps straight from the NCHW image - eight scattered, bounds-tested 4-byte loads per
+  // 16-byte store - ran at 1.4 TB/s of patch writes: 290 us for the 403 MB of a 16-frame 512x512 batch.)
   constexpr int PACK = TT<T>::PACK;
+  constexpr int TPMAX = 40, LW = 2 * TPMAX + 8;  // LDS row pitch (floats)
+  __shared__ float win[3][7][LW];
   const int cpr = (int)(ld / PACK);              // chunks per row (ld is a multiple of PACK)
-  const int ppb = 256 / cpr;                     // pixels per workgroup pass
-  const int ch = threadIdx.x % cpr, pl = threadIdx.x / cpr;
-  if (pl >= ppb) return;
-  int dy[PACK], dx[PACK]; long coff[PACK];
+  const int ppb = 256 / cpr;                     // pixels per pass
+  const int TP = min(TPMAX, 4 * ppb);
+  const int tiles_x = (Wo + TP - 1) / TP;
+  const int tx = blockIdx.x % tiles_x;
+  const int y = (blockIdx.x / tiles_x) % Ho, f = blockIdx.x / (tiles_x * Ho);
+  const int x0 = tx * TP, ncols = 2 * TP + 5;
+  const float* base = img + (long)f * 3 * H * W;
+  for (int i = threadIdx.x; i < 3 * 7 * ncols; i += 256) {
+    const int c = i / (7 * ncols), r = (i / ncols) % 7, q = i % ncols;
+    const int yy = 2 * y - 3 + r, xx = 2 * x0 - 3 + q;
+    win[c][r][q] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? base[((long)c * H + yy) * W + xx] : 0.f;
+  }
+  __syncthreads();
+  const int ch = threadIdx.x % cpr, pl0 = threadIdx.x / cpr;
+  if (pl0 >= ppb) return;
+  int off[PACK];                                 // LDS offset of tap element e relative to the pixel's window origin, or -1
 #pragma unroll
   for (int e = 0; e < PACK; ++e) {
-    const int col = ch * PACK + e, t = col / 3;
-    dy[e] = t < 49 ? t / 7 - 3 : -100000;        // invalid taps fail the bounds test below
-    dx[e] = t % 7 - 3;
-    coff[e] = (long)(col - 3 * t) * H * W;
+    const int col = ch * PACK + e, t = col / 3, c = col - 3 * t;
+    off[e] = t < 49 ? (c * 7 + t / 7) * LW + t % 7 : -1;
   }
-  const long npx = (long)frames * Ho * Wo;
-  for (long px = (long)blockIdx.x * ppb + pl; px < npx; px += (long)gridDim.x * ppb) {
-    const int x = px % Wo, y = (px / Wo) % Ho, f = px / ((long)Wo * Ho);
-    const float* base = img + (long)f * 3 * H * W;
+  const long row0 = ((long)f * Ho + y) * Wo;
+  for (int pl = pl0; pl < TP && x0 + pl < Wo; pl += ppb) {
     Vec16<T> o;
 #pragma unroll
-    for (int e = 0; e < PACK; ++e) {
-      const int yy = y * 2 + dy[e], xx = x * 2 + dx[e];
-      float v = 0.f;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = base[coff[e] + (long)yy * W + xx];
-      o.set(e, v);
-    }
-    *(decltype(o.v)*)(patches + px * ld + ch * PACK) = o.v;
+    for (int e = 0; e < PACK; ++e) o.set(e, off[e] >= 0 ? (&win[0][0][0])[off[e] + 2 * pl] : 0.f);
+    *(decltype(o.v)*)(patches + (row0 + x0 + pl) * ld + ch * PACK) = o.v;
   }
 }
 
@@ -602,9 +611,10 @@ extern "C" int stswin_stem_im2col(int dtype, const float* img, void* patches, lo
   if (ld < 147 || ld > 192) return -1109;
   const int pk_ = dtype == 0 ? 8 : 4;
   if (ld % pk_) return -1109;
-  const long ppb = 256 / (ld / pk_);
-  const long want = ((long)frames * Ho * Wo + ppb - 1) / ppb;
-  dim3 grid((unsigned)(want < 256 * 32 ? want : 256 * 32));
+  const int ppb = 256 / (int)(ld / pk_), TP = 4 * ppb < 40 ? 4 * ppb : 40;        // must match the kernel
+  const long want = (long)frames * Ho * ((Wo + TP - 1) / TP);
+  if (want > 0x7fffffffL) return -1109;
+  dim3 grid((unsigned)want);
   if (dtype == 0) hipLaunchKernelGGL(stem_im2col_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, img, (bf16*)patches, ld, frames, H, W, Ho, Wo);
   else hipLaunchKernelGGL(stem_im2col_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, img, (float*)patches, ld, frames, H, W, Ho, Wo);
   STSWIN_CHECK_LAUNCH();

@@ -155,3 +155,20 @@ def test_linear_pack_cast_and_transpose(dt, n, k):
     assert torch.equal(fwd, w.to(dt)) and torch.equal(tr, w.t().to(dt).contiguous())
     fwd2, none = hip.linear_pack(w, dt, want_tr=False)
     assert none is None and torch.equal(fwd2, fwd)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("frames,H,W", [(2, 37, 53), (3, 64, 96), (1, 128, 258)])
+def test_stem_im2col_matches_unfold(dtype, frames, H, W):
+    """torchvision conv1 (7x7 / stride 2 / pad 3, resnet.py:98-102) as im2col: patch column (ky*7 + kx)*3 + c, zero padded to 192,
+    against F.unfold; ragged widths (several 40-pixel tiles per row, a partial last one) and odd sizes."""
+    import torch.nn.functional as F
+    torch.manual_seed(H + W)
+    img = torch.randn(frames, 3, H, W)
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    got = hip.stem_im2col(img.cuda(), dtype, Ho, Wo).float().cpu()
+    cols = F.unfold(img, 7, padding=3, stride=2)                                  # [F][3*49][Ho*Wo], row index c*49 + tap
+    ref = cols.view(frames, 3, 49, Ho * Wo).permute(0, 3, 2, 1).reshape(frames * Ho * Wo, 147)   # column tap*3 + c
+    ref = ref.to(dtype).float()
+    assert got.shape == (frames * Ho * Wo, 192)
+    assert torch.equal(got[:, :147], ref) and float(got[:, 147:].abs().max()) == 0.0

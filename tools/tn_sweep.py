@@ -35,7 +35,7 @@ SHAPES = [  # Mk, Ni, Nj, bseg, kind
 def main():
     dev = "cuda"
     only = sys.argv[1:]
-    print(f"{'Mk':>8s} {'Ni':>5s} {'Nj':>5s} {'bseg':>5s} {'map':>4s} | " + " ".join(f"{s:>8s}" for s in ("auto", "t-auto", "t-8", "t-16", "t-32", "ring-1r", "ring-2r")))
+    print(f"{'Mk':>8s} {'Ni':>5s} {'Nj':>5s} {'bseg':>5s} {'map':>4s} | " + " ".join(f"{s:>8s}" for s in ("auto", "t-auto", "t-8", "t-16", "t-32", "t-64", "ring-16", "ring-32", "ring-1r", "ring-2r")))
     for Mk, Ni, Nj, bseg, kind in SHAPES:
         if only and kind not in only and (kind or "plain") not in only:
             continue
@@ -59,7 +59,7 @@ def main():
         t256 = ((Ni + 255) // 256) * ((Nj + 255) // 256)
         r1 = max(1, min(256 // t256, Mk // 32 // 8))
         r2 = max(1, min(512 // t256, Mk // 32 // 8))
-        for splits in (0, NORING, NORING | 8, NORING | 16, NORING | 32, RING | r1, RING | r2):
+        for splits in (0, NORING, NORING | 8, NORING | 16, NORING | 32, NORING | 64, RING | 16, RING | 32, RING | r1, RING | r2):
             try:
                 t = timeit(lambda: hip.gemm_tn(At, Bt, out, Mk=Mk, at_rows=at_rows, bt_rows=bt_rows, bseg=bseg, splits=splits))
                 cells.append(f"{t:8.1f}")
