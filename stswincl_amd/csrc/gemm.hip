@@ -1682,8 +1682,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
 // bf16 partials: 8 outputs per thread (16-byte loads) and eight splits requested before the first is consumed - the pass is a
 // pure HBM stream (splits x Ni x Nj x 2 bytes in, 4 bytes per output out); with 8-byte loads issued one split at a time it
 // ran at 2.5 TB/s (14.5 us for the 16-split 512 x 2048 weight gradients, 1.4 ms per training step over its 80 launches).
-// The loads are ORDINARY loads: non-temporal ones returned stale slab contents (weight gradients off by 100 %, different from run
-// to run) - the partials were written with plain stores by the kernel just before, possibly through another XCD's L2.
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, float* C, long ldc, int Ni, int Nj, int splits,
                                                         int overwrite, int slab_bf16) {
   if (slab_bf16) {

@@ -314,13 +314,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dout, long ld
     const long po = ((long)f * Ho + yo) * Wo + xo;
     Vec16<T> d;
     d.v = *(const decltype(d.v)*)(dout + po * ldo + c);
-    // the PACK winning-tap bytes of this piece as ONE load (they were PACK byte loads per tap: 72 per thread)
-    unsigned long long ab;
-    if constexpr (PACK == 8) ab = *(const unsigned long long*)(arg + po * C + c);
-    else ab = *(const unsigned*)(arg + po * C + c);
 #pragma unroll
     for (int e = 0; e < PACK; ++e)
-      if (((ab >> (8 * e)) & 0xffu) == (unsigned)t) acc[e] += d.get(e);
+      if (arg[po * C + c + e] == t) acc[e] += d.get(e);
   }
   Vec16<T> o;
 #pragma unroll

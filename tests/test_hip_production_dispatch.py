@@ -236,5 +236,3 @@ def test_full_size_step_bf16_vs_fp32_path():
     assert r_loss < 1e-3, (lossb, lossf)
     for n, r in r_g.items():
         assert r < 1.3 * float(yard["rel_grad/" + n]), (n, r, float(yard["rel_grad/" + n]))
-        cos = float((gb[n].double() * gf[n].double()).sum() / (gb[n].double().norm() * gf[n].double().norm()))
-        assert cos > 0.85, (n, cos)
