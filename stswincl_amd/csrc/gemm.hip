@@ -774,6 +774,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
       case E_BIAS: epilogue_body(std::integral_constant<int, E_BIAS>{}); break;
       case E_BIAS | E_SCALE: epilogue_body(std::integral_constant<int, E_BIAS | E_SCALE>{}); break;
       case E_BIAS | E_GELU | E_C2: epilogue_body(std::integral_constant<int, E_BIAS | E_GELU | E_C2>{}); break;
+      case E_BIAS | E_GELU: epilogue_body(std::integral_constant<int, E_BIAS | E_GELU>{}); break;      // fc1 of a no-grad forward
       case E_BIAS | E_RESID: epilogue_body(std::integral_constant<int, E_BIAS | E_RESID>{}); break;
       case E_RESID: epilogue_body(std::integral_constant<int, E_RESID>{}); break;
       case E_BIAS | E_GELU | E_C2 | E_C2D: epilogue_body(std::integral_constant<int, E_BIAS | E_GELU | E_C2 | E_C2D>{}); break;

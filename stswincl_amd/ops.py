@@ -236,14 +236,20 @@ class SwinBlockFn(torch.autograd.Function):
         x1 = torch.empty(M, C, dtype=dt, device=dev)
         hip.gemm_nt(o, wcast(proj_w, dt), x1, M=M, c_rows=rmap, bias=_f32(proj_b), resid=X2, r_rows=rmap,
                     flags=hip.GF_RESID)
-        n2, mean2, rstd2 = hip.layernorm_fwd(x1, _f32(n2_w), _f32(n2_b), M=M)
+        # no gradient wanted (the momentum-key passes of the contrastive step, evaluation): nothing is kept for a backward, and the
+        # fc1 epilogue skips its second output (the GELU' tile: 268 MB and a third of the epilogue's polynomial work at stage 1)
+        need_bwd = any(ctx.needs_input_grad)
+        n2, mean2, rstd2 = hip.layernorm_fwd(x1, _f32(n2_w), _f32(n2_b), M=M, save_stats=need_bwd)
         h = torch.empty(M, fc1_w.shape[0], dtype=dt, device=dev)
-        h_pre = torch.empty_like(h)
+        h_pre = torch.empty_like(h) if need_bwd else None
         # out2 = gelu'(fc1 pre-activation): the backward epilogue is then a plain multiply (Phi is shared with the GELU here)
-        hip.gemm_nt(n2, wcast(fc1_w, dt), h, M=M, bias=_f32(fc1_b), out2=h_pre, flags=hip.GF_GELU | hip.GF_C2_DGELU)
+        hip.gemm_nt(n2, wcast(fc1_w, dt), h, M=M, bias=_f32(fc1_b), out2=h_pre,
+                    flags=(hip.GF_GELU | hip.GF_C2_DGELU) if need_bwd else hip.GF_GELU)
         y2 = torch.empty(M, C, dtype=dt, device=dev)
         hip.gemm_nt(h, wcast(fc2_w, dt), y2, M=M, bias=_f32(fc2_b), resid=x1, flags=hip.GF_RESID)
-        out, mean1, rstd1 = hip.layernorm_fwd(y2, _f32(n1_w), _f32(n1_b), M=M)
+        out, mean1, rstd1 = hip.layernorm_fwd(y2, _f32(n1_w), _f32(n1_b), M=M, save_stats=need_bwd)
+        if not need_bwd:
+            return out.view(Bp, T, L, C)
         ctx.geom = geom
         ctx.dt = dt
         ctx.in_dtype = x.dtype
