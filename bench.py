@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--profile-stride", type=int, default=9,
                     help="bracket one launch in n of each kernel family (seeded random choice) with HIP events (1 = all; the "
                          "records cost host time)")
+    ap.add_argument("--bank", default="sample", choices=["sample", "batch", "world"],
+                    help="contrast workload: key set a query pixel sees - its own sample (the reference), every sample of the rank, "
+                         "or every sample of every rank (RCCL all-gather of the keys: the inter-video bank of BASELINE configs[3])")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short contrastive run that fills `secondary`")
     ap.add_argument("--secondary-steps", type=int, default=4)
     ap.add_argument("--dump-prof", default=None,
@@ -196,7 +199,7 @@ def capture(step_fn, zero_grad):
     return replay
 
 
-def contrast_run(a, ctx, steps, warmup, profile_stride, batch=8):
+def contrast_run(a, ctx, steps, warmup, profile_stride, batch=8, bank="sample"):
     """BASELINE.json configs[3] as far as the reference can run it: ConsistencyLoss (PixPro-style, 2 query + 6 momentum-key
     encoder passes) at 256x256 (224 is illegal for the window sizes), B clips/GPU, LARS over SGD-momentum as in
     main_pretrain_swinv5.py:37-47.  Reports contrastive pairs/s = 2 directions x B x HW x 5 HW per step."""
@@ -208,7 +211,7 @@ def contrast_run(a, ctx, steps, warmup, profile_stride, batch=8):
     S, B = 256, batch
     args = types.SimpleNamespace(pixpro_p=1.0, pixpro_momentum=0.99, pixpro_clamp_value=0.0, pixpro_transform_layer=1,
                                  pixpro_ins_loss_weight=0.0, pixpro_pos_ratio=0.7, data="endo18", tag="1", pretrainpth=None,
-                                 num_instances=2235, batch_size=B, epochs=150, start_epoch=1)
+                                 num_instances=2235, batch_size=B, epochs=150, start_epoch=1, pixpro_bank=bank)
     torch.manual_seed(0)
     model = ConsistencyLoss(args, input_resolution=(S // 8, S // 8)).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
@@ -235,13 +238,18 @@ def contrast_run(a, ctx, steps, warmup, profile_stride, batch=8):
         step = capture(step, lambda: opt.zero_grad(set_to_none=True))
     dt, prof, loss = timed_steps(ctx, step, steps, warmup, profile_stride)
     hw = (S // 8) ** 2
-    pairs = world * 2 * B * hw * 5 * hw * steps
+    visible = {"sample": hw, "batch": B * hw, "world": world * B * hw}[bank]      # key pixels of one key map a query pixel sees
+    pairs = world * 2 * B * hw * 5 * visible * steps
     res = {"metric": f"contrastive pairs/s, ConsistencyLoss fwd+bwd+{opt_name} (2 query + 6 key encoder passes), 256x256",
            "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16", "data": "synthetic",
            "config": {"workload": f"BASELINE.json configs[3]: PixPro-style ConsistencyLoss, {B} x 6 clips/GPU x T=4 x 3x{S}x{S} "
-                                  f"(224 is illegal for windows 8/4), per-sample label-guided loss as in the reference; {opt_name}",
+                                  f"(224 is illegal for windows 8/4), " +
+                                  ("per-sample label-guided loss as in the reference" if bank == "sample" else
+                                   f"inter-video key bank of {visible} entries per key map ({bank}: " +
+                                   ("all-gathered over the ranks)" if bank == "world" else "every sample of the rank)")) + f"; {opt_name}",
+                      "bank_entries_per_key_map": visible,
                       "clips_per_gpu": 6 * B, "parallelism": f"dp{world}",
                       "input_frames_per_s": world * 6 * B * 4 * steps / dt, "loss": float(loss),
                       "launch": "hipGraph replay of the whole step" if graphed else "eager launches"},
@@ -381,7 +389,8 @@ def main():
     from stswincl_amd import hip
     hip.load()
     if a.workload == "contrast":
-        res = contrast_run(a, ctx, a.steps, a.warmup, 0 if a.no_profile else a.profile_stride, batch=(a.batch if a.batch != 4 else 8))
+        res = contrast_run(a, ctx, a.steps, a.warmup, 0 if a.no_profile else a.profile_stride, batch=(a.batch if a.batch != 4 else 8),
+                           bank=a.bank)
     else:
         res = seg_run(a, ctx)
         if not a.no_secondary:

@@ -41,6 +41,10 @@ rm -rf /tmp/prof_ktc
 rocprofv3 --output-format csv --kernel-trace --stats -d /tmp/prof_ktc -o kt -- python3 bench.py --workload contrast --steps 4 --warmup 2 --no-profile --graph 0 > $OUT/bench_contrast_under_rocprof.log 2>&1
 KTC=$(find /tmp/prof_ktc -name "*kernel_trace.csv" | head -1)
 [ -n "$KTC" ] && python3 tools/prof_summary.py "$KTC" --last-ms 120 --top 50 > $OUT/${TAG}_contrast_steady_state_kernels.txt 2>&1
+python3 bench.py --workload contrast --bank batch --steps 6 --warmup 2 > $OUT/bench_contrast_bank.log 2>&1
+tail -1 $OUT/bench_contrast_bank.log > $OUT/${TAG}_bench_contrast_bank_line.json
+python3 bench.py --batch 8 --steps 8 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_b8.log 2>&1
+tail -1 $OUT/bench_b8.log > $OUT/${TAG}_bench_batch8_line.json
 # 5. kernel micro-benchmarks
 python3 tools/bench_attn.py > $OUT/${TAG}_attention_kernels.txt 2>&1
 python3 tools/bench_contrast.py > $OUT/${TAG}_contrast_kernels.txt 2>&1
