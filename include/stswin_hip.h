@@ -34,6 +34,9 @@ extern "C" {
                                     * receives (plain stores, no atomics) the column sums of output rows 128b..128b+127;
                                     * stswin_cs_reduce then adds the rows into the bias gradient.  M/128 same-address atomics cost
                                     * 38 us on a 65536 x 512 output; the table + reduce cost ~5 us (N % 4 == 0). */
+#define STSWIN_GF_CS_SQ 65536   /* with STSWIN_GF_CS_PARTIAL: `colsum` holds TWO planes [2][2*ceil(M/256)][N]; the second receives the column
+                                  * sums of SQUARES of the same values: the BatchNorm statistics of a convolution output come out of
+                                  * the convolution (stswin_cs_group_reduce + stswin_bn_finalize with x = NULL) */
 #define STSWIN_GF_BIG 128       /* tuning: force the 256x256 4-stage-ring kernel (bf16) */
 #define STSWIN_GF_MID 512       /* tuning: 256x128x32 tile, 3-stage ring, 2 workgroups per CU (bf16) */
 #define STSWIN_GF_NOPIPE 1024   /* tuning: 256x256 ring kernel without software-pipelined LDS fragment reads */
@@ -202,6 +205,17 @@ int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, l
  * statistics of base18.py:86-89 need no frame-major copy of the batch. */
 int stswin_colstats(int dtype, const void* x, long ldx, float* sum, float* sumsq, int M, int C, int groups, int unit_rows,
                     void* stream);
+/* sum / sumsq [groups][N] of the statistic groups from the two-plane table a STSWIN_GF_CS_SQ stswin_gemm_nt wrote (same M, N; groups
+ * of whole 256-row tiles: contiguous, or interleaved units of unit_rows rows).  Then stswin_bn_finalize with x = NULL (raw sums, no
+ * pivot) replaces stswin_colstats: nn.BatchNorm2d batch statistics (resnet.py:42-51, ASPP.py:37-50) without a pass over the tensor. */
+int stswin_cs_group_reduce(const float* table, int M, int N, int groups, int unit_rows, float* sum, float* sumsq, void* stream);
+
+/* BatchNorm(train) statistics from a gemm_nt STSWIN_GF_CS_SQ table in one launch: mean / rstd [groups][N] and the running
+ * statistic updates applied group by group in order (the sequential per-frame BatchNorm calls of seg18/net/Ours/base18.py:86-89;
+ * torch.nn.BatchNorm2d semantics: biased variance to normalise, unbiased into running_var).  Same group geometry rules as
+ * stswin_cs_group_reduce; groups <= 16.  running_* may be NULL. */
+int stswin_bn_table_finalize(const float* table, int M, int N, int groups, int unit_rows, float* mean, float* rstd,
+                             float* running_mean, float* running_var, float eps, float momentum, void* stream);
 int stswin_bn_finalize(int dtype, const void* x, long ldx, const float* sum, const float* sumsq, float* mean, float* rstd,
                        float* running_mean, float* running_var, int M, int C, int groups, float eps, float momentum,
                        int unit_rows, void* stream);
@@ -214,7 +228,10 @@ int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx,
                   float* s1, float* s2, void* dx, long lddx, void* dresid, long lddr,
                   int M, int C, int groups, int relu, int training,
                   int phase /* 0 both passes, 1 reduce only, 2 dx only: SyncBatchNorm all-reduces s1/s2 in between */,
-                  long rows_total /* rows per group over all ranks (0 = local) */, int unit_rows, void* stream);
+                  long rows_total /* rows per group over all ranks (0 = local) */, int unit_rows,
+                  float* group_sums /* optional fp32 [2][C], written by the dx pass: s1 | s2 summed over the groups = the
+                                       bias | weight gradients of the BatchNorm (ASPP.py:37-50 etc.: autograd of nn.BatchNorm2d) */,
+                  void* stream);
 /* out[r][c] (+)= v[r / (M/groups)][c] * scale : image-pool broadcast (ASPP.py:46) and avg-pool backward */
 int stswin_rows_broadcast(int dtype, const float* v, void* out, long ldo, int M, int C, int groups, float scale,
                           int accumulate, void* stream);

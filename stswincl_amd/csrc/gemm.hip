@@ -39,6 +39,8 @@ enum {
   GF_STREAM = 1 << 25,    // tuning: persistent streaming 256x256 variant (measured no faster: both wave rows idle through each other's epilogue)
   GF_DUO = 1 << 24,       // tuning: 128x256 tiles, 4 waves, two workgroups per CU
   GF_CS_PARTIAL = 1 << 15,  // colsum is fp32 [2*ceil(M/256)][N]: row b = column sums of output rows 128b..128b+127, stored (not added)
+  GF_CS_SQ = 1 << 16,       // with GF_CS_PARTIAL: a second table plane (offset 2*ceil(M/256)*N floats) receives the column sums of
+                            // SQUARES of the same values - the BatchNorm statistics of a convolution output without a pass over it
   GF_NOSTREAM = 1 << 23,  // tuning: 256x256 ring without the persistent streaming variant
   GF_NOREGEPI = 1 << 22,  // tuning: 256x256 ring with the LDS-staged fp32 epilogue instead of the register epilogue
   GF_WAVES4 = 64,    // tuning: 4 waves of 64x64 per tile instead of the default 8 waves of 64x32 (4 waves/SIMD)
@@ -60,6 +62,11 @@ struct GemmNT {
 // Column sum `v` of output rows [128*blk, 128*blk + 128*nblk) of column gn.  Default: one fp32 atomic per (tile, column) -
 // M/128 same-address atomics serialise at ~40 ns each (38 us on a 65536 x 512 output).  GF_CS_PARTIAL: plain stores into
 // per-block rows that cs_reduce_kernel sums afterwards (every (block, column) cell is written by exactly one tile).
+__device__ __forceinline__ void cs_emit_sq(const GemmNT& p, int blk, int nblk, int gn, float v2) {
+  float* t2 = p.colsum + (long)(2 * ((p.M + 255) / 256)) * p.N;
+  t2[(long)blk * p.N + gn] = v2;
+  if (nblk == 2) t2[(long)(blk + 1) * p.N + gn] = 0.f;
+}
 __device__ __forceinline__ void cs_emit(const GemmNT& p, int blk, int nblk, int gn, float v) {
   if (p.flags & GF_CS_PARTIAL) {
     p.colsum[(long)blk * p.N + gn] = v;
@@ -318,9 +325,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
         ct[(wr * 64 + i * 16 + 4 * fq + r) * BN + wc * (16 * JN) + j * 16 + fr] = acc[i][j][r];
   __syncthreads();
 
-  float bv[8], cs[8];
+  float bv[8], cs[8], cs2[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && e < ncols) ? p.bias[gn0 + e] : 0.f; cs[e] = 0.f; }
+  for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && e < ncols) ? p.bias[gn0 + e] : 0.f; cs[e] = 0.f; cs2[e] = 0.f; }
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
     const int rr = pass * RG + tid / CG;
@@ -334,6 +341,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
       for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
     }
     epi_piece<T>(p, v, bv, cs, gm, gn0, ncols, rp[pass], pre_r);
+    if (p.flags & GF_CS_SQ) {                            // (epi_piece leaves the stored values in v)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs2[e] += v[e] * v[e];
+    }
   }
   if (p.colsum) {                 // fold the 16 row groups through LDS (the C image is no longer needed), 1 atomic / column
     __syncthreads();
@@ -345,6 +356,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
       for (int k = 0; k < RG; ++k) t += ct[k * BN + tid];
       cs_emit(p, m0 / 128, BM / 128, n0 + tid, t);
+    }
+    if (p.flags & GF_CS_SQ) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ct[(tid / CG) * BN + c8 + e] = cs2[e];
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < RG; ++k) t += ct[k * BN + tid];
+        cs_emit_sq(p, m0 / 128, BM / 128, n0 + tid, t);
+      }
     }
   }
 }
@@ -543,7 +566,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   // The per-tile flag combination is resolved ONCE (epi_dispatch below) into a straight-line instantiation of this body:
   // with the flags tested per fragment the 32 fragments of a wave spent 3.6 us of a 24 us tile in scalar branches
   // (tools/gemm_timeline.py).  MD >= 0: compile-time mode bits; MD < 0: generic fallback testing the runtime flags.
-  enum { E_BIAS = 1, E_SCALE = 2, E_GELU = 4, E_C2 = 8, E_RESID = 16, E_DGELU = 32, E_COLSUM = 64, E_RELU = 128, E_MULR = 256, E_C2D = 512 };
+  enum { E_BIAS = 1, E_SCALE = 2, E_GELU = 4, E_C2 = 8, E_RESID = 16, E_DGELU = 32, E_COLSUM = 64, E_RELU = 128, E_MULR = 256, E_C2D = 512,
+         E_COLSQ = 1024 };
   auto epilogue_body = [&](auto tag) __attribute__((always_inline)) {
     constexpr int MD = decltype(tag)::value;
 #define EPI_HAS(bit, rt) (MD >= 0 ? ((MD & (bit)) != 0) : (rt))
@@ -554,6 +578,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     const bool do_resid = EPI_HAS(E_RESID, (p.flags & GF_RESID) != 0), do_dgelu = EPI_HAS(E_DGELU, (p.flags & GF_MUL_DGELU) != 0);
     const bool do_cs = EPI_HAS(E_COLSUM, p.colsum != nullptr) && !dbg_ts, do_relu = EPI_HAS(E_RELU, (p.flags & GF_RELU) != 0);
     const bool do_mulr = EPI_HAS(E_MULR, (p.flags & GF_MUL_R) != 0), c2_dgelu = EPI_HAS(E_C2D, (p.flags & GF_C2_DGELU) != 0);
+    const bool do_sq = do_cs && EPI_HAS(E_COLSQ, (p.flags & GF_CS_SQ) != 0);
     const bool has_r = do_resid || do_dgelu || do_mulr;
     const int colb = n0 + wc * TN + 4 * fq;           // + j*16: first of this lane's 4 columns
     f32x4 bj[FJ];
@@ -653,9 +678,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
         for (int j = 0; j < FJ; ++j) asm volatile("" : "+v"(bj[j]));
       }
     }
-    f32x4 cs[FJ];
+    f32x4 cs[FJ], cs2[FJ];
 #pragma unroll
-    for (int j = 0; j < FJ; ++j) cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FJ; ++j) { cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; cs2[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     // R (residual / GELU' factor): the whole [BM][BN] tile comes in by LDS-DMA, straight into the image positions that
     // the results will overwrite (same row-major layout, same chunk ^ row swizzle, so a lane reads its 8-byte piece and
     // later writes its 8-byte result to the very same address).  16 bytes per lane and whole 512-byte rows per request
@@ -717,7 +742,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
           }
         }
         if (do_relu) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
-        if (do_cs) { if (row_ok) cs[j] += v; }
+        if (do_cs) { if (row_ok) { cs[j] += v; if (do_sq) cs2[j] += v * v; } }
         put(i, j, v);
         if (do_gelu || do_dgelu) __builtin_amdgcn_sched_barrier(0);   // one fragment's polynomial temporaries at a time
       }
@@ -736,6 +761,10 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
           if (fr == 0 && gn < p.N) {                   // (register epilogue = SWAP kernels only: TM is 128 there)
             if (TM % 128 == 0) cs_emit(p, (m0 + wr * TM) / 128, TM / 128, gn, t);
             else atomicAdd(p.colsum + gn, t);
+          }
+          if (do_sq) {
+            const float t2 = sum16(cs2[j][e]);
+            if (fr == 0 && gn < p.N && TM % 128 == 0) cs_emit_sq(p, (m0 + wr * TM) / 128, TM / 128, gn, t2);
           }
         }
     }
@@ -767,7 +796,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     const int mode = (p.bias ? E_BIAS : 0) | (p.scale_cols > 0 ? E_SCALE : 0) | ((p.flags & GF_GELU) ? E_GELU : 0) |
                      (p.C2 ? E_C2 : 0) | ((p.flags & GF_RESID) ? E_RESID : 0) | ((p.flags & GF_MUL_DGELU) ? E_DGELU : 0) |
                      (p.colsum ? E_COLSUM : 0) | ((p.flags & GF_RELU) ? E_RELU : 0) | ((p.flags & GF_MUL_R) ? E_MULR : 0) |
-                     ((p.flags & GF_C2_DGELU) ? E_C2D : 0);
+                     ((p.flags & GF_C2_DGELU) ? E_C2D : 0) | ((p.colsum && (p.flags & GF_CS_SQ)) ? E_COLSQ : 0);
     switch (mode) {                                   // the combinations the Swin / conv paths issue; anything else: generic
       case 0: epilogue_body(std::integral_constant<int, 0>{}); break;
 #ifndef STSWIN_DEBUG_ONLY_PLAIN_EPI                   // diagnosis build: a kernel with ONE epilogue body (code size experiment)
@@ -781,6 +810,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
       case E_MULR | E_COLSUM: epilogue_body(std::integral_constant<int, E_MULR | E_COLSUM>{}); break;
       case E_DGELU | E_COLSUM: epilogue_body(std::integral_constant<int, E_DGELU | E_COLSUM>{}); break;
       case E_COLSUM: epilogue_body(std::integral_constant<int, E_COLSUM>{}); break;
+      case E_COLSUM | E_COLSQ: epilogue_body(std::integral_constant<int, E_COLSUM | E_COLSQ>{}); break;          // conv + BatchNorm statistics
+      case E_BIAS | E_COLSUM | E_COLSQ: epilogue_body(std::integral_constant<int, E_BIAS | E_COLSUM | E_COLSQ>{}); break;
       default: epilogue_body(std::integral_constant<int, -1>{}); break;
 #else
       default: epilogue_body(std::integral_constant<int, E_COLSUM>{}); break;   // (the timeline runs pass the stamp buffer as colsum)
@@ -1779,8 +1810,13 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
   const int bk = dtype == 0 ? 64 : 32;
   if (Kseg <= 0 || Kseg % bk || S <= 0) return -1001;
   if ((flags & GF_ACCUM) && !(flags & GF_OUT_F32)) return -1002;
-  if ((flags & GF_CS_PARTIAL) && colsum && ((M + 127) / 128) % 2)   // 128-row tiles never touch the last row of the [2*ceil(M/256)][N] table
+  if ((flags & GF_CS_SQ) && (!(flags & GF_CS_PARTIAL) || !colsum || (flags & (GF_MID | GF_HALF | GF_DUO | GF_STREAM | GF_NOREGEPI))))
+    return -1006;                                            // squares need the per-block table and a kernel that writes them
+  if ((flags & GF_CS_PARTIAL) && colsum && ((M + 127) / 128) % 2) { // 128-row tiles never touch the last row of the [2*ceil(M/256)][N] table
     (void)hipMemsetAsync(colsum + (long)(2 * ((M + 255) / 256) - 1) * N, 0, sizeof(float) * N, (hipStream_t)stream);
+    if (flags & GF_CS_SQ)
+      (void)hipMemsetAsync(colsum + (long)(4 * ((M + 255) / 256) - 1) * N, 0, sizeof(float) * N, (hipStream_t)stream);
+  }
   GemmNT p{A, lda, a_rows, B, ldb, C, ldc, c_rows, C2, ldc2, bias, R, ldr, r_rows, M, N, Kseg, S, scale, scale_cols, flags, colsum};
   const int nblk = ((M + 127) / 128) * ((N + 127) / 128);
   static int once = set_lds_once((const void*)gemm_nt_kernel<bf16, 4>) | set_lds_once((const void*)gemm_nt_kernel<float, 4>) |
@@ -1826,6 +1862,7 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
                         (!R || (uintptr_t)R % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0);
     static int once_swap = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)once_swap;
+    if ((flags & GF_CS_SQ) && (!regepi || (flags & GF_NOPIPE))) return -1006;   // (only the register epilogue sums squares)
     // persistent streaming variant: plain Linear GEMMs (S = 1, no A gather) with the register epilogue
     const bool streamk = regepi && S == 1 && !a_rows && (flags & GF_STREAM) && !(flags & (GF_NOPIPE | GF_NOSTREAM));
     if (streamk) {

@@ -92,7 +92,7 @@ __global__ void bn_finalize_kernel(const T* x, long ldx, const float* sum, const
   if (c >= C) return;
   float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
   for (int g = 0; g < G; ++g) {
-    const float pivot = to_f32<T>(x[group_first_row(g, group_rows, unit) * ldx + c]);
+    const float pivot = x ? to_f32<T>(x[group_first_row(g, group_rows, unit) * ldx + c]) : 0.f;   // (sums from a GEMM epilogue: raw)
     const float ms = sum[(long)g * C + c] / group_rows;
     const float var = fmaxf(sumsq[(long)g * C + c] / group_rows - ms * ms, 0.f);
     mean[(long)g * C + c] = pivot + ms;
@@ -200,13 +200,23 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* dy, long lddy, 
                                                          const float* s1, const float* s2, T* dx, long lddx, T* dres,
                                                          long lddr, int C, int group_rows, int chunks_per_group,
                                                          int rows_per_chunk, int relu, int training, int cpb, float inv_n,
-                                                         const float* beta, int unit) {
+                                                         const float* beta, int unit, float* gsum) {
   constexpr int PACK = TT<T>::PACK;
   const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
   const int c = (blockIdx.x * cpb + cp) * PACK;
   if (c >= C) return;
   const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
   const long gr0 = group_row0(g, ch, rows_per_chunk, group_rows, unit, gridDim.y / chunks_per_group);
+  if (gsum && blockIdx.y == 0 && rl == 0) {              // parameter gradients: dbeta | dgamma = s1 | s2 summed over the groups
+    const int G = gridDim.y / chunks_per_group;
+#pragma unroll
+    for (int e = 0; e < PACK; ++e) {
+      float a = 0.f, b = 0.f;
+      for (int gg = 0; gg < G; ++gg) { a += s1[(long)gg * C + c + e]; b += s2[(long)gg * C + c + e]; }
+      gsum[c + e] = a;
+      gsum[C + c + e] = b;
+    }
+  }
   // dx = A*dyr + B*x + D  with  A = gamma*rstd, B = -A*rstd*s2/n, D = -A*s1/n - B*mean      (training)
   const bool remask = relu && y == nullptr;              // mask recomputed exactly as in bn_bwd_reduce_kernel
   float ka[8], kb[8], kd[8], mu[8], rs[8], ga[8], be[8];
@@ -504,7 +514,7 @@ extern "C" int stswin_bn_apply(int dtype, const void* x, long ldx, const float* 
 extern "C" int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const void* y, long ldy,
                              const float* mean, const float* rstd, const float* gamma, const float* beta, float* s1, float* s2,
                              void* dx, long lddx, void* dresid, long lddr, int M, int C, int groups, int relu, int training,
-                             int phase, long rows_total, int unit_rows, void* stream) {
+                             int phase, long rows_total, int unit_rows, float* gsum, void* stream) {
   const int pk = PACK_OF(dtype);
   if (C % pk || ldx % pk || lddy % pk || lddx % pk || (relu && y && ldy % pk) || groups <= 0 || M % groups) return -1403;
   if (relu && !y && !beta) return -1404;               // no stored output: the mask is recomputed and needs beta
@@ -523,8 +533,8 @@ extern "C" int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb, gamma, beta, unit_rows),
              hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb, gamma, beta, unit_rows));
   if (phase != 1)
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16>, g2, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, gamma, s1, s2, (bf16*)dx, lddx, (bf16*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n, beta, unit_rows),
-             hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, gamma, s1, s2, (float*)dx, lddx, (float*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n, beta, unit_rows));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16>, g2, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, gamma, s1, s2, (bf16*)dx, lddx, (bf16*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n, beta, unit_rows, gsum),
+             hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, gamma, s1, s2, (float*)dx, lddx, (float*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n, beta, unit_rows, gsum));
   STSWIN_CHECK_LAUNCH();
   return 0;
 }
@@ -767,6 +777,119 @@ extern "C" int stswin_upsample_argmax(int dtype, const void* logits, unsigned ch
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 0) hipLaunchKernelGGL(upsample_argmax_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)logits, labels, gt, counts, frames, nc, h, w, H, W);
   else hipLaunchKernelGGL(upsample_argmax_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, labels, gt, counts, frames, nc, h, w, H, W);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+
+// ----------------------------------------------------------------------------------------- statistics from a GEMM epilogue
+// A convolution GEMM launched with STSWIN_GF_CS_PARTIAL | STSWIN_GF_CS_SQ leaves per-128-row-block column sums and sums of
+// squares of its output in a table [2 planes][nb = 2*ceil(M/256)][N]; this folds the blocks of every BatchNorm statistic group
+// (contiguous groups, or interleaved units of unit_rows rows: group = unit index % G) into sum / sumsq [G][N] for
+// stswin_bn_finalize (x = NULL: no pivot) - the colstats pass over the activation (one of the three HBM passes of a train-mode
+// BatchNorm forward) disappears.  Grid (N / 64, G); 256 threads = 64 columns x 4 block lanes.
+__global__ __launch_bounds__(256) void cs_group_reduce_kernel(const float* tab, int nb, int N, int G, int group_rows, int unit,
+                                                               float* sum, float* sumsq) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, g = blockIdx.y;
+  float a = 0.f, b = 0.f;
+  if (c < N) {
+    const float* t1 = tab + c;
+    const float* t2 = tab + (long)nb * N + c;
+    if (unit <= 0) {
+      const int b0 = (int)((long)g * group_rows / 128), b1 = (int)((long)(g + 1) * group_rows / 128);
+      for (int k = b0 + bl; k < b1; k += 4) { a += t1[(long)k * N]; b += t2[(long)k * N]; }
+    } else {
+      const int bpu = unit / 128, units = (int)((long)G * group_rows / unit);
+      for (int u = g; u < units; u += G)
+        for (int k = u * bpu + bl; k < (u + 1) * bpu; k += 4) { a += t1[(long)k * N]; b += t2[(long)k * N]; }
+    }
+  }
+  red[0][bl][cl] = a;
+  red[1][bl][cl] = b;
+  __syncthreads();
+  if (bl == 0 && c < N) {
+    sum[(long)g * N + c] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    sumsq[(long)g * N + c] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+  }
+}
+
+// BatchNorm statistics straight from a gemm_nt GF_CS_SQ table: group sums over the 128-row blocks, mean / rstd and the
+// sequential running-statistic updates (group 0, 1, ... as the per-frame calls of base18.py:86-89 would make them) in ONE
+// launch.  1024 threads = 16 columns x 64 block lanes (a 262144-row output has 2048 table rows: 32 independent loads per
+// lane and plane); final combination in double.
+__global__ __launch_bounds__(1024) void bn_table_finalize_kernel(const float* tab, int nb, int N, int G, int group_rows, int unit,
+                                                                 float* mean, float* rstd, float* running_mean, float* running_var,
+                                                                 float eps, float momentum) {
+  extern __shared__ float red[];                       // [G][2][16 waves][16 columns]
+  const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 16 + cl;
+  const bool ok = c < N;
+  const float* t1 = tab + (ok ? c : 0);
+  const float* t2 = t1 + (long)nb * N;
+  for (int g = 0; g < G; ++g) {
+    float a = 0.f, b = 0.f;
+    if (unit <= 0) {
+      const int b0 = (int)((long)g * group_rows / 128), b1 = (int)((long)(g + 1) * group_rows / 128);
+#pragma unroll 4
+      for (int k = b0 + bl; k < b1; k += 64) { a += t1[(long)k * N]; b += t2[(long)k * N]; }
+    } else {
+      const int bpu = unit / 128, total = (int)((long)group_rows / 128);      // blocks of this group: unit u = g + G * (j / bpu)
+#pragma unroll 4
+      for (int j = bl; j < total; j += 64) {
+        const long k = ((long)g + (long)G * (j / bpu)) * bpu + j % bpu;
+        a += t1[k * N];
+        b += t2[k * N];
+      }
+    }
+    a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+    a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+    if ((threadIdx.x & 63) < 16) {
+      red[((g * 2 + 0) * 16 + wave) * 16 + cl] = a;
+      red[((g * 2 + 1) * 16 + wave) * 16 + cl] = b;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x >= 16 || !ok) return;
+  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+  for (int g = 0; g < G; ++g) {
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      s += (double)red[((g * 2 + 0) * 16 + w) * 16 + cl];
+      q += (double)red[((g * 2 + 1) * 16 + w) * 16 + cl];
+    }
+    const double m = s / group_rows;
+    const float var = fmaxf((float)(q / group_rows - m * m), 0.f);
+    mean[(long)g * N + c] = (float)m;
+    rstd[(long)g * N + c] = rsqrtf(var + eps);
+    rm = (1.f - momentum) * rm + momentum * (float)m;
+    rv = (1.f - momentum) * rv + momentum * var * ((float)group_rows / (float)max(group_rows - 1, 1));
+  }
+  if (running_mean) { running_mean[c] = rm; running_var[c] = rv; }
+}
+
+extern "C" int stswin_bn_table_finalize(const float* table, int M, int N, int groups, int unit_rows, float* mean, float* rstd,
+                                        float* running_mean, float* running_var, float eps, float momentum, void* stream) {
+  if (M <= 0 || N <= 0 || groups <= 0 || groups > 16 || M % groups) return -1413;
+  const int gr = M / groups;
+  if (unit_rows > 0 ? (unit_rows % 256 || M % ((long)groups * unit_rows)) : (gr % 256)) return -1414;   // whole 256-row tiles per group
+  const int nb = 2 * ((M + 255) / 256);
+  hipLaunchKernelGGL(bn_table_finalize_kernel, dim3((unsigned)((N + 15) / 16)), dim3(1024), (size_t)groups * 2 * 16 * 16 * sizeof(float),
+                     (hipStream_t)stream, table, nb, N, groups, gr, unit_rows, mean, rstd, running_mean, running_var, eps, momentum);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_cs_group_reduce(const float* table, int M, int N, int groups, int unit_rows, float* sum, float* sumsq,
+                                      void* stream) {
+  if (M <= 0 || N <= 0 || groups <= 0 || M % groups) return -1411;
+  const int gr = M / groups;
+  if (unit_rows > 0 ? (unit_rows % 256 || M % ((long)groups * unit_rows)) : (gr % 256)) return -1412;   // whole 256-row tiles per group
+  const int nb = 2 * ((M + 255) / 256);
+  hipLaunchKernelGGL(cs_group_reduce_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)groups), dim3(256), 0, (hipStream_t)stream, table, nb,
+                     N, groups, gr, unit_rows, sum, sumsq);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

@@ -140,7 +140,7 @@ class ConvTokFn(torch.autograd.Function):
     whose B operand is tap-segmented.  ASPP.py:13-31, base18.py:60-77, resnet.py:31-38, PixPro_swin_v5.py:24-26."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, geom, lin, lout):
+    def forward(ctx, x, weight, bias, geom, lin, lout, want_stats=False):
         frames, Hin, Win, k, stride, pad, dil = geom
         dt = compute_dtype(x)
         X = x.detach().to(dt)
@@ -148,14 +148,20 @@ class ConvTokFn(torch.autograd.Function):
         Mi, Mo = frames * Hin * Win, frames * Hout * Wout
         assert X.shape == (Mi, lin.width) and X.stride(1) == 1 and weight.shape[-1] == k
         y = torch.empty(Mo, lout.width, dtype=dt, device=x.device)
+        # want_stats: the GEMM epilogue also leaves per-128-row-block column sums and sums of squares of y (the statistics
+        # of the BatchNorm that follows: no colstats pass over y)
+        tab = hip.stats_table(Mo, lout.width, x.device) if want_stats else None
         hip.gemm_nt(X, _conv_mats(weight, dt, lin, lout, False), y, M=Mo, a_rows=fmap, S=k * k,
-                    bias=lout.pad_vec(bias) if bias is not None else None)
+                    bias=lout.pad_vec(bias) if bias is not None else None, stats_out=tab)
         ctx.cfg = (k, lin, lout, dt, x.dtype, bias is not None, Mi, Mo)
         ctx.save_for_backward(X, weight, fmap, imap)
+        if want_stats:
+            ctx.mark_non_differentiable(tab)
+            return y, tab
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dtab=None):
         X, weight, fmap, imap = ctx.saved_tensors
         k, lin, lout, dt, in_dtype, has_bias, Mi, Mo = ctx.cfg
         co, ci = weight.shape[:2]
@@ -181,18 +187,30 @@ class ConvTokFn(torch.autograd.Function):
             dbp = hip.zeros(lout.width, device=X.device)
             hip.colsum(g, dbp)
             db = lout.unpad_vec(dbp)
-        return dx, dw.reshape(co, ci, k, k), db, None, None, None
+        return dx, dw.reshape(co, ci, k, k), db, None, None, None, None
 
 
-def conv_tokens(x_tok, conv: torch.nn.Conv2d, frames, Hin, Win, lin=None, lout=None):
-    """Apply an nn.Conv2d's parameters to a token matrix; returns (y_tokens, Hout, Wout)."""
+_FUSED_BN_STATS = os.environ.get("STSWIN_NO_FUSED_BN_STATS") != "1"      # (A/B switch)
+
+
+def conv_tokens(x_tok, conv: torch.nn.Conv2d, frames, Hin, Win, lin=None, lout=None, stats=None):
+    """Apply an nn.Conv2d's parameters to a token matrix; returns (y_tokens, Hout, Wout), or with stats = True / False
+    (y_tokens, Hout, Wout, table or None): the BatchNorm statistics table of y for batchnorm_tokens(stats=...) when asked for
+    (True: a train-mode BatchNorm follows) and the output is eligible (bf16 path, >= 8192 rows in whole 256-row tiles)."""
     k, stride, pad, dil = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
     lin = lin or Layout.dense(conv.in_channels)
     lout = lout or Layout.dense(conv.out_channels)
-    y = ConvTokFn.apply(x_tok, conv.weight, conv.bias, (frames, Hin, Win, k, stride, pad, dil), lin, lout)
     Hout = (Hin + 2 * pad - dil * (k - 1) - 1) // stride + 1
     Wout = (Win + 2 * pad - dil * (k - 1) - 1) // stride + 1
-    return y, Hout, Wout
+    Mo = frames * Hout * Wout
+    want = (stats and _FUSED_BN_STATS and compute_dtype(x_tok) == torch.bfloat16 and Mo >= 8192 and Mo % 256 == 0
+            and lout.width % 4 == 0)
+    geom = (frames, Hin, Win, k, stride, pad, dil)
+    if want:
+        y, tab = ConvTokFn.apply(x_tok, conv.weight, conv.bias, geom, lin, lout, True)
+    else:
+        y, tab = ConvTokFn.apply(x_tok, conv.weight, conv.bias, geom, lin, lout), None
+    return (y, Hout, Wout) if stats is None else (y, Hout, Wout, tab)
 
 
 class StemConvFn(torch.autograd.Function):
@@ -275,7 +293,7 @@ class BNTokFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, relu, resid, groups, lay, eps, momentum, world=1,
-                unit=0):
+                unit=0, stats=None):
         dt = compute_dtype(x)
         X = x.detach().to(dt)
         M, Cp = X.shape
@@ -309,12 +327,21 @@ class BNTokFn(torch.autograd.Function):
             running_var.copy_(lay.unpad_vec(rv))
             mean, rstd = mean.contiguous(), rstd.contiguous()
         elif training:
-            s, ss = hip.colstats(X, groups=groups, unit=unit)
+            # statistics: from the producing convolution's epilogue table when one came along and the groups are whole 256-row
+            # tiles (raw sums, no pivot), else a colstats pass over X (pivot-shifted sums)
+            raw = stats is not None and groups <= 16 and ((unit % 256 == 0) if unit > 0 else ((M // groups) % 256 == 0))
+
+            def finalize(rm, rv):
+                if raw:                                   # table -> mean / rstd / running statistics in one launch
+                    return hip.bn_table_finalize(stats, M, rm, rv, groups, eps, momentum, unit=unit)
+                s, ss = hip.colstats(X, groups=groups, unit=unit)
+                return hip.bn_finalize(X, s, ss, rm, rv, groups, eps, momentum, unit=unit)
+
             if lay.is_identity:
-                mean, rstd = hip.bn_finalize(X, s, ss, running_mean, running_var, groups, eps, momentum, unit=unit)
+                mean, rstd = finalize(running_mean, running_var)
             else:
                 rm, rv = lay.pad_vec(running_mean), lay.pad_vec(running_var, 1.0)
-                mean, rstd = hip.bn_finalize(X, s, ss, rm, rv, groups, eps, momentum, unit=unit)
+                mean, rstd = finalize(rm, rv)
                 running_mean.copy_(lay.unpad_vec(rm))
                 running_var.copy_(lay.unpad_vec(rv))
         else:
@@ -348,7 +375,12 @@ class BNTokFn(torch.autograd.Function):
                        sums=(both[0].contiguous(), both[1].contiguous()), rows_total=rows_total, beta=bp, unit=ctx.unit)
             s1, s2 = loc1, loc2
         else:
-            s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, beta=bp, unit=ctx.unit)
+            # (the dx pass also writes s1 | s2 summed over the statistic groups: the parameter gradients, no torch reduction)
+            gs = torch.empty(2, X.shape[1], dtype=torch.float32, device=X.device) if groups > 1 else None
+            s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, beta=bp, unit=ctx.unit,
+                                group_sums=gs)
+            if gs is not None:
+                s1, s2, groups = gs[0:1], gs[1:2], 1
         if groups > 1:                                   # s1 / s2 are the two halves of one [2][groups][C] buffer: one reduce
             if s1._base is not None and s2._base is s1._base and s2.storage_offset() == s1.storage_offset() + s1.numel():
                 both = torch.as_strided(s1, (2, groups, s1.shape[-1]), (groups * s1.shape[-1], s1.shape[-1], 1)).sum(1)
@@ -358,7 +390,7 @@ class BNTokFn(torch.autograd.Function):
         dgamma = lay.unpad_vec(s2[0])
         dbeta = lay.unpad_vec(s1[0])
         return (dx.to(in_dtype), dgamma, dbeta, None, None, None, None, dres.to(in_dtype) if has_res else None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 _NBT_PENDING = None
@@ -416,7 +448,7 @@ class deferred_bn_counters:
 
 
 def batchnorm_tokens(x, bn: torch.nn.BatchNorm2d, relu=True, resid=None, groups=1, lay: Optional[Layout] = None,
-                     il_frames: int = 0):
+                     il_frames: int = 0, stats=None):
     """il_frames = F > 0: the rows are F frames stored clip-major and statistic group g = frames g, g + groups, ... (frame t
     of every clip); 0: `groups` contiguous row blocks."""
     lay = lay or Layout.dense(bn.num_features)
@@ -435,9 +467,11 @@ def batchnorm_tokens(x, bn: torch.nn.BatchNorm2d, relu=True, resid=None, groups=
             _NBT_PENDING.append((bn.num_batches_tracked, groups))
         else:
             bn.num_batches_tracked += groups
+    world = _sync_world(bn) if training else 1
     return BNTokFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, relu, resid, groups, lay,
-                         bn.eps, bn.momentum if bn.momentum is not None else 0.1, _sync_world(bn) if training else 1,
-                         (x.shape[0] // il_frames) if (il_frames and groups > 1) else 0)
+                         bn.eps, bn.momentum if bn.momentum is not None else 0.1, world,
+                         (x.shape[0] // il_frames) if (il_frames and groups > 1) else 0,
+                         stats if (training and world == 1) else None)
 
 
 class BilinearTokFn(torch.autograd.Function):
@@ -569,8 +603,9 @@ def conv_bn_relu(x_tok, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, l
     """conv -> BatchNorm (-> + resid) (-> ReLU) on tokens; geom = (frames, Hin, Win).  Returns the output tokens."""
     frames, Hh, Ww = geom
     lout = lout or Layout.dense(conv.out_channels)
-    y, _, _ = conv_tokens(x_tok, conv, frames, Hh, Ww, lin, lout)
-    return batchnorm_tokens(y, bn, relu=relu, resid=resid, groups=groups, lay=lout)
+    training = bn.training or bn.running_mean is None
+    y, _, _, tab = conv_tokens(x_tok, conv, frames, Hh, Ww, lin, lout, stats=training)
+    return batchnorm_tokens(y, bn, relu=relu, resid=resid, groups=groups, lay=lout, stats=tab)
 
 
 def conv1x1_tokens(x_tok, conv: torch.nn.Conv2d, frames, Hh, Ww, lin=None, lout=None):

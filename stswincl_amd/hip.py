@@ -19,6 +19,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 GF_GELU, GF_RESID, GF_MUL_DGELU, GF_OUT_F32, GF_ACCUM, GF_RELU, GF_WAVES4, GF_BIG, GF_NOBIG, GF_MID, GF_NOPIPE, GF_HALF, GF_NOHALF = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
 GF_MUL_R, GF_C2_DGELU, GF_CS_PARTIAL = 8192, 16384, 32768
+GF_CS_SQ = 1 << 16
 GF_NOREGEPI = 1 << 22
 GF_NOSTREAM = 1 << 23
 GF_DUO = 1 << 24
@@ -298,9 +299,32 @@ def maxpool3x3s2(src, dst, arg, frames, H, W, Ho, Wo, backward=False):
 
 
 # ----------------------------------------------------------------------------------------------- GEMMs
+def stats_table(M: int, N: int, device) -> torch.Tensor:
+    """fp32 [2][2*ceil(M/256)][N] table for gemm_nt(stats_out=...): per-128-row-block column sums | sums of squares."""
+    return torch.empty(2, 2 * ((M + 255) // 256), N, dtype=torch.float32, device=device)
+
+
+def cs_group_reduce(table: torch.Tensor, M: int, groups: int, unit: int = 0):
+    """-> (sum, sumsq) fp32 [groups][N] of the statistic groups from a stats_table a gemm_nt filled."""
+    N = table.shape[2]
+    both = torch.empty(2, groups, N, dtype=torch.float32, device=table.device)
+    _check(load().stswin_cs_group_reduce(_p(table), M, N, groups, unit, _p(both[0]), _p(both[1]), _stream()), "cs_group_reduce")
+    return both[0], both[1]
+
+
+def bn_table_finalize(table: torch.Tensor, M: int, running_mean, running_var, groups=1, eps=1e-5, momentum=0.1, unit=0):
+    """-> (mean, rstd) fp32 [groups][N] from a stats_table a gemm_nt filled; running statistics updated in place."""
+    N = table.shape[2]
+    mean = torch.empty(groups, N, dtype=torch.float32, device=table.device)
+    rstd = torch.empty_like(mean)
+    _check(load().stswin_bn_table_finalize(_p(table), M, N, groups, unit, _p(mean), _p(rstd), _p(running_mean), _p(running_var),
+                                           _c_float(eps), _c_float(momentum), _stream()), "bn_table_finalize")
+    return mean, rstd
+
+
 def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_rows=None, c_rows=None, bias=None,
             resid=None, r_rows=None, out2=None, S: int = 1, scale: float = 1.0, scale_cols: int = 0, flags: int = 0,
-            colsum_out=None):
+            colsum_out=None, stats_out=None):
     """out[c_rows[m]] = epi(sum_s A[a_rows[s][m], :Kseg] @ Bw[:, s*Kseg:(s+1)*Kseg].T); see include/stswin_hip.h."""
     N, Ktot = Bw.shape
     assert Ktot % S == 0
@@ -311,7 +335,11 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
     else:
         assert out.dtype == torch.float32
     cs_table = None
-    if colsum_out is not None and M >= _CS_PARTIAL_MIN_M and N % 4 == 0 and not (flags & (1 << 19)):
+    if stats_out is not None:        # BatchNorm statistics of the output: per-block sums and sums of squares, no reduce here
+        assert colsum_out is None and stats_out.shape == (2, 2 * ((M + 255) // 256), N) and stats_out.is_contiguous()
+        flags |= GF_CS_PARTIAL | GF_CS_SQ
+        colsum_out = stats_out
+    elif colsum_out is not None and M >= _CS_PARTIAL_MIN_M and N % 4 == 0 and not (flags & (1 << 19)):
         # >= 64 row tiles would each add into the same N addresses: per-block partial sums + one small reduce instead
         cs_table = _cs_table(A.device, 2 * ((M + 255) // 256) * N)
         flags |= GF_CS_PARTIAL
@@ -495,12 +523,13 @@ def colstats(x, groups=1, squares=True, M=None, unit=0):
     return s, ss
 
 
-def bn_finalize(x, s, ss, running_mean, running_var, groups=1, eps=1e-5, momentum=0.1, M=None, unit=0):
+def bn_finalize(x, s, ss, running_mean, running_var, groups=1, eps=1e-5, momentum=0.1, M=None, unit=0, raw=False):
+    """raw=True: s / ss are plain sums (from a GEMM epilogue, hip.cs_group_reduce), not pivot-shifted ones (hip.colstats)."""
     M = x.shape[0] if M is None else M
     C = x.shape[1]
     mean = torch.empty(groups, C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(groups, C, dtype=torch.float32, device=x.device)
-    _check(load().stswin_bn_finalize(_dt(x), _p(x), _c_long(_ld(x)), _p(s), _p(ss), _p(mean), _p(rstd), _p(running_mean),
+    _check(load().stswin_bn_finalize(_dt(x), _p(None if raw else x), _c_long(_ld(x)), _p(s), _p(ss), _p(mean), _p(rstd), _p(running_mean),
                                      _p(running_var), M, C, groups, _c_float(eps), _c_float(momentum), unit, _stream()),
            "bn_finalize")
     return mean, rstd
@@ -515,7 +544,7 @@ def bn_apply(x, mean, rstd, gamma, beta, out, resid=None, groups=1, relu=True, M
 
 
 def bn_bwd(dy, x, y, mean, rstd, gamma, dx, dresid=None, groups=1, relu=True, training=True, M=None, phase=0, sums=None,
-           rows_total=0, beta=None, unit=0):
+           rows_total=0, beta=None, unit=0, group_sums=None):
     M = x.shape[0] if M is None else M
     C = x.shape[1]
     if sums is None:
@@ -526,7 +555,8 @@ def bn_bwd(dy, x, y, mean, rstd, gamma, dx, dresid=None, groups=1, relu=True, tr
     _check(load().stswin_bn_bwd(_dt(x), _p(dy), _c_long(_ld(dy)), _p(x), _c_long(_ld(x)), _p(y),
                                 _c_long(_ld(y) if y is not None else 0), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(s1), _p(s2),
                                 _p(dx), _c_long(_ld(dx)), _p(dresid), _c_long(_ld(dresid) if dresid is not None else 0), M, C,
-                                groups, 1 if relu else 0, 1 if training else 0, phase, _c_long(rows_total), unit, _stream()), "bn_bwd")
+                                groups, 1 if relu else 0, 1 if training else 0, phase, _c_long(rows_total), unit, _p(group_sums),
+                                _stream()), "bn_bwd")
     return s1, s2
 
 

@@ -73,17 +73,19 @@ class BasicBlock(nn.Module):
 
 def _block_tokens(blk, x, frames, h, w, groups, il=False):
     """out = relu(bn2(conv2(relu(bn1(conv1(x))))) + downsample(x))   (resnet.py:42-51)."""
-    y, ho, wo = H.conv_tokens(x, blk.conv1, frames, h, w)
+    # (train mode: the BatchNorm statistics of each convolution output come from that convolution's GEMM epilogue)
+    tr = blk.bn1.training
+    y, ho, wo, tab = H.conv_tokens(x, blk.conv1, frames, h, w, stats=tr)
     ilf = frames if il else 0
-    y = H.batchnorm_tokens(y, blk.bn1, relu=True, groups=groups, il_frames=ilf)
-    y, _, _ = H.conv_tokens(y, blk.conv2, frames, ho, wo)
+    y = H.batchnorm_tokens(y, blk.bn1, relu=True, groups=groups, il_frames=ilf, stats=tab)
+    y, _, _, tab2 = H.conv_tokens(y, blk.conv2, frames, ho, wo, stats=tr)
     ds = blk.downsample
     if ds is not None and len(ds) > 0:
-        idn, _, _ = H.conv_tokens(x, ds[0], frames, h, w)
-        idn = H.batchnorm_tokens(idn, ds[1], relu=False, groups=groups, il_frames=ilf)
+        idn, _, _, tabd = H.conv_tokens(x, ds[0], frames, h, w, stats=tr)
+        idn = H.batchnorm_tokens(idn, ds[1], relu=False, groups=groups, il_frames=ilf, stats=tabd)
     else:
         idn = x
-    return H.batchnorm_tokens(y, blk.bn2, relu=True, resid=idn, groups=groups, il_frames=ilf), ho, wo
+    return H.batchnorm_tokens(y, blk.bn2, relu=True, resid=idn, groups=groups, il_frames=ilf, stats=tab2), ho, wo
 
 
 class ResNet_BasicBlock_OS8(nn.Module):

@@ -112,6 +112,48 @@ def test_gemm_nt_colsum_partial_table(m, n, k, flags, monkeypatch):
     assert float((cs_at - ref).abs().max()) <= tol, "atomics"
 
 
+@pytest.mark.parametrize("m,n,k,flags,bias", [(8192, 512, 128, 0, False), (8192 + 512, 512, 128, hip.GF_NOBIG, False),
+                                              (16384, 64, 64, 0, False), (8192 + 256, 768, 64, hip.GF_BIG, True),
+                                              (8192, 128, 576, 0, True), (8192, 256, 128, hip.GF_NOBIG, True)])
+def test_gemm_nt_statistics_table(m, n, k, flags, bias):
+    """GF_CS_SQ: per-128-row-block column sums AND sums of squares of the output (the BatchNorm statistics of a convolution
+    output) + stswin_cs_group_reduce over contiguous and interleaved statistic groups, against fp32 torch."""
+    torch.manual_seed(7)
+    a = torch.randn(m, k).bfloat16().cuda()
+    w = (torch.randn(n, k) / k ** 0.5).bfloat16().cuda()
+    b = torch.randn(n, device="cuda") if bias else None
+    out = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    tab = hip.stats_table(m, n, "cuda").fill_(float("nan"))
+    hip.gemm_nt(a, w, out, M=m, bias=b, flags=flags, stats_out=tab)
+    lin = F.linear(a.float(), w.float(), b)
+    assert float((out.float() - lin).abs().max()) < 0.05
+    s, ss = hip.cs_group_reduce(tab, m, 1)
+    assert float((s[0] - lin.sum(0)).abs().max()) <= 1e-4 * float(lin.sum(0).abs().max()) + 2e-2
+    assert float((ss[0] / (lin * lin).sum(0) - 1).abs().max()) < 1e-4
+    if m % 1024 == 0:
+        G = 4
+        s, ss = hip.cs_group_reduce(tab, m, G)                              # contiguous groups
+        ref = lin.view(G, m // G, n)
+        assert float((s - ref.sum(1)).abs().max()) <= 2e-2 and float((ss / (ref * ref).sum(1) - 1).abs().max()) < 1e-4
+        unit = 256
+        s, ss = hip.cs_group_reduce(tab, m, G, unit)                        # group g = units g, g + G, ...
+        ref = lin.view(m // (G * unit), G, unit, n).transpose(0, 1).reshape(G, -1, n)
+        assert float((s - ref.sum(1)).abs().max()) <= 2e-2 and float((ss / (ref * ref).sum(1) - 1).abs().max()) < 1e-4
+        rm, rv = torch.zeros(n, device="cuda"), torch.ones(n, device="cuda")
+        mean, rstd = hip.bn_table_finalize(tab, m, rm, rv, G, 1e-5, 0.1, unit=unit)        # one launch: + running statistics
+        var = ref.var(1, unbiased=False)
+        assert float((mean - ref.mean(1)).abs().max()) < 1e-4 and float((rstd * torch.sqrt(var + 1e-5) - 1).abs().max()) < 1e-4
+        erm, erv = torch.zeros(n, device="cuda"), torch.ones(n, device="cuda")
+        for g in range(G):
+            erm = 0.9 * erm + 0.1 * ref[g].mean(0)
+            erv = 0.9 * erv + 0.1 * ref[g].var(0, unbiased=True)
+        assert float((rm - erm).abs().max()) < 1e-4 and float((rv / erv - 1).abs().max()) < 1e-4
+    with pytest.raises(RuntimeError):
+        hip.cs_group_reduce(tab, m, 3 if m % 3 else 5)
+    with pytest.raises(RuntimeError):
+        hip.bn_table_finalize(tab, m, None, None, 3 if m % 3 else 5)
+
+
 @pytest.mark.parametrize("variant", ["ring", "stream"])
 def test_gemm_nt_ring_register_epilogues(variant):
     """256x256 ring kernel (forced; also its persistent streaming variant): every mode-specialised register epilogue

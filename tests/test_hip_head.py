@@ -129,6 +129,58 @@ def test_batchnorm_tokens(mode, tol, groups, relu, res, training):
         assert int(bng.num_batches_tracked) == int(bn.num_batches_tracked)
 
 
+@pytest.mark.parametrize("cin,cout,k,dil,stride,side,il", [(64, 64, 3, 1, 1, 32, True), (64, 128, 3, 1, 2, 64, True),
+                                                           (64, 128, 1, 1, 2, 64, False), (128, 256, 3, 2, 1, 32, True),
+                                                           (256, 512, 3, 4, 1, 32, False), (512, 256, 3, 1, 1, 32, False)])
+def test_conv_bn_statistics_from_gemm_epilogue(cin, cout, k, dil, stride, side, il, monkeypatch):
+    """conv -> BatchNorm(train) with the statistics taken in the convolution's GEMM epilogue (production path for >= 8192
+    output rows, bf16) against the same modules with the colstats pass: outputs, every gradient, running statistics; 4
+    statistic groups (contiguous / interleaved).  The fused path must actually have run."""
+    from stswincl_amd import hip
+    torch.manual_seed(cin + cout + k)
+    f, G = 16, 4
+    conv = nn.Conv2d(cin, cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil, bias=False).cuda()
+    bn_a, bn_b = nn.BatchNorm2d(cout).cuda(), nn.BatchNorm2d(cout).cuda()
+    bn_a.weight.data = 1 + 0.2 * torch.randn(cout, device="cuda"); bn_a.bias.data = 0.2 * torch.randn(cout, device="cuda")
+    bn_b.load_state_dict(bn_a.state_dict())
+    x = torch.randn(f * side * side, cin, device="cuda").bfloat16()
+    calls = []
+    real = hip.bn_table_finalize
+    monkeypatch.setattr(hip, "bn_table_finalize", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+
+    def run(bn, fused):
+        monkeypatch.setattr(H, "_FUSED_BN_STATS", fused)
+        conv.weight.grad = None
+        xt = x.clone().requires_grad_(True)
+        with ac("bf16"):
+            y, ho, wo, tab = H.conv_tokens(xt, conv, f, side, side, stats=True)
+            assert (tab is not None) == fused
+            z = H.batchnorm_tokens(y, bn, relu=True, groups=G, il_frames=f if il else 0, stats=tab)
+        torch.manual_seed(1)
+        (z.float() * torch.randn(z.shape, device="cuda")).sum().backward()
+        return z, xt.grad, conv.weight.grad.clone(), bn.weight.grad, bn.bias.grad
+
+    outs_a, outs_b = run(bn_a, True), run(bn_b, False)
+    assert len(calls) == 1
+    for name, a, b in zip(("y", "dx", "dW", "dgamma", "dbeta"), outs_a, outs_b):
+        # statistics of the fp32 accumulators vs of the bf16-rounded outputs: differences of rounding size only
+        assert rel(a, b) < 1.2e-2, name
+    # (means are ~0 against a standard deviation of ~1: an absolute bound in units of the deviation)
+    mclose = lambda a, b, v: float((a - b).abs().max()) < 1e-3 * float(v.sqrt().max())          # noqa: E731
+    assert mclose(bn_a.running_mean, bn_b.running_mean, bn_b.running_var) and rel(bn_a.running_var, bn_b.running_var) < 2e-3
+    # and against fp32 torch on the same bf16 inputs
+    xi = H.from_tokens(x.float(), f, side, side)
+    yr = F.conv2d(xi, conv.weight.float(), None, stride, dil if k == 3 else 0, dil)
+    fr = (lambda t: t.view(f // G, G, *t.shape[1:]).transpose(0, 1).reshape(t.shape)) if il else (lambda t: t)
+    yg = fr(yr).view(G, f // G, *yr.shape[1:])
+    mean, var = yg.mean((1, 3, 4)), yg.var((1, 3, 4), unbiased=False)
+    rm = torch.zeros(cout, device="cuda"); rv = torch.ones(cout, device="cuda")
+    for g in range(G):
+        n = yg[g].numel() // cout
+        rm = 0.9 * rm + 0.1 * mean[g]; rv = 0.9 * rv + 0.1 * var[g] * n / (n - 1)
+    assert mclose(bn_a.running_mean, rm, rv) and rel(bn_a.running_var, rv) < 2e-3
+
+
 @pytest.mark.parametrize("mode,tol", MODES)
 @pytest.mark.parametrize("h,w,H_,W_", [(8, 8, 16, 16), (6, 10, 12, 20), (4, 4, 32, 32), (5, 7, 13, 9)])
 def test_bilinear_tokens(mode, tol, h, w, H_, W_):
