@@ -44,6 +44,8 @@ enum {
   GF_NOSTREAM = 1 << 23,  // tuning: 256x256 ring without the persistent streaming variant
   GF_NOREGEPI = 1 << 22,  // tuning: 256x256 ring with the LDS-staged fp32 epilogue instead of the register epilogue
   GF_WAVES4 = 64,    // tuning: 4 waves of 64x64 per tile instead of the default 8 waves of 64x32 (4 waves/SIMD)
+  GF_NODEEP = 1 << 27,    // tuning: the 128x64 few-tiles kernel with its double buffer instead of the 4-stage ring
+  GF_DEEP = 1 << 28,      // tuning: 3-stage rings for the 128x128 / 256x64 kernels too (one workgroup per CU)
 };
 
 struct GemmNT {
@@ -188,13 +190,26 @@ DEVI void epi_piece(const GemmNT& p, float (&v)[8], const float (&bv)[8], float 
 
 // BM x BN tile (128x128 by default; 256x64 for N <= 64 so that narrow convolutions do not multiply a half-empty tile),
 // NW waves as (BM/64) x WN, wave tile 64 x (BN/WN).
-template <typename T, int NW, int BM = 128, int BN = 128>
+template <int N> DEVI void wait_vmcnt() {
+#define STSWIN_VMCNT_CASE(k) else if constexpr (N == k) asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STSWIN_VMCNT_CASE(1) STSWIN_VMCNT_CASE(2) STSWIN_VMCNT_CASE(3) STSWIN_VMCNT_CASE(4) STSWIN_VMCNT_CASE(5) STSWIN_VMCNT_CASE(6)
+  STSWIN_VMCNT_CASE(7) STSWIN_VMCNT_CASE(8) STSWIN_VMCNT_CASE(9) STSWIN_VMCNT_CASE(10) STSWIN_VMCNT_CASE(12) STSWIN_VMCNT_CASE(15)
+  STSWIN_VMCNT_CASE(16)
+  else static_assert(N == 0, "add the literal");
+#undef STSWIN_VMCNT_CASE
+}
+
+// NST = 2: double buffer, the loads of tile t+1 fly while tile t multiplies (2+ workgroups per CU hide the rest).  NST > 2: a
+// ring with prefetch distance NST-1 and counted vmcnt waits behind a raw s_barrier, for the shapes that leave one workgroup
+// per CU alone with the memory latency (few tiles, long K: ASPP's dilated 3x3 convolutions at M = 4096).
+template <typename T, int NW, int BM = 128, int BN = 128, int NST = 2>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
   constexpr int WM = BM / 64, WN = NW / WM;  // wave rows / columns; wave tile = 64 x (BN / WN)
   constexpr int JN = BN / WN / 16;           // 16-wide fragments per wave along N: 4 (NW=4) or 2 (NW=8)
   constexpr int NIA = BM / 8 / NW, NIB = BN / 8 / NW;   // LDS-DMA instructions per wave per operand per K tile (8 rows each)
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
-  static_assert(WM * WN == NW && JN >= 1 && NIA >= 1 && NIB >= 1 && BM * BN * 4 <= 2 * STAGE, "tile shape");
+  static_assert(WM * WN == NW && JN >= 1 && NIA >= 1 && NIB >= 1 && BM * BN * 4 <= NST * STAGE && NST >= 2, "tile shape");
   constexpr int PACK = TT<T>::PACK;
   constexpr int BK = 8 * PACK;               // 128-byte rows
   constexpr int ROWB = 128;
@@ -244,17 +259,26 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
 
   int seg = 0;
   load_a_bases(0);
-  stage(0, 0, 0);
+  auto issue = [&](int tile) {                // K tiles are staged in order: `seg` follows the staging front
+    const int nseg = tile / kps;
+    if (nseg != seg) { seg = nseg; load_a_bases(seg); }
+    stage(tile, tile - nseg * kps, tile % NST);
+  };
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < nt) issue(s0);
   const int fr = l & 15, fq = l >> 4;
   for (int ktg = 0; ktg < nt; ++ktg) {
-    wait_vm0();
-    __syncthreads();
-    if (ktg + 1 < nt) {
-      const int nseg = (ktg + 1) / kps;
-      if (nseg != seg) { seg = nseg; load_a_bases(seg); }
-      stage(ktg + 1, (ktg + 1) - nseg * kps, (ktg + 1) & 1);
+    if constexpr (NST == 2) {
+      wait_vm0();
+      __syncthreads();
+    } else {                                  // tiles ktg+1 .. ktg+NST-2 stay in flight
+      if (ktg + NST - 1 <= nt) wait_vmcnt<(NST - 2) * (NIA + NIB)>();
+      else wait_vm0();
+      __builtin_amdgcn_s_barrier();
     }
-    const char* Ab = smem + (ktg & 1) * STAGE;
+    if (ktg + NST - 1 < nt) issue(ktg + NST - 1);
+    const char* Ab = smem + (ktg % NST) * STAGE;
     const char* Bb = Ab + A_BYTES;
     if constexpr (TT<T>::IS_BF16) {
 #pragma unroll
@@ -382,19 +406,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
 // 16-lane group touch 16 distinct 16-byte slots.  bf16 only (the fp32 parity path uses the 128x128 kernel).
 // =====================================================================================================
 DEVI int swz64(int row) { return (4 - ((row >> 2) & 3)) & 3; }
-
-template <int N> DEVI void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else static_assert(N == 0, "add the literal");
-}
 
 // BM x BN x 32 tile, 8 waves as WM x WN, NST-stage ring (prefetch distance NST-1), epilogue in EH row slabs.
 //   <256,256,2,4,4>: 128 KB LDS, 1 workgroup / CU (128 FLOP per L2 byte)
@@ -1908,7 +1919,11 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     (void)once_n;
     const int nb = ((M + 255) / 256) * ((N + 63) / 64);
     g_last_variant[0] = STSWIN_VAR_NT_256x64 + (dtype ? STSWIN_VAR_F32 : 0);
-    if (dtype == 0) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8, 256, 64>), dim3(nb), dim3(512), 81920, (hipStream_t)stream, p);
+    if (dtype == 0 && (flags & GF_DEEP)) {
+      static int once_nd = (int)hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16, 8, 256, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 122880);
+      (void)once_nd;
+      hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8, 256, 64, 3>), dim3(nb), dim3(512), 122880, (hipStream_t)stream, p);
+    } else if (dtype == 0) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8, 256, 64>), dim3(nb), dim3(512), 81920, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_nt_kernel<float, 8, 256, 64>), dim3(nb), dim3(512), 81920, (hipStream_t)stream, p);
     STSWIN_CHECK_LAUNCH();
     return 0;
@@ -1916,11 +1931,24 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
   // few 128x128 tiles (ASPP's dilated 3x3 convolutions: M = 4096 -> 128 tiles on 256 CUs, K = 9216): 128x64 tiles double
   // the workgroups; each CU can hold two of them
   if (dtype == 0 && w8 && nblk <= 160 && N >= 128 && M >= 128 && !(flags & GF_NONARROW)) {
-    static int once_s = (int)hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16, 8, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
+    static int once_s = (int)hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16, 8, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152) |
+                        (int)hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16, 8, 128, 64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
     (void)once_s;
     const int nb = ((M + 127) / 128) * ((N + 63) / 64);
     g_last_variant[0] = STSWIN_VAR_NT_128x64;
-    hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8, 128, 64>), dim3(nb), dim3(512), 49152, (hipStream_t)stream, p);
+    // <= 1 workgroup per CU and a long K: nothing but its own prefetch depth hides the memory latency -> 4-stage ring
+    if (!(flags & GF_NODEEP) && (long)S * Kseg >= 1024)
+      hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8, 128, 64, 4>), dim3(nb), dim3(512), 98304, (hipStream_t)stream, p);
+    else
+      hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8, 128, 64>), dim3(nb), dim3(512), 49152, (hipStream_t)stream, p);
+    STSWIN_CHECK_LAUNCH();
+    return 0;
+  }
+  if (dtype == 0 && w8 && (flags & GF_DEEP)) {
+    static int once_d = (int)hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16, 8, 128, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    (void)once_d;
+    g_last_variant[0] = STSWIN_VAR_NT_128x128;
+    hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8, 128, 128, 3>), dim3(nblk), dim3(512), 98304, (hipStream_t)stream, p);
     STSWIN_CHECK_LAUNCH();
     return 0;
   }

@@ -7,6 +7,8 @@ the GPU: there is no CPU path.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -152,6 +154,70 @@ class PatchMerging(nn.Module):
         return ops.PatchMergeFn.apply(x, self.norm.weight, self.norm.bias, self.reduction.weight, self.input_resolution)
 
 
+_FRAME_GRAD_LINK = os.environ.get("STSWIN_NO_FRAME_GRAD_LINK") != "1"      # (A/B switch)
+
+
+class _TakeFramesFn(torch.autograd.Function):
+    """x_v[:, start:stop] as a contiguous tensor - the input of the layer that runs on the middle frame pair
+    (swin_512.py:302-307).  Together with _PutFramesFn it hands x_v ONE gradient tensor: autograd on slice + cat builds three
+    zero-filled full-size tensors and adds them up (6 passes over the clip per layer); here the gradient of the output is
+    passed through as the gradient of x_v, and the gradient that comes back out of the layer overwrites its frames
+    start:stop in place (they are dead by then: only the layer's backward read them)."""
+
+    @staticmethod
+    def forward(ctx, x_v, start, stop, link):
+        ctx.sl, ctx.link, ctx.shape = (start, stop), link, x_v.shape
+        return x_v[:, start:stop].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        start, stop = ctx.sl
+        full = ctx.link.pop("g", None)
+        if full is None:                     # the output of _PutFramesFn got no gradient: this is x_v's only one
+            full = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+            full[:, start:stop].copy_(g)
+            return full, None, None, None
+        full[:, start:stop].copy_(g)         # `full` already travels to x_v's producer as _PutFramesFn's gradient
+        return None, None, None, None
+
+
+class _FenceFn(torch.autograd.Function):
+    """Identity whose output is consumed by _TakeFramesFn and _PutFramesFn only: the gradient buffer they share is then never
+    summed with a third consumer's gradient before _TakeFramesFn has written into it."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _PutFramesFn(torch.autograd.Function):
+    """x_v with frames start:stop replaced by `mid` (the other frames pass through)."""
+
+    @staticmethod
+    def forward(ctx, x_v, mid, start, stop, link):
+        ctx.sl, ctx.link = (start, stop), link
+        return torch.cat([x_v[:, :start], mid, x_v[:, stop:]], dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        start, stop = ctx.sl
+        if not g.is_contiguous() or g._base is not None:      # never write into somebody else's storage
+            g = g.contiguous() if not g.is_contiguous() else g.clone()
+        gm = g[:, start:stop]
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            ctx.link["g"] = g                # frames start:stop are stale until _TakeFramesFn.backward overwrites them
+            return g, gm, None, None, None
+        if ctx.needs_input_grad[0]:
+            g = g.clone()
+            g[:, start:stop].zero_()
+            return g, None, None, None, None
+        return None, gm, None, None, None
+
+
 class SwinTransformerLayerv5(nn.Module):
     """6 temporal Swin layers over a 4-frame clip in two stages; swin_512.py:280-327.
 
@@ -185,8 +251,13 @@ class SwinTransformerLayerv5(nn.Module):
         if len(pairs) == 2:
             return layer(x_v.reshape(B * 2, 2, L, C)).reshape(B, T, L, C)
         p = pairs[0]
-        mid = layer(x_v[:, p].contiguous())
-        return torch.cat([x_v[:, :p.start], mid.to(x_v.dtype), x_v[:, p.stop:]], dim=1)
+        if not (torch.is_grad_enabled() and x_v.requires_grad and _FRAME_GRAD_LINK):
+            mid = layer(x_v[:, p].contiguous())
+            return torch.cat([x_v[:, :p.start], mid.to(x_v.dtype), x_v[:, p.stop:]], dim=1)
+        link = {}
+        x_v = _FenceFn.apply(x_v)            # exactly two consumers below, whatever else uses the caller's tensor
+        mid = layer(_TakeFramesFn.apply(x_v, p.start, p.stop, link))
+        return _PutFramesFn.apply(x_v, mid.to(x_v.dtype), p.start, p.stop, link)
 
     def forward_tokens(self, x):
         """(B, 4, L, C) tokens -> ((B, 4, L, C), (B, 4, L/4, 2C)) tokens."""

@@ -127,3 +127,35 @@ def test_window_attention_and_mlp_modules_fp32():
     # partition / reverse helpers are exact
     t = torch.randn(2, 16, 16, 32)
     assert torch.equal(S.window_partition(t.cuda(), 4).cpu(), O.window_partition(t, 4))
+
+
+@pytest.mark.parametrize("extra_use", [False, True])
+def test_middle_pair_gradient_link_equals_slice_and_cat(extra_use, monkeypatch):
+    """The middle frame pair of layers 1 / 4 (swin_512.py:302-307): one shared gradient buffer for the pass-through frames and the
+    layer's input gradient (_TakeFramesFn / _PutFramesFn) against autograd's slice + cat - the input gradient bitwise, also when the layer
+    input has a third consumer outside (the fence keeps that gradient apart)."""
+    torch.manual_seed(3)
+    net = S.SwinTransformerLayerv5(dim=128, input_resolution=(16, 16), num_heads=4).cuda()
+    x0 = torch.randn(2, 4, 256, 128, device="cuda")
+    w = torch.randn(2, 4, 256, 128, device="cuda")
+
+    def run(link):
+        monkeypatch.setattr(S, "_FRAME_GRAD_LINK", link)
+        net.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        h = x * 1.5                                    # a non-leaf layer input
+        y = net._single_layer_forward(h, net.pairs[1], 1)
+        loss = (y * w).sum()
+        if extra_use:
+            loss = loss + (h * w).sum() * 0.5
+        loss.backward()
+        return x.grad, [p.grad.clone() for p in net.layers[1].parameters()]
+
+    xa, pa = run(True)
+    xb, pb = run(False)
+    assert torch.equal(xa, xb)
+    for a, b in zip(pa, pb):                           # (column-sum atomics: last-digit differences run to run)
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+    # frames outside the pair pass through: gradient = 1.5 * w (+ the extra use)
+    exp = 1.5 * w[:, 0] * (1.5 if extra_use else 1.0)
+    assert torch.allclose(xa[:, 0], exp, rtol=1e-6, atol=1e-6)
