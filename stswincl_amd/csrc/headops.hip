@@ -16,6 +16,14 @@ static int reduce_rows_per_chunk(int group_rows, int other_blocks, int nrl) {
   while (rpc < 64 * nrl && (long)other_blocks * ((group_rows + 2 * rpc - 1) / (2 * rpc)) >= 1024) rpc *= 2;
   return rpc;
 }
+// Rows per thread of the BatchNorm backward passes: as many as leave about 512 workgroups (tools/bench_bn.py: 16 rows for the
+// 33 MB maps, 32 for layer5's 67 MB, 64 for the stem's 134 MB; with 8 rows everywhere the per-thread prologue - 40 channel
+// constants - and, in pass 1, 512 atomics per workgroup on 2 x groups x C addresses cost as much as the rows themselves).
+static int bn_bwd_rows(long rows_all_groups, int col_blocks, int nrl, int max_rows) {
+  int rows = 8;
+  while (rows < max_rows && (long)col_blocks * (rows_all_groups / ((long)2 * rows * nrl)) >= 512) rows *= 2;
+  return rows;
+}
 
 // First physical row of the rows a block works on, minus its first row index inside the group: contiguous groups
 // (unit == 0) start at g * group_rows; interleaved groups (unit > 0: group g owns the units g, g + G, g + 2G, ... of `unit`
@@ -140,12 +148,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, long ldx, con
 }
 
 // pass 1 of the backward: s1[g][c] = sum dyr, s2[g][c] = sum dyr*xhat, dyr = dy * (y > 0 if relu)
+// Both passes walk their rows four at a time with all loads of the four rows issued first (one row per iteration left a
+// thread with 2-3 requests in flight: 2.0-3.6 TB/s against the 5.4-6.5 TB/s of bn_apply, tools/bench_bn.py).
+// ReLU mask: from the stored output y, or - when there is no residual, y == NULL - recomputed from x with bn_apply's own
+// expression x * (rstd*gamma) + (beta - mean*rstd*gamma) > 0 (the same operations in the same order: the same sign): one
+// tensor less to read in both passes.
+#define BN_BWD_U 4
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, long lddy, const T* x, long ldx, const T* y, long ldy,
                                                              const float* mean, const float* rstd, float* s1, float* s2,
                                                              int C, int group_rows, int chunks_per_group, int rows_per_chunk,
                                                              int relu, int cpb, const float* gamma, const float* beta, int unit) {
   constexpr int PACK = TT<T>::PACK;
+  constexpr int U = BN_BWD_U;
   __shared__ float part[2][256 * 8];
   const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
   const int c = (blockIdx.x * cpb + cp) * PACK;
@@ -153,29 +168,38 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, long ld
   const long gr0 = group_row0(g, ch, rows_per_chunk, group_rows, unit, gridDim.y / chunks_per_group);
   float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c < C) {
-    // ReLU mask: from the stored output y, or - when there is no residual, y == NULL - recomputed from x (the sign of
-    // (x - mean) * rstd * gamma + beta): one tensor less to read in both passes
-    const bool remask = relu && y == nullptr;
-    float mu[8], rs[8], ga[8], be[8];
+    const bool remask = relu && y == nullptr, ymask = relu && y != nullptr;
+    float mu[8], rs[8], pm[8], qm[8];
 #pragma unroll
     for (int e = 0; e < PACK; ++e) {
       mu[e] = mean[(long)g * C + c + e]; rs[e] = rstd[(long)g * C + c + e];
-      ga[e] = remask ? gamma[c + e] : 0.f; be[e] = remask ? beta[c + e] : 0.f;
+      pm[e] = remask ? rs[e] * gamma[c + e] : 0.f;
+      qm[e] = remask ? beta[c + e] - mu[e] * pm[e] : 0.f;
     }
     const int r_end = min(group_rows, (ch + 1) * rows_per_chunk);
-    for (int r = ch * rows_per_chunk + rl; r < r_end; r += nrl) {
-      Vec16<T> d, xi, yo;
-      d.v = *(const decltype(d.v)*)(dy + (gr0 + r) * lddy + c);
-      xi.v = *(const decltype(xi.v)*)(x + (gr0 + r) * ldx + c);
-      if (relu && !remask) yo.v = *(const decltype(yo.v)*)(y + (gr0 + r) * ldy + c);
+    for (int r = ch * rows_per_chunk + rl; r < r_end; r += U * nrl) {
+      Vec16<T> d[U], xi[U], yo[U];
 #pragma unroll
-      for (int e = 0; e < PACK; ++e) {
-        float dv = d.get(e);
-        const float xh = (xi.get(e) - mu[e]) * rs[e];
-        if (relu && !((remask ? xh * ga[e] + be[e] : yo.get(e)) > 0.f)) dv = 0.f;
-        a1[e] += dv;
-        a2[e] += dv * xh;
-      }
+      for (int u = 0; u < U; ++u)
+        if (r + u * nrl < r_end) {
+          const long row = gr0 + r + u * nrl;
+          d[u].v = *(const decltype(d[u].v)*)(dy + row * lddy + c);
+          xi[u].v = *(const decltype(xi[u].v)*)(x + row * ldx + c);
+          if (ymask) yo[u].v = *(const decltype(yo[u].v)*)(y + row * ldy + c);
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (r + u * nrl < r_end) {
+#pragma unroll
+          for (int e = 0; e < PACK; ++e) {
+            float dv = d[u].get(e);
+            const float xv = xi[u].get(e);
+            if (remask) { if (!(xv * pm[e] + qm[e] > 0.f)) dv = 0.f; }
+            else if (ymask) { if (!(yo[u].get(e) > 0.f)) dv = 0.f; }
+            a1[e] += dv;
+            a2[e] += dv * ((xv - mu[e]) * rs[e]);
+          }
+        }
     }
   }
 #pragma unroll
@@ -202,6 +226,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* dy, long lddy, 
                                                          int rows_per_chunk, int relu, int training, int cpb, float inv_n,
                                                          const float* beta, int unit, float* gsum) {
   constexpr int PACK = TT<T>::PACK;
+  constexpr int U = BN_BWD_U;
   const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
   const int c = (blockIdx.x * cpb + cp) * PACK;
   if (c >= C) return;
@@ -218,32 +243,47 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* dy, long lddy, 
     }
   }
   // dx = A*dyr + B*x + D  with  A = gamma*rstd, B = -A*rstd*s2/n, D = -A*s1/n - B*mean      (training)
-  const bool remask = relu && y == nullptr;              // mask recomputed exactly as in bn_bwd_reduce_kernel
-  float ka[8], kb[8], kd[8], mu[8], rs[8], ga[8], be[8];
+  const bool remask = relu && y == nullptr, ymask = relu && y != nullptr;
+  float ka[8], kb[8], kd[8], pm[8], qm[8];
 #pragma unroll
   for (int e = 0; e < PACK; ++e) {
     const long gc = (long)g * C + c + e;
-    const float A = gamma[c + e] * rstd[gc];
-    mu[e] = mean[gc]; rs[e] = rstd[gc]; ga[e] = gamma[c + e]; be[e] = remask ? beta[c + e] : 0.f;
+    const float rsd = rstd[gc], mu = mean[gc], ga = gamma[c + e];
+    const float A = ga * rsd;
     ka[e] = A;
-    kb[e] = training ? -A * rstd[gc] * s2[gc] * inv_n : 0.f;
-    kd[e] = training ? -A * s1[gc] * inv_n - kb[e] * mean[gc] : 0.f;
+    kb[e] = training ? -A * rsd * s2[gc] * inv_n : 0.f;
+    kd[e] = training ? -A * s1[gc] * inv_n - kb[e] * mu : 0.f;
+    pm[e] = remask ? rsd * ga : 0.f;
+    qm[e] = remask ? beta[c + e] - mu * pm[e] : 0.f;
   }
   const int r_end = min(group_rows, (ch + 1) * rows_per_chunk);
-  for (int r = ch * rows_per_chunk + rl; r < r_end; r += nrl) {
-    Vec16<T> d, xi, yo, o, od;
-    d.v = *(const decltype(d.v)*)(dy + (gr0 + r) * lddy + c);
-    xi.v = *(const decltype(xi.v)*)(x + (gr0 + r) * ldx + c);
-    if (relu && !remask) yo.v = *(const decltype(yo.v)*)(y + (gr0 + r) * ldy + c);
+  for (int r = ch * rows_per_chunk + rl; r < r_end; r += U * nrl) {
+    Vec16<T> d[U], xi[U], yo[U];
 #pragma unroll
-    for (int e = 0; e < PACK; ++e) {
-      float dv = d.get(e);
-      if (relu && !((remask ? (xi.get(e) - mu[e]) * rs[e] * ga[e] + be[e] : yo.get(e)) > 0.f)) dv = 0.f;
-      o.set(e, ka[e] * dv + kb[e] * xi.get(e) + kd[e]);
-      od.set(e, dv);
-    }
-    *(decltype(o.v)*)(dx + (gr0 + r) * lddx + c) = o.v;
-    if (dres) *(decltype(od.v)*)(dres + (gr0 + r) * lddr + c) = od.v;
+    for (int u = 0; u < U; ++u)
+      if (r + u * nrl < r_end) {
+        const long row = gr0 + r + u * nrl;
+        d[u].v = *(const decltype(d[u].v)*)(dy + row * lddy + c);
+        xi[u].v = *(const decltype(xi[u].v)*)(x + row * ldx + c);
+        if (ymask) yo[u].v = *(const decltype(yo[u].v)*)(y + row * ldy + c);
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (r + u * nrl < r_end) {
+        const long row = gr0 + r + u * nrl;
+        Vec16<T> o, od;
+#pragma unroll
+        for (int e = 0; e < PACK; ++e) {
+          float dv = d[u].get(e);
+          const float xv = xi[u].get(e);
+          if (remask) { if (!(xv * pm[e] + qm[e] > 0.f)) dv = 0.f; }
+          else if (ymask) { if (!(yo[u].get(e) > 0.f)) dv = 0.f; }
+          o.set(e, ka[e] * dv + kb[e] * xv + kd[e]);
+          od.set(e, dv);
+        }
+        *(decltype(o.v)*)(dx + row * lddx + c) = o.v;
+        if (dres) *(decltype(od.v)*)(dres + row * lddr + c) = od.v;
+      }
   }
 }
 
@@ -520,8 +560,9 @@ extern "C" int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x
   if (relu && !y && !beta) return -1404;               // no stored output: the mask is recomputed and needs beta
   const int ppr = C / pk, cpb = pick_cpb(ppr);
   if (unit_rows > 0 && M % ((long)groups * unit_rows)) return -1405;
-  const int gr = M / groups, rpc = fit_chunk(reduce_rows_per_chunk(gr, groups * ((ppr + cpb - 1) / cpb), 256 / cpb), unit_rows);
-  const int rpc2 = fit_chunk(8 * (256 / cpb), unit_rows);
+  const int gr = M / groups, xb = (ppr + cpb - 1) / cpb, nrl = 256 / cpb;
+  const int rpc = fit_chunk(bn_bwd_rows(M, xb, nrl, 64) * nrl, unit_rows);
+  const int rpc2 = fit_chunk(bn_bwd_rows(M, xb, nrl, 32) * nrl, unit_rows);
   if (rpc <= 0 || rpc2 <= 0) return -1405;
   const int cpg = (gr + rpc - 1) / rpc;
   dim3 g1((ppr + cpb - 1) / cpb, groups * cpg);
