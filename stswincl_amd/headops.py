@@ -220,7 +220,7 @@ class StemConvFn(torch.autograd.Function):
     rebuilt in backward."""
 
     @staticmethod
-    def forward(ctx, img, weight, dt):
+    def forward(ctx, img, weight, dt, want_stats=False):
         F_, _, Hh, Ww = img.shape
         Ho, Wo = (Hh + 6 - 7) // 2 + 1, (Ww + 6 - 7) // 2 + 1
         im = img.detach().float().contiguous()
@@ -228,21 +228,35 @@ class StemConvFn(torch.autograd.Function):
         wm = torch.zeros(64, 192, dtype=torch.float32, device=img.device)
         wm[:, :147] = weight.detach().float().permute(0, 2, 3, 1).reshape(64, 147)
         y = torch.empty(F_ * Ho * Wo, 64, dtype=dt, device=img.device)
-        hip.gemm_nt(patches, wm.to(dt), y, M=y.shape[0])
+        tab = hip.stats_table(y.shape[0], 64, img.device) if want_stats else None    # BatchNorm statistics of y (see ConvTokFn)
+        hip.gemm_nt(patches, wm.to(dt), y, M=y.shape[0], stats_out=tab)
         keep = patches.numel() * patches.element_size() <= (2 << 30)
         ctx.cfg = (dt, Ho, Wo, keep)
         ctx.save_for_backward(patches if keep else im)
+        if want_stats:
+            ctx.mark_non_differentiable(tab)
+            return y, tab
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dtab=None):
         (saved,) = ctx.saved_tensors
         dt, Ho, Wo, keep = ctx.cfg
         patches = saved if keep else hip.stem_im2col(saved, dt, Ho, Wo)
         im = saved
         dw = torch.empty(64, 192, dtype=torch.float32, device=im.device)
         hip.gemm_tn(dy.detach().to(dt).contiguous(), patches, dw, Mk=patches.shape[0], overwrite=True)
-        return None, dw[:, :147].reshape(64, 7, 7, 3).permute(0, 3, 1, 2), None
+        return None, dw[:, :147].reshape(64, 7, 7, 3).permute(0, 3, 1, 2), None, None
+
+
+def stem_conv_tokens(img, weight, dt, stats=False):
+    """-> (tokens [F*Ho*Wo][64], statistics table or None): the stem convolution, with the BatchNorm statistics of its output
+    from the GEMM epilogue when asked for and eligible (same rule as conv_tokens)."""
+    F_, _, Hh, Ww = img.shape
+    M = F_ * ((Hh - 1) // 2 + 1) * ((Ww - 1) // 2 + 1)
+    if stats and _FUSED_BN_STATS and dt == torch.bfloat16 and M >= 8192 and M % 256 == 0:
+        return StemConvFn.apply(img, weight, dt, True)
+    return StemConvFn.apply(img, weight, dt), None
 
 
 class MaxPoolTokFn(torch.autograd.Function):

@@ -108,9 +108,9 @@ class ResNet_BasicBlock_OS8(nn.Module):
         ... (clip-major clips of `groups` frames: no reordering of the batch)."""
         f, _, hh, ww = img.shape
         dt = compute_dtype(img)
-        x = H.StemConvFn.apply(img, self.resnet[0].weight, dt)
+        x, tab = H.stem_conv_tokens(img, self.resnet[0].weight, dt, stats=self.resnet[1].training)
         h, w = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
-        x = H.batchnorm_tokens(x, self.resnet[1], relu=True, groups=groups, il_frames=f if il else 0)
+        x = H.batchnorm_tokens(x, self.resnet[1], relu=True, groups=groups, il_frames=f if il else 0, stats=tab)
         x = H.MaxPoolTokFn.apply(x, (f, h, w))
         h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         for layer in (self.resnet[4], self.resnet[5], self.layer4, self.layer5):

@@ -298,3 +298,45 @@ def test_ohem_select_matches_sorted_reference(n, n_min, kind):
             assert float(sel[0]) == float(srt[n_min - 1]), "k-th largest loss (bit exact)"
             assert float(sel[2]) == 1.0 and float(sel[1]) == pytest.approx(1.0 / n_min, rel=1e-6)
         assert float(value) == pytest.approx(float(ref), rel=2e-6, abs=1e-7)
+
+
+def test_resnet_statistics_from_epilogues_no_worse_than_colstats_path(monkeypatch):
+    """ResNet18-OS8 in train mode, bf16: every conv -> BatchNorm pair (stem included) takes its statistics from the GEMM epilogue.
+    Two bf16 runs whose statistics differ in the last bit drift apart through 17 layers, so the yardstick is the fp32 path of the
+    same weights: the epilogue-statistics run must be as close to it as the colstats run (outputs, running statistics, weight
+    gradients)."""
+    from stswincl_amd.net.Ours.resnet import ResNet18_OS8
+    torch.manual_seed(0)
+    nets = [ResNet18_OS8().cuda() for _ in range(3)]
+    for n in nets[1:]:
+        n.load_state_dict(nets[0].state_dict())
+    x = torch.randn(2, 4, 3, 256, 256, device="cuda")
+
+    def run(net, mode, fused):
+        monkeypatch.setattr(H, "_FUSED_BN_STATS", fused)
+        with ac(mode):
+            tok, h, w = net.forward_frames(x)
+        torch.manual_seed(1)
+        (tok.float() * torch.randn(tok.shape, device="cuda")).sum().backward()
+        return tok
+
+    calls = []
+    from stswincl_amd import hip
+    real = hip.bn_table_finalize
+    monkeypatch.setattr(hip, "bn_table_finalize", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    ta = run(nets[0], "bf16", True)
+    n_fused = len(calls)
+    tb, tc = run(nets[1], "bf16", False), run(nets[2], "fp32", False)
+    assert n_fused == 20 and len(calls) == n_fused          # stem + 16 block + 3 downsample convolutions (>= 8192 rows each)
+    ea, eb = rel(ta, tc), rel(tb, tc)
+    assert ea < 1.25 * eb + 2e-3 and ea < 6e-2, (ea, eb)
+    sd = [n.state_dict() for n in nets]
+    for k in sd[0]:
+        if k.endswith("running_var") or k.endswith("running_mean"):
+            scale = float(sd[2][k.replace("mean", "var")].sqrt().max()) if k.endswith("mean") else float(sd[2][k].abs().max())
+            da, db = float((sd[0][k] - sd[2][k]).abs().max()) / scale, float((sd[1][k] - sd[2][k]).abs().max()) / scale
+            assert da < 1.5 * db + 2e-3, (k, da, db)
+    g = [dict(n.named_parameters()) for n in nets]
+    for k in ("resnet.0.weight", "resnet.4.0.conv1.weight", "layer5.1.conv2.weight"):
+        ga, gb = rel(g[0][k].grad, g[2][k].grad), rel(g[1][k].grad, g[2][k].grad)
+        assert ga < 1.5 * gb + 1e-2, (k, ga, gb)
