@@ -213,7 +213,7 @@ int stswin_cs_group_reduce(const float* table, int M, int N, int groups, int uni
 /* BatchNorm(train) statistics from a gemm_nt STSWIN_GF_CS_SQ table in one launch: mean / rstd [groups][N] and the running
  * statistic updates applied group by group in order (the sequential per-frame BatchNorm calls of seg18/net/Ours/base18.py:86-89;
  * torch.nn.BatchNorm2d semantics: biased variance to normalise, unbiased into running_var).  Same group geometry rules as
- * stswin_cs_group_reduce; groups <= 16.  running_* may be NULL. */
+ * stswin_cs_group_reduce; groups <= 32.  running_* may be NULL. */
 int stswin_bn_table_finalize(const float* table, int M, int N, int groups, int unit_rows, float* mean, float* rstd,
                              float* running_mean, float* running_var, float eps, float momentum, void* stream);
 int stswin_bn_finalize(int dtype, const void* x, long ldx, const float* sum, const float* sumsq, float* mean, float* rstd,

@@ -913,7 +913,7 @@ __global__ __launch_bounds__(1024) void bn_table_finalize_kernel(const float* ta
 
 extern "C" int stswin_bn_table_finalize(const float* table, int M, int N, int groups, int unit_rows, float* mean, float* rstd,
                                         float* running_mean, float* running_var, float eps, float momentum, void* stream) {
-  if (M <= 0 || N <= 0 || groups <= 0 || groups > 16 || M % groups) return -1413;
+  if (M <= 0 || N <= 0 || groups <= 0 || groups > 32 || M % groups) return -1413;      // (32 groups = 64 KB of LDS partials)
   const int gr = M / groups;
   if (unit_rows > 0 ? (unit_rows % 256 || M % ((long)groups * unit_rows)) : (gr % 256)) return -1414;   // whole 256-row tiles per group
   const int nb = 2 * ((M + 255) / 256);

@@ -343,7 +343,7 @@ class BNTokFn(torch.autograd.Function):
         elif training:
             # statistics: from the producing convolution's epilogue table when one came along and the groups are whole 256-row
             # tiles (raw sums, no pivot), else a colstats pass over X (pivot-shifted sums)
-            raw = stats is not None and groups <= 16 and ((unit % 256 == 0) if unit > 0 else ((M // groups) % 256 == 0))
+            raw = stats is not None and groups <= 32 and ((unit % 256 == 0) if unit > 0 else ((M // groups) % 256 == 0))
 
             def finalize(rm, rv):
                 if raw:                                   # table -> mean / rstd / running statistics in one launch

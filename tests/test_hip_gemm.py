@@ -148,6 +148,12 @@ def test_gemm_nt_statistics_table(m, n, k, flags, bias):
             erm = 0.9 * erm + 0.1 * ref[g].mean(0)
             erv = 0.9 * erv + 0.1 * ref[g].var(0, unbiased=True)
         assert float((rm - erm).abs().max()) < 1e-4 and float((rv / erv - 1).abs().max()) < 1e-4
+    if m == 8192:                                                           # the cap: 32 groups (24 = 6 key views x 4 frames in the
+        G = 32                                                              # contrastive step), one 256-row unit each
+        mean, rstd = hip.bn_table_finalize(tab, m, None, None, G, 1e-5, 0.1, unit=256)
+        ref = lin.view(G, 256, n)
+        assert float((mean - ref.mean(1)).abs().max()) < 1e-4
+        assert float((rstd * torch.sqrt(ref.var(1, unbiased=False) + 1e-5) - 1).abs().max()) < 1e-4
     with pytest.raises(RuntimeError):
         hip.cs_group_reduce(tab, m, 3 if m % 3 else 5)
     with pytest.raises(RuntimeError):
