@@ -140,7 +140,8 @@ class ConvTokFn(torch.autograd.Function):
     whose B operand is tap-segmented.  ASPP.py:13-31, base18.py:60-77, resnet.py:31-38, PixPro_swin_v5.py:24-26."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, geom, lin, lout, want_stats=False):
+    def forward(ctx, x, weight, bias, geom, lin, lout, want_stats=False, link=None):
+        ctx.link = link
         frames, Hin, Win, k, stride, pad, dil = geom
         dt = compute_dtype(x)
         X = x.detach().to(dt)
@@ -157,6 +158,7 @@ class ConvTokFn(torch.autograd.Function):
         ctx.save_for_backward(X, weight, fmap, imap)
         if want_stats:
             ctx.mark_non_differentiable(tab)
+            ctx.set_materialize_grads(False)             # (else autograd zero-fills a "gradient" of the table for backward)
             return y, tab
         return y
 
@@ -170,8 +172,15 @@ class ConvTokFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(Mi, lin.width, dtype=dt, device=X.device)
-            hip.gemm_nt(g, _conv_mats(weight, dt, lin, lout, True), dx, M=Mi, a_rows=imap, S=S)
+            # GradLink: the gradient another consumer of x has already produced (the residual branch of the block, or the other
+            # convolution reading x) rides in as the R operand of this GEMM's epilogue instead of an autograd add over the map
+            pend = ctx.link.take(dt, dx.shape) if ctx.link is not None else None
+            hip.gemm_nt(g, _conv_mats(weight, dt, lin, lout, True), dx, M=Mi, a_rows=imap, S=S, resid=pend,
+                        flags=hip.GF_RESID if pend is not None else 0)
             dx = dx.to(in_dtype)
+            if ctx.link is not None and not ctx.link.last():
+                ctx.link.put(dx)                          # a later consumer's backward adds it in; autograd gets no gradient from here
+                dx = None
         dwp = torch.empty(lout.width, S * lin.width, dtype=torch.float32, device=X.device)
         hip.gemm_tn(g, X, dwp, Mk=Mo, bt_rows=fmap, bseg=lin.width if fmap is not None else 0, overwrite=True)
         if lin.is_identity and lout.is_identity:
@@ -187,13 +196,39 @@ class ConvTokFn(torch.autograd.Function):
             dbp = hip.zeros(lout.width, device=X.device)
             hip.colsum(g, dbp)
             db = lout.unpad_vec(dbp)
-        return dx, dw.reshape(co, ci, k, k), db, None, None, None, None
+        return dx, dw.reshape(co, ci, k, k), db, None, None, None, None, None
 
 
+class GradLink:
+    """The consumers of ONE tensor inside a residual block (resnet.py:42-51: conv1 and the shortcut - the residual input of bn2,
+    or the downsample convolution) pass its gradient along instead of leaving the sum to autograd: every consumer but the last
+    to run hands its gradient to the link and returns None, the last one (a convolution: `convs` of them take part) adds the
+    pending gradient in its input-gradient GEMM's epilogue and returns the total.  The backward order inside a block is fixed by
+    the data flow (bn2 before conv1), between two convolutions it is whatever the engine picks - either works."""
+
+    def __init__(self, convs: int):
+        self.left, self.g = convs, None
+
+    def put(self, g):
+        self.g = g if self.g is None else self.g + g
+
+    def take(self, dt, shape):
+        g, self.g = self.g, None
+        self.left -= 1
+        if g is None:
+            return None
+        assert tuple(g.shape) == tuple(shape)
+        return g.to(dt).contiguous()
+
+    def last(self):
+        return self.left <= 0
+
+
+_RESID_GRAD_LINK = os.environ.get("STSWIN_NO_RESID_GRAD_LINK") != "1"      # (A/B switch)
 _FUSED_BN_STATS = os.environ.get("STSWIN_NO_FUSED_BN_STATS") != "1"      # (A/B switch)
 
 
-def conv_tokens(x_tok, conv: torch.nn.Conv2d, frames, Hin, Win, lin=None, lout=None, stats=None):
+def conv_tokens(x_tok, conv: torch.nn.Conv2d, frames, Hin, Win, lin=None, lout=None, stats=None, link=None):
     """Apply an nn.Conv2d's parameters to a token matrix; returns (y_tokens, Hout, Wout), or with stats = True / False
     (y_tokens, Hout, Wout, table or None): the BatchNorm statistics table of y for batchnorm_tokens(stats=...) when asked for
     (True: a train-mode BatchNorm follows) and the output is eligible (bf16 path, >= 8192 rows in whole 256-row tiles)."""
@@ -207,9 +242,9 @@ def conv_tokens(x_tok, conv: torch.nn.Conv2d, frames, Hin, Win, lin=None, lout=N
             and lout.width % 4 == 0)
     geom = (frames, Hin, Win, k, stride, pad, dil)
     if want:
-        y, tab = ConvTokFn.apply(x_tok, conv.weight, conv.bias, geom, lin, lout, True)
+        y, tab = ConvTokFn.apply(x_tok, conv.weight, conv.bias, geom, lin, lout, True, link)
     else:
-        y, tab = ConvTokFn.apply(x_tok, conv.weight, conv.bias, geom, lin, lout), None
+        y, tab = ConvTokFn.apply(x_tok, conv.weight, conv.bias, geom, lin, lout, False, link), None
     return (y, Hout, Wout) if stats is None else (y, Hout, Wout, tab)
 
 
@@ -235,6 +270,7 @@ class StemConvFn(torch.autograd.Function):
         ctx.save_for_backward(patches if keep else im)
         if want_stats:
             ctx.mark_non_differentiable(tab)
+            ctx.set_materialize_grads(False)
             return y, tab
         return y
 
@@ -307,7 +343,8 @@ class BNTokFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, relu, resid, groups, lay, eps, momentum, world=1,
-                unit=0, stats=None):
+                unit=0, stats=None, link=None):
+        ctx.link = link
         dt = compute_dtype(x)
         X = x.detach().to(dt)
         M, Cp = X.shape
@@ -403,8 +440,11 @@ class BNTokFn(torch.autograd.Function):
                 s1, s2 = s1.sum(0, keepdim=True), s2.sum(0, keepdim=True)
         dgamma = lay.unpad_vec(s2[0])
         dbeta = lay.unpad_vec(s1[0])
-        return (dx.to(in_dtype), dgamma, dbeta, None, None, None, None, dres.to(in_dtype) if has_res else None,
-                None, None, None, None, None, None, None)
+        dres = dres.to(in_dtype) if has_res else None
+        if dres is not None and ctx.link is not None:    # the shortcut's gradient travels to conv1's input-gradient GEMM
+            ctx.link.put(dres)
+            dres = None
+        return (dx.to(in_dtype), dgamma, dbeta, None, None, None, None, dres, None, None, None, None, None, None, None, None)
 
 
 _NBT_PENDING = None
@@ -462,7 +502,7 @@ class deferred_bn_counters:
 
 
 def batchnorm_tokens(x, bn: torch.nn.BatchNorm2d, relu=True, resid=None, groups=1, lay: Optional[Layout] = None,
-                     il_frames: int = 0, stats=None):
+                     il_frames: int = 0, stats=None, resid_link=None):
     """il_frames = F > 0: the rows are F frames stored clip-major and statistic group g = frames g, g + groups, ... (frame t
     of every clip); 0: `groups` contiguous row blocks."""
     lay = lay or Layout.dense(bn.num_features)
@@ -485,7 +525,7 @@ def batchnorm_tokens(x, bn: torch.nn.BatchNorm2d, relu=True, resid=None, groups=
     return BNTokFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, relu, resid, groups, lay,
                          bn.eps, bn.momentum if bn.momentum is not None else 0.1, world,
                          (x.shape[0] // il_frames) if (il_frames and groups > 1) else 0,
-                         stats if (training and world == 1) else None)
+                         stats if (training and world == 1) else None, resid_link if resid is not None else None)
 
 
 class BilinearTokFn(torch.autograd.Function):

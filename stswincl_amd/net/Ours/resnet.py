@@ -75,17 +75,19 @@ def _block_tokens(blk, x, frames, h, w, groups, il=False):
     """out = relu(bn2(conv2(relu(bn1(conv1(x))))) + downsample(x))   (resnet.py:42-51)."""
     # (train mode: the BatchNorm statistics of each convolution output come from that convolution's GEMM epilogue)
     tr = blk.bn1.training
-    y, ho, wo, tab = H.conv_tokens(x, blk.conv1, frames, h, w, stats=tr)
+    ds = blk.downsample
+    has_ds = ds is not None and len(ds) > 0
+    # x has two consumers (conv1 and the shortcut): their gradients are joined in a GEMM epilogue, not by an autograd add
+    link = H.GradLink(2 if has_ds else 1) if (H._RESID_GRAD_LINK and torch.is_grad_enabled() and x.requires_grad) else None
+    y, ho, wo, tab = H.conv_tokens(x, blk.conv1, frames, h, w, stats=tr, link=link)
     ilf = frames if il else 0
     y = H.batchnorm_tokens(y, blk.bn1, relu=True, groups=groups, il_frames=ilf, stats=tab)
     y, _, _, tab2 = H.conv_tokens(y, blk.conv2, frames, ho, wo, stats=tr)
-    ds = blk.downsample
-    if ds is not None and len(ds) > 0:
-        idn, _, _, tabd = H.conv_tokens(x, ds[0], frames, h, w, stats=tr)
+    if has_ds:
+        idn, _, _, tabd = H.conv_tokens(x, ds[0], frames, h, w, stats=tr, link=link)
         idn = H.batchnorm_tokens(idn, ds[1], relu=False, groups=groups, il_frames=ilf, stats=tabd)
-    else:
-        idn = x
-    return H.batchnorm_tokens(y, blk.bn2, relu=True, resid=idn, groups=groups, il_frames=ilf, stats=tab2), ho, wo
+        return H.batchnorm_tokens(y, blk.bn2, relu=True, resid=idn, groups=groups, il_frames=ilf, stats=tab2), ho, wo
+    return H.batchnorm_tokens(y, blk.bn2, relu=True, resid=x, groups=groups, il_frames=ilf, stats=tab2, resid_link=link), ho, wo
 
 
 class ResNet_BasicBlock_OS8(nn.Module):

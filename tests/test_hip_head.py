@@ -340,3 +340,39 @@ def test_resnet_statistics_from_epilogues_no_worse_than_colstats_path(monkeypatc
     for k in ("resnet.0.weight", "resnet.4.0.conv1.weight", "layer5.1.conv2.weight"):
         ga, gb = rel(g[0][k].grad, g[2][k].grad), rel(g[1][k].grad, g[2][k].grad)
         assert ga < 1.5 * gb + 1e-2, (k, ga, gb)
+
+
+@pytest.mark.parametrize("mode,train", [("fp32", False), ("bf16", False), ("bf16", True)])
+def test_resnet_residual_gradient_link_equals_autograd_sum(mode, train, monkeypatch):
+    """The two consumers of a block input (conv1 + shortcut: identity residual of bn2 in 6 blocks, downsample convolution in 2) join
+    their gradients in the epilogue of an input-gradient GEMM (GradLink) instead of an autograd add: every parameter gradient
+    against the plain autograd graph of the same weights.  With eval-mode BatchNorm the chain is deterministic and benign: 2e-5 in
+    fp32, 2e-2 in bf16 (sum rounded once instead of twice).  In train mode 17 untrained BatchNorm layers on 128-sample groups
+    amplify any last-bit difference (2-3e-3 run to run even in fp32, 0.2 for a bf16 rounding): only a sanity bound there - a lost
+    contribution would be an error of order 1 on every layer below it."""
+    from stswincl_amd.net.Ours.resnet import ResNet18_OS8
+    torch.manual_seed(0)
+    net = ResNet18_OS8().cuda().train(train)
+    x0 = torch.randn(4, 3, 64, 64, device="cuda")
+    gout = None
+
+    def run(link):
+        nonlocal gout
+        monkeypatch.setattr(H, "_RESID_GRAD_LINK", link)
+        net.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        img = x * 1.0                                       # (the stem has no input gradient: give the first block one through a scale)
+        with ac(mode):
+            tok, h, w = net.forward_tokens(img, groups=2)
+        if gout is None:
+            gout = torch.randn(tok.shape, device="cuda")
+        (tok.float() * gout).sum().backward()
+        return {k: p.grad.clone() for k, p in net.named_parameters()}
+
+    ga, gb, gc = run(True), run(False), run(False)
+    noise = max(rel(gc[k], gb[k]) for k in ga)
+    worst = max(rel(ga[k], gb[k]) for k in ga)
+    if not train:
+        assert noise < 1e-5 and worst < (2e-5 if mode == "fp32" else 2e-2), (worst, noise)
+    else:
+        assert sorted(rel(ga[k], gb[k]) for k in ga)[len(ga) // 2] < 0.5, worst
