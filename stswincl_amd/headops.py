@@ -164,6 +164,8 @@ class ConvTokFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dtab=None):
+        if dy is None:                                    # (grads are not materialised when the statistics table is an output)
+            return (None,) * 8
         X, weight, fmap, imap = ctx.saved_tensors
         k, lin, lout, dt, in_dtype, has_bias, Mi, Mo = ctx.cfg
         co, ci = weight.shape[:2]
@@ -276,6 +278,8 @@ class StemConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dtab=None):
+        if dy is None:
+            return None, None, None, None
         (saved,) = ctx.saved_tensors
         dt, Ho, Wo, keep = ctx.cfg
         patches = saved if keep else hip.stem_im2col(saved, dt, Ho, Wo)
