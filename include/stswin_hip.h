@@ -108,10 +108,17 @@ int stswin_cs_reduce(const float* partials, int M, int N, float* out, void* stre
  * uninitialised; saves the caller's zero fill); bits 28-30 are tuning overrides (forbid / force the 256x256 ring kernel,
  * 4-wave 128x128 variant) used by tools/tn_sweep.py; the low bits are the split count, 0 = automatic. */
 #define STSWIN_TN_OVERWRITE (1 << 27)
+#define STSWIN_TN_NO_COMBINE (1 << 26)   /* with a workspace: leave the partials there; the caller runs stswin_tn_combine */
 int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, const void* Bt, long ldb, const int* bt_rows,
                    float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg,
                    float* workspace /* optional caller-owned scratch: split-K partials are stored there and combined by a
                                        second kernel instead of fp32 atomics */, long workspace_floats, void* stream);
+/* The combine pass of a stswin_gemm_tn launched with STSWIN_TN_NO_COMBINE, for callers that run it on a second stream (it then
+ * overlaps the input-gradient GEMM that follows every weight-gradient GEMM of a backward pass instead of standing between two
+ * launches; ordering between the two streams is the caller's: events).  splits / slab_bf16 as stswin_last_variant(1) reported
+ * them for that launch (no partials were written if it reported no slab bit: nothing to combine, C is final). */
+int stswin_tn_combine(const float* workspace, float* C, long ldc, int Ni, int Nj, int splits, int overwrite, int slab_bf16,
+                      void* stream);
 /* Which kernel the launcher chose for the calling thread's most recent stswin_gemm_nt (family 0) / stswin_gemm_tn
  * (family 1) call: one of the codes below (family 1: | slab bits | split count << 16).  Test instrumentation only - the
  * parity suite asserts that the production shapes of the training step run the production kernels

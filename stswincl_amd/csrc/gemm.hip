@@ -1969,6 +1969,10 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
                               float* workspace, long workspace_floats, void* stream) {
   if (Mk <= 0 || Ni <= 0 || Nj <= 0) return 0;
   const int overwrite = (splits > 0 && (splits & (1 << 27))) ? 1 : 0;         // C = result instead of C += result
+  // bit 26: leave the split-K partials in the workspace - the caller runs stswin_tn_combine itself (on another stream, so that
+  // the combine overlaps the next GEMM instead of standing between two launches); stswin_last_variant(1) tells it how many
+  const int no_combine = (splits > 0 && (splits & (1 << 26))) ? 1 : 0;
+  if (splits > 0) splits &= ~(1 << 26);
   // bf16 operands: the split-K partials are stored as bf16 (each the fp32 sum of Mk / splits products, rounded once; the
   // combine pass adds them in fp32) - half the slab traffic of the weight gradients, the relative rounding error of a
   // gradient is 2^-9 / sqrt(splits) (a bf16 autocast GEMM rounds its whole result once, 2^-9).  STSWIN_TN_F32_SLABS=1: fp32.
@@ -2028,7 +2032,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
       else if (bt_rows && bseg > 0) hipLaunchKernelGGL(gemm_tn_ring_kernel<3>, grid, dim3(512), 131072, (hipStream_t)stream, q);
       else if (bt_rows) hipLaunchKernelGGL(gemm_tn_ring_kernel<2>, grid, dim3(512), 131072, (hipStream_t)stream, q);
       else hipLaunchKernelGGL(gemm_tn_ring_kernel<0>, grid, dim3(512), 131072, (hipStream_t)stream, q);
-      if (slabs) {
+      if (slabs && !no_combine) {
         const long n4 = slab_bf16 ? ((long)Ni * Nj + 7) / 8 : ((long)Ni * Nj + 3) / 4;
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, C, ldc,
                            Ni, Nj, rs, overwrite, slab_bf16);
@@ -2070,11 +2074,23 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
     if (w8) hipLaunchKernelGGL((gemm_tn_kernel<float, 8>), grid, dim3(512), 65536, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_tn_kernel<float, 4>), grid, dim3(256), 65536, (hipStream_t)stream, p);
   }
-  if (use_slabs) {
+  if (use_slabs && !no_combine) {
     const long n4 = slab_bf16 ? ((long)Ni * Nj + 7) / 8 : ((long)Ni * Nj + 3) / 4;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, C, ldc,
                        Ni, Nj, splits, overwrite, slab_bf16);
   }
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+// Second half of a stswin_gemm_tn launched with STSWIN_TN_NO_COMBINE: C (+)= sum of the `splits` partial results in `workspace`
+// (bf16 or fp32 slabs, as stswin_last_variant(1) reported for that launch).
+extern "C" int stswin_tn_combine(const float* workspace, float* C, long ldc, int Ni, int Nj, int splits, int overwrite, int slab_bf16,
+                                 void* stream) {
+  if (!workspace || !C || Ni <= 0 || Nj <= 0 || splits < 2) return -1007;
+  const long n4 = slab_bf16 ? ((long)Ni * Nj + 7) / 8 : ((long)Ni * Nj + 3) / 4;
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, C, ldc, Ni, Nj,
+                     splits, overwrite, slab_bf16);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

@@ -163,6 +163,7 @@ class ConvTokFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @hip.tn_deferred_backward
     def backward(ctx, dy, _dtab=None):
         if dy is None:                                    # (grads are not materialised when the statistics table is an output)
             return (None,) * 8
@@ -171,6 +172,9 @@ class ConvTokFn(torch.autograd.Function):
         co, ci = weight.shape[:2]
         S = k * k
         g = dy.detach().to(dt).contiguous()
+        # weight gradient first: its split-K combine then runs beside the input-gradient GEMM (hip.tn_deferred)
+        dwp = torch.empty(lout.width, S * lin.width, dtype=torch.float32, device=X.device)
+        hip.gemm_tn(g, X, dwp, Mk=Mo, bt_rows=fmap, bseg=lin.width if fmap is not None else 0, overwrite=True)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(Mi, lin.width, dtype=dt, device=X.device)
@@ -183,8 +187,7 @@ class ConvTokFn(torch.autograd.Function):
             if ctx.link is not None and not ctx.link.last():
                 ctx.link.put(dx)                          # a later consumer's backward adds it in; autograd gets no gradient from here
                 dx = None
-        dwp = torch.empty(lout.width, S * lin.width, dtype=torch.float32, device=X.device)
-        hip.gemm_tn(g, X, dwp, Mk=Mo, bt_rows=fmap, bseg=lin.width if fmap is not None else 0, overwrite=True)
+        hip.tn_join()                                     # dwp is complete from here on (the layout copies below read it)
         if lin.is_identity and lout.is_identity:
             dw = dwp.view(co, S, ci).permute(0, 2, 1)
         else:
@@ -277,6 +280,7 @@ class StemConvFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @hip.tn_deferred_backward
     def backward(ctx, dy, _dtab=None):
         if dy is None:
             return None, None, None, None
@@ -286,6 +290,7 @@ class StemConvFn(torch.autograd.Function):
         im = saved
         dw = torch.empty(64, 192, dtype=torch.float32, device=im.device)
         hip.gemm_tn(dy.detach().to(dt).contiguous(), patches, dw, Mk=patches.shape[0], overwrite=True)
+        hip.tn_join()
         return None, dw[:, :147].reshape(64, 7, 7, 3).permute(0, 3, 1, 2), None, None
 
 

@@ -385,6 +385,53 @@ def _tn_workspace(device, floats=48 * 1024 * 1024):
     return ws
 
 
+TN_NO_COMBINE = 1 << 26
+_TN_SIDE = {}            # device -> side stream of the deferred combines
+_TN_DEFER = 0            # nesting depth of tn_deferred()
+_TN_PENDING = None       # event of the last combine launched on the side stream (one at a time: the partials share one workspace)
+# OFF by default: measured 0.8-1.0 ms per step SLOWER than the inline combine (536-539 vs 552-556 frames/s, eager and under hipGraph
+# replay alike): every cross-stream event edge costs more than the 8 us kernel it hides.  STSWIN_TN_DEFERRED_COMBINE=1 enables it.
+_TN_DEFER_ON = os.environ.get("STSWIN_TN_DEFERRED_COMBINE") == "1"
+
+
+class tn_deferred:
+    """with tn_deferred(): the split-K combine of every gemm_tn inside runs on a side stream, ordered behind its GEMM by an event,
+    and the calling stream waits for the last one when the block ends - so each combine (5-12 us of a kernel too small to fill
+    the chip, plus a launch boundary on either side) overlaps the input-gradient GEMM that follows every weight-gradient GEMM of a
+    backward pass.  The next gemm_tn waits for the previous combine before it overwrites the shared partials."""
+
+    def __enter__(self):
+        global _TN_DEFER
+        _TN_DEFER += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _TN_DEFER
+        _TN_DEFER -= 1
+        if _TN_DEFER == 0:
+            tn_join()
+        return False
+
+
+def tn_deferred_backward(fn):
+    """Decorator for autograd backward functions that issue weight-gradient GEMMs: body inside tn_deferred()."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(ctx, *grads):
+        with tn_deferred():
+            return fn(ctx, *grads)
+    return wrapper
+
+
+def tn_join():
+    """The current stream waits for the outstanding deferred combine (if any)."""
+    global _TN_PENDING
+    if _TN_PENDING is not None:
+        torch.cuda.current_stream().wait_event(_TN_PENDING)
+        _TN_PENDING = None
+
+
 def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: int, at_rows=None, bt_rows=None,
             splits: int = 0, bseg: int = 0, atomics: bool = False, overwrite: bool = False, debug_ts: bool = False):
     """out_f32[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]  (fp32); overwrite=True stores instead of adding, so
@@ -397,11 +444,29 @@ def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: in
     name = "gemm_tn_bf16" if At.dtype == torch.bfloat16 else "gemm_tn_f32"
     if _SHAPE_NAMES:
         name += f" Mk={Mk} Ni={Ni} Nj={Nj} bseg={bseg} a={int(at_rows is not None)} b={int(bt_rows is not None)}"
+    defer = _TN_DEFER > 0 and _TN_DEFER_ON and ws is not None and not debug_ts
+    tn_join()                                            # the previous combine still reads the workspace this launch overwrites
     with _Span(name, 2.0 * Mk * Ni * Nj):
         rc = load().stswin_gemm_tn(_dt(At), _p(At), _c_long(_ld(At)), _p(at_rows), _p(Bt), _c_long(_ld(Bt)),
-                                   _p(bt_rows), _p(out_f32), _c_long((-1 if debug_ts is True else -int(debug_ts)) if debug_ts else _ld(out_f32)), Mk, Ni, Nj, splits, bseg, _p(ws),
+                                   _p(bt_rows), _p(out_f32), _c_long((-1 if debug_ts is True else -int(debug_ts)) if debug_ts else _ld(out_f32)), Mk, Ni, Nj,
+                                   (splits | TN_NO_COMBINE) if defer else splits, bseg, _p(ws),
                                    _c_long(ws.numel() if ws is not None else 0), _stream())
     _check(rc, "gemm_tn")
+    if defer:
+        v = load().stswin_last_variant(1)
+        if v & (VAR_TN_SLABS_F32 | VAR_TN_SLABS_BF16):   # partials are waiting in the workspace
+            global _TN_PENDING
+            cur = torch.cuda.current_stream()
+            side = _TN_SIDE.get(At.device)
+            if side is None:
+                side = _TN_SIDE[At.device] = torch.cuda.Stream(device=At.device)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            side.wait_event(ev)
+            _check(load().stswin_tn_combine(_p(ws), _p(out_f32), _c_long(_ld(out_f32)), Ni, Nj, v >> 16, 1 if (splits & TN_OVERWRITE) else 0,
+                                            1 if v & VAR_TN_SLABS_BF16 else 0, ctypes.c_void_p(side.cuda_stream)), "tn_combine")
+            _TN_PENDING = torch.cuda.Event()
+            _TN_PENDING.record(side)
     return out_f32
 
 

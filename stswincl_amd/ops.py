@@ -259,6 +259,7 @@ class SwinBlockFn(torch.autograd.Function):
         return out.view(Bp, T, L, C)
 
     @staticmethod
+    @hip.tn_deferred_backward
     def backward(ctx, dout):
         (X2, rmap, qkv, biasT, maskT, o, x1, mean2, rstd2, n2, h_pre, h, y2, mean1, rstd1,
          qkv_w, proj_w, n1_w, n2_w, fc1_w, fc2_w, index) = ctx.saved_tensors
@@ -330,6 +331,7 @@ class PatchMergeFn(torch.autograd.Function):
         return y.view(B, T, L // 4, 2 * C)
 
     @staticmethod
+    @hip.tn_deferred_backward
     def backward(ctx, dy):
         X2, rows, n, mean, rstd, norm_w, red_w = ctx.saved_tensors
         B, T, L, C = ctx.shape
@@ -371,6 +373,7 @@ class WindowAttentionFn(torch.autograd.Function):
         return y.view(B_, T, N, C)
 
     @staticmethod
+    @hip.tn_deferred_backward
     def backward(ctx, dy):
         X2, qkv, biasT, maskT, o, qkv_w, proj_w, index = ctx.saved_tensors
         ws, heads, nW, T = ctx.cfg
@@ -417,6 +420,7 @@ class LinearFn(torch.autograd.Function):
         return y.view(*x.shape[:-1], w.shape[0])
 
     @staticmethod
+    @hip.tn_deferred_backward
     def backward(ctx, dy):
         X2, w, aux = ctx.saved_tensors
         dt = ctx.dt

@@ -276,3 +276,38 @@ def test_gemm_tn_row_maps(dtype):
     hip.gemm_tn(at.cuda(), bt.cuda(), out, Mk=mk, at_rows=am.cuda(), bt_rows=bm.cuda())
     bsel = torch.where((bm >= 0)[:, None], bt.float()[bm.clamp(min=0).long()], torch.zeros(mk, nj))
     _close(out, at.float()[am.long()].t() @ bsel, dtype, "tn maps")
+
+
+def test_gemm_tn_deferred_combine_equals_inline_combine(monkeypatch):
+    """hip.tn_deferred(): the split-K combine on a side stream (stswin_gemm_tn with STSWIN_TN_NO_COMBINE + stswin_tn_combine) gives
+    bitwise the result of the inline combine, for a chain of GEMMs that share the workspace (each launch waits for the previous
+    combine), with overwrite and with accumulation, and the calling stream sees the results after the block."""
+    monkeypatch.setattr(hip, "_TN_DEFER_ON", True)         # (off by default: slower end to end, see hip.py)
+    torch.manual_seed(3)
+    shapes = [(65536, 512, 512, True), (16384, 1024, 256, False), (65536, 256, 2048, True), (8192, 128, 384, True)]
+    ops = []
+    for mk, ni, nj, ow in shapes:
+        at = torch.randn(mk, ni, device="cuda").bfloat16()
+        bt = torch.randn(mk, nj, device="cuda").bfloat16()
+        ops.append((at, bt, mk, ni, nj, ow))
+
+    def run(deferred):
+        outs = []
+        ctx = hip.tn_deferred() if deferred else None
+        if ctx:
+            ctx.__enter__()
+        for at, bt, mk, ni, nj, ow in ops:
+            out = torch.empty(ni, nj, device="cuda") if ow else torch.ones(ni, nj, device="cuda")
+            hip.gemm_tn(at, bt, out, Mk=mk, overwrite=ow)
+            outs.append(out)
+        if ctx:
+            assert hip._TN_PENDING is not None            # a combine is in flight on the side stream
+            ctx.__exit__(None, None, None)
+            assert hip._TN_PENDING is None
+        return [o.clone() for o in outs]                  # (clone on the calling stream: ordered behind the join)
+
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    ref = ops[1][0].float().t() @ ops[1][1].float() + 1.0
+    assert float((a[1] - ref).abs().max()) < 2e-2 * float(ref.abs().max())
