@@ -193,3 +193,46 @@ def test_fused_adam_steps_reach_the_gemm_weight_cache():
     # (Adam divides by sqrt(v): with atomically summed gradients the two runs drift apart by ~1e-3 per step - loose bound)
     for a, b in zip(losses["fused"], losses["torch"]):
         assert abs(a - b) < 3e-2 * abs(b), (losses["fused"], losses["torch"])
+
+
+@pytest.mark.parametrize("opt_name", ["torch", "fused"])
+def test_reference_amp_loop_idiom_autocast_default_and_gradscaler(opt_name):
+    """The training loop of seg18/train_swin.py:160-173 verbatim: `with amp.autocast():` (no dtype: fp16 on CUDA - the HIP path
+    computes in bf16 under any autocast), `scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()`.  The 2^16 loss
+    scale is exact in bf16 / fp32 and nothing overflows, so the steps must be taken (scale never backs off) and the losses must
+    follow those of the plain bf16 loop."""
+    from torch.cuda import amp
+    from stswincl_amd.optim import FusedAdam
+    runs = {}
+    for scaled in (True, False):
+        g, m = _model()
+        m.train()
+        opt = FusedAdam(m.parameters(), 1e-4) if opt_name == "fused" else torch.optim.Adam(m.parameters(), 1e-4)
+        scaler = amp.GradScaler()
+        x = gu.det_tensor("tswinplus/x", (2, 4, 3, 128, 128)).cuda()
+        labels = torch.from_numpy(g["labels"]).long().cuda()
+        crit = OhemCELoss2D(128 * 128 // 16)
+        ls = []
+        for _ in range(3):
+            if scaled:
+                with amp.autocast():
+                    loss = crit(m(x), labels)
+                opt.zero_grad()
+                scaler.scale(loss).backward()
+                scaler.step(opt)
+                scaler.update()
+            else:
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    loss = crit(m(x), labels)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            ls.append(float(loss.detach()))
+        if scaled:
+            assert scaler.get_scale() >= 65536.0, "a step was skipped: inf / nan in the scaled gradients"
+        assert all(torch.isfinite(p).all() for p in m.parameters())
+        runs[scaled] = ls
+    assert runs[True][0] == pytest.approx(runs[False][0], rel=2e-2)
+    for a, b in zip(runs[True], runs[False]):
+        assert abs(a - b) < 8e-2 * abs(b), runs
+    assert runs[True][2] != runs[True][0]
