@@ -188,7 +188,9 @@ class ConvTokFn(torch.autograd.Function):
                 ctx.link.put(dx)                          # a later consumer's backward adds it in; autograd gets no gradient from here
                 dx = None
         hip.tn_join()                                     # dwp is complete from here on (the layout copies below read it)
-        if lin.is_identity and lout.is_identity:
+        if lin.is_identity and lout.is_identity and S == 1:
+            dw = dwp                                      # 1x1: already [co][ci] with the strides autograd / DDP buckets expect
+        elif lin.is_identity and lout.is_identity:
             dw = dwp.view(co, S, ci).permute(0, 2, 1)
         else:
             dw = torch.zeros(co, ci, S, dtype=torch.float32, device=X.device)
@@ -201,7 +203,7 @@ class ConvTokFn(torch.autograd.Function):
             dbp = hip.zeros(lout.width, device=X.device)
             hip.colsum(g, dbp)
             db = lout.unpad_vec(dbp)
-        return dx, dw.reshape(co, ci, k, k), db, None, None, None, None, None
+        return dx, (dw.view(co, ci, 1, 1) if dw is dwp else dw.reshape(co, ci, k, k)), db, None, None, None, None, None
 
 
 class GradLink:

@@ -86,3 +86,54 @@ def test_consistency_loss_step_matches_reference(views, mode, monkeypatch):
         t = sd_after[key[len("probe/"):]].double()
         assert abs(float(t.abs().sum()) - float(g[key][1])) < (1e-3 if mode == "fp32" or "running" not in key else 2e-2) * float(g[key][1]) + 1e-9, key
     assert all(p.grad is None for p in net.pixpro.encoder_k_2.parameters())
+
+
+def test_reference_pretrain_loop_idiom_ddp_lars_gradscaler():
+    """build_model + train of pixcontrast_18/main_pretrain_swinv5.py:28-54,156-171 verbatim on one rank: LARS(torch.optim.SGD(
+    add_weight_decay(model.pixpro, wd))) from contrast/lars.py, torch's own DistributedDataParallel(find_unused_parameters=True,
+    broadcast_buffers=False) over RCCL, `with amp.autocast():` + GradScaler.  Two steps: finite losses, every step taken, the
+    query encoder moves, the momentum key encoder follows, the step counter of PixPro advances."""
+    import os
+    import torch.distributed as dist
+    from torch.cuda import amp
+    from torch.nn.parallel import DistributedDataParallel
+    from stswincl_amd.contrast.lars import LARS, add_weight_decay
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29617")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        g = gu.load("consistency.npz")
+        hh, ww = [int(v) for v in g["hw"]]
+        torch.manual_seed(0)
+        model = P.ConsistencyLoss(_args(), input_resolution=(hh // 8, ww // 8)).cuda()
+        params = add_weight_decay(model.pixpro, 1e-5)
+        optimizer = LARS(torch.optim.SGD(params, lr=2 * 1 / 256 * 1.0, momentum=0.9))
+        model = DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, find_unused_parameters=True)
+        scaler = amp.GradScaler()
+        model.train()
+        q0 = model.module.pixpro.encoder_1.resnet[0].weight.detach().clone()
+        k0 = model.module.pixpro.encoder_k_1.resnet[0].weight.detach().clone()
+        kk = model.module.pixpro.k
+        ims = [gu.det_tensor(f"consistency/im{i}", (2, 4, 3, hh, ww)).cuda() for i in range(6)]
+        masks = [torch.floor(gu.det_tensor(f"consistency/mask{i}", (2, 1, hh // 8, ww // 8), "uniform", 12.0))
+                 .clamp(0, 11).repeat_interleave(8, 2).repeat_interleave(8, 3).cuda() for i in range(6)]
+        losses = []
+        for _ in range(2):
+            optimizer.zero_grad()
+            with amp.autocast():
+                loss = model(*ims, *masks)
+            scaler.scale(loss).backward()
+            scaler.step(optimizer)
+            scaler.update()
+            losses.append(float(loss.detach()))
+        assert all(l == l and abs(l) < 1e4 for l in losses), losses
+        assert scaler.get_scale() >= 65536.0
+        assert model.module.pixpro.k == kk + 2
+        assert not torch.equal(model.module.pixpro.encoder_1.resnet[0].weight, q0)
+        assert not torch.equal(model.module.pixpro.encoder_k_1.resnet[0].weight, k0)
+    finally:
+        if created:
+            dist.destroy_process_group()
