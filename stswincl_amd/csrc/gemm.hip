@@ -428,7 +428,18 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   const int wr = w / WN, wc = w % WN;
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+  int tm = t / tiles_n, tn = t % tiles_n;
+  // Wide outputs (>= 24 column tiles; none in the training step): row-major order hands the 32 CUs of an XCD one tile row at a
+  // time = 1 A panel + 32 B panels through a 4 MB L2 (8192^3: all of B re-streamed per tile row, 4.3 GB, HBM-bound at 1.25
+  // PFLOP/s).  Groups of 8 tile rows walked column-major give them 8 + 4 panels instead.
+  if (tiles_n >= 24) {
+    constexpr int GM = 8;
+    const int per_group = GM * tiles_n, grp = t / per_group, first = grp * GM;
+    const int rows = min(GM, tiles_m - first), in = t - grp * per_group;
+    tm = first + in % rows;
+    tn = in / rows;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
 
   // Copies are BUFFER-addressed LDS-DMA: a 128-bit descriptor in SGPRs per operand, one 32-bit byte offset per lane and
   // copy instruction (row * pitch + swizzled chunk), and the K position as the instruction's scalar offset.  A stage
