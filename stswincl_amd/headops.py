@@ -669,7 +669,7 @@ def conv_bn_relu(x_tok, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, l
     frames, Hh, Ww = geom
     lout = lout or Layout.dense(conv.out_channels)
     training = bn.training or bn.running_mean is None
-    y, _, _, tab = conv_tokens(x_tok, conv, frames, Hh, Ww, lin, lout, stats=training)
+    y, _, _, tab = conv_tokens(x_tok, conv, frames, Hh, Ww, lin, lout, stats=training and _sync_world(bn) == 1)
     return batchnorm_tokens(y, bn, relu=relu, resid=resid, groups=groups, lay=lout, stats=tab)
 
 

@@ -74,7 +74,7 @@ class BasicBlock(nn.Module):
 def _block_tokens(blk, x, frames, h, w, groups, il=False):
     """out = relu(bn2(conv2(relu(bn1(conv1(x))))) + downsample(x))   (resnet.py:42-51)."""
     # (train mode: the BatchNorm statistics of each convolution output come from that convolution's GEMM epilogue)
-    tr = blk.bn1.training
+    tr = blk.bn1.training and H._sync_world(blk.bn1) == 1      # (SyncBatchNorm across ranks gathers pivot-shifted colstats instead)
     ds = blk.downsample
     has_ds = ds is not None and len(ds) > 0
     # x has two consumers (conv1 and the shortcut): their gradients are joined in a GEMM epilogue, not by an autograd add
@@ -110,7 +110,7 @@ class ResNet_BasicBlock_OS8(nn.Module):
         ... (clip-major clips of `groups` frames: no reordering of the batch)."""
         f, _, hh, ww = img.shape
         dt = compute_dtype(img)
-        x, tab = H.stem_conv_tokens(img, self.resnet[0].weight, dt, stats=self.resnet[1].training)
+        x, tab = H.stem_conv_tokens(img, self.resnet[0].weight, dt, stats=self.resnet[1].training and H._sync_world(self.resnet[1]) == 1)
         h, w = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
         x = H.batchnorm_tokens(x, self.resnet[1], relu=True, groups=groups, il_frames=f if il else 0, stats=tab)
         x = H.MaxPoolTokFn.apply(x, (f, h, w))

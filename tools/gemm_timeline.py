@@ -62,3 +62,12 @@ def tn_timeline(Mk=65536, Ni=2048, Nj=512, mapped=False):
 if len(sys.argv) > 1 and sys.argv[1] == "tn":
     tn_timeline(mapped=False)
     tn_timeline(Ni=1536, mapped=True)
+
+
+if os.environ.get("STSWIN_TL_XCD") == "1" and not TN_MODE:
+    # per-XCD view (workgroup b runs on XCD b % 8): is the CU-to-CU spread systematic?
+    import collections
+    print("  per-XCD: mean main loop / mean lifetime / mean end time of the first 256 workgroups (us)")
+    for x in range(8):
+        idx = torch.arange(x, min(nblk, 256), 8)
+        print(f"    XCD {x}: {float(d[idx, 2].mean()):7.2f} {float(life[idx].mean()):7.2f} {float(t[idx, 6].mean()):7.2f}   max end {float(t[idx, 6].max()):7.2f}")
