@@ -236,3 +236,31 @@ def test_reference_amp_loop_idiom_autocast_default_and_gradscaler(opt_name):
     for a, b in zip(runs[True], runs[False]):
         assert abs(a - b) < 8e-2 * abs(b), runs
     assert runs[True][2] != runs[True][0]
+
+
+def test_tswinplus_reference_native_resolution_512x640():
+    """The reference constructs TswinPlus with input_resolution (64, 80) = 512 x 640 frames (base18.py:57, train_swin.py:110).
+    Default constructor, B = 2 clips: bf16 train step (forward, OHEM-CE, backward) and the fp32 path of the same weights -
+    shapes, finite gradients for every parameter, bf16 logits within the bf16 yardstick of the fp32 ones; eval forward."""
+    torch.manual_seed(0)
+    m = TswinPlus(12).cuda().train()
+    assert tuple(m.swin.input_resolution) == (64, 80)
+    x = torch.randn(2, 4, 3, 512, 640, device="cuda")
+    labels = torch.randint(0, 12, (2, 512, 640), device="cuda")
+    crit = OhemCELoss2D(512 * 640 // 16)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(x)
+        loss = crit(y, labels)
+    assert y.shape == (2, 12, 512, 640) and torch.isfinite(y).all()
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    m2 = TswinPlus(12).cuda().train()
+    m2.load_state_dict({k: v for k, v in m.state_dict().items() if "num_batches_tracked" not in k and "running_" not in k}, strict=False)
+    y32 = m2(x)
+    # (untrained weights, train-mode BatchNorm on 2 clips: the reference's own bf16 autocast sits 0.06-0.09 from its fp32 run at
+    #  128 x 128, tests above; 0.069 measured here)
+    assert rel(y.float(), y32.detach().cpu()) < 0.12
+    m.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        ye = m(x[:1])
+    assert ye.shape == (1, 12, 512, 640) and torch.isfinite(ye).all()
