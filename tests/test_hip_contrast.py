@@ -137,3 +137,19 @@ def test_reference_pretrain_loop_idiom_ddp_lars_gradscaler():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_consistency_loss_non_square_256x448():
+    """The resolution the reference's pre-training actually ran at in SURVEY section 8c's import check (B = 2, 256 x 448: Swin
+    resolution (32, 56), stage 2 (16, 28)): forward + backward in bf16, finite loss and gradients, step counter."""
+    torch.manual_seed(0)
+    net = P.ConsistencyLoss(_args(), input_resolution=(32, 56)).cuda().train()
+    ims = [torch.randn(2, 4, 3, 256, 448, device="cuda") for _ in range(6)]
+    masks = [torch.randint(0, 12, (2, 1, 32, 56), device="cuda").float().repeat_interleave(8, 2).repeat_interleave(8, 3) for _ in range(6)]
+    k0 = net.pixpro.k
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = net(*ims, *masks)
+    assert torch.isfinite(loss) and net.pixpro.k == k0 + 1
+    loss.backward()
+    gs = [p.grad for p in net.pixpro.parameters() if p.requires_grad and p.grad is not None]
+    assert len(gs) > 100 and all(torch.isfinite(g).all() for g in gs)
