@@ -264,3 +264,21 @@ def test_tswinplus_reference_native_resolution_512x640():
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         ye = m(x[:1])
     assert ye.shape == (1, 12, 512, 640) and torch.isfinite(ye).all()
+
+
+@pytest.mark.parametrize("B,hw", [(3, (64, 64)), (5, (64, 128)), (2, (128, 64))])
+def test_tswinplus_odd_batches_and_shapes_vs_oracle(B, hw):
+    """Edge shapes against the CPU oracle (fp32, train mode, random default init shared through the state dict): odd clip counts
+    (the pair-batched Swin calls and the per-frame BatchNorm groups must not assume even B) and non-square frames whose Swin
+    resolution is a single window tall or wide."""
+    from oracle import stswin_oracle as O
+    torch.manual_seed(B)
+    h, w = hw
+    m = TswinPlus(12, (h // 8, w // 8))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(B, 4, 3, h, w)
+    with torch.no_grad():
+        ref = O.tswin_plus(x, {k: v.clone() for k, v in sd.items()}, training=True)
+    y = m.cuda().train()(x.cuda())
+    assert y.shape == ref.shape == (B, 12, h, w)
+    assert rel(y, ref) < 1e-3, rel(y, ref)
