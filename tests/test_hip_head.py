@@ -376,3 +376,28 @@ def test_resnet_residual_gradient_link_equals_autograd_sum(mode, train, monkeypa
         assert noise < 1e-5 and worst < (2e-5 if mode == "fp32" else 2e-2), (worst, noise)
     else:
         assert sorted(rel(ga[k], gb[k]) for k in ga)[len(ga) // 2] < 0.5, worst
+
+
+@pytest.mark.parametrize("il", [True, False])
+def test_conv_bn_epilogue_statistics_with_24_groups(il, monkeypatch):
+    """24 statistic groups (6 batched key views x 4 frames of the contrastive step): the per-group table reduce + finalize path
+    (one block per group) against the colstats path - outputs and the sequentially updated running statistics."""
+    from stswincl_amd import hip
+    torch.manual_seed(5)
+    f, G, side, c = 48, 24, 32, 64
+    conv = nn.Conv2d(c, c, 3, 1, 1, bias=False).cuda()
+    bn_a, bn_b = nn.BatchNorm2d(c).cuda(), nn.BatchNorm2d(c).cuda()
+    x = torch.randn(f * side * side, c, device="cuda").bfloat16()
+    calls = []
+    real = hip.cs_group_reduce
+    monkeypatch.setattr(hip, "cs_group_reduce", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    outs = []
+    for bn, fused in ((bn_a, True), (bn_b, False)):
+        monkeypatch.setattr(H, "_FUSED_BN_STATS", fused)
+        with ac("bf16"), torch.no_grad():
+            y, ho, wo, tab = H.conv_tokens(x, conv, f, side, side, stats=True)
+            outs.append(H.batchnorm_tokens(y, bn, relu=True, groups=G, il_frames=f if il else 0, stats=tab))
+    assert len(calls) == 1
+    assert rel(outs[0], outs[1]) < 6e-3
+    assert float((bn_a.running_mean - bn_b.running_mean).abs().max()) < 1e-3 * float(bn_b.running_var.sqrt().max())
+    assert rel(bn_a.running_var, bn_b.running_var) < 2e-3
