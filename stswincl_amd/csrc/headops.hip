@@ -860,16 +860,20 @@ __global__ __launch_bounds__(256) void cs_group_reduce_kernel(const float* tab, 
 // sequential running-statistic updates (group 0, 1, ... as the per-frame calls of base18.py:86-89 would make them) in ONE
 // launch.  1024 threads = 16 columns x 64 block lanes (a 262144-row output has 2048 table rows: 32 independent loads per
 // lane and plane); final combination in double.
+// PER_GROUP (many groups: the 24 of the batched key views): one workgroup per (16 columns, group) - blockIdx.y = group - writes
+// mean / rstd only; bn_running_update_kernel then applies the running-statistic updates in group order.
+template <bool PER_GROUP>
 __global__ __launch_bounds__(1024) void bn_table_finalize_kernel(const float* tab, int nb, int N, int G, int group_rows, int unit,
                                                                  float* mean, float* rstd, float* running_mean, float* running_var,
                                                                  float eps, float momentum) {
-  extern __shared__ float red[];                       // [G][2][16 waves][16 columns]
+  extern __shared__ float red[];                       // [G][2][16 waves][16 columns]   (PER_GROUP: [1][2][16][16])
   const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 16 + cl;
   const bool ok = c < N;
   const float* t1 = tab + (ok ? c : 0);
   const float* t2 = t1 + (long)nb * N;
-  for (int g = 0; g < G; ++g) {
+  const int g_lo = PER_GROUP ? (int)blockIdx.y : 0, g_hi = PER_GROUP ? g_lo + 1 : G;
+  for (int g = g_lo; g < g_hi; ++g) {
     float a = 0.f, b = 0.f;
     if (unit <= 0) {
       const int b0 = (int)((long)g * group_rows / 128), b1 = (int)((long)(g + 1) * group_rows / 128);
@@ -887,19 +891,19 @@ __global__ __launch_bounds__(1024) void bn_table_finalize_kernel(const float* ta
     a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
     a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
     if ((threadIdx.x & 63) < 16) {
-      red[((g * 2 + 0) * 16 + wave) * 16 + cl] = a;
-      red[((g * 2 + 1) * 16 + wave) * 16 + cl] = b;
+      red[(((g - g_lo) * 2 + 0) * 16 + wave) * 16 + cl] = a;
+      red[(((g - g_lo) * 2 + 1) * 16 + wave) * 16 + cl] = b;
     }
   }
   __syncthreads();
   if (threadIdx.x >= 16 || !ok) return;
-  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
-  for (int g = 0; g < G; ++g) {
+  float rm = (!PER_GROUP && running_mean) ? running_mean[c] : 0.f, rv = (!PER_GROUP && running_var) ? running_var[c] : 0.f;
+  for (int g = g_lo; g < g_hi; ++g) {
     double s = 0.0, q = 0.0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
-      s += (double)red[((g * 2 + 0) * 16 + w) * 16 + cl];
-      q += (double)red[((g * 2 + 1) * 16 + w) * 16 + cl];
+      s += (double)red[(((g - g_lo) * 2 + 0) * 16 + w) * 16 + cl];
+      q += (double)red[(((g - g_lo) * 2 + 1) * 16 + w) * 16 + cl];
     }
     const double m = s / group_rows;
     const float var = fmaxf((float)(q / group_rows - m * m), 0.f);
@@ -908,7 +912,24 @@ __global__ __launch_bounds__(1024) void bn_table_finalize_kernel(const float* ta
     rm = (1.f - momentum) * rm + momentum * (float)m;
     rv = (1.f - momentum) * rv + momentum * var * ((float)group_rows / (float)max(group_rows - 1, 1));
   }
-  if (running_mean) { running_mean[c] = rm; running_var[c] = rv; }
+  if (!PER_GROUP && running_mean) { running_mean[c] = rm; running_var[c] = rv; }
+}
+
+// running statistics from per-group mean / rstd, group 0 first (var = 1 / rstd^2 - eps)
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const float* mean, const float* rstd, float* running_mean, float* running_var,
+                                                                int N, int G, int group_rows, float eps, float momentum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float rm = running_mean[c], rv = running_var[c];
+  const float unb = (float)group_rows / (float)max(group_rows - 1, 1);
+  for (int g = 0; g < G; ++g) {
+    const float r = rstd[(long)g * N + c];
+    const float var = fmaxf(1.f / (r * r) - eps, 0.f);
+    rm = (1.f - momentum) * rm + momentum * mean[(long)g * N + c];
+    rv = (1.f - momentum) * rv + momentum * var * unb;
+  }
+  running_mean[c] = rm;
+  running_var[c] = rv;
 }
 
 extern "C" int stswin_bn_table_finalize(const float* table, int M, int N, int groups, int unit_rows, float* mean, float* rstd,
@@ -917,8 +938,16 @@ extern "C" int stswin_bn_table_finalize(const float* table, int M, int N, int gr
   const int gr = M / groups;
   if (unit_rows > 0 ? (unit_rows % 256 || M % ((long)groups * unit_rows)) : (gr % 256)) return -1414;   // whole 256-row tiles per group
   const int nb = 2 * ((M + 255) / 256);
-  hipLaunchKernelGGL(bn_table_finalize_kernel, dim3((unsigned)((N + 15) / 16)), dim3(1024), (size_t)groups * 2 * 16 * 16 * sizeof(float),
-                     (hipStream_t)stream, table, nb, N, groups, gr, unit_rows, mean, rstd, running_mean, running_var, eps, momentum);
+  if (groups > 8) {                                    // the one-launch kernel walks its groups serially: 19.8 us for 24 of them
+    hipLaunchKernelGGL(bn_table_finalize_kernel<true>, dim3((unsigned)((N + 15) / 16), (unsigned)groups), dim3(1024), (size_t)2 * 16 * 16 * sizeof(float),
+                       (hipStream_t)stream, table, nb, N, groups, gr, unit_rows, mean, rstd, running_mean, running_var, eps, momentum);
+    if (running_mean && running_var)
+      hipLaunchKernelGGL(bn_running_update_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mean, rstd, running_mean,
+                         running_var, N, groups, gr, eps, momentum);
+  } else {
+    hipLaunchKernelGGL(bn_table_finalize_kernel<false>, dim3((unsigned)((N + 15) / 16)), dim3(1024), (size_t)groups * 2 * 16 * 16 * sizeof(float),
+                       (hipStream_t)stream, table, nb, N, groups, gr, unit_rows, mean, rstd, running_mean, running_var, eps, momentum);
+  }
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

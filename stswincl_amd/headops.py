@@ -394,11 +394,8 @@ class BNTokFn(torch.autograd.Function):
             raw = stats is not None and groups <= 32 and ((unit % 256 == 0) if unit > 0 else ((M // groups) % 256 == 0))
 
             def finalize(rm, rv):
-                if raw and groups <= 8:                   # table -> mean / rstd / running statistics in one launch
+                if raw:                                   # table -> mean / rstd / running statistics (one launch up to 8 groups)
                     return hip.bn_table_finalize(stats, M, rm, rv, groups, eps, momentum, unit=unit)
-                if raw:                                   # many groups (24 = 6 batched key views x 4 frames): the one-launch kernel
-                    s, ss = hip.cs_group_reduce(stats, M, groups, unit)      # walks them serially (19.8 us); one block per group
-                    return hip.bn_finalize(X, s, ss, rm, rv, groups, eps, momentum, unit=unit, raw=True)   # + the tiny finalize
                 s, ss = hip.colstats(X, groups=groups, unit=unit)
                 return hip.bn_finalize(X, s, ss, rm, rv, groups, eps, momentum, unit=unit)
 

@@ -380,8 +380,9 @@ def test_resnet_residual_gradient_link_equals_autograd_sum(mode, train, monkeypa
 
 @pytest.mark.parametrize("il", [True, False])
 def test_conv_bn_epilogue_statistics_with_24_groups(il, monkeypatch):
-    """24 statistic groups (6 batched key views x 4 frames of the contrastive step): the per-group table reduce + finalize path
-    (one block per group) against the colstats path - outputs and the sequentially updated running statistics."""
+    """24 statistic groups (6 batched key views x 4 frames of the contrastive step): the one-workgroup-per-group form of
+    stswin_bn_table_finalize (+ the running-statistic kernel) against the colstats path - outputs and the sequentially updated
+    running statistics."""
     from stswincl_amd import hip
     torch.manual_seed(5)
     f, G, side, c = 48, 24, 32, 64
@@ -389,8 +390,8 @@ def test_conv_bn_epilogue_statistics_with_24_groups(il, monkeypatch):
     bn_a, bn_b = nn.BatchNorm2d(c).cuda(), nn.BatchNorm2d(c).cuda()
     x = torch.randn(f * side * side, c, device="cuda").bfloat16()
     calls = []
-    real = hip.cs_group_reduce
-    monkeypatch.setattr(hip, "cs_group_reduce", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    real = hip.bn_table_finalize
+    monkeypatch.setattr(hip, "bn_table_finalize", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
     outs = []
     for bn, fused in ((bn_a, True), (bn_b, False)):
         monkeypatch.setattr(H, "_FUSED_BN_STATS", fused)
