@@ -243,7 +243,7 @@ class SwinTransformerLayerv5(nn.Module):
                 SwinTransformerBlock(dim * 2, (H // 2, W // 2), num_heads, window_size=4, shift_size=2)))
         self.downsample = PatchMerging(self.input_resolution, dim)
 
-    def _single_layer_forward(self, x_v, pairs, layer_idx):
+    def _single_layer_forward(self, x_v, pairs, layer_idx, own_input=False):
         """Frames inside `pairs` are replaced by layer(pair); the others pass through (swin_512.py:302-307).
         The two disjoint pairs of layers 0/2 share weights, so they run as ONE call with the pair as batch."""
         layer = self.layers[layer_idx]
@@ -253,6 +253,9 @@ class SwinTransformerLayerv5(nn.Module):
         p = pairs[0]
         if not (torch.is_grad_enabled() and x_v.requires_grad and _FRAME_GRAD_LINK):
             mid = layer(x_v[:, p].contiguous())
+            if own_input and not torch.is_grad_enabled():   # a temporary of forward_tokens, no graph: the pair goes back in place
+                x_v[:, p].copy_(mid)                        # (momentum-key passes, evaluation: no cat over the whole clip)
+                return x_v
             return torch.cat([x_v[:, :p.start], mid.to(x_v.dtype), x_v[:, p.stop:]], dim=1)
         link = {}
         x_v = _FenceFn.apply(x_v)            # exactly two consumers below, whatever else uses the caller's tensor
@@ -265,11 +268,11 @@ class SwinTransformerLayerv5(nn.Module):
         assert T == 4, "input feature has wrong size"
         x = x.to(ops.compute_dtype(x))
         for i in range(3):
-            x = self._single_layer_forward(x, self.pairs[i], i)
+            x = self._single_layer_forward(x, self.pairs[i], i, own_input=i > 0)       # (i > 0: x is the previous layer's output)
         out1 = x
         x = self.downsample(x)
         for i in range(3):
-            x = self._single_layer_forward(x, self.pairs[i], 3 + i)
+            x = self._single_layer_forward(x, self.pairs[i], 3 + i, own_input=True)
         return out1, x
 
     def forward(self, x_v):
