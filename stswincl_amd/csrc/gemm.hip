@@ -2027,6 +2027,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
       if (blocks < 176 || (blocks > 256 && blocks % 256 != 0 && blocks % 256 < 200)) ring = false;
     }
     if (rs > nst) rs = nst;
+    { const int per = (nst + rs - 1) / rs; rs = (nst + per - 1) / per; }   // no empty split (its slab would never be written)
     if (ring) {
       const bool slabs = workspace && rs > 1 && (long)rs * Ni * Nj <= workspace_floats;
       if (overwrite && !slabs) (void)hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)Nj * sizeof(float), (size_t)Ni, (hipStream_t)stream);
@@ -2068,6 +2069,9 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
     else { int p2 = 1; while (p2 * 2 <= splits) p2 *= 2; splits = p2; }
   }
   if (splits > ntile) splits = ntile;
+  // ceil(ntile / splits) tiles per split can leave the last splits WITHOUT a tile (259 tiles over 64 splits: 5 each, 12 splits
+  // empty): such a workgroup returns before it writes its slab and the combine would add whatever the workspace held
+  { const int per = (ntile + splits - 1) / splits; splits = (ntile + per - 1) / per; }
   const bool use_slabs = workspace && splits > 1 && (long)splits * Ni * Nj <= workspace_floats;
   if (overwrite && !use_slabs) (void)hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)Nj * sizeof(float), (size_t)Ni, (hipStream_t)stream);
   GemmTN p{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, splits, bseg, use_slabs ? workspace : nullptr, slab_bf16};

@@ -311,3 +311,20 @@ def test_gemm_tn_deferred_combine_equals_inline_combine(monkeypatch):
         assert torch.equal(x, y)
     ref = ops[1][0].float().t() @ ops[1][1].float() + 1.0
     assert float((a[1] - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("mk,ni,nj,ow", [(16544, 200, 896, True), (41504, 88, 728, False), (61824, 88, 192, False), (33088, 448, 136, True),
+                                         (2112, 512, 512, True), (8224, 256, 2048, True)])
+def test_gemm_tn_ragged_contraction_no_empty_split(mk, ni, nj, ow):
+    """A contraction length that does not divide into the automatic split count (259 K tiles over 64 splits = 5 each: 12 splits
+    would be empty) must not leave splits without work: their workgroups return before writing a slab and the combine pass would
+    add whatever the shared workspace held (found by tools/fuzz_gemm.py).  The workspace is poisoned with NaN first."""
+    torch.manual_seed(mk)
+    at = torch.randn(mk, ni, device="cuda").bfloat16()
+    bt = torch.randn(mk, nj, device="cuda").bfloat16()
+    hip._tn_workspace(at.device).fill_(float("nan"))
+    c = torch.empty(ni, nj, device="cuda") if ow else torch.ones(ni, nj, device="cuda")
+    hip.gemm_tn(at, bt, c, Mk=mk, overwrite=ow)
+    ref = at.float().t() @ bt.float() + (0.0 if ow else 1.0)
+    assert torch.isfinite(c).all()
+    assert float((c - ref).abs().max()) < 1e-2 * float(ref.abs().max())
