@@ -402,3 +402,20 @@ def test_conv_bn_epilogue_statistics_with_24_groups(il, monkeypatch):
     assert rel(outs[0], outs[1]) < 6e-3
     assert float((bn_a.running_mean - bn_b.running_mean).abs().max()) < 1e-3 * float(bn_b.running_var.sqrt().max())
     assert rel(bn_a.running_var, bn_b.running_var) < 2e-3
+
+
+def test_single_frame_nchw_input_to_tokens():
+    """One NCHW frame with a 64-multiple channel count: permute + reshape is a strided VIEW there, not a copy - to_tokens must still
+    hand the kernels row-major tokens (ASPP on a single feature map, found by tools/fuzz_ops.py)."""
+    torch.manual_seed(0)
+    x = torch.randn(1, 128, 5, 7, device="cuda")
+    t = H.to_tokens(x)
+    assert t.is_contiguous() and torch.equal(t, x[0].permute(1, 2, 0).reshape(35, 128))
+    conv = nn.Conv2d(128, 64, 3, padding=2, dilation=2).cuda()
+    y, ho, wo = H.conv_tokens(t, conv, 1, 5, 7)
+    assert rel(H.from_tokens(y, 1, ho, wo), conv(x)) < 1e-3
+    net = ASPP(num_classes=256).cuda().eval()
+    fm = torch.randn(1, 1024, 6, 6, device="cuda")
+    with torch.no_grad():
+        out = net(fm)
+    assert out.shape == (1, 256, 6, 6) and torch.isfinite(out).all()

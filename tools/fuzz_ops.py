@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the module-level HIP paths against torch / the CPU oracle: convolutions on tokens (random
+geometry), BatchNorm on tokens (groups, interleaved units, residual, train / eval), Swin blocks and PatchMerging (random
+resolution / window / shift / batch), max-pool, bilinear, OHEM, regression_loss, fused optimizers.  fp32 path unless noted.
+Prints every mismatch; exit code 1 if any.   usage: fuzz_ops.py [cases per family] [seed]"""
+import os, sys, random
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from oracle import stswin_oracle as O
+from stswincl_amd import headops as H
+from stswincl_amd.net.Ours import swin_512 as S
+from stswincl_amd.utils.losses import OhemCELoss2D
+from stswincl_amd.contrast.models import PixPro_swin_v5 as P
+from stswincl_amd.optim import FusedAdam, FusedSGD
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def check(name, r, tol, info):
+    global bad
+    if not (r < tol):
+        bad += 1
+        print(f"MISMATCH {name}: rel {r:.3e} (tol {tol}) {info}", flush=True)
+
+
+def fuzz_conv():
+    cin, cout = 8 * rng.randint(1, 40), 4 * rng.randint(1, 70)
+    k = rng.choice([1, 3]); stride = rng.choice([1, 1, 2]); dil = rng.choice([1, 1, 2, 4, 6]) if k == 3 else 1
+    f, h, w = rng.randint(1, 5), rng.randint(3, 20), rng.randint(3, 20)
+    bias = rng.random() < 0.5
+    info = f"conv cin={cin} cout={cout} k={k} s={stride} d={dil} f={f} h={h} w={w} bias={bias}"
+    globals()["LAST"] = info
+    conv = nn.Conv2d(cin, cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil, bias=bias)
+    x = torch.randn(f, cin, h, w, requires_grad=True)
+    y = conv(x); g = torch.randn_like(y); (y * g).sum().backward()
+    convg = nn.Conv2d(cin, cout, k, stride=stride, padding=dil if k == 3 else 0, dilation=dil, bias=bias).cuda()
+    convg.load_state_dict(conv.state_dict())
+    lin, lout = H.Layout.dense(cin), H.Layout.dense(cout)
+    xt = H.pad_cols(H.to_tokens(x.detach().cuda()), lin.width).requires_grad_(True)
+    yt, ho, wo = H.conv_tokens(xt, convg, f, h, w)
+    check("conv/y", rel(H.from_tokens(yt, f, ho, wo)[:, :cout], y), 1e-3, info)
+    (yt.float() * H.pad_cols(H.to_tokens(g.cuda()), lout.width)).sum().backward()
+    check("conv/dx", rel(H.from_tokens(xt.grad, f, h, w)[:, :cin], x.grad), 2e-3, info)
+    check("conv/dw", rel(convg.weight.grad, conv.weight.grad), 2e-3, info)
+    if bias:
+        check("conv/db", rel(convg.bias.grad, conv.bias.grad), 2e-3, info)
+
+
+def fuzz_bn():
+    c = 8 * rng.randint(1, 64); groups = rng.choice([1, 1, 2, 4]); clips = rng.randint(1, 3)
+    f = groups * clips; h, w = rng.randint(2, 12), rng.randint(2, 12)
+    relu, res, training, il = rng.random() < 0.6, rng.random() < 0.4, rng.random() < 0.8, rng.random() < 0.5 and groups > 1
+    info = f"bn c={c} groups={groups} f={f} h={h} w={w} relu={relu} res={res} train={training} il={il}"
+    bn = nn.BatchNorm2d(c); bn.weight.data = 1 + 0.2 * torch.randn(c); bn.bias.data = 0.2 * torch.randn(c)
+    bn.running_mean.data = 0.1 * torch.randn(c); bn.running_var.data = 0.5 + torch.rand(c)
+    bng = nn.BatchNorm2d(c).cuda(); bng.load_state_dict(bn.state_dict()); bn.train(training); bng.train(training)
+    x = (torch.randn(f, c, h, w) * 2 + 1).requires_grad_(True); r = torch.randn(f, c, h, w, requires_grad=True); g = torch.randn(f, c, h, w)
+    # group of frame i: contiguous -> i // clips ; interleaved (clip-major clips of `groups` frames) -> i % groups
+    gid = [(i % groups) if il else (i // clips) for i in range(f)]
+    ys = [None] * f
+    for gi in range(groups):                       # sequential per-group calls, group 0 first (base18.py:86-89)
+        idx = [i for i in range(f) if gid[i] == gi]
+        out = bn(x[idx])
+        for j, i in enumerate(idx):
+            ys[i] = out[j:j + 1]
+    y = torch.cat(ys, 0)
+    if res: y = y + r
+    if relu: y = F.relu(y)
+    (y * g).sum().backward()
+    lay = H.Layout.dense(c)
+    xt = H.pad_cols(H.to_tokens(x.detach().cuda()).contiguous(), lay.width).requires_grad_(True)
+    rt = H.pad_cols(H.to_tokens(r.detach().cuda()).contiguous(), lay.width).requires_grad_(True) if res else None
+    yt = H.batchnorm_tokens(xt, bng, relu=relu, resid=rt, groups=groups, il_frames=f if il else 0)
+    check("bn/y", rel(H.from_tokens(yt, f, h, w)[:, :c], y), 1e-3, info)
+    (yt.float() * H.pad_cols(H.to_tokens(g.cuda()), lay.width)).sum().backward()
+    check("bn/dx", rel(H.from_tokens(xt.grad, f, h, w)[:, :c], x.grad), 3e-3, info)
+    check("bn/dgamma", rel(bng.weight.grad, bn.weight.grad), 3e-3, info)
+    check("bn/dbeta", rel(bng.bias.grad, bn.bias.grad), 3e-3, info)
+    if res: check("bn/dres", rel(H.from_tokens(rt.grad, f, h, w)[:, :c], r.grad), 3e-3, info)
+    if training:
+        check("bn/rm", rel(bng.running_mean, bn.running_mean), 1e-3, info); check("bn/rv", rel(bng.running_var, bn.running_var), 1e-3, info)
+
+
+def fuzz_swin_block():
+    ws = rng.choice([4, 8]); heads = 4; dim = heads * rng.choice([32, 64, 128] if ws == 8 else [32, 64, 128])   # (head dims the attention kernels are built for)
+    res = (ws * rng.randint(1, 3), ws * rng.randint(1, 4)); shift = rng.choice([0, ws // 2]); B = rng.randint(1, 3)
+    info = f"swin dim={dim} res={res} ws={ws} shift={shift} B={B}"
+    torch.manual_seed(rng.randint(0, 1 << 30))
+    blk = S.SwinTransformerBlock(dim, res, heads, window_size=ws, shift_size=shift)
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and not k.endswith("attn_mask"):
+            sd[k] = v + 0.05 * torch.randn_like(v)
+    blk.load_state_dict(sd)
+    L = res[0] * res[1]
+    x = torch.randn(B, 2, L, dim); g = torch.randn(B, 2, L, dim)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not k.endswith("attn_mask")}
+    sdo = dict(sd); sdo.update(params)
+    xo = x.clone().requires_grad_(True)
+    yo = O.swin_block(xo, sdo, "", res, heads, ws, shift); (yo * g).sum().backward()
+    blk = blk.cuda(); xg = x.cuda().requires_grad_(True)
+    y = blk(xg); (y.float() * g.cuda()).sum().backward()
+    check("swin/y", rel(y, yo), 1e-3, info); check("swin/dx", rel(xg.grad, xo.grad), 2e-3, info)
+    for k, p in blk.named_parameters():
+        check("swin/d" + k, rel(p.grad, params[k].grad), 3e-3, info)
+
+
+def fuzz_patch_merge():
+    dim = 16 * rng.randint(1, 8); res = (2 * rng.randint(1, 8), 2 * rng.randint(1, 8)); B = rng.randint(1, 3)      # (4 dim: whole 64-wide K tiles)
+    info = f"merge dim={dim} res={res} B={B}"
+    pm = S.PatchMerging(res, dim)
+    sd = {k: v.clone() + 0.05 * torch.randn_like(v) for k, v in pm.state_dict().items()}
+    pm.load_state_dict(sd)
+    x = torch.randn(B, 4, res[0] * res[1], dim)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    yo = O.patch_merging(xo, params, "", res); g = torch.randn_like(yo); (yo * g).sum().backward()
+    pm = pm.cuda(); xg = x.cuda().requires_grad_(True)
+    y = pm(xg); (y.float() * g.cuda()).sum().backward()
+    check("merge/y", rel(y, yo), 1e-3, info); check("merge/dx", rel(xg.grad, xo.grad), 2e-3, info)
+    for k, p in pm.named_parameters():
+        check("merge/d" + k, rel(p.grad, params[k].grad), 3e-3, info)
+
+
+def fuzz_pool_bilinear():
+    f, c, h, w = rng.randint(1, 4), 8 * rng.randint(1, 16), rng.randint(3, 30), rng.randint(3, 30)
+    info = f"pool f={f} c={c} h={h} w={w}"
+    x = torch.randn(f, c, h, w, requires_grad=True)
+    y = F.max_pool2d(x, 3, 2, 1); g = torch.randn_like(y); (y * g).sum().backward()
+    xt = H.to_tokens(x.detach().cuda()).contiguous().requires_grad_(True)
+    yt = H.MaxPoolTokFn.apply(xt, (f, h, w)); ho, wo = y.shape[2:]
+    check("maxpool/y", rel(H.from_tokens(yt, f, ho, wo), y), 1e-6, info)
+    (yt.float() * H.to_tokens(g.cuda())).sum().backward()
+    check("maxpool/dx", rel(H.from_tokens(xt.grad, f, h, w), x.grad), 1e-6, info)
+    H2, W2 = rng.randint(2, 40), rng.randint(2, 40)
+    x2 = torch.randn(f, c, h, w, requires_grad=True)
+    y2 = F.interpolate(x2, (H2, W2), mode="bilinear", align_corners=False); g2 = torch.randn_like(y2); (y2 * g2).sum().backward()
+    xt2 = H.to_tokens(x2.detach().cuda()).contiguous().requires_grad_(True)
+    yt2 = H.BilinearTokFn.apply(xt2, (f, h, w, H2, W2))
+    check("bilinear/y", rel(H.from_tokens(yt2, f, H2, W2), y2), 1e-5, info + f" -> {H2}x{W2}")
+    (yt2.float() * H.to_tokens(g2.cuda())).sum().backward()
+    check("bilinear/dx", rel(H.from_tokens(xt2.grad, f, h, w), x2.grad), 1e-5, info + f" -> {H2}x{W2}")
+
+
+def fuzz_ohem():
+    b, nc, h, w = rng.randint(1, 3), rng.choice([2, 5, 12, 21]), rng.randint(4, 64), rng.randint(4, 64)
+    n_min = max(1, (b * h * w) // rng.choice([2, 16, 64])); thresh = rng.choice([0.3, 0.7, 0.9])
+    info = f"ohem b={b} nc={nc} h={h} w={w} n_min={n_min} thresh={thresh}"
+    logits = (torch.randn(b, nc, h, w) * rng.choice([0.5, 2.0, 6.0])).requires_grad_(True)
+    labels = torch.randint(0, nc, (b, h, w))
+    if rng.random() < 0.5:
+        labels[torch.rand(b, h, w) < 0.2] = -1
+    lo = O.ohem_ce(logits, labels, n_min, thresh); lo.backward()
+    lg = logits.detach().cuda().requires_grad_(True)
+    out = OhemCELoss2D(n_min, thresh)(lg, labels.cuda()); out.backward()
+    check("ohem/loss", abs(float(out) - float(lo)) / (abs(float(lo)) + 1e-9), 1e-4, info)
+    check("ohem/dlogits", rel(lg.grad, logits.grad), 1e-3, info)
+
+
+def fuzz_regression_loss():
+    nb, c, h, w = rng.randint(1, 3), rng.choice([32, 64, 128, 256]), rng.randint(2, 20), rng.randint(2, 20)
+    ncls = rng.choice([2, 5, 12])
+    info = f"regloss n={nb} c={c} h={h} w={w} classes={ncls}"
+    feats = [F.normalize(torch.randn(nb, c, h, w), dim=1) for _ in range(6)]
+    labs = [torch.randint(0, ncls, (nb, 1, h, w)).float() for _ in range(6)]
+    q = feats[0].clone().requires_grad_(True)
+    lo = O.regression_loss(q, *feats[1:], *labs, ncls); lo.backward()
+    qg = feats[0].clone().cuda().requires_grad_(True)
+    lg = P.regression_loss(qg, *[f_.cuda() for f_ in feats[1:]], *[l.cuda() for l in labs], ncls); lg.backward()
+    check("regloss/loss", abs(float(lg) - float(lo)) / (abs(float(lo)) + 1e-9), 1e-4, info)
+    check("regloss/dq", rel(qg.grad, q.grad), 2e-3, info)
+
+
+def fuzz_optim():
+    shapes = [tuple(rng.randint(1, 70) for _ in range(rng.randint(1, 3))) for _ in range(rng.randint(1, 60))]
+    kind = rng.choice(["adam", "sgd"]); wd = rng.choice([0.0, 1e-4]); steps = rng.randint(1, 3)
+    info = f"optim {kind} tensors={len(shapes)} wd={wd} steps={steps}"
+    ref = [torch.randn(s) for s in shapes]
+    pa = [nn.Parameter(t.clone().cuda()) for t in ref]; pb = [nn.Parameter(t.clone().cuda()) for t in ref]
+    if kind == "adam":
+        oa, ob = FusedAdam(pa, 1e-2, weight_decay=wd), torch.optim.Adam(pb, 1e-2, weight_decay=wd)
+    else:
+        oa, ob = FusedSGD(pa, 1e-2, momentum=0.9, weight_decay=wd), torch.optim.SGD(pb, 1e-2, momentum=0.9, weight_decay=wd)
+    for _ in range(steps):
+        gs = [torch.randn(s).cuda() for s in shapes]
+        for p, q_, g in zip(pa, pb, gs):
+            p.grad, q_.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    worst = max(rel(p, q_) for p, q_ in zip(pa, pb))
+    check("optim", worst, 1e-5, info)
+
+
+FAMILIES = [fuzz_conv, fuzz_bn, fuzz_swin_block, fuzz_patch_merge, fuzz_pool_bilinear, fuzz_ohem, fuzz_regression_loss, fuzz_optim]
+only = os.environ.get("FUZZ_ONLY")
+for fam in FAMILIES:
+    if only and only not in fam.__name__:
+        continue
+    for i in range(n):
+        torch.manual_seed(rng.randint(0, 1 << 30))
+        try:
+            fam()
+        except Exception as e:                      # noqa: BLE001  (a crash is a finding too)
+            bad += 1
+            import traceback
+            tb = traceback.extract_tb(e.__traceback__)
+            where = "; ".join(f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.line}" for fr in tb[-2:])
+            print(f"EXCEPTION in {fam.__name__}: {type(e).__name__}: {str(e)[:200]} @ {where} [{globals().get('LAST', '')}]", flush=True)
+    print(f"{fam.__name__}: {n} cases done, {bad} findings so far", flush=True)
+sys.exit(1 if bad else 0)
