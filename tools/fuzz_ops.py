@@ -200,7 +200,86 @@ def fuzz_optim():
     check("optim", worst, 1e-5, info)
 
 
-FAMILIES = [fuzz_conv, fuzz_bn, fuzz_swin_block, fuzz_patch_merge, fuzz_pool_bilinear, fuzz_ohem, fuzz_regression_loss, fuzz_optim]
+def fuzz_bank():
+    from stswincl_amd import hip
+    C = rng.choice([64, 128, 256]); maps = rng.randint(2, 6); qb = rng.choice([rng.randint(20, 300), 63, 64, 256])
+    nblk = rng.randint(1, 3)
+    if rng.random() < 0.6:
+        seg, bb = nblk * qb, qb                    # per-sample blocks: query block i sees bank block i of every map
+    else:
+        nblk = 1; seg = rng.randint(qb, 3000); bb = seg      # one query block sees the whole segment (the library's other legal form)
+    M = nblk * qb
+    sets = rng.choice([1, 2]) if maps >= 3 else 1
+    gmap = [[m for m in range(maps) if m != s_] for s_ in range(sets)] if sets == 2 else [list(range(maps))]
+    Mq = M * sets
+    info = f"bank C={C} maps={maps} q_block={qb} blocks={nblk} seg={seg} bank_block={bb} sets={sets}"
+    globals()["LAST"] = info
+    q = F.normalize(torch.randn(Mq, C), dim=1); bank = F.normalize(torch.randn(maps, seg, C), dim=2)
+    lq = torch.randint(0, 12, (Mq,), dtype=torch.int32); lb = torch.randint(0, 12, (maps, seg), dtype=torch.int32)
+    pos, tot, rmax, lse = hip.contrast_bank_fwd(q.cuda(), lq.cuda(), bank.cuda(), lb.cuda(), q_sets=len(gmap), q_block=qb, bank_block=bb,
+                                                gmap=gmap, inv_tau=5.0, want_lse=True)
+    rp, rn, rm, rl = O.bank_scores(q, lq.long(), bank, lb.long(), gmap, qb, bb, inv_tau=5.0)
+    scale = float((rp + rn).abs().max()) + 1e-6
+    check("bank/pos", float((pos.cpu() - rp).abs().max()) / scale, 5e-5, info)
+    check("bank/neg", float(((tot - pos).cpu() - rn).abs().max()) / scale, 5e-5, info)
+    check("bank/max", float((rmax.cpu() - rm).abs().max()), 1e-4, info)
+    check("bank/lse", float((lse.cpu() - rl).abs().max()), 2e-4, info)
+
+
+def fuzz_argmax():
+    from stswincl_amd.utils import EndoMetric as E
+    f, nc, h, w = rng.randint(1, 3), rng.choice([2, 8, 12]), rng.randint(4, 70), rng.randint(4, 90)
+    Hh, Ww = rng.randint(h, 4 * h), rng.randint(w, 4 * w)
+    info = f"argmax f={f} nc={nc} {h}x{w} -> {Hh}x{Ww}"
+    globals()["LAST"] = info
+    logits = torch.randn(f, nc, h, w) * 3
+    gt = torch.randint(0, nc, (f, Hh, Ww))
+    ref = torch.argmax(F.interpolate(logits, (Hh, Ww), mode="bilinear", align_corners=True), dim=1)
+    labels, dices, ious = E.predict_and_score(logits.cuda(), (Hh, Ww), gt.cuda())
+    check("argmax/labels", float((labels.cpu().long() != ref).float().mean()), 5e-4, info)
+
+
+def fuzz_conv_bn_stats():
+    """bf16, >= 8192 output rows: statistics from the GEMM epilogue against the colstats pass (both HIP)."""
+    cin, cout = 64 * rng.randint(1, 8), 64 * rng.randint(1, 8); k = rng.choice([1, 3]); dil = rng.choice([1, 2, 4]) if k == 3 else 1
+    G = rng.choice([1, 2, 4]); side = rng.choice([16, 32, 48, 64]); f = G * rng.randint(1, 4)
+    while f * side * side < 8192: f += G
+    il = rng.random() < 0.5 and G > 1
+    info = f"conv+bn stats cin={cin} cout={cout} k={k} d={dil} G={G} f={f} side={side} il={il}"
+    globals()["LAST"] = info
+    conv = nn.Conv2d(cin, cout, k, padding=dil if k == 3 else 0, dilation=dil, bias=rng.random() < 0.3).cuda()
+    bns = [nn.BatchNorm2d(cout).cuda() for _ in range(2)]
+    x = torch.randn(f * side * side, cin, device="cuda").bfloat16()
+    outs = []
+    for bn, fused in zip(bns, (True, False)):
+        H._FUSED_BN_STATS = fused
+        with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+            y, ho, wo, tab = H.conv_tokens(x, conv, f, side, side, stats=True)
+            if fused and (f * side * side) % 256 == 0 and tab is None:
+                check("stats/eligible", 1.0, 0.5, info)
+            outs.append(H.batchnorm_tokens(y, bn, relu=True, groups=G, il_frames=f if il else 0, stats=tab))
+    H._FUSED_BN_STATS = True
+    check("stats/y", rel(outs[0], outs[1]), 8e-3, info)
+    check("stats/rv", rel(bns[0].running_var, bns[1].running_var), 3e-3, info)
+    check("stats/rm", float((bns[0].running_mean - bns[1].running_mean).abs().max()) / float(bns[1].running_var.sqrt().max()), 2e-3, info)
+
+
+def fuzz_tswinplus():
+    from stswincl_amd.net.Ours.base18 import TswinPlus
+    B = rng.randint(2, 4); h, w = 64 * rng.randint(1, 2), 64 * rng.randint(1, 3)
+    info = f"tswinplus B={B} {h}x{w}"
+    globals()["LAST"] = info
+    m = TswinPlus(12, (h // 8, w // 8))
+    sd = {k_: v.clone() for k_, v in m.state_dict().items()}
+    x = torch.randn(B, 4, 3, h, w)
+    with torch.no_grad():
+        ref = O.tswin_plus(x, sd, training=True)
+    y = m.cuda().train()(x.cuda())
+    check("tswinplus/y", rel(y, ref), 1e-3, info)
+
+
+FAMILIES = [fuzz_conv, fuzz_bn, fuzz_swin_block, fuzz_patch_merge, fuzz_pool_bilinear, fuzz_ohem, fuzz_regression_loss, fuzz_optim,
+            fuzz_bank, fuzz_argmax, fuzz_conv_bn_stats, fuzz_tswinplus]
 only = os.environ.get("FUZZ_ONLY")
 for fam in FAMILIES:
     if only and only not in fam.__name__:
