@@ -1856,6 +1856,12 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
   const bool fits32 = (a_rows || (long)M * lda * 2 <= 0xFFFF0000L) && (long)N * ldb * 2 <= 0xFFFF0000L;
   bool big = dtype == 0 && Kseg % 32 == 0 && N >= 256 && M >= 256 && fills && fits32 && !(flags & (GF_NOBIG | GF_WAVES4));
   if ((flags & GF_BIG) && dtype == 0 && Kseg % 32 == 0 && fits32) big = true;
+  // sums of squares exist in the ring kernel's register epilogue only; an output that cannot take it (a pointer or pitch that is
+  // not 16-byte aligned: a column slice of a wider buffer) goes to the 128x128 family, whose epilogue has them for any alignment
+  const bool regepi_ok = !(flags & (GF_OUT_F32 | GF_ACCUM | GF_NOREGEPI)) && N % 8 == 0 && ldc % 8 == 0 && (!C2 || ldc2 % 8 == 0) &&
+                         (!R || ldr % 8 == 0) && ((uintptr_t)C % 16 == 0) && (!C2 || (uintptr_t)C2 % 16 == 0) &&
+                         (!R || (uintptr_t)R % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0);
+  if ((flags & GF_CS_SQ) && !regepi_ok && !(flags & GF_BIG)) big = false;
   const bool mid_ok = dtype == 0 && Kseg % 32 == 0 && fits32 && !(flags & (GF_NOBIG | GF_WAVES4));
   const bool mid = (flags & GF_MID) && mid_ok;
   // 256x128 ping-pong ring (twice the tiles of the 256x256 one): for shapes whose 256x256 grid leaves CUs idle

@@ -47,8 +47,11 @@ for case in range(n_cases):
         lin = A[:M].float() @ W.float().t()
     if bias is not None:
         lin = lin + bias
-    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    info = f"M={M} N={N} K={K} S={S} gather={gather} bias={bias is not None} mode={mode}"
+    # outputs (and residuals) as column slices of wider buffers: pitch != N, first column at a 16-byte (or only 8-byte) offset
+    pad_l = rng.choice([0, 0, 8, 16, 4]); pad_r = rng.choice([0, 8, 40])
+    obuf = torch.empty(M, pad_l + N + pad_r, device=dev, dtype=torch.bfloat16)
+    out = obuf[:, pad_l:pad_l + N]
+    info = f"M={M} N={N} K={K} S={S} gather={gather} bias={bias is not None} mode={mode} out_off={pad_l} pitch={obuf.shape[1]}"
     kw = dict(M=M, a_rows=a_rows if a_rows is None or S > 1 else a_rows[0].contiguous(), S=S, bias=bias)
     try:
         if mode == "plain":
@@ -64,7 +67,7 @@ for case in range(n_cases):
             d = (0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5).float()
             check(mode, out, F.gelu(lin), 2e-2, info); check(mode + "/d", o2, d, 2e-2, info)
         elif mode in ("resid", "mulr"):
-            R = torch.randn(M, N, device=dev).bfloat16()
+            R = torch.randn(M, N + pad_r, device=dev).bfloat16()[:, :N]
             hip.gemm_nt(A, W, out, resid=R, flags=hip.GF_RESID if mode == "resid" else hip.GF_MUL_R, **kw)
             check(mode, out, lin + R.float() if mode == "resid" else lin * R.float(), 2e-2, info)
         elif mode == "colsum":
