@@ -296,7 +296,87 @@ def fuzz_tswinplus():
     check("tswinplus/y", rel(y, ref), 1e-3, info)
 
 
-FAMILIES = [fuzz_conv, fuzz_bn, fuzz_swin_block, fuzz_patch_merge, fuzz_pool_bilinear, fuzz_ohem, fuzz_regression_loss, fuzz_optim,
+def fuzz_window_attention():
+    """WindowAttention at the production head shapes (ws 8 / C 512 and ws 4 / C 1024, 4 heads) and the reduced ones, random window
+    counts, with and without an SW-MSA style mask, against the oracle; fp32 or bf16 (FUZZ_BF16)."""
+    ws, C = rng.choice([(8, 512), (4, 1024), (8, 128), (4, 256), (8, 256), (4, 512), (4, 128)])
+    nW = rng.choice([1, 2, 4, 6]); groups = rng.randint(1, 3); B_ = nW * groups
+    masked = rng.random() < 0.5 and nW > 1
+    info = f"winattn ws={ws} C={C} nW={nW} B_={B_} masked={masked}"
+    globals()["LAST"] = info
+    att = S.WindowAttention(C, (ws, ws), 4)
+    sd = {k_: (v + 0.02 * torch.randn_like(v) if v.is_floating_point() else v) for k_, v in att.state_dict().items()}
+    att.load_state_dict(sd)
+    N = ws * ws
+    x = torch.randn(B_, 2, N, C) * 0.5; g = torch.randn(B_, 2, N, C)
+    mask = None
+    if masked:
+        mask = torch.zeros(nW, N, N)
+        for wi in range(nW):
+            ids = torch.randint(0, 3, (N,))
+            mask[wi] = (ids[:, None] != ids[None, :]).float() * -100.0
+    params = {k_: v.clone().requires_grad_(True) for k_, v in sd.items() if v.is_floating_point()}
+    sdo = dict(sd); sdo.update(params)
+    xo = x.clone().requires_grad_(True)
+    yo = O.window_attention(xo, sdo, "", 4, ws, mask); (yo * g).sum().backward()
+    att = att.cuda(); xg = x.cuda().requires_grad_(True)
+    with amp():
+        y = att(xg, mask.cuda() if mask is not None else None)
+    (y.float() * g.cuda()).sum().backward()
+    tol = 0.04 if BF16 else 1e-3
+    check("winattn/y", rel(y, yo), tol, info); check("winattn/dx", rel(xg.grad, xo.grad), 2 * tol, info)
+    for k_, p_ in att.named_parameters():
+        check("winattn/d" + k_, rel(p_.grad, params[k_].grad), 3 * tol, info)
+
+
+def fuzz_ohem_edges():
+    b, nc, h, w = 2, 12, 16, 16
+    kind = rng.choice(["all_ignored", "one_valid", "all_below", "all_above", "n_min_ge_count"])
+    info = f"ohem edge {kind}"
+    globals()["LAST"] = info
+    logits = torch.randn(b, nc, h, w).requires_grad_(True)
+    labels = torch.randint(0, nc, (b, h, w)); n_min, thresh = b * h * w // 16, 0.7
+    if kind == "all_ignored": labels[:] = -1
+    if kind == "one_valid": labels[:] = -1; labels[0, 3, 4] = 5
+    if kind == "all_below":
+        logits = (F.one_hot(labels, nc).permute(0, 3, 1, 2).float() * 30).requires_grad_(True)
+    if kind == "all_above": thresh = 0.01
+    if kind == "n_min_ge_count": n_min = b * h * w - 1
+    lo = O.ohem_ce(logits, labels, n_min, thresh); lo.backward()
+    lg = logits.detach().cuda().requires_grad_(True)
+    out = OhemCELoss2D(n_min, thresh)(lg, labels.cuda()); out.backward()
+    same_nan = (float(lo) != float(lo)) and (float(out) != float(out))
+    if not same_nan:
+        check("ohemedge/loss", abs(float(out) - float(lo)) / (abs(float(lo)) + 1e-6), 1e-4, info + f" ref={float(lo)} got={float(out)}")
+        check("ohemedge/dlogits", float((lg.grad.cpu() - logits.grad).abs().max()), 1e-5, info)
+
+
+def fuzz_optim_groups():
+    """Parameter groups with their own lr / weight decay, frozen parameters (grad None) and repeated steps."""
+    kind = rng.choice(["adam", "sgd"])
+    shapes = [tuple(rng.randint(1, 40) for _ in range(rng.randint(1, 3))) for _ in range(rng.randint(2, 30))]
+    ref = [torch.randn(s_) for s_ in shapes]
+    pa = [nn.Parameter(t.clone().cuda()) for t in ref]; pb = [nn.Parameter(t.clone().cuda()) for t in ref]
+    cut = rng.randint(1, len(shapes) - 1)
+    ga = [{"params": pa[:cut], "lr": 1e-2, "weight_decay": 1e-4}, {"params": pa[cut:], "lr": 3e-3, "weight_decay": 0.0}]
+    gb = [{"params": pb[:cut], "lr": 1e-2, "weight_decay": 1e-4}, {"params": pb[cut:], "lr": 3e-3, "weight_decay": 0.0}]
+    info = f"optim groups {kind} tensors={len(shapes)} cut={cut}"
+    globals()["LAST"] = info
+    if kind == "adam":
+        oa, ob = FusedAdam(ga, 1e-3), torch.optim.Adam(gb, 1e-3)
+    else:
+        oa, ob = FusedSGD(ga, 1e-3, momentum=0.9), torch.optim.SGD(gb, 1e-3, momentum=0.9)
+    for step in range(3):
+        for i, (p_, q_) in enumerate(zip(pa, pb)):
+            if rng.random() < 0.2:
+                p_.grad = q_.grad = None
+            else:
+                gten = torch.randn(shapes[i]).cuda(); p_.grad, q_.grad = gten.clone(), gten.clone()
+        oa.step(); ob.step()
+    check("optimgroups", max(rel(p_, q_) for p_, q_ in zip(pa, pb)), 1e-5, info)
+
+
+FAMILIES = [fuzz_window_attention, fuzz_ohem_edges, fuzz_optim_groups, fuzz_conv, fuzz_bn, fuzz_swin_block, fuzz_patch_merge, fuzz_pool_bilinear, fuzz_ohem, fuzz_regression_loss, fuzz_optim,
             fuzz_bank, fuzz_argmax, fuzz_conv_bn_stats, fuzz_tswinplus]
 only = os.environ.get("FUZZ_ONLY")
 for fam in FAMILIES:
