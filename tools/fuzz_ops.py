@@ -376,7 +376,32 @@ def fuzz_optim_groups():
     check("optimgroups", max(rel(p_, q_) for p_, q_ in zip(pa, pb)), 1e-5, info)
 
 
-FAMILIES = [fuzz_window_attention, fuzz_ohem_edges, fuzz_optim_groups, fuzz_conv, fuzz_bn, fuzz_swin_block, fuzz_patch_merge, fuzz_pool_bilinear, fuzz_ohem, fuzz_regression_loss, fuzz_optim,
+def fuzz_consistency():
+    """Whole ConsistencyLoss step (2 query + 6 key passes, EMA, both regression_loss terms) against the oracle in fp32: random
+    clip counts and (non-square) frame sizes, batched and sequential views."""
+    import types
+    B = rng.randint(2, 3); h, w = 64 * rng.randint(1, 2), 64 * rng.randint(1, 2)
+    seq = rng.random() < 0.3
+    os.environ["STSWIN_SEQUENTIAL_VIEWS"] = "1" if seq else "0"
+    info = f"consistency B={B} {h}x{w} sequential={seq}"
+    globals()["LAST"] = info
+    args = types.SimpleNamespace(pixpro_p=1.0, pixpro_momentum=0.99, pixpro_clamp_value=0.0, pixpro_transform_layer=1,
+                                 pixpro_ins_loss_weight=0.0, pixpro_pos_ratio=0.7, data="endo18", tag="1", pretrainpth="none",
+                                 num_instances=2235, batch_size=B, epochs=150, start_epoch=1)
+    net = P.ConsistencyLoss(args, input_resolution=(h // 8, w // 8))
+    sd = {"pixpro." + k_: v.clone() for k_, v in net.pixpro.state_dict().items()}
+    pkeys = [k_ for k_, _ in net.pixpro.named_parameters()]
+    ims = [torch.randn(B, 4, 3, h, w) for _ in range(6)]
+    masks = [torch.randint(0, 12, (B, 1, h // 8, w // 8)).float().repeat_interleave(8, 2).repeat_interleave(8, 3) for _ in range(6)]
+    with torch.no_grad():
+        lo, _ = O.consistency_loss(ims, masks, {k_: v.clone() for k_, v in sd.items()}, pkeys, net.pixpro.k, net.pixpro.K)
+    net = net.cuda().train()
+    with torch.no_grad():
+        lg = net(*[i.cuda() for i in ims], *[m_.cuda() for m_ in masks])
+    check("consistency/loss", abs(float(lg) - float(lo)) / abs(float(lo)), 2e-3, info + f" ref={float(lo):.5f} got={float(lg):.5f}")
+
+
+FAMILIES = [fuzz_consistency, fuzz_window_attention, fuzz_ohem_edges, fuzz_optim_groups, fuzz_conv, fuzz_bn, fuzz_swin_block, fuzz_patch_merge, fuzz_pool_bilinear, fuzz_ohem, fuzz_regression_loss, fuzz_optim,
             fuzz_bank, fuzz_argmax, fuzz_conv_bn_stats, fuzz_tswinplus]
 only = os.environ.get("FUZZ_ONLY")
 for fam in FAMILIES:
