@@ -650,7 +650,7 @@ def to_tokens(x: torch.Tensor) -> torch.Tensor:
     """(F, C, H, W) logical -> [F*H*W][C] (free when x is channels-last)."""
     f, c, h, w = x.shape
     t = x.permute(0, 2, 3, 1).reshape(f * h * w, c)
-    # (a single NCHW frame reshapes to a VIEW with strides (1, H*W): the kernels want rows, found by tools/fuzz_ops.py)
+    # (a single NCHW frame reshapes to a VIEW with strides (1, H*W): the kernels want rows, found by tests/fuzz/fuzz_ops.py)
     return t if t.is_contiguous() else t.contiguous()
 
 

@@ -2,7 +2,7 @@
 """Randomised parity sweep of gemm_nt / gemm_tn (bf16) against fp32 torch: random shapes (ragged M, N multiples of 8, K multiples
 of 64), row maps, epilogue combinations, column sums / statistics tables.  Prints every mismatch; exit code 1 if any."""
 import os, sys, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.nn.functional as F
 from stswincl_amd import hip

@@ -2,9 +2,10 @@
 """Randomised parity sweep of the module-level HIP paths against torch / the CPU oracle: convolutions on tokens (random
 geometry), BatchNorm on tokens (groups, interleaved units, residual, train / eval), Swin blocks and PatchMerging (random
 resolution / window / shift / batch), max-pool, bilinear, OHEM, regression_loss, fused optimizers.  fp32 path unless noted.
-Prints every mismatch; exit code 1 if any.   usage: fuzz_ops.py [cases per family] [seed]"""
+Prints every mismatch; exit code 1 if any.   usage: fuzz_ops.py [cases per family] [seed]   (FUZZ_ONLY / FUZZ_SKIP: family name substrings, FUZZ_BF16=1)
+Test infrastructure: lives under tests/ because it checks against oracle/."""
 import os, sys, random
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import torch.nn as nn
@@ -404,8 +405,9 @@ def fuzz_consistency():
 FAMILIES = [fuzz_consistency, fuzz_window_attention, fuzz_ohem_edges, fuzz_optim_groups, fuzz_conv, fuzz_bn, fuzz_swin_block, fuzz_patch_merge, fuzz_pool_bilinear, fuzz_ohem, fuzz_regression_loss, fuzz_optim,
             fuzz_bank, fuzz_argmax, fuzz_conv_bn_stats, fuzz_tswinplus]
 only = os.environ.get("FUZZ_ONLY")
+skip = [t for t in os.environ.get("FUZZ_SKIP", "").split(",") if t]
 for fam in FAMILIES:
-    if only and only not in fam.__name__:
+    if (only and only not in fam.__name__) or any(t in fam.__name__ for t in skip):
         continue
     for i in range(n):
         torch.manual_seed(rng.randint(0, 1 << 30))

@@ -318,7 +318,7 @@ def test_gemm_tn_deferred_combine_equals_inline_combine(monkeypatch):
 def test_gemm_tn_ragged_contraction_no_empty_split(mk, ni, nj, ow):
     """A contraction length that does not divide into the automatic split count (259 K tiles over 64 splits = 5 each: 12 splits
     would be empty) must not leave splits without work: their workgroups return before writing a slab and the combine pass would
-    add whatever the shared workspace held (found by tools/fuzz_gemm.py).  The workspace is poisoned with NaN first."""
+    add whatever the shared workspace held (found by tests/fuzz/fuzz_gemm.py).  The workspace is poisoned with NaN first."""
     torch.manual_seed(mk)
     at = torch.randn(mk, ni, device="cuda").bfloat16()
     bt = torch.randn(mk, nj, device="cuda").bfloat16()

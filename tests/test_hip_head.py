@@ -406,7 +406,7 @@ def test_conv_bn_epilogue_statistics_with_24_groups(il, monkeypatch):
 
 def test_single_frame_nchw_input_to_tokens():
     """One NCHW frame with a 64-multiple channel count: permute + reshape is a strided VIEW there, not a copy - to_tokens must still
-    hand the kernels row-major tokens (ASPP on a single feature map, found by tools/fuzz_ops.py)."""
+    hand the kernels row-major tokens (ASPP on a single feature map, found by tests/fuzz/fuzz_ops.py)."""
     torch.manual_seed(0)
     x = torch.randn(1, 128, 5, 7, device="cuda")
     t = H.to_tokens(x)
