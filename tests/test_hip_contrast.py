@@ -100,9 +100,11 @@ def test_reference_pretrain_loop_idiom_ddp_lars_gradscaler():
     from stswincl_amd.contrast.lars import LARS, add_weight_decay
     created = False
     if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29617")
-        dist.init_process_group("nccl", rank=0, world_size=1)
+        import socket
+        with socket.socket() as sock:                       # a free port: nothing else may own 29xxx on the box
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
         created = True
     try:
         g = gu.load("consistency.npz")
