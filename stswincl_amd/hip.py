@@ -82,7 +82,14 @@ def _p(t: Optional[torch.Tensor]):
     return _c_void_p(t.data_ptr())
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    # the raw handle of the calling thread's current stream on the current device: torch.cuda.current_stream() builds a Stream
+    # object per call (9 us, ~460 calls per training step = 4 ms of host time); the private accessor is 20x cheaper
+    if _RAW_STREAM is not None:
+        return _c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return _c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
