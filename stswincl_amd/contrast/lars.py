@@ -82,7 +82,10 @@ class LARS:
 
     @torch.no_grad()
     def step(self, closure=None):
-        loss = closure() if closure is not None else None
+        loss = None
+        if closure is not None:                    # (torch.optim re-enables grad for the closure: it runs forward + backward)
+            with torch.enable_grad():
+                loss = closure()
         for group in self.optim.param_groups:
             if group.get("dampening", 0) != 0 or group.get("nesterov", False) or group.get("maximize", False):
                 raise hip.StswinHipError("fused LARS wraps plain SGD-momentum (dampening 0, nesterov off)")

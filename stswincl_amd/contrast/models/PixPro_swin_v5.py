@@ -308,6 +308,7 @@ class PixPro(nn.Module):
     def forward(self, seq_1, seq_2, seq_3, seq_4, seq_5, seq_6):
         # (the num_batches_tracked increments of the 8 encoder passes - 240 one-element add kernels - are applied by one
         # foreach add on exit; the accumulators of all passes come out of one zero-filled block)
+        H.refuse_replica(self)
         hip.arena_reset(seq_1.device)
         seqs = (seq_1, seq_2, seq_3, seq_4, seq_5, seq_6)
         with H.deferred_bn_counters():

@@ -173,7 +173,11 @@ class ConvTokFn(torch.autograd.Function):
         S = k * k
         g = dy.detach().to(dt).contiguous()
         # weight gradient first: its split-K combine then runs beside the input-gradient GEMM (hip.tn_deferred)
-        dwp = torch.empty(lout.width, S * lin.width, dtype=torch.float32, device=X.device)
+        # (1x1 with dense layouts: the GEMM output IS the gradient - written straight into the data-parallel bucket slice)
+        from .ops import wgrad_buffer
+        direct = lin.is_identity and lout.is_identity and S == 1
+        dwp = (wgrad_buffer(weight, (lout.width, lin.width), X.device) if direct
+               else torch.empty(lout.width, S * lin.width, dtype=torch.float32, device=X.device))
         hip.gemm_tn(g, X, dwp, Mk=Mo, bt_rows=fmap, bseg=lin.width if fmap is not None else 0, overwrite=True)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -203,7 +207,15 @@ class ConvTokFn(torch.autograd.Function):
             dbp = hip.zeros(lout.width, device=X.device)
             hip.colsum(g, dbp)
             db = lout.unpad_vec(dbp)
-        return dx, (dw.view(co, ci, 1, 1) if dw is dwp else dw.reshape(co, ci, k, k)), db, None, None, None, None, None
+        if dw is dwp:
+            dw = dw.view(co, ci, 1, 1)
+        else:
+            dw = dw.reshape(co, ci, k, k)                 # a strided view (tap-major GEMM output): autograd would clone it into the
+            from .dp import grad_dest                     # parameter's layout anyway - make that copy land in the all-reduce bucket
+            dest = grad_dest(weight) if getattr(weight, "_stswin_grad_dest", None) is not None else None
+            if dest is not None:
+                dw = dest.copy_(dw)
+        return dx, dw, db, None, None, None, None, None
 
 
 class GradLink:
@@ -274,7 +286,7 @@ class StemConvFn(torch.autograd.Function):
         hip.gemm_nt(patches, wm.to(dt), y, M=y.shape[0], stats_out=tab)
         keep = patches.numel() * patches.element_size() <= (2 << 30)
         ctx.cfg = (dt, Ho, Wo, keep)
-        ctx.save_for_backward(patches if keep else im)
+        ctx.save_for_backward(patches if keep else im, weight)
         if want_stats:
             ctx.mark_non_differentiable(tab)
             ctx.set_materialize_grads(False)
@@ -286,14 +298,17 @@ class StemConvFn(torch.autograd.Function):
     def backward(ctx, dy, _dtab=None):
         if dy is None:
             return None, None, None, None
-        (saved,) = ctx.saved_tensors
+        saved, weight = ctx.saved_tensors
         dt, Ho, Wo, keep = ctx.cfg
         patches = saved if keep else hip.stem_im2col(saved, dt, Ho, Wo)
         im = saved
         dw = torch.empty(64, 192, dtype=torch.float32, device=im.device)
         hip.gemm_tn(dy.detach().to(dt).contiguous(), patches, dw, Mk=patches.shape[0], overwrite=True)
         hip.tn_join()
-        return None, dw[:, :147].reshape(64, 7, 7, 3).permute(0, 3, 1, 2), None, None
+        dwv = dw[:, :147].reshape(64, 7, 7, 3).permute(0, 3, 1, 2)
+        from .dp import grad_dest
+        dest = grad_dest(weight) if getattr(weight, "_stswin_grad_dest", None) is not None else None
+        return None, (dest.copy_(dwv) if dest is not None else dwv), None, None
 
 
 def stem_conv_tokens(img, weight, dt, stats=False):
@@ -342,6 +357,22 @@ def combine_bn_stats(mean_r: torch.Tensor, m2_r: torch.Tensor, n_r: torch.Tensor
     return mean, m2 / n, n
 
 
+def refuse_replica(module) -> None:
+    """nn.DataParallel over several GPUs (seg18/train_swin.py:131-135) runs replicas of the model on Python threads of ONE
+    process.  The caches of this package (zero arena, packed-weight cache keyed on parameter objects, BatchNorm-counter and
+    view-batching contexts) are per process, and DataParallel re-broadcasts the weights and re-packs them every step - racing on
+    them silently would be the worst outcome, so a replica refuses to run.  One process per GPU is the supported layout."""
+    if getattr(module, "_is_replica", False):
+        raise hip.StswinHipError(
+            "stswincl_amd modules do not run as nn.DataParallel replicas (several GPUs driven by threads of one process). Use one "
+            "process per GPU instead: `python -m torch.distributed.run --nproc-per-node N train.py` with "
+            "torch.nn.parallel.DistributedDataParallel or stswincl_amd.dp.GradBucketReducer (see INTEGRATION.md, 'Data parallel'); "
+            "nn.DataParallel(model, device_ids=[torch.cuda.current_device()]) - a single device - is fine.")
+
+
+COLLECTIVES: dict = {}     # collective launches of this module so far, by kind (tests assert the per-step budget)
+
+
 def _sync_world(bn) -> int:
     import torch.distributed as dist
     if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
@@ -374,17 +405,23 @@ class BNTokFn(torch.autograd.Function):
             pivot = (X.view(-1, unit, Cp)[:groups, 0, :] if unit > 0 else X.view(groups, n_loc, Cp)[:, 0, :]).float()
             mean_l = pivot + s / n_loc
             m2_l = ss - s * s / n_loc
-            pack = torch.stack([mean_l, m2_l])                                  # [2][groups][C]
-            allp = torch.empty(world * 2, *pack.shape[1:], dtype=pack.dtype, device=pack.device)   # (gloo wants the dim-0 concat form)
+            # the rank's rows per group ride in the same payload (third plane): ranks may hold different row counts (an uneven
+            # last batch, a sampler without padding) and nn.SyncBatchNorm weighs by count too.  Everything stays on the device.
+            pack = torch.stack([mean_l, m2_l, torch.full_like(mean_l, float(n_loc))])   # [3][groups][C]
+            allp = torch.empty(world * 3, *pack.shape[1:], dtype=pack.dtype, device=pack.device)   # (gloo wants the dim-0 concat form)
             dist.all_gather_into_tensor(allp, pack)
-            allp = allp.view(world, 2, *pack.shape[1:])
-            rows_total = world * n_loc
-            mean, var, _ = combine_bn_stats(allp[:, 0], allp[:, 1], torch.full((world,), float(n_loc), device=pack.device))
+            COLLECTIVES["syncbn_all_gather"] = COLLECTIVES.get("syncbn_all_gather", 0) + 1
+            allp = allp.view(world, 3, *pack.shape[1:])
+            n_r = allp[:, 2, 0, 0]                                              # [world] rows per group of every rank
+            mean, var, n_tot = combine_bn_stats(allp[:, 0], allp[:, 1], n_r)
             rstd = torch.rsqrt(var + eps)
+            unbias = n_tot / (n_tot - 1).clamp(min=1)
+            # backward: the kernel divides the cross-rank sums by ITS rows per group; pre-scaling them by n_loc / n_tot makes that 1 / n_tot
+            ctx.sum_scale = float(n_loc) / n_tot
             rm, rv = lay.pad_vec(running_mean), lay.pad_vec(running_var, 1.0)
             for g in range(groups):
                 rm = (1 - momentum) * rm + momentum * mean[g]
-                rv = (1 - momentum) * rv + momentum * var[g] * (rows_total / max(rows_total - 1, 1))
+                rv = (1 - momentum) * rv + momentum * var[g] * unbias
             running_mean.copy_(lay.unpad_vec(rm))
             running_var.copy_(lay.unpad_vec(rv))
             mean, rstd = mean.contiguous(), rstd.contiguous()
@@ -433,8 +470,10 @@ class BNTokFn(torch.autograd.Function):
             loc1, loc2 = s1.clone(), s2.clone()                 # weight/bias grads stay local sums (DDP averages them)
             both = torch.stack([s1, s2])
             dist.all_reduce(both)
+            COLLECTIVES["syncbn_all_reduce"] = COLLECTIVES.get("syncbn_all_reduce", 0) + 1
+            both = both * ctx.sum_scale                         # (rows of all ranks, a device scalar: see forward)
             hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, dres, groups, relu, training, phase=2,
-                       sums=(both[0].contiguous(), both[1].contiguous()), rows_total=rows_total, beta=bp, unit=ctx.unit)
+                       sums=(both[0].contiguous(), both[1].contiguous()), rows_total=0, beta=bp, unit=ctx.unit)
             s1, s2 = loc1, loc2
         else:
             # (the dx pass also writes s1 | s2 summed over the statistic groups: the parameter gradients, no torch reduction)

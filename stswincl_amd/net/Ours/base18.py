@@ -60,6 +60,7 @@ class TswinPlus(nn.Module):
 
     def forward(self, x):
         hi, wi = x.shape[3:]
+        H.refuse_replica(self)
         hip.arena_reset(x.device)                           # one zero-fill block per step (forward + backward accumulators)
         with H.deferred_bn_counters():
             cat, (b, h, w) = decode_tokens(self.resnet, self.swin, self.aspp, self.project1, self.project2, self.project3, x)

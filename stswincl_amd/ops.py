@@ -173,6 +173,15 @@ def zeros_like_list(shapes, device, fill=True):
     return [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
 
 
+def wgrad_buffer(p: torch.Tensor, shape, device) -> torch.Tensor:
+    """Uninitialised fp32 buffer for the weight gradient of parameter p that an overwriting kernel fills: p's slice of its
+    data-parallel all-reduce bucket when a dp.GradBucketReducer manages p (the gradient is then born flat: no copy into the
+    bucket), else a fresh allocation."""
+    from .dp import grad_dest
+    d = grad_dest(p, shape) if getattr(p, "_stswin_grad_dest", None) is not None else None
+    return d if d is not None else torch.empty(shape, dtype=torch.float32, device=device)
+
+
 def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if p is None else p.detach().float().contiguous()
 
@@ -274,7 +283,8 @@ class SwinBlockFn(torch.autograd.Function):
         (dn1_w, dn1_b, dfc2_b, dfc1_b, dn2_w, dn2_b, dproj_b, dbiasT, dqkv_b, dtable) = zeros_like_list(
             [(C,), (C,), (C,), (hid,), (C,), (C,), (C,), (heads, N, N), (3 * C,), (tsz, heads)], dev)
         # the weight gradients are written by gemm_tn(overwrite=True): no zero fill for the large buffers
-        dfc2_w, dfc1_w, dproj_w, dqkv_w = zeros_like_list([(C, hid), (hid, C), (C, C), (3 * C, C)], dev, fill=False)
+        dfc2_w, dfc1_w, dproj_w, dqkv_w = (wgrad_buffer(fc2_w, (C, hid), dev), wgrad_buffer(fc1_w, (hid, C), dev),
+                                           wgrad_buffer(proj_w, (C, C), dev), wgrad_buffer(qkv_w, (3 * C, C), dev))
         g = dout.detach().to(dt).contiguous().view(M, C)
         # norm1 (its dx column sums are fc2's bias gradient)
         dy2 = hip.layernorm_bwd(g, y2, _f32(n1_w), mean1, rstd1, dn1_w, dn1_b, M=M, dxsum=dfc2_b)
@@ -339,7 +349,7 @@ class PatchMergeFn(torch.autograd.Function):
         M4 = n.shape[0]
         dev = X2.device
         g = dy.detach().to(dt).contiguous().view(M4, 2 * C)
-        dred = torch.empty(2 * C, 4 * C, dtype=torch.float32, device=dev)
+        dred = wgrad_buffer(red_w, (2 * C, 4 * C), dev)
         hip.gemm_tn(g, n, dred, Mk=M4, overwrite=True)
         dn = torch.empty(M4, 4 * C, dtype=dt, device=dev)
         hip.gemm_nt(g, wcast(red_w, dt, True), dn, M=M4)
@@ -435,7 +445,7 @@ class LinearFn(torch.autograd.Function):
             # possible, so compute it with the GEMM epilogue on the weight-gradient path instead
             dpre = (g.float() * _dgelu(aux.float())).to(dt)
             g = dpre
-        dw = torch.empty(Nn, K, dtype=torch.float32, device=X2.device)
+        dw = wgrad_buffer(w, (Nn, K), X2.device)
         hip.gemm_tn(g, X2, dw, Mk=M, overwrite=True)
         db = None
         if ctx.has_b:

@@ -42,7 +42,10 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        loss = closure() if closure is not None else None
+        loss = None
+        if closure is not None:                    # (torch.optim re-enables grad for the closure: it runs forward + backward)
+            with torch.enable_grad():
+                loss = closure()
         for group in self.param_groups:
             b1, b2 = group["betas"]
             by_step = {}          # torch.optim.Adam keeps the step count PER PARAMETER (bias corrections differ when a branch
@@ -55,7 +58,9 @@ class FusedAdam(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["step"] = int(st["step"]) + 1
+                if not isinstance(st["step"], int):          # a state loaded from torch.optim.Adam holds tensor steps: one host
+                    st["step"] = int(st["step"])             # read, here, before any capture (see load_state_dict)
+                st["step"] += 1
                 ps, gs, ms, vs = by_step.setdefault(st["step"], ([], [], [], []))
                 ps.append(p.data)
                 touched.append(p)
@@ -69,13 +74,26 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
 
+    def load_state_dict(self, state_dict):
+        """torch.optim.Adam checkpoints keep `step` as a (possibly GPU) tensor per parameter; the fused kernel takes the bias
+        corrections as host scalars, so the counts become Python ints here - once, outside any hipGraph capture - instead of
+        forcing a device-to-host read inside step()."""
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if "step" in st and not isinstance(st["step"], int):
+                st["step"] = int(st["step"])
+
+
 class FusedSGD(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
 
     @torch.no_grad()
     def step(self, closure=None):
-        loss = closure() if closure is not None else None
+        loss = None
+        if closure is not None:                    # (torch.optim re-enables grad for the closure: it runs forward + backward)
+            with torch.enable_grad():
+                loss = closure()
         for group in self.param_groups:
             first, later, touched = ([], [], []), ([], [], []), []
             for p in group["params"]:

@@ -10,13 +10,14 @@
 Same function names and key handling as seg18/utils/LoadModel.py: ``load_model`` strips ``module.`` only from
 ``module.resnet*`` keys (:55-59), ``load_model_full`` strips nothing (:96-100), ``load_model_full_fortest`` strips it from
 every ``module*`` key (:128-132), ``load_model_mswin_CL`` remaps the contrastive prefixes (:14-28); all four keep the model's
-own tensor where shapes differ.  Deviations: ``map_location`` is the model's device instead of a hard-coded 'cuda:0'; a
-``{'model': state_dict, ...}`` wrapper is unwrapped by the three raw loaders as well; the GEMM operand caches are dropped
-after a load (ops.clear_caches).
+own tensor where shapes differ; which keys each loader takes from which file layout is pinned against the reference's own
+functions (tests/golden/loadmodel.npz, tools/gen_golden.py --only loadmodel).  Deviations: ``map_location`` is the model's
+device instead of a hard-coded 'cuda:0'; the GEMM operand caches are dropped after a load (ops.clear_caches).
 
 The reference's contrastive checkpoints hold ``{'opt': argparse.Namespace, 'model', 'optimizer', 'scheduler', 'epoch'}``
 (main_pretrain_swinv5.py:91-102); torch >= 2.6 refuses the Namespace under its default ``weights_only=True``, so
-``_torch_load`` allow-lists it and, for other trusted reference pickles, falls back to ``weights_only=False``.
+``_torch_load`` allow-lists it; any other global is refused unless the caller opts in (``trusted=True`` /
+``STSWIN_TRUST_CHECKPOINTS=1``).
 """
 from __future__ import annotations
 
@@ -28,14 +29,25 @@ _CL_PREFIXES = (("pixpro.encoder_1", "resnet"), ("pixpro.encoder_2", "swin"), ("
                 ("pixpro.proj1", "project1"), ("pixpro.proj2", "project2"), ("pixpro.proj3", "project3"))
 
 
-def _torch_load(path, map_location):
+def _torch_load(path, map_location, trusted=None):
+    """torch.load with the safe unpickler (``weights_only=True``; ``argparse.Namespace`` - the ``'opt'`` entry of the
+    reference's contrastive checkpoints - is the only extra global allowed).  A checkpoint that needs other globals is
+    refused with the unpickler's message unless the caller opts in: ``trusted=True`` or ``STSWIN_TRUST_CHECKPOINTS=1``
+    (full pickle: runs whatever code the file holds - only for checkpoints you wrote yourself)."""
     import argparse
+    import os
     import pickle
+    if trusted is None:
+        trusted = os.environ.get("STSWIN_TRUST_CHECKPOINTS") == "1"
     try:
         with torch.serialization.safe_globals([argparse.Namespace]):
             return torch.load(path, map_location=map_location, weights_only=True)
-    except (pickle.UnpicklingError, RuntimeError, AttributeError):
-        return torch.load(path, map_location=map_location, weights_only=False)   # trusted checkpoints of the reference's own scripts
+    except pickle.UnpicklingError as e:
+        if trusted:
+            return torch.load(path, map_location=map_location, weights_only=False)
+        raise pickle.UnpicklingError(
+            f"{path}: refused by the safe unpickler ({e}).  If this checkpoint comes from a source you trust, pass trusted=True "
+            "to the loader or set STSWIN_TRUST_CHECKPOINTS=1 to unpickle it without restrictions.") from e
 
 
 def _device_of(model):
@@ -53,8 +65,7 @@ def strip_module_prefix(state_dict):
 def remap_contrastive_keys(cl_state_dict):
     """``pixpro.encoder_1.* -> resnet.*`` etc. (seg18/utils/LoadModel.py:14-28); other keys are dropped."""
     out = OrderedDict()
-    for key, val in cl_state_dict.items():
-        key = key[7:] if key.startswith("module.") else key
+    for key, val in cl_state_dict.items():          # (a DDP 'module.' prefix matches no branch there: the file is saved from model.module)
         for src, dst in _CL_PREFIXES:
             if key.startswith(src):
                 out[dst + key[len(src):]] = val
@@ -91,34 +102,32 @@ def _after_load(model):
     return model
 
 
-def _raw_state_dict(pretrain_dir, model):
-    ckpt = _torch_load(pretrain_dir, _device_of(model))
+def _raw_state_dict(pretrain_dir, model, trusted=None):
+    ckpt = _torch_load(pretrain_dir, _device_of(model), trusted)
     print('loaded pretrained weights form %s !' % pretrain_dir)
-    if isinstance(ckpt, dict) and 'model' in ckpt and not any(str(k).endswith('.weight') for k in ckpt):
-        ckpt = ckpt['model']
     return ckpt
 
 
-def load_model_mswin_CL(model, pretrain_dir, log=True):
-    ckpt = _torch_load(pretrain_dir, _device_of(model))
+def load_model_mswin_CL(model, pretrain_dir, log=True, trusted=None):
+    ckpt = _torch_load(pretrain_dir, _device_of(model), trusted)
     print('loaded pretrained weights form %s !' % pretrain_dir)
     return _after_load(_merge_into(model, remap_contrastive_keys(ckpt['model']), log))
 
 
-def load_model(model, pretrain_dir, log=True):
+def load_model(model, pretrain_dir, log=True, trusted=None):
     """Raw seg checkpoint; only ``module.resnet*`` keys lose their DataParallel prefix (LoadModel.py:55-59)."""
-    sd = _raw_state_dict(pretrain_dir, model)
+    sd = _raw_state_dict(pretrain_dir, model, trusted)
     sd = OrderedDict((k[7:] if (k.startswith('module.resnet') and not k.startswith('module_list')) else k, v) for k, v in sd.items())
     return _after_load(_merge_into(model, sd, log))
 
 
-def load_model_full(model, pretrain_dir, log=True):
+def load_model_full(model, pretrain_dir, log=True, trusted=None):
     """Raw checkpoint, keys taken as they are (LoadModel.py:96-100)."""
-    return _after_load(_merge_into(model, OrderedDict(_raw_state_dict(pretrain_dir, model)), log))
+    return _after_load(_merge_into(model, OrderedDict(_raw_state_dict(pretrain_dir, model, trusted)), log))
 
 
-def load_model_full_fortest(model, pretrain_dir, log=True):
+def load_model_full_fortest(model, pretrain_dir, log=True, trusted=None):
     """Raw checkpoint saved from nn.DataParallel: every ``module*`` key loses its first 7 characters (LoadModel.py:128-132)."""
-    sd = _raw_state_dict(pretrain_dir, model)
+    sd = _raw_state_dict(pretrain_dir, model, trusted)
     sd = OrderedDict((k[7:] if (k.startswith('module') and not k.startswith('module_list')) else k, v) for k, v in sd.items())
     return _after_load(_merge_into(model, sd, log))

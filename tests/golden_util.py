@@ -80,3 +80,62 @@ def skeleton_sd(keys, shapes, dtypes) -> Dict[str, torch.Tensor]:
 
 def shape_str(t: torch.Tensor) -> str:
     return "x".join(str(int(v)) for v in t.shape) if t.dim() else "scalar"
+
+
+# ------------------------------------------------------------------ checkpoint-loader fixture
+def toy_seg_model() -> torch.nn.Module:
+    """A small module with TswinPlus's top-level attribute names (the loaders of seg18/utils/LoadModel.py only look at
+    state-dict keys and shapes, so the fixture does not need the 60 M-parameter model).  Built identically by
+    tools/gen_golden.py (which feeds it to the REFERENCE loaders) and by tests/test_loadmodel.py."""
+    import torch.nn as nn
+
+    class Swin(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.qkv = nn.Linear(3, 6)
+            self.register_buffer("attn_mask", torch.zeros(4, 2, 2))
+
+    m = nn.Module()
+    m.resnet = nn.Sequential(nn.Conv2d(2, 3, 1, bias=False), nn.BatchNorm2d(3))
+    m.swin = Swin()
+    m.aspp = nn.Sequential(nn.Conv2d(3, 2, 1))
+    m.project1 = nn.Sequential(nn.Conv2d(3, 2, 1, bias=False), nn.BatchNorm2d(2))
+    m.project2 = nn.Sequential(nn.Conv2d(3, 2, 1, bias=False), nn.BatchNorm2d(2))
+    m.project3 = nn.Sequential(nn.Conv2d(6, 2, 1, bias=False), nn.BatchNorm2d(2))
+    m.classifier = nn.Sequential(nn.Conv2d(6, 4, 3, padding=1, bias=False), nn.BatchNorm2d(4), nn.ReLU(), nn.Conv2d(4, 5, 1))
+    m.module_list = nn.ModuleList([nn.Linear(2, 2)])
+    det_fill(m.state_dict(), salt=11)          # (state_dict tensors alias the parameters)
+    return m
+
+
+def toy_checkpoints(model: torch.nn.Module):
+    """-> {case: object to torch.save}: the on-disk shapes the reference writes (raw state-dict with / without the DataParallel
+    prefix, seg18/utils/summary.py:76-88; the contrastive stage's {'opt', 'model', ...}, main_pretrain_swinv5.py:87-103),
+    each with a shape mismatch (attn_mask of another resolution), a key the model lacks and a model key the file lacks."""
+    import argparse
+    sd = model.state_dict()
+    val = lambda k, v: (det_tensor("ckpt/" + k, tuple(v.shape)) if v.is_floating_point() else v.clone() + 7)  # noqa: E731
+
+    def raw(prefix):
+        out = {}
+        for k, v in sd.items():
+            if k.startswith("classifier.3"):
+                continue                                            # missing in the file: the model keeps its own
+            kk = k if k.startswith("module_list") else prefix + k
+            out[kk] = det_tensor("ckpt/" + k, (9, 2, 2)) if k.endswith("attn_mask") else val(k, v)
+        out[prefix + "head.extra.weight"] = torch.ones(3)           # not in the model: dropped
+        return out
+
+    cl = {}
+    names = (("pixpro.encoder_1", "resnet"), ("pixpro.encoder_2", "swin"), ("pixpro.encoder_3", "aspp"),
+             ("pixpro.proj1", "project1"), ("pixpro.proj2", "project2"), ("pixpro.proj3", "project3"))
+    for k, v in sd.items():
+        for pre, dst in names:
+            if k.startswith(dst + "."):
+                cl[pre + k[len(dst):]] = det_tensor("ckpt/" + k, (9, 2, 2)) if k.endswith("attn_mask") else val(k, v)
+    cl["pixpro.encoder_1_k.0.weight"] = torch.ones(3, 2, 1, 1)     # momentum branch: startswith('pixpro.encoder_1') too!
+    cl["pixpro.projector.linear1.weight"] = torch.ones(3)
+    cl["module.pixpro.proj1.0.weight"] = torch.ones(2, 3, 1, 1)     # a DDP-prefixed key matches no branch of the reference
+    return {"raw_dataparallel": raw("module."), "raw_plain": raw(""),
+            "contrastive": {"opt": argparse.Namespace(batch_size=8, amp_opt_level="O0"), "model": cl, "optimizer": {}, "scheduler": {},
+                            "epoch": 3}}

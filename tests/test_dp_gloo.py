@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from stswincl_amd.dp import GradBucketReducer, all_gather_embeddings, shard_indices
+from stswincl_amd.dp import GradBucketReducer, all_gather_embeddings, grad_dest, shard_indices
 
 
 def _free_port():
@@ -132,6 +132,108 @@ def test_accumulation_none_grads_and_double_backward_world2():
     for rank, err, raised in res:
         assert err < 1e-6, (rank, err)
         assert raised, "a second backward() before finish() must raise"
+
+
+class _DirectLinear(torch.autograd.Function):
+    """A weight-gradient producer that follows the protocol of stswincl_amd.ops.wgrad_buffer: it asks for the parameter's
+    bucket slice, OVERWRITES it and returns it as the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        buf = grad_dest(w, w.shape)
+        if buf is None:
+            buf = torch.empty_like(w)
+        torch.mm(g.t(), x, out=buf)
+        return g @ w, buf
+
+
+def _worker_direct(rank, world, port, comm_dtype, q):
+    """Bucket slices as gradient destinations: gradients written in place are not copied (copied_bytes counts only the
+    torch-produced bias gradients), p.grad IS the bucket slice after finish(), one collective per bucket per step, a
+    parameter used twice in one graph and zero_grad(set_to_none=False) both still give the right sums; and the
+    compressed-wire variant (comm_dtype=bf16: the conversion back runs behind the collective)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        lins = [torch.nn.Linear(16, 16) for _ in range(4)]
+        params = [p for l in lins for p in l.parameters()]
+        red = GradBucketReducer(params, bucket_mb=0.001, comm_dtype=comm_dtype)
+        nb = len(red.buckets)
+        x = torch.arange(6 * 16, dtype=torch.float32).reshape(6, 16) / 50 + rank
+
+        def fwd(xx, twice):
+            h = xx
+            for l in lins:
+                h = torch.tanh(_DirectLinear.apply(h, l.weight) + l.bias)
+            if twice:                                      # lins[0].weight a second time in the same graph
+                h = h + _DirectLinear.apply(xx, lins[0].weight)
+            return h.pow(2).mean()
+
+        out = {}
+        for step, (twice, to_none) in enumerate([(False, True), (True, True), (False, False)]):
+            for p in params:
+                if to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
+            c0, b0 = red.collectives, red.copied_bytes
+            fwd(x, twice).backward()
+            red.finish()
+            refs = []
+            for r in range(world):
+                ls = [torch.nn.Linear(16, 16) for _ in range(4)]
+                for a, b in zip(ls, lins):
+                    a.load_state_dict(b.state_dict())
+                xr = torch.arange(6 * 16, dtype=torch.float32).reshape(6, 16) / 50 + r
+                h = xr
+                for l in ls:
+                    h = torch.tanh(h @ l.weight.t() + l.bias)
+                if twice:
+                    h = h + xr @ ls[0].weight.t()
+                h.pow(2).mean().backward()
+                refs.append([p.grad for l in ls for p in l.parameters()])
+            err = max(float((p.grad - sum(rf[i] for rf in refs) / world).abs().max() / (refs[0][i].abs().max() + 1e-12))
+                      for i, p in enumerate(params))
+            views = {id(p): v for b, vs in zip(red.buckets, red._views) for p, v in zip(b, vs)}
+            in_bucket = all(p.grad.data_ptr() == views[id(p)].data_ptr() for p in params)
+            out[step] = (err, in_bucket, red.collectives - c0, red.copied_bytes - b0)
+        q.put((rank, nb, sum(l.bias.numel() * 4 for l in lins), out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm_dtype", [None, torch.bfloat16])
+def test_bucket_slices_as_gradient_destinations_world2(comm_dtype):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_direct, args=(r, 2, port, comm_dtype, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    tol = 1e-5 if comm_dtype is None else 2e-2
+    for rank, nb, bias_bytes, out in res:
+        assert nb >= 3
+        for step, (err, in_bucket, ncoll, copied) in out.items():
+            assert err < tol, (rank, step, err)
+            assert in_bucket, (rank, step)
+            assert ncoll == nb, (rank, step, ncoll, nb)             # one all-reduce per bucket per step, never per tensor
+        # step 0: only the biases (torch-produced) were copied; step 1: the twice-used weight's two gradients are summed by the
+        # engine's input buffer before they reach the parameter (the slice was handed out once; the sum may live elsewhere and
+        # is then copied: at most one weight more); step 2 (zero_grad in place): everything accumulates into the slices
+        assert out[0][3] == bias_bytes, out[0]
+        assert out[1][3] in (bias_bytes, bias_bytes + 16 * 16 * 4), out[1]
+        assert out[2][3] == 0, out[2]
 
 
 def _worker_bank(rank, world, port, q):

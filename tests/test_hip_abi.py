@@ -34,3 +34,14 @@ def test_no_cpu_fallback():
     x = torch.zeros(8, 64)
     with pytest.raises(hip.StswinHipError):
         hip.layernorm_fwd(x, torch.ones(64), torch.zeros(64), M=8)
+
+
+def test_dataparallel_replica_threads_are_refused_loudly():
+    """seg18/train_swin.py:131-135 wraps the model in nn.DataParallel.  Over several GPUs that means replica threads inside one
+    process, which the per-process caches of this package do not support: a replica must raise with the one-process-per-GPU
+    recipe instead of racing (a single-device DataParallel calls the module itself and is unaffected)."""
+    from stswincl_amd.net.Ours.base18 import TswinPlus
+    m = TswinPlus(12, (8, 8))
+    m._is_replica = True                       # what torch.nn.parallel.replicate sets on every replica module
+    with pytest.raises(hip.StswinHipError, match="one\\s+process per GPU"):
+        m(torch.zeros(1, 4, 3, 64, 64))

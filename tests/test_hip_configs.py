@@ -1,0 +1,218 @@
+"""BASELINE.json configs that the bench line does not time, as `-m gpu` tests:
+
+* configs[2]: the per-GPU batch of the 8-GPU DDP run (B = 8 clips at 512x512) - one full training step, bf16 path against
+  the fp32 path of the same kernels (same assertions as the B = 4 step of test_hip_production_dispatch.py);
+* configs[4]: the joint fine-tune step of seg18/train_CL_ft_mswin_sgd_minput.py (contrastive checkpoint -> TswinPlus,
+  SGD with the script's 7 parameter groups, poly schedule, autocast + GradScaler) with the fp8 attention mode on and off;
+* the CaDIS class counts of segcata/ (8 / 17 / 25 classes) through the model and the OHEM loss, against the CPU oracle;
+* f4 post-processing at the evaluation size of seg18/test.py:155 (512x640 logits -> 1024x1280 labels)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def test_config2_per_gpu_batch8_step_bf16_vs_fp32_path():
+    """BASELINE configs[2] per-GPU work: B = 8 clips x 4 frames x 3x512x512 (M = 131072 token rows at stage 1: three more
+    rounds of 256x256 tiles per GEMM than the B = 4 bench step, other split-K factors).  Bounds as in the B = 4 test: 1.3 x the
+    deviation of the reference's own bf16-autocast run from its fp32 run (tests/golden/bf16_yardstick.npz)."""
+    from stswincl_amd.net.Ours.base18 import TswinPlus
+    from stswincl_amd.utils.losses import OhemCELoss2D
+    S, B = 512, 8
+    torch.manual_seed(0)
+    model = TswinPlus(12, (S // 8, S // 8)).cuda().train()
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    torch.manual_seed(4321)
+    x = torch.randn(B, 4, 3, S, S, device="cuda")
+    y = torch.randint(0, 12, (B, S, S), device="cuda")
+    crit = OhemCELoss2D(S * S // 16)
+    names = ["swin.layers.0.0.attn.qkv.weight", "swin.layers.1.1.mlp.fc1.weight", "swin.layers.5.1.mlp.fc2.weight",
+             "swin.downsample.reduction.weight", "resnet.layer5.1.conv2.weight", "aspp.conv_3x3_2.weight", "classifier.0.weight"]
+    res = {}
+    for mode in ("fp32", "bf16"):
+        model.load_state_dict(sd0)
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=BF, enabled=(mode == "bf16")):
+            out = model(x)
+            loss = crit(out, y)
+        loss.backward()
+        params = dict(model.named_parameters())
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+        res[mode] = (out.detach().float().cpu(), float(loss), {n: params[n].grad.detach().float().cpu() for n in names})
+        del out, loss
+        torch.cuda.empty_cache()
+    (lf, lossf, gf), (lb, lossb, gb) = res["fp32"], res["bf16"]
+    yard = gu.load("bf16_yardstick.npz")
+    r_log, r_loss = rel(lb, lf), abs(lossb - lossf) / abs(lossf)
+    r_g = {n: rel(gb[n], gf[n]) for n in names}
+    print(f"B=8 bf16 vs fp32: logits {r_log:.3e} loss {r_loss:.3e} grads {r_g}")
+    assert r_log < 1.3 * float(yard["rel_logits_256"]), r_log
+    assert r_loss < 1e-3, (lossb, lossf)
+    for n, r in r_g.items():
+        assert r < 1.3 * float(yard["rel_grad/" + n]), (n, r)
+
+
+@pytest.mark.parametrize("nc", [8, 17, 25])
+def test_cadis_class_counts_model_and_ohem_vs_oracle(nc):
+    """segcata/ (CaDIS, num_class_table: 8 / 17 / 25 classes) is the same graph with another classifier width; the classifier's
+    1x1 convolution, the logits upsample and the OHEM kernels take nc as a run-time value.  fp32 path against the CPU oracle
+    (1e-3 gate), train mode, forward + loss + the classifier's gradients; bf16 path: finite and close."""
+    from oracle import stswin_oracle as O
+    from stswincl_amd.net.Ours.base18 import TswinPlus
+    from stswincl_amd.utils.losses import OhemCELoss2D
+    torch.manual_seed(nc)
+    hw = 128
+    m = TswinPlus(nc, (hw // 8, hw // 8))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 4, 3, hw, hw)
+    y = torch.randint(0, nc, (2, hw, hw))
+    y[0, :8, :8] = -1 if nc == 17 else y[0, :8, :8]         # (one case with ignored pixels)
+    sdo = {k: v.clone() for k, v in sd.items()}
+    w_last = sdo["classifier.3.weight"].requires_grad_(True)
+    ref = O.tswin_plus(x, sdo, training=True)
+    ref_loss = O.ohem_ce(ref, y, hw * hw // 16)
+    ref_loss.backward()
+    m = m.cuda().train()
+    out = m(x.cuda())
+    assert out.shape == (2, nc, hw, hw)
+    assert rel(out, ref) < 1e-3, rel(out, ref)
+    loss = OhemCELoss2D(hw * hw // 16)(out, y.cuda())
+    assert abs(float(loss) - float(ref_loss)) < 1e-3 * abs(float(ref_loss))
+    loss.backward()
+    assert rel(m.classifier[3].weight.grad, w_last.grad) < 2e-3
+    m.zero_grad(set_to_none=True)
+    m.load_state_dict(sd)
+    with torch.autocast("cuda", dtype=BF):
+        ob = m(x.cuda())
+        lb = OhemCELoss2D(hw * hw // 16)(ob, y.cuda())
+    lb.backward()
+    assert ob.shape == (2, nc, hw, hw) and torch.isfinite(ob).all()
+    assert abs(float(lb) - float(ref_loss)) < 2e-2 * abs(float(ref_loss))
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def _contrastive_checkpoint(path, nc=12, res=(32, 32)):
+    """A file in the layout main_pretrain_swinv5.py:87-103 writes, holding the encoder weights of a (seeded) TswinPlus."""
+    import argparse
+    from stswincl_amd.net.Ours.base18 import TswinPlus
+    from stswincl_amd.utils.LoadModel import _CL_PREFIXES
+    torch.manual_seed(77)
+    src = TswinPlus(nc, res)
+    cl = {}
+    for k, v in src.state_dict().items():
+        for pre, dst in _CL_PREFIXES:
+            if k.startswith(dst + "."):
+                cl[pre + k[len(dst):]] = v.clone()
+    torch.save({"opt": argparse.Namespace(batch_size=8, amp_opt_level="O0"), "model": cl, "optimizer": {}, "scheduler": {}, "epoch": 150},
+               path)
+    return src
+
+
+def _finetune_run(ckpt, fp8: bool, steps=3, S=256, B=2):
+    """train_CL_ft_mswin_sgd_minput.py:126-129 (load_model_mswin_CL), :147-165 (7 groups, classifier lr x 10, SGD momentum +
+    weight decay, OHEM, poly LR_Scheduler_Head), :192-205 (scheduler call, zero_grad, autocast, GradScaler) on the fused path."""
+    from torch.cuda import amp
+    from stswincl_amd.net.Ours.base18 import TswinPlus
+    from stswincl_amd.optim import FusedSGD
+    from stswincl_amd.utils.LoadModel import load_model_mswin_CL
+    from stswincl_amd.utils.losses import OhemCELoss2D
+    os.environ["STSWIN_FP8_ATTN"] = "1" if fp8 else "0"
+    try:
+        torch.manual_seed(5)
+        model = TswinPlus(12, (S // 8, S // 8))
+        model = load_model_mswin_CL(model, ckpt, log=False).cuda().train()
+        lr, iters = 0.01, 100
+        groups = [{"params": model.resnet.parameters(), "lr": lr}, {"params": model.aspp.parameters(), "lr": lr},
+                  {"params": model.swin.parameters(), "lr": lr}, {"params": model.project1.parameters(), "lr": lr},
+                  {"params": model.project2.parameters(), "lr": lr}, {"params": model.project3.parameters(), "lr": lr},
+                  {"params": model.classifier.parameters(), "lr": lr * 10}]
+        opt = FusedSGD(groups, lr=lr, momentum=0.9, weight_decay=1e-4)
+        assert len(opt.param_groups) == 7 and opt.param_groups[-1]["lr"] == pytest.approx(10 * lr)
+        crit = OhemCELoss2D(S * S // 16)
+        scaler = amp.GradScaler()
+        torch.manual_seed(6)
+        lab = torch.randint(0, 12, (B, S // 32, S // 32), device="cuda").repeat_interleave(32, 1).repeat_interleave(32, 2)
+        x = torch.randn(B, 4, 3, S, S, device="cuda") + F.one_hot(lab, 12).permute(0, 3, 1, 2)[:, None, :3].float() * 2.0
+        losses = []
+        for it in range(steps):
+            cur = lr * pow(1 - 1.0 * it / iters, 0.9)                 # LR_Scheduler 'poly' (lr_scheduler.py:56-58) ...
+            for g in opt.param_groups:                                # ... and LR_Scheduler_Head sets every group to it (:76-83)
+                g["lr"] = cur
+            opt.zero_grad()
+            with amp.autocast():
+                loss = crit(model(x), lab)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            losses.append(float(loss.detach()))
+        assert scaler.get_scale() >= 65536.0, "a step was skipped (inf / nan gradients)"
+        assert all(torch.isfinite(p).all() for p in model.parameters())
+        probe = model.swin.layers[0][0].attn.qkv.weight.detach().float().cpu().clone()
+        return losses, probe
+    finally:
+        os.environ.pop("STSWIN_FP8_ATTN", None)
+
+
+def test_config4_joint_finetune_steps_fp8_attention_vs_bf16(tmp_path):
+    """BASELINE configs[4]: the fine-tune step of the joint script with fp8 (e4m3) attention against the same steps with the bf16
+    attention core: same checkpoint, same data.  The fp8 core perturbs each attention output by ~4-5e-2 rel-L2 (kernel test);
+    through the post-norm residual stream that must stay a perturbation of the trajectory: first-step losses within 2 %, every
+    step within 5 %, the loss falls in both runs, and the updated weights of the first Swin block agree to 1e-2 rel-L2 after
+    three SGD steps (the weights themselves, not their increments)."""
+    ckpt = str(tmp_path / "ckpt_epoch_150.pth")
+    src = _contrastive_checkpoint(ckpt, res=(32, 32))
+    l8, w8 = _finetune_run(ckpt, fp8=True)
+    l16, w16 = _finetune_run(ckpt, fp8=False)
+    print(f"configs[4] losses fp8 {l8} bf16 {l16}; qkv.weight rel {rel(w8, w16):.3e}")
+    w0 = src.state_dict()["swin.layers.0.0.attn.qkv.weight"]
+    assert rel(w16, w0) > 1e-5, "the checkpoint was loaded and the weights moved"
+    assert abs(l8[0] - l16[0]) < 2e-2 * abs(l16[0]), (l8, l16)
+    for a, b in zip(l8, l16):
+        assert a == a and abs(a - b) < 5e-2 * abs(b), (l8, l16)
+    assert l8[-1] < l8[0] and l16[-1] < l16[0], (l8, l16)
+    assert rel(w8, w16) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
+def test_postprocessing_at_the_evaluation_size_1024x1280(dtype):
+    """seg18/test.py:153-157 at its real size: 512x640 logits -> bilinear (align_corners=True) to 1024x1280 -> softmax ->
+    arg-max, fused in stswin_upsample_argmax.  Every pixel whose label differs from the reference formulation must be a
+    numerical tie: the reference's own top-2 interpolated logits there differ by less than the fp32 rounding of the
+    interpolation (1e-5 of the logit scale); and there must be only a handful of them."""
+    from stswincl_amd.utils import EndoMetric as E
+    torch.manual_seed(1)
+    f, nc, h, w, H, W = 1, 12, 512, 640, 1024, 1280
+    logits = (torch.randn(f, nc, h // 8, w // 8) * 3)
+    logits = (F.interpolate(logits, (h, w), mode="bilinear") + 0.3 * torch.randn(f, nc, h, w)).to(dtype)   # smooth maps + noise
+    gt = torch.randint(0, nc, (f, H // 64, W // 64)).repeat_interleave(64, 1).repeat_interleave(64, 2)
+    up = F.interpolate(logits.float(), (H, W), mode="bilinear", align_corners=True)
+    ref = torch.argmax(F.softmax(up, dim=1), dim=1)
+    labels, dices, ious = E.predict_and_score(logits.cuda(), (H, W), gt.cuda())
+    lab = labels.cpu().long()
+    assert lab.shape == (f, H, W)
+    mism = lab != ref
+    n_mis = int(mism.sum())
+    if n_mis:
+        top2 = up.permute(0, 2, 3, 1)[mism].topk(2, dim=1).values
+        margin = float((top2[:, 0] - top2[:, 1]).max())
+        print(f"{n_mis} of {H * W} labels differ; largest top-2 margin among them {margin:.2e}")
+        assert margin < 1e-5 * float(up.abs().max()), margin
+    assert n_mis < 1e-5 * H * W + 5
+    rd = E.general_dice(gt[0].numpy(), lab[0].numpy())
+    rj = E.general_jaccard(gt[0].numpy(), lab[0].numpy())
+    assert [c for c, _ in rd] == [c for c, _ in dices[0]]
+    assert np.allclose([v for _, v in rd], [v for _, v in dices[0]], rtol=1e-12)
+    assert np.allclose([v for _, v in rj], [v for _, v in ious[0]], rtol=1e-12)

@@ -68,7 +68,28 @@ def _worker(rank, world, port, q):
             e_il = max(e_il, float((y2[grp::2] - outs[grp][mine]).abs().max()), float((dx2[grp::2] - xrs[grp][mine]).abs().max()))
         e_il = max(e_il, float((sbn2.running_mean.cpu() - ref2.running_mean).abs().max()),
                    float((sbn2.running_var.cpu() - ref2.running_var).abs().max()))
-        q.put((rank, e_y, e_dx, e_rm, e_rv, e_dw, e_il, int(sbn2.num_batches_tracked)))
+        # uneven shards (an unpadded last batch): rank 0 holds 3 frames, rank 1 one frame; statistics, running statistics and the
+        # input gradient must still be those of the 4-frame batch (counts ride in the all-gather payload, nn.SyncBatchNorm does the same)
+        bn3 = torch.nn.BatchNorm2d(c)
+        bn3.load_state_dict(bn.state_dict())
+        ref3 = torch.nn.BatchNorm2d(c)
+        ref3.load_state_dict(bn.state_dict())
+        xr3 = x.clone().requires_grad_(True)
+        yr3 = torch.relu(ref3(xr3))
+        (yr3 * g).sum().backward()
+        sbn3 = torch.nn.SyncBatchNorm.convert_sync_batchnorm(torch.nn.Sequential(bn3))[0].cuda().train()
+        sl3 = slice(0, 3) if rank == 0 else slice(3, 4)
+        nf = 3 if rank == 0 else 1
+        c0 = dict(H.COLLECTIVES)
+        xt3 = H.to_tokens(x[sl3].cuda()).contiguous().requires_grad_(True)
+        yt3 = H.batchnorm_tokens(xt3, sbn3, relu=True)
+        (yt3 * H.to_tokens(g[sl3].cuda())).sum().backward()
+        e_un = max(float((H.from_tokens(yt3, nf, h, w).cpu() - yr3[sl3].detach()).abs().max()),
+                   float((H.from_tokens(xt3.grad, nf, h, w).cpu() - xr3.grad[sl3]).abs().max()),
+                   float((sbn3.running_mean.cpu() - ref3.running_mean).abs().max()),
+                   float((sbn3.running_var.cpu() - ref3.running_var).abs().max()))
+        n_coll = (H.COLLECTIVES["syncbn_all_gather"] - c0["syncbn_all_gather"], H.COLLECTIVES["syncbn_all_reduce"] - c0["syncbn_all_reduce"])
+        q.put((rank, e_y, e_dx, e_rm, e_rv, e_dw, e_il, int(sbn2.num_batches_tracked), e_un, n_coll))
     finally:
         dist.destroy_process_group()
 
@@ -87,6 +108,80 @@ def test_sync_batchnorm_two_ranks_one_gpu():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, e_y, e_dx, e_rm, e_rv, e_dw, e_il, nbt in res:
+    for rank, e_y, e_dx, e_rm, e_rv, e_dw, e_il, nbt, e_un, n_coll in res:
+        assert e_un < 2e-4, (rank, e_un)
+        assert n_coll == (1, 1), n_coll          # one all-gather per BatchNorm forward, one all-reduce per backward
         assert e_y < 1e-4 and e_dx < 1e-4 and e_rm < 1e-5 and e_rv < 1e-4 and e_dw < 1e-3, (rank, e_y, e_dx, e_rm, e_rv, e_dw)
         assert e_il < 2e-4 and nbt == 2, (rank, e_il, nbt)
+
+
+def _worker_budget(rank, world, port, q):
+    """One data-parallel ConsistencyLoss step (2 ranks sharing the GPU over gloo, GradBucketReducer, SyncBatchNorm): counts the
+    collectives the step issues."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import types
+        from stswincl_amd import headops as H
+        from stswincl_amd.contrast.models import PixPro_swin_v5 as P
+        from stswincl_amd.dp import GradBucketReducer
+        args = types.SimpleNamespace(pixpro_p=1.0, pixpro_momentum=0.99, pixpro_clamp_value=0.0, pixpro_transform_layer=1,
+                                     pixpro_ins_loss_weight=0.0, pixpro_pos_ratio=0.7, data="endo18", tag="1", pretrainpth="none",
+                                     num_instances=2235, batch_size=2, epochs=150, start_epoch=1)
+        torch.manual_seed(0)
+        net = P.ConsistencyLoss(args, input_resolution=(8, 8)).cuda().train()
+        px = net.pixpro
+        q_mods = (px.encoder_1, px.encoder_2, px.encoder_3, px.proj1, px.proj2, px.proj3, px.projector)
+        k_mods = (px.encoder_k_1, px.encoder_k_2, px.encoder_k_3, px.proj_k_1, px.proj_k_2, px.proj_k_3, px.projector_k)
+        n_q = sum(isinstance(m, torch.nn.SyncBatchNorm) for mod in q_mods for m in mod.modules())
+        n_k = sum(isinstance(m, torch.nn.SyncBatchNorm) for mod in k_mods for m in mod.modules())
+        red = GradBucketReducer([p for p in net.parameters() if p.requires_grad], bucket_mb=32.0)
+        torch.manual_seed(10 + rank)
+        ims = [torch.randn(2, 4, 3, 64, 64, device="cuda") for _ in range(6)]
+        masks = [torch.randint(0, 12, (2, 1, 8, 8), device="cuda").float().repeat_interleave(8, 2).repeat_interleave(8, 3) for _ in range(6)]
+        counts = []
+        for _ in range(2):
+            c0, r0, b0 = dict(H.COLLECTIVES), red.collectives, red.copied_bytes
+            for p in net.parameters():
+                p.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = net(*ims, *masks)
+            loss.backward()
+            red.finish()
+            torch.cuda.synchronize()
+            counts.append((H.COLLECTIVES.get("syncbn_all_gather", 0) - c0.get("syncbn_all_gather", 0),
+                           H.COLLECTIVES.get("syncbn_all_reduce", 0) - c0.get("syncbn_all_reduce", 0),
+                           red.collectives - r0, red.copied_bytes - b0))
+        gsum = float(sum(p.grad.double().abs().sum() for p in net.parameters() if p.grad is not None))
+        q.put((rank, n_q, n_k, len(red.buckets), red.bytes_per_step(), counts, float(loss.detach()), gsum))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collective_budget_of_a_data_parallel_contrastive_step():
+    """What a step may cost on the wire (checked without multi-GPU hardware): SyncBatchNorm = ONE all-gather per BatchNorm layer
+    per batched pass (the 2 query views are one pass, the 6 key views another - not one exchange per view) + ONE all-reduce per
+    query-side layer in backward; gradients = one all-reduce per 32 MB bucket; and the large weight gradients are born inside
+    their bucket slices (most bytes are never copied).  Both ranks end with identical averaged gradients."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_budget, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, n_q, n_k, nb, nbytes, counts, loss, gsum in res:
+        assert n_q == n_k and n_q > 30
+        for ag, ar, coll, copied in counts:
+            assert ag == n_q + n_k, (ag, n_q, n_k)
+            assert ar == n_q, (ar, n_q)
+            assert coll == nb, (coll, nb)
+            assert copied < 0.35 * nbytes, (copied, nbytes)         # the Swin / 1x1 weight gradients (most of the bytes) are written in place
+        assert loss == loss
+    assert abs(res[0][7] - res[1][7]) <= 1e-6 * abs(res[0][7])

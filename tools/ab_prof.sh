@@ -3,6 +3,7 @@
 #   tools/ab_prof.sh TAG VAR=VALUE [bench args...]  ->  gpurun_out/TAG/{a,b}_kernels.txt  (a = default, b = with the switch)
 set -u
 TAG=$1; SW=$2; shift 2
+for arg in "$@"; do case "$arg" in --gpus*) echo "ab_prof.sh: profiled runs are single-GPU (bench.py would become a launcher under rocprofv3)"; exit 2;; esac; done
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

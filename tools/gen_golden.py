@@ -511,6 +511,42 @@ def gen_bf16_yardstick(swin, base, losses):
     save("bf16_yardstick.npz", **res)
 
 
+def gen_loadmodel():
+    """f3: the REFERENCE's four checkpoint loaders (seg18/utils/LoadModel.py) on the toy model / files of golden_util: for
+    every (loader, file) the fixture stores which model keys ended up holding the file's values and a checksum of the
+    resulting state-dict (or the exception type when the reference loader fails on that file)."""
+    _purge(["utils"])
+    sys.path[:] = [p for p in sys.path if not p.startswith(REF)]
+    sys.path.insert(0, os.path.join(REF, "seg18"))
+    LM = importlib.import_module("utils.LoadModel")
+    import tempfile
+    real_load = torch.load
+    LM.torch = types.SimpleNamespace(load=lambda path, map_location=None: real_load(path, map_location="cpu", weights_only=False))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        files = {}
+        for case, obj in gu.toy_checkpoints(gu.toy_seg_model()).items():
+            files[case] = os.path.join(td, case + ".pth")
+            torch.save(obj, files[case])
+        for fn in ("load_model", "load_model_full", "load_model_full_fortest", "load_model_mswin_CL"):
+            for case, path in files.items():
+                m = gu.toy_seg_model()
+                before = {k: v.clone() for k, v in m.state_dict().items()}
+                tag = f"{fn}/{case}"
+                try:
+                    getattr(LM, fn)(m, path, log=False)
+                except Exception as e:      # e.g. load_model_mswin_CL on a raw state-dict: KeyError('model')
+                    res[tag + "/error"] = np.array(type(e).__name__)
+                    print(f"  {tag}: {type(e).__name__}")
+                    continue
+                after = m.state_dict()
+                changed = [k for k in after if not torch.equal(after[k], before[k])]
+                res[tag + "/changed"] = np.array(changed if changed else [""])
+                res[tag + "/checksum"] = np.array(float(sum(v.double().sum() for v in after.values())))
+                print(f"  {tag}: {len(changed)} keys taken from the file")
+    save("loadmodel.npz", **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -520,6 +556,8 @@ def main():
     def want(n):
         return a.only in (None, n)
 
+    if want("loadmodel"):
+        gen_loadmodel()
     swin, base, aspp_mod, losses = import_seg()
     if want("index_maps"):
         gen_index_maps(swin)
