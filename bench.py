@@ -84,7 +84,7 @@ def physical_cores():
     return (len(cores) or len(allowed)), len(allowed)
 
 
-def cpu_baseline(size: int, budget_s: float = 28.0):
+def cpu_baseline(size: int, budget_s: float = 45.0):
     """The oracle (a port of the reference graph) doing the same training step on the host cores (SURVEY 8(d) protocol).
 
     fwd+bwd+Adam steps of B = 2 clips (B = 1 cannot train: ASPP's BatchNorm on a 1x1 map) in fp32, BEST OF 3 at the largest of

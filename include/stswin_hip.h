@@ -145,8 +145,19 @@ int stswin_tn_combine(const float* workspace, float* C, long ldc, int Ni, int Nj
 #define STSWIN_VAR_TN_SLABS_BF16 0x2000    /* ... bf16 partials */
 int stswin_last_variant(int family);
 
+/* ---- deterministic cross-workgroup sums.  No kernel of this library adds fp32 values with atomics any more: every kernel that sums
+ * over workgroups (bias / LayerNorm / BatchNorm parameter gradients, BatchNorm statistics, the relative-position-bias gradient, the
+ * OHEM statistics) stores one partial vector per workgroup ("slab") into caller-owned scratch and stswin_slab_fold's kernel adds the
+ * slabs in a fixed order behind the launch boundary, so a training step gives the same bits every time it runs.  The `scratch`
+ * arguments below are that space: uninitialised fp32, at least stswin_<entry>_scratch(...) floats, 16-byte aligned, private to the
+ * call until the next kernel on the stream has run (one buffer per stream can serve every call).
+ *   out_s[b*obs + j] (+)= sum_{p < nslabs} ws[b*ws_batch_stride + p*slab_stride + s*seg_len + j],  s < nseg <= 3, j < seg_len */
+int stswin_slab_fold(const float* ws, long slab_stride, long ws_batch_stride, int nslabs, int seg_len, int nseg, float* out0, float* out1,
+                     float* out2, long out_batch_stride, int batch, int accumulate, void* stream);
+
 /* out[n] += sum_m Y[m][n]  (bias gradients) */
-int stswin_colsum(int dtype, const void* y, long ldy, float* out, int M, int N, void* stream);
+long stswin_colsum_scratch(int M, int N);
+int stswin_colsum(int dtype, const void* y, long ldy, float* out, int M, int N, float* scratch, void* stream);
 
 /* ---- nn.LayerNorm (swin_512.py:160,166 norm1/norm2; :253,:274 PatchMerging.norm with the 2x2 gather fused:
  * row r = concat_s x[rows[s][r]][0:Cseg]).  mean/rstd (fp32 [M]) are saved for the backward. */
@@ -156,11 +167,10 @@ int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, lo
                          const float* gamma, const float* mean, const float* rstd, void* dx, long lddx, float* dgamma,
                          float* dbeta, int M, int accumulate_dx,
                          float* dxsum /* optional fp32 [S*Cseg]: += column sums of the dx written */,
-                         float* workspace /* optional caller-owned, ZERO-FILLED fp32 [STSWIN_LN_BWD_REPLICAS][3][S*Cseg]: the
-                                             M/32 workgroups spread their dgamma / dbeta / dxsum atomics over the replicas
-                                             (same-address fp32 atomics serialise) and a fold kernel adds them up */,
+                         float* scratch /* >= stswin_layernorm_bwd_scratch(M, S*Cseg) floats: one [3][S*Cseg] slab (dgamma | dbeta |
+                                           dxsum partial sums) per workgroup; folded into dgamma / dbeta / dxsum (+=) in slab order */,
                          void* stream);
-#define STSWIN_LN_BWD_REPLICAS 32
+long stswin_layernorm_bwd_scratch(int M, int C);
 
 /* out[i] = map[i] >= 0 ? v[map[i]] : fill, i < n: padding of per-channel parameter vectors (BatchNorm weight / bias / running
  * statistics) to the 64-aligned channel layout of the token matrices and the gather back (base18.py:60-77 concat layout). */
@@ -172,12 +182,15 @@ int stswin_vec_gather(const float* v, const int* map, float* out, int n, float f
  * table / dtable fp32 [(2ws-1)^2][heads], index int64 [N*N] (the module's relative_position_index buffer). */
 int stswin_bias_expand(const float* table, const long* index, const float* mask, float* out, int N, int heads, int nW,
                        void* stream);
-int stswin_bias_scatter(const float* dbiasT, const long* index, float* dtable, int N, int heads, void* stream);
+/* scatter in gather form (one workgroup per table row adds its (i, j) pairs in a fixed order: no atomics); table_rows = (2ws-1)^2;
+ * nslabs > 1: dbiasT is [nslabs][heads][N][N] and the slabs are added on the way. */
+int stswin_bias_scatter(const float* dbiasT, const long* index, float* dtable, int N, int heads, int table_rows, int nslabs, void* stream);
 
 /* ---- a6: windowed attention core (swin_512.py:117-138).  qkv [nB_*T*N][3C] = q (pre-scaled) | k | v in window
  * order; biasT [heads][N][N] and maskT [nW][N][N] are the expanded relative-position bias (:122-124) and the
  * SW-MSA mask (:126-131), both transposed to [key][query]; out [nB_*T*N][C] is the (B_, T*N, heads*d) layout of :136.
- * bwd: dqkv gets (scale*dS k | dS^T q_s | P^T dO); dbiasT [heads][N][N] is atomically accumulated.
+ * bwd: dqkv gets (scale*dS k | dS^T q_s | P^T dO); dbiasT [heads][N][N] += the bias gradient (per-workgroup partial slabs in
+ * `scratch`, folded in a fixed order: deterministic).
  * bias_windows = 1: biasT is [heads][N][N] and maskT (or NULL) is added per window as in :126-131.
  * bias_windows = nW: biasT is [nW][heads][N][N] = bias + mask already summed by the caller, maskT must be NULL
  * (one table read per score instead of two).
@@ -199,7 +212,9 @@ int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, l
                            The other two thirds need no pass over dqkv: sum_rows dk = 0 exactly (rows of dS sum to
                            zero) and sum_rows dv = column sums of dout (softmax rows sum to one) */,
                         int nB_, int nW, int T_frames, int ws,
-                        int heads, int C, float scale, int bias_windows, const int* bias_index, void* stream);
+                        int heads, int C, float scale, int bias_windows, const int* bias_index,
+                        float* scratch /* >= stswin_win_attn_bwd_scratch(nB_, ws, heads, C) floats */, long scratch_floats, void* stream);
+long stswin_win_attn_bwd_scratch(int nB_, int ws, int heads, int C);
 
 /* ---- decode head on NHWC token matrices [M = frames*H*W][C]  (ASPP.py:33-52, base18.py:60-106) ---------------
  * Grouped BatchNorm2d: rows are `groups` equal groups with separate batch statistics (1 for the head; the number of
@@ -210,8 +225,9 @@ int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, l
  * unit_rows = 0: the groups are contiguous row blocks.  unit_rows > 0: group g owns the units g, g + groups, g + 2 groups, ...
  * of unit_rows rows each - frame t of every clip when the 4-frame clips are stored clip-major, so that the per-frame
  * statistics of base18.py:86-89 need no frame-major copy of the batch. */
-int stswin_colstats(int dtype, const void* x, long ldx, float* sum, float* sumsq, int M, int C, int groups, int unit_rows,
-                    void* stream);
+int stswin_colstats(int dtype, const void* x, long ldx, float* sum /* += */, float* sumsq /* += */, int M, int C, int groups, int unit_rows,
+                    float* scratch /* >= stswin_colstats_scratch(...) floats */, void* stream);
+long stswin_colstats_scratch(int dtype, int M, int C, int groups, int unit_rows);
 /* sum / sumsq [groups][N] of the statistic groups from the two-plane table a STSWIN_GF_CS_SQ stswin_gemm_nt wrote (same M, N; groups
  * of whole 256-row tiles: contiguous, or interleaved units of unit_rows rows).  Then stswin_bn_finalize with x = NULL (raw sums, no
  * pivot) replaces stswin_colstats: nn.BatchNorm2d batch statistics (resnet.py:42-51, ASPP.py:37-50) without a pass over the tensor. */
@@ -238,7 +254,9 @@ int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx,
                   long rows_total /* rows per group over all ranks (0 = local) */, int unit_rows,
                   float* group_sums /* optional fp32 [2][C], written by the dx pass: s1 | s2 summed over the groups = the
                                        bias | weight gradients of the BatchNorm (ASPP.py:37-50 etc.: autograd of nn.BatchNorm2d) */,
+                  float* scratch /* phases 0 / 1: >= stswin_bn_bwd_scratch(...) floats (per-chunk partial sums, folded into s1 / s2) */,
                   void* stream);
+long stswin_bn_bwd_scratch(int dtype, int M, int C, int groups, int unit_rows);
 /* out[r][c] (+)= v[r / (M/groups)][c] * scale : image-pool broadcast (ASPP.py:46) and avg-pool backward */
 int stswin_rows_broadcast(int dtype, const float* v, void* out, long ldo, int M, int C, int groups, float scale,
                           int accumulate, void* stream);
@@ -251,7 +269,8 @@ int stswin_logits_upsample(int dtype, const void* tokens, long ldt, void* nchw, 
                            int nc, int backward, void* stream);
 
 /* ---- a15: OHEM cross entropy (seg18/utils/losses.py:32-40).  ce_fwd: per-pixel CE (ignore_index -> 0) and
- * stats[0] = #(loss > thresh), stats[1] = sum of those.  ce_bwd: dlogits = gscale[0] * sel[1] * (softmax - onehot) for
+ * stats (fp32 [4], zeroed by the caller, 8-byte aligned): [0] = #(loss > thresh) (an exact integer count), [2..3] = one unsigned 64-bit
+ * sum of those losses in 2^-32 fixed point (integer atomics: associative, so the value is reproducible).  ce_bwd: dlogits = gscale[0] * sel[1] * (softmax - onehot) for
  * pixels with loss > sel[0] (>= when sel[2] != 0); sel/gscale live on the device, so no host sync is needed. */
 int stswin_ce_fwd(int dtype, const void* logits, const long* labels, float* loss, float* stats, int frames, long HW, int nc,
                   int ignore_index, float thresh, void* stream);
@@ -259,7 +278,7 @@ int stswin_ce_fwd(int dtype, const void* logits, const long* labels, float* loss
  * stats = output of ce_fwd; if stats[0] = #(loss > thresh) > n_min the threshold branch is taken, otherwise the mean of the
  * n_min largest losses is computed by an exact 3-level radix select (counts + sums per bin).  work: caller-owned scratch
  * of >= STSWIN_OHEM_WORK_BYTES bytes (zeroed by the call). */
-#define STSWIN_OHEM_WORK_BYTES (3 * 2048 * 8 + 48)
+#define STSWIN_OHEM_WORK_BYTES (3 * 2048 * 12 + 48)
 int stswin_ohem_select(const float* loss, long n, long n_min, float thresh, const float* stats, void* work, long work_bytes,
                        float* value, float* sel, void* stream);
 int stswin_ce_bwd(int dtype, const void* logits, const long* labels, const float* loss, const float* sel,
@@ -296,7 +315,8 @@ int stswin_contrast_bank_fwd(int dtype, const void* Q, long ldq, const int* lq, 
  * fp32 [M][C].  cnt[m][g] (fp32) = number of visible rows of group g with label lq[m]: where it equals bank_block the negative
  * set is empty and its term is skipped, so the gradient is exactly zero like the reference's masked products (:103-113). */
 int stswin_contrast_class_sums(int dtype, const void* bank, long ldb, const int* lb, int maps, int seg, int bank_block, int C,
-                               int ncls, float* ksum, void* stream);
+                               int ncls, float* ksum, float* scratch /* >= stswin_contrast_class_sums_scratch(...) floats */, void* stream);
+long stswin_contrast_class_sums_scratch(int maps, int seg, int bank_block, int C, int ncls);
 int stswin_contrast_bank_dq(const float* dpos, const float* dneg, const float* cnt, const int* lq, const float* ksum, float* dq,
                             long lddq, int M, int C, int q_sets, int q_block, int seg, int bank_block, int ncls, int groups, const int* gmap,
                             void* stream);
@@ -315,11 +335,11 @@ int stswin_multi_tensor(int mode, int count, void* const* p, const void* const* 
                         const int* n, float lr, float b1, float b2, float eps, float wd, float c1, float c2, void* stream);
 
 /* LARS over SGD-momentum (pixcontrast_18/contrast/lars.py:109-152 wrapping torch.optim.SGD, main_pretrain_swinv5.py:37-47) for up
- * to 48 fp32 tensors of ONE parameter group, two launches: per-tensor ||p||^2 and ||g + wd p||^2 into `norms` (caller-owned
- * fp32 [count][2], zeroed by the call), then g' = (g + wd p) * (adaptive && both norms > 0 ? trust_coef ||p|| / (||g'|| + eps) : 1),
+ * to 48 fp32 tensors of ONE parameter group, three launches: per-block partial ||p||^2 and ||g + wd p||^2, their fixed-order fold
+ * into `norms` (caller-owned fp32 scratch, norms_floats >= 2 * count + 2 * sum_i ceil(n_i / 8192); no atomics: reproducible), then g' = (g + wd p) * (adaptive && both norms > 0 ? trust_coef ||p|| / (||g'|| + eps) : 1),
  * buf = first ? g' : momentum * buf + g', p -= lr * buf.  adaptive = 0: the 'ignore' group of add_weight_decay (biases, norms). */
 int stswin_multi_tensor_lars(int count, void* const* p, const void* const* g, void* const* m, const int* n, float* norms,
-                             float lr, float momentum, float wd, float trust_coef, float eps, int first, int adaptive,
+                             long norms_floats, float lr, float momentum, float wd, float trust_coef, float eps, int first, int adaptive,
                              void* stream);
 
 /* ---- device self-test of the MFMA / LDS primitives the kernels are built on; writes a report into `out`

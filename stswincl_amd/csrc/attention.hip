@@ -21,8 +21,9 @@ struct AttnArgs {
   const void* dout; long lddo;    // bwd only: dO [rows][C]
   const float* biasT;             // [heads][N][N]   biasT[h][key n][query n]
   const float* maskT;             // [nW][N][N] or null
-  float* dbiasT;                  // bwd: [heads][N][N] fp32, atomically accumulated
+  float* dbiasT;                  // bwd: [heads][N][N] fp32, += the folded per-slot partial sums
   float* dqkv_colsum;             // bwd, optional: [C] fp32 += column sums of the dq third of dqkv (see include/stswin_hip.h)
+  float* slabs;                   // bwd: caller-owned scratch [problem slots][N*N + HD]: per-slot partial sums of the two above
   int nB_, nW, heads, C, N;       // nB_ = number of (clip, window) problems = B*nW
   float scale;                    // bwd: dq = scale * (dS k)
   int bias_windows;               // 1: biasT is [heads][N][N]; > 1: biasT is [bias_windows][heads][N][N] with the mask already added
@@ -700,31 +701,42 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     const int tb = kbuf; kbuf = xbuf; xbuf = tb;   // the spare buffer now holds the next K
   }
   }
-  if (a.dbiasT) {
-    const int N = NC ? NC : a.N, qn = (qt * 32 + lr) % N;
-    float* db = a.dbiasT + (long)head * N * N + qn;
-    if constexpr (NC == 16 && NTOK == 32) {
-      // 16-entry windows: registers r and r+8 and lanes lr and lr+16 hit the same table entry - fold them first
-      // (1 K addresses take every atomic of this kernel; 4x fewer of them)
+  // ---- hand-over of the register-accumulated sums, WITHOUT atomics (bitwise reproducible): every wave parks its entries in a
+  // private LDS plane ([NTOK key rows][32 queries] + [HD]); the workgroup then adds, in a fixed order, the T x T entries that share
+  // a bias-table cell (key n = row mod N, query n = column mod N) and the waves of a problem that share a dq column, and stores ONE
+  // partial slab per problem slot (blockIdx.x * PPB + sp) of a.slabs = [slots][N*N + HD]; slab_fold_kernel adds the slots of a head
+  // in slot order behind the launch (launch_attn).
+  if (a.slabs && !dbg_ts) {
+    constexpr int PLANE = NTOK * 32 + HD;
+    const int N = NC ? NC : a.N;
+    __syncthreads();                               // every tile is dead
+    float* plane = (float*)smem + (long)w * PLANE;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        float v = dbacc[0][r] + dbacc[0][r + 8];
-        v += __shfl_xor(v, 16);
-        if (lr < 16) atomicAdd(db + (crow32(r, half) % 16) * 16, v);
-      }
-    } else {
+    for (int kt = 0; kt < Cfg::KT; ++kt)
 #pragma unroll
-      for (int kt = 0; kt < Cfg::KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(db + ((kt * 32 + crow32(r, half)) % N) * N, dbacc[kt][r]);
-    }
-  }
-  if (a.dqkv_colsum && !dbg_ts) {
+      for (int r = 0; r < 16; ++r) plane[(kt * 32 + crow32(r, half)) * 32 + lr] = dbacc[kt][r];
 #pragma unroll
     for (int dt = 0; dt < Cfg::DT; ++dt) {
       float csum = csacc[dt];
       csum += __shfl_xor(csum, 32);
-      if (half == 0) atomicAdd(a.dqkv_colsum + head * HD + dt * 32 + lr, csum);
+      if (half == 0) plane[NTOK * 32 + dt * 32 + lr] = csum;
+    }
+    __syncthreads();
+    const float* pl0 = (const float*)smem + (long)sp * Cfg::QW * PLANE;
+    float* slab = a.slabs + ((long)blockIdx.x * Cfg::PPB + sp) * ((long)N * N + HD);
+    const int tl = threadIdx.x - sp * Cfg::QW * 64;
+    for (int e = tl; e < N * N; e += Cfg::QW * 64) {
+      const int kn = e / N, qn = e - kn * N;
+      float t = 0.f;
+      for (int x = qn; x < NTOK; x += N)
+        for (int y = kn; y < NTOK; y += N) t += pl0[(long)(x >> 5) * PLANE + y * 32 + (x & 31)];
+      slab[e] = t;
+    }
+    for (int c = tl; c < HD; c += Cfg::QW * 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int q2 = 0; q2 < Cfg::QW; ++q2) t += pl0[(long)q2 * PLANE + NTOK * 32 + c];
+      slab[(long)N * N + c] = t;
     }
   }
 }
@@ -1062,24 +1074,56 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
     stamp(11);
     { const int t0 = kb, t1 = vb; kb = xb; vb = pb; xb = t0; pb = t1; }     // next K sits in xb, next V in pb
   }
-  if (a.dbiasT) {
-    float* db = a.dbiasT + (long)head * N * N + qn;
+  // ---- deterministic hand-over (see attn_bwd_kernel): wave (qt, hw) parks its 64 key rows x 32 queries + its 64 dq columns in a
+  // private LDS plane; fixed-order sums of the T x T entries per table cell and of the four query tiles per dq column; one slab per
+  // workgroup
+  if (a.slabs && !dbg_ts) {
+    constexpr int PLANE = 64 * 32 + 64;
+    __syncthreads();
+    float* plane = (float*)smem + (long)w * PLANE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) atomicAdd(db + (((2 * hw + kk) * 32 + crow32(r, half)) % N) * N, dbacc[kk][r]);
-  }
-  if (a.dqkv_colsum && !dbg_ts) {
+      for (int r = 0; r < 16; ++r) plane[(kk * 32 + crow32(r, half)) * 32 + lr] = dbacc[kk][r];
 #pragma unroll
     for (int dd = 0; dd < 2; ++dd) {
       float csum = csacc[dd];
       csum += __shfl_xor(csum, 32);
-      if (half == 0) atomicAdd(a.dqkv_colsum + head * HD + (2 * hw + dd) * 32 + lr, csum);
+      if (half == 0) plane[64 * 32 + dd * 32 + lr] = csum;
+    }
+    __syncthreads();
+    const float* pl = (const float*)smem;
+    float* slab = a.slabs + (long)blockIdx.x * ((long)N * N + HD);
+    for (int e = threadIdx.x; e < N * N; e += 512) {
+      const int kn = e / N, qn2 = e - kn * N;
+      float t = 0.f;
+      for (int x = qn2; x < NTOK; x += N)            // query tile x / 32, column x % 32
+        for (int y = kn; y < NTOK; y += N)           // key half y / 64 (= hw), local row y % 64
+          t += pl[(long)((y >> 6) * 4 + (x >> 5)) * PLANE + (y & 63) * 32 + (x & 31)];
+      slab[e] = t;
+    }
+    for (int c = threadIdx.x; c < HD; c += 512) {    // dq column c: wave half c / 64, local column c % 64
+      float t = 0.f;
+#pragma unroll
+      for (int q2 = 0; q2 < 4; ++q2) t += pl[(long)((c >> 6) * 4 + q2) * PLANE + 64 * 32 + (c & 63)];
+      slab[(long)N * N + c] = t;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
+// dbiasT[h] += sum of the slots h, h + heads, ... of a.slabs (first N*N floats of a slot), dqkv_colsum[h * HD ..] += their last HD
+// floats: fixed slot order (rowops.hip slab_fold_kernel) - the backward's parameter gradients are bitwise reproducible.
+static thread_local long a_scratch_floats = 0;
+static int attn_bwd_fold(const AttnArgs& a, int slots, int HD, hipStream_t st) {
+  if (!a.slabs || (a.bias_windows & (1 << 30))) return 0;
+  const int NN = a.N * a.N;
+  const int len[3] = {NN, HD, 0};
+  float* const out[3] = {a.dbiasT, a.dqkv_colsum, nullptr};
+  const long obs[3] = {NN, HD, 0};
+  return stswin_fold3_launch(a.slabs, (long)a.heads * (NN + HD), NN + HD, slots / a.heads, len, out, obs, a.heads, 1, st);
+}
+
 template <typename T, int NTOK, int HD, int NC>
 static int launch_attn(const AttnArgs& a, bool bwd, hipStream_t st) {
   using Cfg = AttnCfg<T, NTOK, HD>;
@@ -1106,7 +1150,10 @@ static int launch_attn(const AttnArgs& a, bool bwd, hipStream_t st) {
       g = (g / a.heads) * a.heads;
       if (g < a.heads) g = a.heads;
       if (grid % a.heads == 0 && g >= a.heads) {
+        if (a.slabs && (long)g * (a.N * a.N + HD) > a_scratch_floats) return -1205;
         hipLaunchKernelGGL((attn_bwd8_kernel<NC>), dim3(g), dim3(512), Cfg::BWD_LDS, st, a);
+        const int rf = attn_bwd_fold(a, g, HD, st);
+        if (rf) return rf;
         STSWIN_CHECK_LAUNCH();
         return 0;
       }
@@ -1122,7 +1169,11 @@ static int launch_attn(const AttnArgs& a, bool bwd, hipStream_t st) {
     if (g > grid) g = grid;
     g = (g / step) * step;
     if (g < step) g = step;
+    static_assert(4 * (NTOK * 32 + HD) * 4 <= Cfg::BWD_LDS, "LDS planes of the deterministic hand-over");
+    if (a.slabs && (long)g * Cfg::PPB * (a.N * a.N + HD) > a_scratch_floats) return -1205;
     hipLaunchKernelGGL((attn_bwd_kernel<T, NTOK, HD, NC>), dim3(g), dim3(256), lds, st, a);
+    const int rf = attn_bwd_fold(a, g * Cfg::PPB, HD, st);
+    if (rf) return rf;
   } else {
     hipLaunchKernelGGL((attn_fwd_kernel<T, NTOK, HD, NC>), dim3(grid), dim3(256), lds, st, a);
   }
@@ -1158,19 +1209,29 @@ extern "C" int stswin_win_attn_fwd(int dtype, const void* qkv, long ld, void* ou
                                    const float* maskT, int nB_, int nW, int T_frames, int ws, int heads, int C,
                                    int bias_windows, const int* bias_index, void* stream) {
   if (bias_windows != 1 && ((!bias_index && bias_windows != nW) || maskT)) return -1204;
-  AttnArgs a{qkv, ld, out, ldo, nullptr, 0, biasT, maskT, nullptr, nullptr, nB_, nW, heads, C, 0, 1.0f, bias_windows, bias_index};
+  AttnArgs a{qkv, ld, out, ldo, nullptr, 0, biasT, maskT, nullptr, nullptr, nullptr, nB_, nW, heads, C, 0, 1.0f, bias_windows, bias_index};
   return attn_common(dtype, a, T_frames, ws, false, stream);
+}
+
+/* floats of scratch stswin_win_attn_bwd needs: one [N*N + C/heads] slab per resident problem slot (an upper bound) */
+extern "C" long stswin_win_attn_bwd_scratch(int nB_, int ws, int heads, int C) {
+  if (heads <= 0 || C % heads || nB_ <= 0) return -1203;
+  long slots = (long)nB_ * heads + 3;
+  if (slots > 8192) slots = 8192;
+  return slots * ((long)ws * ws * ws * ws + C / heads);
 }
 
 extern "C" int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const void* dout, long lddo, void* dqkv, long lddq,
                                    const float* biasT, const float* maskT, float* dbiasT, float* dqkv_colsum, int nB_,
                                    int nW, int T_frames, int ws, int heads, int C, float scale, int bias_windows,
-                                   const int* bias_index, void* stream) {
+                                   const int* bias_index, float* scratch, long scratch_floats, void* stream) {
   const int dbg = bias_windows & (1 << 30);    // DBG (tools/attn_timeline.py): dqkv_colsum is a u64 [workgroups][16] timestamp buffer
   bias_windows &= ~(1 << 30);
   if (bias_windows != 1 && ((!bias_index && bias_windows != nW) || maskT)) return -1204;
-  AttnArgs a{qkv, ld, dqkv, lddq, dout, lddo, biasT, maskT, dbiasT, dqkv_colsum, nB_, nW, heads, C, 0, scale, bias_windows | dbg,
-             bias_index};
+  if (!dbg && (dbiasT || dqkv_colsum) && !scratch) return -1205;
+  AttnArgs a{qkv, ld, dqkv, lddq, dout, lddo, biasT, maskT, dbiasT, dqkv_colsum, dbg ? nullptr : scratch, nB_, nW, heads, C, 0, scale,
+             bias_windows | dbg, bias_index};
+  a_scratch_floats = scratch_floats;
   return attn_common(dtype, a, T_frames, ws, true, stream);
 }
 
@@ -1191,7 +1252,7 @@ extern "C" int stswin_win_attn_fwd_fp8(const void* qkv, long ld, void* out, long
                                        int nW, int T_frames, int ws, int heads, int C, int bias_windows, const int* bias_index,
                                        void* stream) {
   if (bias_windows != 1 && ((!bias_index && bias_windows != nW) || maskT)) return -1204;
-  AttnArgs a{qkv, ld, out, ldo, nullptr, 0, biasT, maskT, nullptr, nullptr, nB_, nW, heads, C, ws * ws, 1.0f, bias_windows, bias_index};
+  AttnArgs a{qkv, ld, out, ldo, nullptr, 0, biasT, maskT, nullptr, nullptr, nullptr, nB_, nW, heads, C, ws * ws, 1.0f, bias_windows, bias_index};
   const int ntok = T_frames * ws * ws;
   if (C % heads || nW <= 0 || nB_ % nW) return -1203;
   const int hd = C / heads;

@@ -24,6 +24,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define DEVI __device__ __forceinline__
 
+// rowops.hip: deterministic sum of per-workgroup partial vectors ("slabs") behind a launch boundary (see slab_fold_kernel)
+int stswin_fold_launch(const float* ws, long slab_stride, long ws_batch_stride, int nslabs, int seg_len, int nseg, float* o0, float* o1,
+                       float* o2, long out_batch_stride, int batch, int accumulate, hipStream_t st);
+int stswin_fold3_launch(const float* ws, long slab_stride, long ws_batch_stride, int nslabs, const int* len /* [3] */, float* const* out /* [3] */,
+                        const long* obs /* [3] batch strides of the outputs */, int batch, int accumulate, hipStream_t st);
+
 // 256 B of zeros in device memory: the source of every padded / out-of-range 16-byte chunk.
 static __device__ uint4 g_stswin_zero[16];  // per-TU copy (no -fgpu-rdc); zero-initialised
 

@@ -518,43 +518,41 @@ extern "C" int stswin_contrast_bank_fwd(int dtype, const void* Q, long ldq, cons
 // masked products (their denominators are 0 + 1e-6, so a 1e-7 residual would become a 0.1 gradient): an empty positive set
 // has an untouched (zero) class row; an empty negative set (cnt == visible rows) is skipped by its count.
 // ---------------------------------------------------------------------------------------------------------------------
-// ksum [maps][nb][ncls + 1][C] fp32 (zeroed by the caller), nb = seg / bank_block; slot ncls = sum over all rows.
+// part [maps * nb][row chunks][ncls + 1][C] fp32: per-workgroup partial class sums (nb = seg / bank_block; slot ncls = all rows);
+// the launcher's slab fold adds the row chunks in order into ksum.  No atomics: every (row lane, column pair) thread owns its cells
+// of a per-row-lane LDS table [rlanes][ncls + 1][C], the lanes are added in lane order - reproducible bits.
 template <typename T>
 __global__ __launch_bounds__(256) void contrast_class_sums_kernel(const T* bank, long ldk, const int* lb, int seg, int bank_block,
-                                                                  int C, int ncls, int rows_per_wg, float* ksum) {
+                                                                  int C, int ncls, int rows_per_wg, float* part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* tab = (float*)smem;                         // [ncls + 1][C]
+  float* tab = (float*)smem;                         // [rlanes][ncls + 1][C]
   const int nb = seg / bank_block;
   const int map = blockIdx.y / nb, b = blockIdx.y - map * nb;
   const int r0 = blockIdx.x * rows_per_wg, r1 = min(bank_block, r0 + rows_per_wg);
-  if (r0 >= r1) return;
-  for (int i = threadIdx.x; i < (ncls + 1) * C; i += 256) tab[i] = 0.f;
+  const int cpairs = C >> 1, rlanes = max(1, 256 / cpairs), cells = (ncls + 1) * C;
+  for (int i = threadIdx.x; i < rlanes * cells; i += 256) tab[i] = 0.f;
   __syncthreads();
   const long base = (long)map * seg + (long)b * bank_block;
-  // thread = (column pair cp, row lane rl): C / 2 column pairs, 512 / C row lanes; a thread's LDS cells are its own columns of
-  // every class row, but two row lanes may hit the same cell: LDS float atomics
-  const int cpairs = C >> 1, rlanes = max(1, 256 / cpairs);
   const int cp = threadIdx.x % cpairs, rl = threadIdx.x / cpairs;
   if (rl < rlanes) {
+    float* mine = tab + (long)rl * cells;
     float t0 = 0.f, t1 = 0.f;
     for (int r = r0 + rl; r < r1; r += rlanes) {
       const int lab = lb[base + r];
       const T* src = bank + (base + r) * ldk + 2 * cp;
       const float v0 = to_f32<T>(src[0]), v1 = to_f32<T>(src[1]);
       t0 += v0; t1 += v1;
-      if (lab >= 0 && lab < ncls) {
-        atomicAdd(tab + lab * C + 2 * cp, v0);
-        atomicAdd(tab + lab * C + 2 * cp + 1, v1);
-      }
+      if (lab >= 0 && lab < ncls) { mine[lab * C + 2 * cp] += v0; mine[lab * C + 2 * cp + 1] += v1; }
     }
-    atomicAdd(tab + ncls * C + 2 * cp, t0);
-    atomicAdd(tab + ncls * C + 2 * cp + 1, t1);
+    mine[ncls * C + 2 * cp] = t0;
+    mine[ncls * C + 2 * cp + 1] = t1;
   }
   __syncthreads();
-  float* out = ksum + ((long)map * nb + b) * (ncls + 1) * C;
-  for (int i = threadIdx.x; i < (ncls + 1) * C; i += 256) {
-    const float v = tab[i];
-    if (v != 0.f) atomicAdd(out + i, v);
+  float* out = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * cells;
+  for (int i = threadIdx.x; i < cells; i += 256) {
+    float v = 0.f;
+    for (int k = 0; k < rlanes; ++k) v += tab[(long)k * cells + i];
+    out[i] = v;
   }
 }
 
@@ -586,27 +584,45 @@ __global__ __launch_bounds__(256) void contrast_bank_dq_kernel(BankDqArgs p) {
   *(f32x4*)(p.dq + (long)m * p.lddq + c) = acc;
 }
 
-extern "C" int stswin_contrast_class_sums(int dtype, const void* bank, long ldb, const int* lb, int maps, int seg, int bank_block,
-                                          int C, int ncls, float* ksum, void* stream) {
-  if (maps <= 0 || seg <= 0) return 0;
-  if (C % 2 || C > 512 || ncls <= 0 || ncls > 63 || bank_block <= 0 || seg % bank_block) return -1521;
+static void class_sums_geometry(int maps, int seg, int bank_block, int* rows_per_wg, int* chunks) {
   const int nb = seg / bank_block;
-  (void)hipMemsetAsync(ksum, 0, sizeof(float) * (size_t)maps * nb * (ncls + 1) * C, (hipStream_t)stream);
-  int rows_per_wg = 512;
-  while (rows_per_wg > 64 && (long)((bank_block + rows_per_wg - 1) / rows_per_wg) * maps * nb < 512) rows_per_wg >>= 1;
-  const dim3 grid((unsigned)((bank_block + rows_per_wg - 1) / rows_per_wg), (unsigned)(maps * nb));
-  const int lds = (ncls + 1) * C * 4;
+  int r = 512;
+  while (r > 64 && (long)((bank_block + r - 1) / r) * maps * nb < 512) r >>= 1;
+  *rows_per_wg = r; *chunks = (bank_block + r - 1) / r;
+}
+extern "C" long stswin_contrast_class_sums_scratch(int maps, int seg, int bank_block, int C, int ncls) {
+  if (maps <= 0 || seg <= 0 || bank_block <= 0 || seg % bank_block) return -1521;
+  int r, chunks;
+  class_sums_geometry(maps, seg, bank_block, &r, &chunks);
+  return (long)maps * (seg / bank_block) * chunks * (ncls + 1) * C;
+}
+
+extern "C" int stswin_contrast_class_sums(int dtype, const void* bank, long ldb, const int* lb, int maps, int seg, int bank_block,
+                                          int C, int ncls, float* ksum, float* scratch, void* stream) {
+  if (maps <= 0 || seg <= 0) return 0;
+  if (C % 4 || C > 512 || ncls <= 0 || ncls > 63 || bank_block <= 0 || seg % bank_block || !scratch) return -1521;
+  const int nb = seg / bank_block;
+  int rows_per_wg, chunks;
+  class_sums_geometry(maps, seg, bank_block, &rows_per_wg, &chunks);
+  const dim3 grid((unsigned)chunks, (unsigned)(maps * nb));
+  const int cells = (ncls + 1) * C, rlanes = 256 / (C / 2) > 0 ? 256 / (C / 2) : 1;
+  const int lds = rlanes * cells * 4;
+  if (lds > 160 * 1024) return -1521;
+  hipStream_t st = (hipStream_t)stream;
   if (dtype == 0) {
-    static int once = (int)hipFuncSetAttribute((const void*)contrast_class_sums_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    static int once = (int)hipFuncSetAttribute((const void*)contrast_class_sums_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     (void)once;
-    hipLaunchKernelGGL(contrast_class_sums_kernel<bf16>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16*)bank, ldb, lb, seg,
-                       bank_block, C, ncls, rows_per_wg, ksum);
+    hipLaunchKernelGGL(contrast_class_sums_kernel<bf16>, grid, dim3(256), lds, st, (const bf16*)bank, ldb, lb, seg,
+                       bank_block, C, ncls, rows_per_wg, scratch);
   } else {
-    static int once = (int)hipFuncSetAttribute((const void*)contrast_class_sums_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    static int once = (int)hipFuncSetAttribute((const void*)contrast_class_sums_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     (void)once;
-    hipLaunchKernelGGL(contrast_class_sums_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)bank, ldb, lb, seg,
-                       bank_block, C, ncls, rows_per_wg, ksum);
+    hipLaunchKernelGGL(contrast_class_sums_kernel<float>, grid, dim3(256), lds, st, (const float*)bank, ldb, lb, seg,
+                       bank_block, C, ncls, rows_per_wg, scratch);
   }
+  // ksum[map][b] = sum of the row-chunk slabs in chunk order (overwrites: no zero fill needed)
+  const int rf = stswin_fold_launch(scratch, cells, (long)chunks * cells, chunks, cells, 1, ksum, nullptr, nullptr, cells, maps * nb, 0, st);
+  if (rf) return rf;
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

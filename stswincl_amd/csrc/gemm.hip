@@ -1794,32 +1794,15 @@ static int set_lds_once(const void* fn) {
   return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
 }
 
-// out[n] += sum_b part[b][n] over the `rows` 128-row blocks written by a GF_CS_PARTIAL gemm_nt.  Block: 64 columns (16 lanes x
-// float4) x 16 row lanes; grid.y splits the rows, so `out` sees grid.y atomics per column instead of M/128.
-__global__ __launch_bounds__(256) void cs_reduce_kernel(const float* part, int rows, int N, float* out) {
-  __shared__ f32x4 fold[16][16];
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int c = (blockIdx.x * 16 + cl) * 4;
-  const int per = (rows + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
-  f32x4 a = {0.f, 0.f, 0.f, 0.f};
-  if (c < N)
-    for (int r = r0 + rl; r < r1; r += 16) a += *(const f32x4*)(part + (long)r * N + c);
-  fold[rl][cl] = a;
-  __syncthreads();
-  if (rl == 0 && c < N) {
-#pragma unroll
-    for (int k = 1; k < 16; ++k) a += fold[k][cl];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(out + c + e, a[e]);
-  }
-}
-
+// out[n] += sum_b part[b][n] over the `rows` 128-row blocks written by a GF_CS_PARTIAL gemm_nt, in a fixed order (one workgroup per
+// 64 columns: 16 float4 lanes x 16 row lanes, the 16 lane sums added in lane order; one writer per address): deterministic bias
+// gradients.  (= slab_fold_kernel of rowops.hip with slab stride N.)
 extern "C" int stswin_cs_reduce(const float* partials, int M, int N, float* out, void* stream) {
   if (M <= 0 || N <= 0) return 0;
   if (N % 4) return -1004;
   const int rows = 2 * ((M + 255) / 256);
-  hipLaunchKernelGGL(cs_reduce_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)max(1, min(8, rows / 32))), dim3(256), 0,
-                     (hipStream_t)stream, partials, rows, N, out);
+  const int rc = stswin_fold_launch(partials, N, 0, rows, N, 1, out, nullptr, nullptr, 0, 1, 1, (hipStream_t)stream);
+  if (rc) return rc;
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

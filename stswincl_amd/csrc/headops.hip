@@ -47,10 +47,10 @@ static int pick_cpb(int pieces_per_row) {
 }
 
 template <typename T, bool SQ>
-__global__ __launch_bounds__(256) void colstats_kernel(const T* x, long ldx, float* sum, float* sumsq, int C, int group_rows,
+__global__ __launch_bounds__(256) void colstats_kernel(const T* x, long ldx, float* part, int C, int group_rows,
                                                         int chunks_per_group, int rows_per_chunk, int cpb, int unit) {
   constexpr int PACK = TT<T>::PACK;
-  __shared__ float part[2][256 * 8];
+  __shared__ float lpart[2][256 * 8];
   const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
   const int c = (blockIdx.x * cpb + cp) * PACK;
   const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
@@ -76,16 +76,19 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* x, long ldx, flo
     }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { part[0][(rl * cpb + cp) * 8 + e] = a1[e]; part[1][(rl * cpb + cp) * 8 + e] = a2[e]; }
+  for (int e = 0; e < 8; ++e) { lpart[0][(rl * cpb + cp) * 8 + e] = a1[e]; lpart[1][(rl * cpb + cp) * 8 + e] = a2[e]; }
   __syncthreads();
   {   // parallel fold: thread t < cpb*8 owns (column piece t/8, element t%8) and adds the nrl row-lane partials
     const int t = threadIdx.x, fc = t >> 3, fe = t & 7;
     const int cc = (blockIdx.x * cpb + fc) * PACK + fe;
     if (fc < cpb && fe < PACK && cc < C) {
       float s1 = 0.f, s2 = 0.f;
-      for (int k = 0; k < nrl; ++k) { s1 += part[0][(k * cpb + fc) * 8 + fe]; s2 += part[1][(k * cpb + fc) * 8 + fe]; }
-      atomicAdd(sum + (long)g * C + cc, s1);
-      if (SQ) atomicAdd(sumsq + (long)g * C + cc, s2);
+      for (int k = 0; k < nrl; ++k) { s1 += lpart[0][(k * cpb + fc) * 8 + fe]; s2 += lpart[1][(k * cpb + fc) * 8 + fe]; }
+      // slab blockIdx.y = (group, row chunk) of the caller's scratch: [2][C] (plain stores; slab_fold_kernel adds the chunks of a
+      // group in order: deterministic statistics, no same-address atomics)
+      float* slab = part + (long)blockIdx.y * 2 * C;
+      slab[cc] = s1;
+      if (SQ) slab[C + cc] = s2;
     }
   }
 }
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, long ldx, con
 #define BN_BWD_U 4
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, long lddy, const T* x, long ldx, const T* y, long ldy,
-                                                             const float* mean, const float* rstd, float* s1, float* s2,
+                                                             const float* mean, const float* rstd, float* spart,
                                                              int C, int group_rows, int chunks_per_group, int rows_per_chunk,
                                                              int relu, int cpb, const float* gamma, const float* beta, int unit) {
   constexpr int PACK = TT<T>::PACK;
@@ -211,8 +214,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, long ld
     if (fc < cpb && fe < PACK && cc < C) {
       float t1 = 0.f, t2 = 0.f;
       for (int k = 0; k < nrl; ++k) { t1 += part[0][(k * cpb + fc) * 8 + fe]; t2 += part[1][(k * cpb + fc) * 8 + fe]; }
-      atomicAdd(s1 + (long)g * C + cc, t1);
-      atomicAdd(s2 + (long)g * C + cc, t2);
+      float* slab = spart + (long)blockIdx.y * 2 * C;          // [(group, chunk)][2][C]: summed per group by slab_fold_kernel
+      slab[cc] = t1;
+      slab[C + cc] = t2;
     }
   }
 }
@@ -436,6 +440,9 @@ __global__ __launch_bounds__(256) void logits_up_bwd_kernel(const TO* dout, T* d
 // ----------------------------------------------------------------------------------------- OHEM cross entropy
 // per-pixel CE (ignore_index -> 0) + the two scalars the OHEM rule needs: stats[0] = #(loss > thresh),
 // stats[1] = sum of those losses.   losses.py:32-34.
+DEVI unsigned long long loss_to_fix(float v) { return (unsigned long long)((double)fmaxf(v, 0.f) * 4294967296.0); }
+DEVI float fix_to_loss(unsigned long long f) { return (float)((double)f * (1.0 / 4294967296.0)); }
+
 template <typename TL>
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const TL* logits, const long* labels, float* loss, float* stats, int F,
                                                       long HW, int nc, int ignore_index, float thresh) {
@@ -463,8 +470,11 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const TL* logits, const lon
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = cnt; red[1][threadIdx.x >> 6] = sm; }
   __syncthreads();
   if (threadIdx.x == 0) {
+    // stats[0]: a count (integers < 2^24: exact in fp32, so the atomic sum does not depend on the order); the SUM goes to the 64-bit
+    // fixed-point accumulator at stats[2..3] (2^-32 units; losses are >= 0 and n * max loss < 2^32): integer adds are associative,
+    // so two runs give the same bits whatever the order the workgroups finish in
     atomicAdd(stats + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    atomicAdd(stats + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    atomicAdd((unsigned long long*)(stats + 2), loss_to_fix(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
   }
 }
 
@@ -501,22 +511,41 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const TL* logits, const lon
 #define PACK_OF(dt) ((dt) == 0 ? 8 : 4)
 #define DISPATCH_T(dt, CALL_BF16, CALL_F32) do { if ((dt) == 0) { CALL_BF16; } else { CALL_F32; } } while (0)
 
-extern "C" int stswin_colstats(int dtype, const void* x, long ldx, float* sum, float* sumsq, int M, int C, int groups,
-                               int unit_rows, void* stream) {
-  if (C % PACK_OF(dtype) || ldx % PACK_OF(dtype) || groups <= 0 || M % groups) return -1401;
+static int colstats_geometry(int dtype, int M, int C, int groups, int unit_rows, int* cpb_o, int* rpc_o, int* cpg_o) {
+  if (C % PACK_OF(dtype) || groups <= 0 || M % groups) return -1401;
   if (unit_rows > 0 && M % ((long)groups * unit_rows)) return -1405;
   const int ppr = C / PACK_OF(dtype), cpb = pick_cpb(ppr);
   const int gr = M / groups, rpc = fit_chunk(reduce_rows_per_chunk(gr, groups * ((ppr + cpb - 1) / cpb), 256 / cpb), unit_rows);
   if (rpc <= 0) return -1405;
-  const int cpg = (gr + rpc - 1) / rpc;
+  *cpb_o = cpb; *rpc_o = rpc; *cpg_o = (gr + rpc - 1) / rpc;
+  return 0;
+}
+/* floats of scratch stswin_colstats needs for this geometry ([groups * chunks][2][C]); < 0: invalid geometry */
+extern "C" long stswin_colstats_scratch(int dtype, int M, int C, int groups, int unit_rows) {
+  int cpb, rpc, cpg;
+  const int rc = colstats_geometry(dtype, M, C, groups, unit_rows, &cpb, &rpc, &cpg);
+  return rc ? rc : (long)groups * cpg * 2 * C;
+}
+
+extern "C" int stswin_colstats(int dtype, const void* x, long ldx, float* sum, float* sumsq, int M, int C, int groups,
+                               int unit_rows, float* scratch, void* stream) {
+  int cpb, rpc, cpg;
+  const int rc = colstats_geometry(dtype, M, C, groups, unit_rows, &cpb, &rpc, &cpg);
+  if (rc) return rc;
+  if (ldx % PACK_OF(dtype)) return -1401;
+  if (!scratch) return -1406;
+  const int ppr = C / PACK_OF(dtype), gr = M / groups;
   dim3 grid((ppr + cpb - 1) / cpb, groups * cpg);
   hipStream_t st = (hipStream_t)stream;
   if (sumsq)
-    DISPATCH_T(dtype, hipLaunchKernelGGL((colstats_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb, unit_rows),
-               hipLaunchKernelGGL((colstats_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb, unit_rows));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colstats_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)x, ldx, scratch, C, gr, cpg, rpc, cpb, unit_rows),
+               hipLaunchKernelGGL((colstats_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, ldx, scratch, C, gr, cpg, rpc, cpb, unit_rows));
   else
-    DISPATCH_T(dtype, hipLaunchKernelGGL((colstats_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb, unit_rows),
-               hipLaunchKernelGGL((colstats_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, ldx, sum, sumsq, C, gr, cpg, rpc, cpb, unit_rows));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colstats_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)x, ldx, scratch, C, gr, cpg, rpc, cpb, unit_rows),
+               hipLaunchKernelGGL((colstats_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, ldx, scratch, C, gr, cpg, rpc, cpb, unit_rows));
+  // sum[g] | sumsq[g] += the group's chunk slabs, in chunk order
+  const int rf = stswin_fold_launch(scratch, 2L * C, (long)cpg * 2 * C, cpg, C, sumsq ? 2 : 1, sum, sumsq, nullptr, C, groups, 1, st);
+  if (rf) return rf;
   STSWIN_CHECK_LAUNCH();
   return 0;
 }
@@ -551,28 +580,49 @@ extern "C" int stswin_bn_apply(int dtype, const void* x, long ldx, const float* 
   return 0;
 }
 
-extern "C" int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const void* y, long ldy,
-                             const float* mean, const float* rstd, const float* gamma, const float* beta, float* s1, float* s2,
-                             void* dx, long lddx, void* dresid, long lddr, int M, int C, int groups, int relu, int training,
-                             int phase, long rows_total, int unit_rows, float* gsum, void* stream) {
+static int bn_bwd_geometry(int dtype, int M, int C, int groups, int unit_rows, int* cpb_o, int* rpc_o, int* rpc2_o) {
   const int pk = PACK_OF(dtype);
-  if (C % pk || ldx % pk || lddy % pk || lddx % pk || (relu && y && ldy % pk) || groups <= 0 || M % groups) return -1403;
-  if (relu && !y && !beta) return -1404;               // no stored output: the mask is recomputed and needs beta
-  const int ppr = C / pk, cpb = pick_cpb(ppr);
+  if (C % pk || groups <= 0 || M % groups) return -1403;
   if (unit_rows > 0 && M % ((long)groups * unit_rows)) return -1405;
-  const int gr = M / groups, xb = (ppr + cpb - 1) / cpb, nrl = 256 / cpb;
+  const int ppr = C / pk, cpb = pick_cpb(ppr), xb = (ppr + cpb - 1) / cpb, nrl = 256 / cpb;
   const int rpc = fit_chunk(bn_bwd_rows(M, xb, nrl, 64) * nrl, unit_rows);
   const int rpc2 = fit_chunk(bn_bwd_rows(M, xb, nrl, 32) * nrl, unit_rows);
   if (rpc <= 0 || rpc2 <= 0) return -1405;
+  *cpb_o = cpb; *rpc_o = rpc; *rpc2_o = rpc2;
+  return 0;
+}
+/* floats of scratch the reduce pass of stswin_bn_bwd needs ([groups * chunks][2][C]); < 0: invalid geometry */
+extern "C" long stswin_bn_bwd_scratch(int dtype, int M, int C, int groups, int unit_rows) {
+  int cpb, rpc, rpc2;
+  const int rc = bn_bwd_geometry(dtype, M, C, groups, unit_rows, &cpb, &rpc, &rpc2);
+  return rc ? rc : (long)groups * ((M / groups + rpc - 1) / rpc) * 2 * C;
+}
+
+extern "C" int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const void* y, long ldy,
+                             const float* mean, const float* rstd, const float* gamma, const float* beta, float* s1, float* s2,
+                             void* dx, long lddx, void* dresid, long lddr, int M, int C, int groups, int relu, int training,
+                             int phase, long rows_total, int unit_rows, float* gsum, float* scratch, void* stream) {
+  const int pk = PACK_OF(dtype);
+  int cpb, rpc, rpc2;
+  const int rc = bn_bwd_geometry(dtype, M, C, groups, unit_rows, &cpb, &rpc, &rpc2);
+  if (rc) return rc;
+  if (ldx % pk || lddy % pk || lddx % pk || (relu && y && ldy % pk)) return -1403;
+  if (relu && !y && !beta) return -1404;               // no stored output: the mask is recomputed and needs beta
+  if (phase != 2 && !scratch) return -1406;
+  const int ppr = C / pk, gr = M / groups;
   const int cpg = (gr + rpc - 1) / rpc;
   dim3 g1((ppr + cpb - 1) / cpb, groups * cpg);
   const int cpg2 = (gr + rpc2 - 1) / rpc2;
   dim3 g2((ppr + cpb - 1) / cpb, groups * cpg2);
   hipStream_t st = (hipStream_t)stream;
   const float inv_n = 1.0f / (float)(rows_total > 0 ? rows_total : gr);
-  if (phase != 2)
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb, gamma, beta, unit_rows),
-             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, s1, s2, C, gr, cpg, rpc, relu, cpb, gamma, beta, unit_rows));
+  if (phase != 2) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, scratch, C, gr, cpg, rpc, relu, cpb, gamma, beta, unit_rows),
+               hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, scratch, C, gr, cpg, rpc, relu, cpb, gamma, beta, unit_rows));
+    // s1[g] | s2[g] += the group's chunk slabs, in chunk order (deterministic; s1 / s2 arrive zeroed)
+    const int rf = stswin_fold_launch(scratch, 2L * C, (long)cpg * 2 * C, cpg, C, 2, s1, s2, nullptr, C, groups, 1, st);
+    if (rf) return rf;
+  }
   if (phase != 1)
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16>, g2, dim3(256), 0, st, (const bf16*)dy, lddy, (const bf16*)x, ldx, (const bf16*)y, ldy, mean, rstd, gamma, s1, s2, (bf16*)dx, lddx, (bf16*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n, beta, unit_rows, gsum),
              hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, g2, dim3(256), 0, st, (const float*)dy, lddy, (const float*)x, ldx, (const float*)y, ldy, mean, rstd, gamma, s1, s2, (float*)dx, lddx, (float*)dresid, lddr, C, gr, cpg2, rpc2, relu, training, cpb, inv_n, beta, unit_rows, gsum));
@@ -665,25 +715,28 @@ extern "C" int stswin_ce_bwd(int dtype, const void* logits, const long* labels, 
 //   mean = (sum_above + k_rem * kth) / n_min.
 // Three passes over the 4 MB loss vector (L2 resident) + one block of bookkeeping instead of a 1 M-element top-k; every
 // pass returns at once when the threshold branch is taken (stats[0] > n_min).
-struct OhemWork {                       // 4-byte words, zeroed by the launcher
+struct OhemWork {                       // zeroed by the launcher
   unsigned cnt[3][2048];
-  float sum[3][2048];
-  unsigned state[3][4];                 // per level: prefix, k (still to take at this level), sum above (float bits)
+  unsigned long long sum[3][2048];      // sums of the losses per bin in 2^-32 fixed point (see loss_to_fix): integer atomics are
+                                        // associative, so the selected mean does not depend on the order the workgroups finish in
+  unsigned long long sabove[3];         // per level: sum (fixed point) of everything above the level's prefix bin
+  unsigned state[3][2];                 // per level: prefix, k (still to take at this level)
 };
 
 // k-th largest over `nbins` bins (from the top): bin with count(above) < k <= count(above) + count(bin); 256 threads
-__device__ void ohem_scan(const unsigned* cnt, const float* sum, int nbins, unsigned k, unsigned* out /* LDS [3]: bin, k_rem, sum bits */) {
+__device__ void ohem_scan(const unsigned* cnt, const unsigned long long* sum, int nbins, unsigned k, unsigned* out /* LDS [2]: bin, k_rem */,
+                          unsigned long long* out_sum /* LDS [1]: sum above the bin */) {
   __shared__ unsigned pc[256];
-  __shared__ float ps[256];
+  __shared__ unsigned long long ps[256];
   const int t = threadIdx.x, per = nbins / 256;
   unsigned c = 0;
-  float sm = 0.f;
+  unsigned long long sm = 0;
   for (int b = 0; b < per; ++b) { c += cnt[nbins - 1 - (t * per + b)]; sm += sum[nbins - 1 - (t * per + b)]; }
   pc[t] = c; ps[t] = sm;
   __syncthreads();
   for (int d = 1; d < 256; d <<= 1) {                 // inclusive scan over threads (thread 0 = highest bins)
     const unsigned c2 = t >= d ? pc[t - d] : 0u;
-    const float s2 = t >= d ? ps[t - d] : 0.f;
+    const unsigned long long s2 = t >= d ? ps[t - d] : 0ull;
     __syncthreads();
     pc[t] += c2; ps[t] += s2;
     __syncthreads();
@@ -691,11 +744,11 @@ __device__ void ohem_scan(const unsigned* cnt, const float* sum, int nbins, unsi
   const unsigned incl = pc[t], excl = incl - c;
   if (excl < k && k <= incl) {                         // exactly one thread
     unsigned above = excl;
-    float sabove = ps[t] - sm;
+    unsigned long long sabove = ps[t] - sm;
     for (int b = 0; b < per; ++b) {
       const int bin = nbins - 1 - (t * per + b);
       const unsigned cb = cnt[bin];
-      if (above + cb >= k) { out[0] = (unsigned)bin; out[1] = k - above; out[2] = __float_as_uint(sabove); break; }
+      if (above + cb >= k) { out[0] = (unsigned)bin; out[1] = k - above; out_sum[0] = sabove; break; }
       above += cb; sabove += sum[bin];
     }
   }
@@ -705,18 +758,19 @@ __device__ void ohem_scan(const unsigned* cnt, const float* sum, int nbins, unsi
 __global__ __launch_bounds__(256) void ohem_hist_kernel(const float* loss, long n, long n_min, const float* stats, OhemWork* wk, int level) {
   if (stats[0] > (float)n_min) return;                 // threshold branch: the top-k mean is not needed
   __shared__ unsigned hc[2048];
-  __shared__ float hs[2048];
-  __shared__ unsigned sc[3];
-  for (int i = threadIdx.x; i < 2048; i += 256) { hc[i] = 0u; hs[i] = 0.f; }
+  __shared__ unsigned long long hs[2048];
+  __shared__ unsigned sc[2];
+  __shared__ unsigned long long ssum[1];
+  for (int i = threadIdx.x; i < 2048; i += 256) { hc[i] = 0u; hs[i] = 0ull; }
   unsigned prefix = 0;
   if (level > 0) {
     const unsigned k = level == 1 ? (unsigned)n_min : wk->state[1][1];
-    ohem_scan(wk->cnt[level - 1], wk->sum[level - 1], 2048, k, sc);
+    ohem_scan(wk->cnt[level - 1], wk->sum[level - 1], 2048, k, sc, ssum);
     const unsigned up = level == 1 ? 0u : wk->state[1][0];
     prefix = level == 1 ? sc[0] : ((up << 11) | sc[0]);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-      const float sprev = level == 1 ? 0.f : __uint_as_float(wk->state[1][2]);
-      wk->state[level][0] = prefix; wk->state[level][1] = sc[1]; wk->state[level][2] = __float_as_uint(sprev + __uint_as_float(sc[2]));
+      const unsigned long long sprev = level == 1 ? 0ull : wk->sabove[1];
+      wk->state[level][0] = prefix; wk->state[level][1] = sc[1]; wk->sabove[level] = sprev + ssum[0];
     }
   }
   __syncthreads();
@@ -726,7 +780,7 @@ __global__ __launch_bounds__(256) void ohem_hist_kernel(const float* loss, long 
     const float v = loss[i];
     const unsigned key = __float_as_uint(v) & 0x7fffffffu;
     const bool in = level == 0 || (level == 1 ? (key >> 21) == prefix : (key >> 10) == prefix);
-    if (in) { const unsigned b = (key >> shift) & mask; atomicAdd(&hc[b], 1u); atomicAdd(&hs[b], v); }
+    if (in) { const unsigned b = (key >> shift) & mask; atomicAdd(&hc[b], 1u); atomicAdd(&hs[b], loss_to_fix(v)); }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2048; i += 256)
@@ -737,14 +791,18 @@ __global__ __launch_bounds__(256) void ohem_final_kernel(long n_min, float thres
                                                          float* sel) {
   const float n_hard = stats[0];
   if (n_hard > (float)n_min) {                         // loss[n_min] > thresh: mean over loss > thresh
-    if (threadIdx.x == 0) { const float inv = 1.f / fmaxf(n_hard, 1.f); value[0] = stats[1] * inv; sel[0] = thresh; sel[1] = inv; sel[2] = 0.f; }
+    if (threadIdx.x == 0) {
+      const float inv = 1.f / fmaxf(n_hard, 1.f);
+      value[0] = fix_to_loss(*(const unsigned long long*)(stats + 2)) * inv; sel[0] = thresh; sel[1] = inv; sel[2] = 0.f;
+    }
     return;
   }
-  __shared__ unsigned sc[3];
-  ohem_scan(wk->cnt[2], wk->sum[2], 1024, wk->state[2][1], sc);
+  __shared__ unsigned sc[2];
+  __shared__ unsigned long long ssum[1];
+  ohem_scan(wk->cnt[2], wk->sum[2], 1024, wk->state[2][1], sc, ssum);
   if (threadIdx.x == 0) {
     const float kth = __uint_as_float((wk->state[2][0] << 10) | sc[0]);
-    const float total = __uint_as_float(wk->state[2][2]) + __uint_as_float(sc[2]) + (float)sc[1] * kth;
+    const float total = fix_to_loss(wk->sabove[2] + ssum[0]) + (float)sc[1] * kth;
     value[0] = total / (float)n_min; sel[0] = kth; sel[1] = 1.f / (float)n_min; sel[2] = 1.f;
   }
 }

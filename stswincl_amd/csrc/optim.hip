@@ -53,9 +53,28 @@ __global__ __launch_bounds__(256) void mt_norms_kernel(MTArgs a, float* __restri
   __shared__ float fold[4][2];
   if ((threadIdx.x & 63) == 0) { fold[threadIdx.x >> 6][0] = sp; fold[threadIdx.x >> 6][1] = sg; }
   __syncthreads();
+  if (threadIdx.x == 0) {                      // one partial pair per block (no atomics: mt_norms_fold_kernel adds them in block order)
+    norms[2 * (long)blockIdx.x] = fold[0][0] + fold[1][0] + fold[2][0] + fold[3][0];
+    norms[2 * (long)blockIdx.x + 1] = fold[0][1] + fold[1][1] + fold[2][1] + fold[3][1];
+  }
+}
+
+// norms[t] = sum of the block partials of tensor t, in block order (one workgroup per tensor; a fixed strided + tree order)
+__global__ __launch_bounds__(256) void mt_norms_fold_kernel(MTArgs a, const float* __restrict__ part, float* __restrict__ norms) {
+  const int t = blockIdx.x;
+  long b0 = 0;
+  for (int i = 0; i < t; ++i) b0 += (a.n[i] + MT_CHUNK - 1) / MT_CHUNK;
+  const int nb = (a.n[t] + MT_CHUNK - 1) / MT_CHUNK;
+  float sp = 0.f, sg = 0.f;
+  for (int b = threadIdx.x; b < nb; b += 256) { sp += part[2 * (b0 + b)]; sg += part[2 * (b0 + b) + 1]; }
+  sp = wave_sum(sp);
+  sg = wave_sum(sg);
+  __shared__ float fold[4][2];
+  if ((threadIdx.x & 63) == 0) { fold[threadIdx.x >> 6][0] = sp; fold[threadIdx.x >> 6][1] = sg; }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(norms + 2 * t, fold[0][0] + fold[1][0] + fold[2][0] + fold[3][0]);
-    atomicAdd(norms + 2 * t + 1, fold[0][1] + fold[1][1] + fold[2][1] + fold[3][1]);
+    norms[2 * t] = fold[0][0] + fold[1][0] + fold[2][0] + fold[3][0];
+    norms[2 * t + 1] = fold[0][1] + fold[1][1] + fold[2][1] + fold[3][1];
   }
 }
 
@@ -150,9 +169,10 @@ extern "C" int stswin_multi_tensor(int mode, int count, void* const* p, const vo
 
 // LARS over SGD-momentum (contrast/lars.py:109-152 around torch.optim.SGD, main_pretrain_swinv5.py:37-47) for up to 48 tensors
 // of ONE parameter group: g' = g + wd p; adaptive: g' *= trust_coef ||p|| / (||g'|| + eps) when both norms are > 0;
-// buf = first ? g' : momentum buf + g'; p -= lr buf.  `norms` = caller-owned fp32 [count][2] scratch (zeroed here).
+// buf = first ? g' : momentum buf + g'; p -= lr buf.  `norms` = caller-owned fp32 scratch of norms_floats >= 2 * count + 2 * blocks
+// floats (blocks = sum_i ceil(n_i / 8192)): [count][2] norms, then one partial pair per block.
 extern "C" int stswin_multi_tensor_lars(int count, void* const* p, const void* const* g, void* const* m, const int* n,
-                                        float* norms, float lr, float momentum, float wd, float trust_coef, float eps,
+                                        float* norms, long norms_floats, float lr, float momentum, float wd, float trust_coef, float eps,
                                         int first, int adaptive, void* stream) {
   if (count <= 0) return 0;
   if (count > MT_MAX || (adaptive && !norms)) return -1602;
@@ -165,8 +185,10 @@ extern "C" int stswin_multi_tensor_lars(int count, void* const* p, const void* c
   a.count = count; a.lr = lr; a.b1 = momentum; a.b2 = 0.f; a.eps = eps; a.wd = wd; a.c1 = first ? 1.f : 0.f; a.c2 = 0.f; a.mode = 3;
   a.norms = adaptive ? norms : nullptr; a.trust = trust_coef;
   if (adaptive) {
-    (void)hipMemsetAsync(norms, 0, sizeof(float) * 2 * count, (hipStream_t)stream);
-    hipLaunchKernelGGL(mt_norms_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, norms);
+    if (norms_floats < 2 * (long)count + 2 * blocks) return -1603;
+    float* part = norms + 2 * count;
+    hipLaunchKernelGGL(mt_norms_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, part);
+    hipLaunchKernelGGL(mt_norms_fold_kernel, dim3((unsigned)count), dim3(256), 0, (hipStream_t)stream, a, (const float*)part, norms);
   }
   hipLaunchKernelGGL(multi_tensor_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   STSWIN_CHECK_LAUNCH();

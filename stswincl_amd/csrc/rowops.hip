@@ -377,21 +377,71 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, long ldx, const
   }
 }
 
-constexpr int LN_REP = 32;       // replicas of the (dgamma | dbeta | dxsum) accumulators in the caller's workspace
-__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* ws, int C, float* dgamma, float* dbeta, float* dxsum) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= 3 * C) return;
-  float* out = c < C ? dgamma + c : (c < 2 * C ? dbeta + (c - C) : (dxsum ? dxsum + (c - 2 * C) : nullptr));
-  if (!out) return;
-  float t = 0.f;
+// ---- deterministic cross-workgroup sums ---------------------------------------------------------------------------------
+// Every kernel of this library that sums over workgroups (bias / LayerNorm / BatchNorm parameter gradients, BatchNorm
+// statistics, the relative-position-bias gradient) writes ONE partial vector per workgroup with plain stores ("slab" p of a
+// caller-owned scratch buffer) and this kernel adds the slabs in a fixed order behind the launch boundary: no fp32 atomics,
+// so the results do not depend on the order in which workgroups happen to finish - two runs of a training step give the same
+// bits.  (Same-address fp32 atomics also serialise at ~40 ns each.)
+//   out_s[b * obs_s + j] (+)= sum_{p < nslabs} ws[b * ws_batch_stride + p * slab_stride + off_s + j],  j < len_s, off_s = len_0 + .. + len_{s-1}
+// for up to three output vectors s (lengths multiples of 4).  Block: 16 float4 columns x 16 slab lanes; lane q adds the slabs
+// q, q + 16, ... and the 16 lane sums are added in lane order.
+struct FoldArgs {
+  const float* ws; long slab_stride, ws_batch_stride; int nslabs;
+  int len[3]; float* out[3]; long obs[3]; int accumulate;
+};
+__global__ __launch_bounds__(256) void slab_fold_kernel(FoldArgs f) {
+  __shared__ f32x4 fold[16][16];
+  const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int j = (blockIdx.x * 16 + cl) * 4;
+  const bool in = j < f.len[0] + f.len[1] + f.len[2];
+  const float* src = f.ws + (long)blockIdx.y * f.ws_batch_stride + j;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (in)
+    for (int p = q; p < f.nslabs; p += 16) a += *(const f32x4*)(src + (long)p * f.slab_stride);
+  fold[q][cl] = a;
+  __syncthreads();
+  if (q == 0 && in) {
 #pragma unroll
-  for (int r = 0; r < LN_REP; ++r) t += ws[(long)r * 3 * C + c];
-  *out += t;                       // one writer per address, stream-ordered behind ln_bwd_kernel
+    for (int k = 1; k < 16; ++k) a += fold[k][cl];
+    const int sgm = j < f.len[0] ? 0 : (j < f.len[0] + f.len[1] ? 1 : 2);
+    const int jj = j - (sgm > 0 ? f.len[0] : 0) - (sgm > 1 ? f.len[1] : 0);
+    float* out = f.out[sgm];
+    if (out) {
+      f32x4* dst = (f32x4*)(out + (long)blockIdx.y * f.obs[sgm] + jj);
+      *dst = f.accumulate ? *dst + a : a;
+    }
+  }
+}
+
+int stswin_fold3_launch(const float* ws, long slab_stride, long ws_batch_stride, int nslabs, const int* len, float* const* out,
+                        const long* obs, int batch, int accumulate, hipStream_t st) {
+  FoldArgs f;
+  f.ws = ws; f.slab_stride = slab_stride; f.ws_batch_stride = ws_batch_stride; f.nslabs = nslabs; f.accumulate = accumulate;
+  int tot = 0;
+  for (int i = 0; i < 3; ++i) {
+    f.len[i] = len[i]; f.out[i] = out[i]; f.obs[i] = obs[i];
+    if (len[i] < 0 || len[i] % 4 || obs[i] % 4) return -1110;
+    tot += len[i];
+  }
+  if (nslabs <= 0 || tot <= 0 || batch <= 0) return 0;
+  if (slab_stride % 4 || ws_batch_stride % 4) return -1110;
+  hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)((tot + 63) / 64), (unsigned)batch), dim3(256), 0, st, f);
+  return 0;
+}
+
+int stswin_fold_launch(const float* ws, long slab_stride, long ws_batch_stride, int nslabs, int seg_len, int nseg, float* o0, float* o1,
+                       float* o2, long out_batch_stride, int batch, int accumulate, hipStream_t st) {
+  if (nseg <= 0 || nseg > 3 || seg_len <= 0) return nseg > 3 ? -1110 : 0;
+  const int len[3] = {seg_len, nseg > 1 ? seg_len : 0, nseg > 2 ? seg_len : 0};
+  float* const out[3] = {o0, o1, o2};
+  const long obs[3] = {out_batch_stride, out_batch_stride, out_batch_stride};
+  return stswin_fold3_launch(ws, slab_stride, ws_batch_stride, nslabs, len, out, obs, batch, accumulate, st);
 }
 
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma += sum dy*xhat ; dbeta += sum dy.
 // Each wave walks `rows_per_wave` consecutive rows keeping its dgamma/dbeta columns in registers, the block
-// folds its 4 waves through LDS and issues one fp32 atomic per column.
+// folds its 4 waves through LDS and stores one partial row per workgroup (summed by slab_fold_kernel).
 template <typename T, int NP>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, const T* x, long ldx, const int* rows,
                                                       int S, int Cseg, const float* gamma, const float* mean,
@@ -467,17 +517,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, con
     }
   }
   __syncthreads();
-  // M/32 blocks adding into the same C addresses serialise (~40 ns per same-address fp32 atomic: 2048 blocks = the whole
-  // kernel time at M = 65536).  With a workspace the blocks spread over LN_REP replicas [LN_REP][3][C] that
-  // ln_bwd_fold_kernel sums afterwards.
-  if (ws) {
-    float* rep = ws + (long)(blockIdx.x % LN_REP) * 3 * C;
-    dgamma = rep; dbeta = rep + C;
-    if (dxsum) dxsum = rep + 2 * C;
-  }
+  // slab `blockIdx.x` of the caller's scratch: [3][C] = dgamma | dbeta | dxsum partial sums of this workgroup's rows (plain
+  // stores; slab_fold_kernel adds the slabs in order afterwards: deterministic, and no same-address atomics)
+  float* rep = ws + (long)blockIdx.x * 3 * C;
   for (int c = threadIdx.x; c < C; c += 256) {
-    atomicAdd(dgamma + c, sg[c] + sg[C + c] + sg[2 * C + c] + sg[3 * C + c]);
-    atomicAdd(dbeta + c, sb[c] + sb[C + c] + sb[2 * C + c] + sb[3 * C + c]);
+    rep[c] = sg[c] + sg[C + c] + sg[2 * C + c] + sg[3 * C + c];
+    rep[C + c] = sb[c] + sb[C + c] + sb[2 * C + c] + sb[3 * C + c];
   }
   if (dxsum) {                       // column sums of the written dx (= the bias gradient of the Linear that produced x)
     __syncthreads();
@@ -490,15 +535,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, con
       }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dxsum + c, sg[c] + sg[C + c] + sg[2 * C + c] + sg[3 * C + c]);
+    for (int c = threadIdx.x; c < C; c += 256) rep[2 * C + c] = sg[c] + sg[C + c] + sg[2 * C + c] + sg[3 * C + c];
   }
 }
 
-// out[n] += sum_m Y[m][n]   (bias gradients).  Block = 256 threads: 32 column-pieces x 8 row lanes.
+// part[blockIdx.y][n] = sum of rows [blockIdx.y * rows_per_block, ...) of Y[:, n]   (bias gradients; slab_fold_kernel adds the
+// row-block partials into out).  Block = 256 threads: 32 column-pieces x 8 row lanes.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* y, long ldy, float* out, int M, int N, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* y, long ldy, float* part, int M, int N, int rows_per_block) {
   constexpr int PACK = TT<T>::PACK;
-  __shared__ float part[8][32 * 8];
+  __shared__ float red[8][32 * 8];
   const int cp = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = (blockIdx.x * 32 + cp) * PACK;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -512,15 +558,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* y, long ldy, float
     }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) part[rl][cp * 8 + e] = acc[e];
+  for (int e = 0; e < 8; ++e) red[rl][cp * 8 + e] = acc[e];
   __syncthreads();
   if (rl == 0 && c < N) {
 #pragma unroll
     for (int e = 0; e < PACK; ++e) {
-      float s = 0.f;
+      float t = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s += part[k][cp * 8 + e];
-      atomicAdd(out + c + e, s);
+      for (int k = 0; k < 8; ++k) t += red[k][cp * 8 + e];
+      part[(long)blockIdx.y * N + c + e] = t;
     }
   }
 }
@@ -546,12 +592,37 @@ __global__ __launch_bounds__(256) void bias_expand_kernel(const float* table, co
     out[t] = v;
   }
 }
-__global__ __launch_bounds__(256) void bias_scatter_kernel(const float* dbiasT, const long* index, float* dtable, int N, int heads) {
-  const long n = (long)heads * N * N;
-  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
-    const int i = (int)(t % N), j = (int)((t / N) % N), h = (int)(t / ((long)N * N));
-    atomicAdd(dtable + index[(long)i * N + j] * heads + h, dbiasT[t]);
+// Gradient of the gather, in gather form (deterministic: no atomics): workgroup e owns table row e and adds, in a fixed order, the
+// dbiasT entries of the (query i, key j) pairs whose relative position is e (each thread scans N*N / 256 pairs of the index,
+// then a fixed shuffle / LDS tree).  nslabs > 1: dbiasT is [nslabs][heads][N][N] (per-workgroup partial slabs of the attention
+// backward) and the slabs are added on the way.
+__global__ __launch_bounds__(256) void bias_scatter_kernel(const float* dbiasT, const long* index, float* dtable, int N, int heads,
+                                                            int nslabs) {
+  __shared__ float red[4][8];
+  const int e = blockIdx.x;
+  const long NN = (long)N * N;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long pr = threadIdx.x; pr < NN; pr += 256) {          // pr = i * N + j (the index buffer's order)
+    if (index[pr] != e) continue;
+    const int i = (int)(pr / N), j = (int)(pr % N);
+    for (int h = 0; h < heads && h < 8; ++h) {
+      const float* src = dbiasT + ((long)h * N + j) * N + i;  // dbiasT[h][key j][query i]
+      float t = 0.f;
+      for (int sl = 0; sl < nslabs; ++sl) t += src[(long)sl * heads * NN];
+      acc[h] += t;
+    }
   }
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    float v = acc[h];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (l == 0) red[w][h] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < heads && threadIdx.x < 8)
+    dtable[(long)e * heads + threadIdx.x] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -684,6 +755,12 @@ extern "C" int stswin_layernorm_fwd(int dtype, const void* x, long ldx, const in
   return 0;
 }
 
+static int ln_bwd_rows_per_wave(int M) { return M >= 16384 ? 8 : (M >= 4096 ? 4 : 2); }
+extern "C" long stswin_layernorm_bwd_scratch(int M, int C) {
+  const int rpw = ln_bwd_rows_per_wave(M);
+  return (long)((M + 4 * rpw - 1) / (4 * rpw)) * 3 * C;
+}
+
 template <typename T>
 static int ln_bwd_launch(const void* dy, long lddy, const void* x, long ldx, const int* rows, int S, int Cseg,
                          const float* g, const float* mean, const float* rstd, void* dx, long lddx, float* dg, float* db,
@@ -691,10 +768,11 @@ static int ln_bwd_launch(const void* dy, long lddy, const void* x, long ldx, con
   constexpr int PACK = TT<T>::PACK;
   const int C = S * Cseg, np = (C / PACK + 63) / 64;
   // 8 rows per wave: >= 4 waves per SIMD at M = 32768 (the serial row loop with two wave reductions per row is
-  // latency-bound); the dgamma/dbeta atomics grow to M/32 per column, still negligible
-  const int rpw = M >= 16384 ? 8 : (M >= 4096 ? 4 : 2);
+  // latency-bound)
+  const int rpw = ln_bwd_rows_per_wave(M);
   dim3 grid((M + 4 * rpw - 1) / (4 * rpw)), blk(256);
   const size_t lds = (size_t)8 * C * sizeof(float);
+  if (!ws) return -1111;
 #define LN_B(NP) hipLaunchKernelGGL((ln_bwd_kernel<T, NP>), grid, blk, lds, st, (const T*)dy, lddy, (const T*)x, ldx, rows, S, Cseg, g, mean, rstd, (T*)dx, lddx, dg, db, M, rpw, acc, dxsum, ws)
   switch (np) {
     case 1: LN_B(1); break;
@@ -704,8 +782,7 @@ static int ln_bwd_launch(const void* dy, long lddy, const void* x, long ldx, con
     default: return -1104;
   }
 #undef LN_B
-  if (ws) hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((3 * C + 255) / 256), dim3(256), 0, st, ws, C, dg, db, dxsum);
-  return 0;
+  return stswin_fold_launch(ws, 3L * C, 0, (int)grid.x, C, dxsum ? 3 : 2, dg, db, dxsum, 0, 1, 1, st);
 }
 
 extern "C" int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const int* rows, int S,
@@ -722,15 +799,30 @@ extern "C" int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const 
   return 0;
 }
 
-extern "C" int stswin_colsum(int dtype, const void* y, long ldy, float* out, int M, int N, void* stream) {
+extern "C" long stswin_colsum_scratch(int M, int N) { return (long)((M + 511) / 512) * N; }
+extern "C" int stswin_colsum(int dtype, const void* y, long ldy, float* out, int M, int N, float* scratch, void* stream) {
   const int pack = dtype == 0 ? 8 : 4;
   if (N % pack || ldy % pack) return -1107;
+  if (!scratch) return -1111;
+  if (M <= 0) return 0;
   const int rpb = 512;
   dim3 grid((N / pack + 31) / 32, (M + rpb - 1) / rpb);
+  hipStream_t st = (hipStream_t)stream;
   if (dtype == 0)
-    hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)y, ldy, out, M, N, rpb);
+    hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)y, ldy, scratch, M, N, rpb);
   else
-    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, ldy, out, M, N, rpb);
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)y, ldy, scratch, M, N, rpb);
+  const int rc = stswin_fold_launch(scratch, N, 0, (int)grid.y, N, 1, out, nullptr, nullptr, 0, 1, 1, st);
+  if (rc) return rc;
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_slab_fold(const float* ws, long slab_stride, long ws_batch_stride, int nslabs, int seg_len, int nseg, float* out0,
+                                float* out1, float* out2, long out_batch_stride, int batch, int accumulate, void* stream) {
+  const int rc = stswin_fold_launch(ws, slab_stride, ws_batch_stride, nslabs, seg_len, nseg, out0, out1, out2, out_batch_stride, batch,
+                                    accumulate, (hipStream_t)stream);
+  if (rc) return rc;
   STSWIN_CHECK_LAUNCH();
   return 0;
 }
@@ -745,11 +837,11 @@ extern "C" int stswin_bias_expand(const float* table, const long* index, const f
   return 0;
 }
 
-extern "C" int stswin_bias_scatter(const float* dbiasT, const long* index, float* dtable, int N, int heads, void* stream) {
-  if (N <= 0 || heads <= 0) return -1109;
-  const long n = (long)heads * N * N;
-  hipLaunchKernelGGL(bias_scatter_kernel, dim3((unsigned)min(2048L, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dbiasT,
-                     index, dtable, N, heads);
+extern "C" int stswin_bias_scatter(const float* dbiasT, const long* index, float* dtable, int N, int heads, int table_rows, int nslabs,
+                                   void* stream) {
+  if (N <= 0 || heads <= 0 || heads > 8 || table_rows <= 0 || nslabs <= 0) return -1109;
+  hipLaunchKernelGGL(bias_scatter_kernel, dim3((unsigned)table_rows), dim3(256), 0, (hipStream_t)stream, dbiasT, index, dtable, N, heads,
+                     nslabs);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

@@ -39,7 +39,13 @@ def declared_symbols():
     """Every entry point include/stswin_hip.h declares."""
     with open(HEADER_PATH) as f:
         text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(stswin_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|long)\s+(stswin_\w+)\s*\(", text)))
+
+
+def _long_symbols():
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return set(re.findall(r"\blong\s+(stswin_\w+)\s*\(", text))
 
 
 def load() -> ctypes.CDLL:
@@ -54,9 +60,10 @@ def load() -> ctypes.CDLL:
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     if missing and not os.environ.get("STSWIN_HIP_LIB"):     # (an older build named for an A/B run may lack new entries)
         raise StswinHipError(f"libstswin_hip.so lacks declared symbols: {missing}")
+    longs = _long_symbols()
     for s in declared_symbols():
         if s not in missing:
-            getattr(lib, s).restype = _c_int
+            getattr(lib, s).restype = _c_long if s in longs else _c_int
     _lib = lib
     return lib
 
@@ -138,6 +145,26 @@ def zeros(*shape, device) -> torch.Tensor:
     out = st[0][st[1]:st[1] + n].view(shape)
     st[1] += need
     return out
+
+
+# ----------------------------------------------------------------------------------------------- scratch for deterministic sums
+# Kernels that sum over workgroups store per-workgroup partial vectors into caller-owned scratch and a fold kernel adds them in a
+# fixed order (include/stswin_hip.h, "deterministic cross-workgroup sums").  One buffer per device: every use is write-then-read on
+# the launch stream and kernels of a stream run in order.  It only ever grows (warm-up steps size it before a hipGraph capture).
+_SCRATCH = {}
+
+
+def scratch(device, floats: int) -> torch.Tensor:
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    t = _SCRATCH.get(device)
+    if t is None or t.numel() < floats:
+        if t is not None and torch.cuda.is_current_stream_capturing():
+            raise StswinHipError("scratch buffer would have to grow during a hipGraph capture: run the step once before capturing")
+        t = torch.empty(max(int(floats), 1 << 22), dtype=torch.float32, device=device)
+        _SCRATCH[device] = t
+    return t
 
 
 # ----------------------------------------------------------------------------------------------- live profiling
@@ -366,7 +393,7 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
     return out
 
 
-_CS_PARTIAL_MIN_M = int(os.environ.get("STSWIN_CS_PARTIAL_MIN_M", "8192"))
+_CS_PARTIAL_MIN_M = int(os.environ.get("STSWIN_CS_PARTIAL_MIN_M", "1"))   # (the table + fold path is the deterministic one: always)
 _CS_TABLES = {}
 
 
@@ -503,7 +530,9 @@ def vec_gather(v: torch.Tensor, imap: torch.Tensor, fill: float = 0.0) -> torch.
 
 def colsum(y: torch.Tensor, out_f32: torch.Tensor, M: Optional[int] = None):
     M = y.shape[0] if M is None else M
-    _check(load().stswin_colsum(_dt(y), _p(y), _c_long(_ld(y)), _p(out_f32), M, y.shape[1], _stream()), "colsum")
+    lib = load()
+    ws = scratch(y.device, lib.stswin_colsum_scratch(M, y.shape[1]))
+    _check(lib.stswin_colsum(_dt(y), _p(y), _c_long(_ld(y)), _p(out_f32), M, y.shape[1], _p(ws), _stream()), "colsum")
     return out_f32
 
 
@@ -525,7 +554,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, *, M, rows=None, S=1,
     if dx is None:
         dx = torch.empty_like(x)
         accumulate = False
-    ws = zeros(32, 3, S * Cseg, device=x.device) if M >= 4096 and os.environ.get("STSWIN_LN_NO_WS") != "1" else None
+    ws = scratch(x.device, load().stswin_layernorm_bwd_scratch(M, S * Cseg))
     rc = load().stswin_layernorm_bwd(_dt(x), _p(dy), _c_long(_ld(dy)), _p(x), _c_long(_ld(x)), _p(rows), S, Cseg,
                                      _p(gamma), _p(mean), _p(rstd), _p(dx), _c_long(_ld(dx)), _p(dgamma), _p(dbeta), M,
                                      1 if accumulate else 0, _p(dxsum), _p(ws), _stream())
@@ -546,7 +575,8 @@ def bias_expand(table, index, mask, N, heads):
 
 def bias_scatter(dbiasT, index, dtable, N, heads):
     assert dbiasT.is_contiguous() and dtable.is_contiguous() and index.dtype == torch.int64 and index.is_contiguous()
-    _check(load().stswin_bias_scatter(_p(dbiasT), _p(index), _p(dtable), N, heads, _stream()), "bias_scatter")
+    assert dtable.shape[0] * dtable.shape[1] == dtable.numel() and dtable.shape[1] == heads
+    _check(load().stswin_bias_scatter(_p(dbiasT), _p(index), _p(dtable), N, heads, dtable.shape[0], 1, _stream()), "bias_scatter")
     return dtable
 
 
@@ -577,10 +607,15 @@ def win_attn_fwd(qkv, biasT, maskT, *, nB_, nW, T, ws, heads, C, bias_index=None
 def win_attn_bwd(qkv, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, scale, colsum_out=None, debug_ts=False,
                  bias_index=None):
     dqkv = torch.empty_like(qkv)
+    lib = load()
+    need = lib.stswin_win_attn_bwd_scratch(nB_, ws, heads, C)
+    if need < 0:
+        raise StswinHipError(f"win_attn_bwd: bad geometry ({need})")
+    sc = scratch(qkv.device, need)
     rc = load().stswin_win_attn_bwd(_dt(qkv), _p(qkv), _c_long(_ld(qkv)), _p(dout), _c_long(_ld(dout)), _p(dqkv),
                                     _c_long(_ld(dqkv)), _p(biasT), _p(maskT), _p(dbiasT), _p(colsum_out), nB_, nW, T, ws, heads, C,
                                     _c_float(scale), _bias_windows(biasT, maskT, nW, bias_index) | ((1 << 30) if debug_ts else 0),
-                                    _p(bias_index), _stream())
+                                    _p(bias_index), _p(sc), _c_long(sc.numel()), _stream())
     _check(rc, "win_attn_bwd")
     return dqkv
 
@@ -592,7 +627,12 @@ def colstats(x, groups=1, squares=True, M=None, unit=0):
     both = zeros(2 if squares else 1, groups, C, device=x.device)
     s = both[0]
     ss = both[1] if squares else None
-    _check(load().stswin_colstats(_dt(x), _p(x), _c_long(_ld(x)), _p(s), _p(ss), M, C, groups, unit, _stream()), "colstats")
+    lib = load()
+    need = lib.stswin_colstats_scratch(_dt(x), M, C, groups, unit)
+    if need < 0:
+        raise StswinHipError(f"colstats: bad geometry ({need})")
+    _check(lib.stswin_colstats(_dt(x), _p(x), _c_long(_ld(x)), _p(s), _p(ss), M, C, groups, unit, _p(scratch(x.device, need)), _stream()),
+           "colstats")
     return s, ss
 
 
@@ -625,11 +665,15 @@ def bn_bwd(dy, x, y, mean, rstd, gamma, dx, dresid=None, groups=1, relu=True, tr
         s1, s2 = both[0], both[1]
     else:
         s1, s2 = sums
-    _check(load().stswin_bn_bwd(_dt(x), _p(dy), _c_long(_ld(dy)), _p(x), _c_long(_ld(x)), _p(y),
+    lib = load()
+    need = lib.stswin_bn_bwd_scratch(_dt(x), M, C, groups, unit) if phase != 2 else 0
+    if need < 0:
+        raise StswinHipError(f"bn_bwd: bad geometry ({need})")
+    _check(lib.stswin_bn_bwd(_dt(x), _p(dy), _c_long(_ld(dy)), _p(x), _c_long(_ld(x)), _p(y),
                                 _c_long(_ld(y) if y is not None else 0), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(s1), _p(s2),
                                 _p(dx), _c_long(_ld(dx)), _p(dresid), _c_long(_ld(dresid) if dresid is not None else 0), M, C,
                                 groups, 1 if relu else 0, 1 if training else 0, phase, _c_long(rows_total), unit, _p(group_sums),
-                                _stream()), "bn_bwd")
+                                _p(scratch(x.device, need) if phase != 2 else None), _stream()), "bn_bwd")
     return s1, s2
 
 
@@ -657,13 +701,13 @@ def ce_fwd(logits, labels, ignore_index, thresh):
     F_, nc = logits.shape[:2]
     HW = logits[0, 0].numel()
     loss = torch.empty(F_ * HW, dtype=torch.float32, device=logits.device)
-    stats = zeros(2, device=logits.device)
+    stats = zeros(4, device=logits.device)          # [count, -, 64-bit fixed-point sum]: include/stswin_hip.h
     _check(load().stswin_ce_fwd(_dt(logits), _p(logits), _p(labels), _p(loss), _p(stats), F_, _c_long(HW), nc, ignore_index,
                                 _c_float(thresh), _stream()), "ce_fwd")
     return loss, stats
 
 
-_OHEM_WORK_BYTES = 3 * 2048 * 8 + 48
+_OHEM_WORK_BYTES = 3 * 2048 * 12 + 48
 
 
 def ohem_select(loss, stats, n_min: int, thresh: float):
@@ -738,8 +782,12 @@ def contrast_class_sums(bank, lb, bank_block, ncls):
     """-> ksum fp32 [maps][seg / bank_block][ncls + 1][C]: per-class sums of the bank rows (slot ncls: all rows)."""
     maps, seg, C = bank.shape
     ksum = torch.empty(maps, seg // bank_block, ncls + 1, C, dtype=torch.float32, device=bank.device)
-    _check(load().stswin_contrast_class_sums(_dt(bank), _p(bank), _c_long(bank.stride(1)), _p(lb), maps, seg, bank_block, C, ncls,
-                                             _p(ksum), _stream()), "contrast_class_sums")
+    lib = load()
+    need = lib.stswin_contrast_class_sums_scratch(maps, seg, bank_block, C, ncls)
+    if need < 0:
+        raise StswinHipError(f"contrast_class_sums: bad geometry ({need})")
+    _check(lib.stswin_contrast_class_sums(_dt(bank), _p(bank), _c_long(bank.stride(1)), _p(lb), maps, seg, bank_block, C, ncls,
+                                          _p(ksum), _p(scratch(bank.device, need)), _stream()), "contrast_class_sums")
     return ksum
 
 
@@ -794,7 +842,10 @@ def multi_tensor_lars(ps, gs, ms, norms, *, lr, momentum, wd, trust_coef, eps, f
         k = hi - lo
         arr = lambda ts: (_c_void_p * k)(*[t.data_ptr() for t in ts[lo:hi]])  # noqa: E731
         ns = (_c_int * k)(*[t.numel() for t in ps[lo:hi]])
-        _check(lib.stswin_multi_tensor_lars(k, arr(ps), arr(gs), arr(ms), ns, _p(norms), _c_float(lr), _c_float(momentum),
+        need = 2 * k + 2 * sum((t.numel() + 8191) // 8192 for t in ps[lo:hi])
+        if norms is None or norms.numel() < need:
+            norms = scratch(ps[lo].device, need)
+        _check(lib.stswin_multi_tensor_lars(k, arr(ps), arr(gs), arr(ms), ns, _p(norms), _c_long(norms.numel()), _c_float(lr), _c_float(momentum),
                                             _c_float(wd), _c_float(trust_coef), _c_float(eps), 1 if first else 0,
                                             1 if adaptive else 0, st), "multi_tensor_lars")
 

@@ -216,3 +216,73 @@ def test_postprocessing_at_the_evaluation_size_1024x1280(dtype):
     assert [c for c, _ in rd] == [c for c, _ in dices[0]]
     assert np.allclose([v for _, v in rd], [v for _, v in dices[0]], rtol=1e-12)
     assert np.allclose([v for _, v in rj], [v for _, v in ious[0]], rtol=1e-12)
+
+
+def _seg_steps(S, B, steps, graph=False):
+    from stswincl_amd.net.Ours.base18 import TswinPlus
+    from stswincl_amd.optim import FusedAdam
+    from stswincl_amd.utils.losses import OhemCELoss2D
+    torch.manual_seed(0)
+    model = TswinPlus(12, (S // 8, S // 8)).cuda().train()
+    opt = FusedAdam(model.parameters(), 1e-4)
+    crit = OhemCELoss2D(S * S // 16)
+    torch.manual_seed(99)
+    x = torch.randn(B, 4, 3, S, S, device="cuda")
+    y = torch.randint(0, 12, (B, S, S), device="cuda")
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=BF):
+            loss = crit(model(x), y)
+        loss.backward()
+        grads = [p.grad.detach().clone() for p in model.parameters()]
+        opt.step()
+        losses.append(loss.detach().float().view(torch.int32).item())
+    return losses, grads, [p.detach().clone() for p in model.parameters()], [b.detach().clone() for b in model.buffers()]
+
+
+@pytest.mark.parametrize("S,B,steps", [(256, 2, 3), (512, 4, 1)])
+def test_bf16_training_step_is_bitwise_reproducible(S, B, steps):
+    """Two runs of the same bf16 training steps (same seed, same data) must agree BIT FOR BIT: loss, every gradient, every updated
+    parameter, every BatchNorm running statistic.  No kernel sums with fp32 atomics (include/stswin_hip.h, 'deterministic
+    cross-workgroup sums'): per-workgroup partial slabs + fixed-order folds, integer fixed-point for the OHEM sums."""
+    a = _seg_steps(S, B, steps)
+    b = _seg_steps(S, B, steps)
+    assert a[0] == b[0], (a[0], b[0])
+    names = ("gradient", "parameter", "buffer")
+    for which in (1, 2, 3):
+        for i, (u, v) in enumerate(zip(a[which], b[which])):
+            assert torch.equal(u, v), f"{names[which - 1]} {i} differs between two runs: max |d| {float((u.float() - v.float()).abs().max())}"
+
+
+def test_contrastive_step_is_bitwise_reproducible():
+    """Same for the ConsistencyLoss step (batched views, bank kernel, class sums, LARS norms)."""
+    import types
+    from stswincl_amd.contrast.models.PixPro_swin_v5 import ConsistencyLoss
+    from stswincl_amd.optim import make_contrast_optimizer
+    args = types.SimpleNamespace(pixpro_p=1.0, pixpro_momentum=0.99, pixpro_clamp_value=0.0, pixpro_transform_layer=1,
+                                 pixpro_ins_loss_weight=0.0, pixpro_pos_ratio=0.7, data="endo18", tag="1", pretrainpth=None,
+                                 num_instances=2235, batch_size=2, epochs=150, start_epoch=1)
+
+    def run():
+        torch.manual_seed(0)
+        net = ConsistencyLoss(args, input_resolution=(16, 16)).cuda().train()
+        params = [p for p in net.parameters() if p.requires_grad]
+        opt, _ = make_contrast_optimizer(params, batch_size=2)
+        torch.manual_seed(5)
+        ims = [torch.randn(2, 4, 3, 128, 128, device="cuda") for _ in range(6)]
+        masks = [torch.randint(0, 12, (2, 1, 128, 128), device="cuda").float() for _ in range(6)]
+        ls = []
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=BF):
+                loss = net(*ims, *masks)
+            loss.backward()
+            opt.step()
+            ls.append(loss.detach().float().view(torch.int32).item())
+        return ls, [p.detach().clone() for p in net.parameters()]
+
+    a, b = run(), run()
+    assert a[0] == b[0]
+    for i, (u, v) in enumerate(zip(a[1], b[1])):
+        assert torch.equal(u, v), f"parameter {i} differs between two runs"

@@ -177,7 +177,7 @@ def test_collective_budget_of_a_data_parallel_contrastive_step():
         p.join(120)
         assert p.exitcode == 0
     for rank, n_q, n_k, nb, nbytes, counts, loss, gsum in res:
-        assert n_q == n_k and n_q > 30
+        assert n_q == n_k and n_q >= 30
         for ag, ar, coll, copied in counts:
             assert ag == n_q + n_k, (ag, n_q, n_k)
             assert ar == n_q, (ar, n_q)
