@@ -390,20 +390,31 @@ struct FoldArgs {
   const float* ws; long slab_stride, ws_batch_stride; int nslabs;
   int len[3]; float* out[3]; long obs[3]; int accumulate;
 };
+// CL = float4 columns per workgroup (16: few slabs, 64 floats per workgroup; 4: many slabs - 64 slab lanes per column, four times
+// the workgroups); the association of the sum is fixed by (nslabs, CL) alone.
+template <int CL>
 __global__ __launch_bounds__(256) void slab_fold_kernel(FoldArgs f) {
-  __shared__ f32x4 fold[16][16];
-  const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
-  const int j = (blockIdx.x * 16 + cl) * 4;
+  constexpr int QL = 256 / CL;
+  __shared__ f32x4 fold[QL][CL];
+  const int cl = threadIdx.x % CL, q = threadIdx.x / CL;
+  const int j = (blockIdx.x * CL + cl) * 4;
   const bool in = j < f.len[0] + f.len[1] + f.len[2];
   const float* src = f.ws + (long)blockIdx.y * f.ws_batch_stride + j;
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
-  if (in)
-    for (int p = q; p < f.nslabs; p += 16) a += *(const f32x4*)(src + (long)p * f.slab_stride);
+  if (in) {
+    int p = q;
+    for (; p + 3 * QL < f.nslabs; p += 4 * QL) {             // four independent loads in flight per lane
+      const f32x4 v0 = *(const f32x4*)(src + (long)p * f.slab_stride), v1 = *(const f32x4*)(src + (long)(p + QL) * f.slab_stride);
+      const f32x4 v2 = *(const f32x4*)(src + (long)(p + 2 * QL) * f.slab_stride), v3 = *(const f32x4*)(src + (long)(p + 3 * QL) * f.slab_stride);
+      a += v0; a += v1; a += v2; a += v3;
+    }
+    for (; p < f.nslabs; p += QL) a += *(const f32x4*)(src + (long)p * f.slab_stride);
+  }
   fold[q][cl] = a;
   __syncthreads();
   if (q == 0 && in) {
-#pragma unroll
-    for (int k = 1; k < 16; ++k) a += fold[k][cl];
+#pragma unroll 8
+    for (int k = 1; k < QL; ++k) a += fold[k][cl];
     const int sgm = j < f.len[0] ? 0 : (j < f.len[0] + f.len[1] ? 1 : 2);
     const int jj = j - (sgm > 0 ? f.len[0] : 0) - (sgm > 1 ? f.len[1] : 0);
     float* out = f.out[sgm];
@@ -426,7 +437,10 @@ int stswin_fold3_launch(const float* ws, long slab_stride, long ws_batch_stride,
   }
   if (nslabs <= 0 || tot <= 0 || batch <= 0) return 0;
   if (slab_stride % 4 || ws_batch_stride % 4) return -1110;
-  hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)((tot + 63) / 64), (unsigned)batch), dim3(256), 0, st, f);
+  if (nslabs >= 96)
+    hipLaunchKernelGGL(slab_fold_kernel<4>, dim3((unsigned)((tot + 15) / 16), (unsigned)batch), dim3(256), 0, st, f);
+  else
+    hipLaunchKernelGGL(slab_fold_kernel<16>, dim3((unsigned)((tot + 63) / 64), (unsigned)batch), dim3(256), 0, st, f);
   return 0;
 }
 
@@ -457,7 +471,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, con
   for (int p = 0; p < NP; ++p)
 #pragma unroll
     for (int e = 0; e < PACK; ++e) { dg[p][e] = 0.f; db[p][e] = 0.f; ds[p][e] = 0.f; }
-  const int r_begin = (blockIdx.x * 4 + w) * rows_per_wave;
+  // workgroups walk row groups blockIdx.x, blockIdx.x + gridDim.x, ... (the launcher caps the grid at 1024: the parameter-gradient
+  // partial sums stay in registers across a workgroup's groups, so there is one slab per workgroup to fold afterwards)
+  for (int rg = blockIdx.x; rg * 4 * rows_per_wave < M; rg += gridDim.x) {
+  const int r_begin = (rg * 4 + w) * rows_per_wave;
   for (int r = r_begin; r < min(M, r_begin + rows_per_wave); ++r) {
     const float mu = mean[r], rs = rstd[r];
     float g[NP][PACK], xh[NP][PACK];
@@ -504,6 +521,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, con
         *(decltype(o.v)*)dst = o.v;
       }
     }
+  }
   }
   // fold the 4 waves: smem[w][C] x 2
   float* sg = (float*)smem;
@@ -599,17 +617,20 @@ __global__ __launch_bounds__(256) void bias_expand_kernel(const float* table, co
 __global__ __launch_bounds__(256) void bias_scatter_kernel(const float* dbiasT, const long* index, float* dtable, int N, int heads,
                                                             int nslabs) {
   __shared__ float red[4][8];
-  const int e = blockIdx.x;
+  const int e = blockIdx.x, h0 = blockIdx.y * 8, nh = min(8, heads - h0);
   const long NN = (long)N * N;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (long pr = threadIdx.x; pr < NN; pr += 256) {          // pr = i * N + j (the index buffer's order)
     if (index[pr] != e) continue;
     const int i = (int)(pr / N), j = (int)(pr % N);
-    for (int h = 0; h < heads && h < 8; ++h) {
-      const float* src = dbiasT + ((long)h * N + j) * N + i;  // dbiasT[h][key j][query i]
-      float t = 0.f;
-      for (int sl = 0; sl < nslabs; ++sl) t += src[(long)sl * heads * NN];
-      acc[h] += t;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      if (h < nh) {
+        const float* src = dbiasT + ((long)(h0 + h) * N + j) * N + i;  // dbiasT[h][key j][query i]
+        float t = 0.f;
+        for (int sl = 0; sl < nslabs; ++sl) t += src[(long)sl * heads * NN];
+        acc[h] += t;
+      }
     }
   }
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -621,8 +642,8 @@ __global__ __launch_bounds__(256) void bias_scatter_kernel(const float* dbiasT, 
     if (l == 0) red[w][h] = v;
   }
   __syncthreads();
-  if (threadIdx.x < heads && threadIdx.x < 8)
-    dtable[(long)e * heads + threadIdx.x] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if ((int)threadIdx.x < nh)
+    dtable[(long)e * heads + h0 + threadIdx.x] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -756,10 +777,11 @@ extern "C" int stswin_layernorm_fwd(int dtype, const void* x, long ldx, const in
 }
 
 static int ln_bwd_rows_per_wave(int M) { return M >= 16384 ? 8 : (M >= 4096 ? 4 : 2); }
-extern "C" long stswin_layernorm_bwd_scratch(int M, int C) {
-  const int rpw = ln_bwd_rows_per_wave(M);
-  return (long)((M + 4 * rpw - 1) / (4 * rpw)) * 3 * C;
+static int ln_bwd_grid(int M) {
+  const int rpw = ln_bwd_rows_per_wave(M), groups = (M + 4 * rpw - 1) / (4 * rpw);
+  return groups < 1024 ? groups : 1024;
 }
+extern "C" long stswin_layernorm_bwd_scratch(int M, int C) { return (long)ln_bwd_grid(M) * 3 * C; }
 
 template <typename T>
 static int ln_bwd_launch(const void* dy, long lddy, const void* x, long ldx, const int* rows, int S, int Cseg,
@@ -770,7 +792,7 @@ static int ln_bwd_launch(const void* dy, long lddy, const void* x, long ldx, con
   // 8 rows per wave: >= 4 waves per SIMD at M = 32768 (the serial row loop with two wave reductions per row is
   // latency-bound)
   const int rpw = ln_bwd_rows_per_wave(M);
-  dim3 grid((M + 4 * rpw - 1) / (4 * rpw)), blk(256);
+  dim3 grid((unsigned)ln_bwd_grid(M)), blk(256);
   const size_t lds = (size_t)8 * C * sizeof(float);
   if (!ws) return -1111;
 #define LN_B(NP) hipLaunchKernelGGL((ln_bwd_kernel<T, NP>), grid, blk, lds, st, (const T*)dy, lddy, (const T*)x, ldx, rows, S, Cseg, g, mean, rstd, (T*)dx, lddx, dg, db, M, rpw, acc, dxsum, ws)
@@ -839,9 +861,9 @@ extern "C" int stswin_bias_expand(const float* table, const long* index, const f
 
 extern "C" int stswin_bias_scatter(const float* dbiasT, const long* index, float* dtable, int N, int heads, int table_rows, int nslabs,
                                    void* stream) {
-  if (N <= 0 || heads <= 0 || heads > 8 || table_rows <= 0 || nslabs <= 0) return -1109;
-  hipLaunchKernelGGL(bias_scatter_kernel, dim3((unsigned)table_rows), dim3(256), 0, (hipStream_t)stream, dbiasT, index, dtable, N, heads,
-                     nslabs);
+  if (N <= 0 || heads <= 0 || table_rows <= 0 || nslabs <= 0) return -1109;
+  hipLaunchKernelGGL(bias_scatter_kernel, dim3((unsigned)table_rows, (unsigned)((heads + 7) / 8)), dim3(256), 0, (hipStream_t)stream, dbiasT,
+                     index, dtable, N, heads, nslabs);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

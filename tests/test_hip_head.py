@@ -287,7 +287,10 @@ def test_ohem_select_matches_sorted_reference(n, n_min, kind):
     srt = torch.sort(loss.double(), descending=True)[0]
     for thresh in (0.5, 2.9, 10.0):
         n_hard = (loss > thresh).sum().float()
-        stats = torch.stack([n_hard, loss[loss > thresh].sum()]).float()
+        # stats layout of stswin_ce_fwd: [0] count, [2..3] the sum as one unsigned 64-bit integer in 2^-32 fixed point
+        stats = torch.zeros(4, device="cuda")
+        stats[0] = n_hard
+        stats[2:4].view(torch.int64)[0] = int(round(float(loss[loss > thresh].double().sum()) * 4294967296.0))
         value, sel = hip.ohem_select(loss, stats, n_min, thresh)
         if int(n_hard) > n_min:                            # loss[n_min] > thresh
             ref = srt[srt > thresh].mean()
