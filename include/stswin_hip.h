@@ -200,6 +200,15 @@ int stswin_bias_scatter(const float* dbiasT, const long* index, float* dtable, i
 int stswin_win_attn_fwd(int dtype, const void* qkv, long ld, void* out, long ldo, const float* biasT, const float* maskT,
                         int nB_, int nW, int T_frames, int ws, int heads, int C, int bias_windows,
                         const int* bias_index, void* stream);
+/* QKV-fused forward (swin_512.py:115-141 in one kernel; bf16, T * ws * ws = 128 tokens per window, head dim 128: the stage-1 shape):
+ * out = attention(gather(x, rmap) . qkv.weight^T + qkv.bias) per (window, head), where the projection, the q scaling, the bias /
+ * mask table and the softmax never leave the CU.  x [.][C] token rows, rmap int [nB_ * 128] = token row of every window row (-1:
+ * zero row; NULL: identity), w = qkv.weight [3C][C] (bf16), bqkv fp32 [3C] or NULL, biasT as in stswin_win_attn_fwd with
+ * bias_windows / bias_index (the pre-summed bias + mask table; no separate maskT).  qkv_out (optional, [nB_ * 128][3C]) receives
+ * q * scale | k | v for stswin_win_attn_bwd; NULL in no-grad passes, which then never write q, k, v to memory. */
+int stswin_win_attn_qkv_fwd(const void* x, long ldx, const int* rmap, const void* w, long ldw, const float* bqkv, void* qkv_out, long ldq,
+                            void* out, long ldo, const float* biasT, int nB_, int nW, int T_frames, int ws, int heads, int C,
+                            float scale, int bias_windows, const int* bias_index, void* stream);
 /* BASELINE.json configs[4] "fp8 MFMA attention": the forward above with q, k, v and the probabilities quantised to OCP e4m3 in
  * registers (per (window, head) amax scales, P x 128) and both products on v_mfma_f32_32x32x16_fp8_fp8; qkv / out stay bf16 in
  * memory (same arguments, dtype fixed to bf16 storage).  A numerics mode (the non-scaled fp8 MFMA has the bf16 rate on gfx950);

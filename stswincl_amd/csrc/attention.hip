@@ -299,6 +299,200 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // ====================================================================================================
+// QKV-fused forward for the stage-1 shape (bf16, 128 tokens per window pair, head dim 128): the window gather, the QKV
+// projection, the attention core and (when a backward will follow) the q | k | v rows for it, in ONE kernel
+// (swin_512.py:115-141 without the (B_, N, 3C) tensor between nn.Linear and the attention).  north_star: "window partition +
+// cyclic shift fused with Q/K/V packing ... windowed attention as an MFMA bf16 batched-GEMM pair".
+//
+// One (window, head) problem at a time per 8-wave workgroup (persistent over problems; the four heads of a window run on
+// neighbouring workgroups, so its token rows come out of L2):
+//   A  projection  [128 tokens x C] . W_h^T -> [128 x 384]  (W_h = the head's 128 q, k and v rows of qkv.weight):
+//      token rows gathered by the window row map and the weight rows (L2 resident: 1.5 MB) in 32-column chunks through a
+//      4-stage LDS ring (LDS-DMA as raw ISA, requested 3 chunks ahead, counted vmcnt waits, one raw s_barrier per chunk);
+//      every wave owns 48 of the 384 output columns for all 128 rows; MFMA 16x16x32 with the operands swapped (a lane then
+//      holds 4 consecutive output columns of one token row);
+//   A' epilogue: + bias, q * scale, bf16, 8-byte stores into the Q | K | V tiles in LDS (the images the attention core reads);
+//   B  waves 0-3: the forward core of attn_fwd_kernel on the three LDS tiles (S^T = K Q^T + bias + mask, in-register softmax,
+//      O = P V); waves 4-7 meanwhile copy the tiles to qkv_out (only when the backward needs them: a no-grad pass - the six
+//      momentum-key encoder passes of the contrastive step, evaluation - never writes q, k, v to HBM at all).
+struct AttnQkvArgs {
+  const bf16* X; long ldx; const int* rmap;      // tokens [.][C]; rmap[window row] = token row or -1 (null: identity)
+  const bf16* W; long ldw; const float* bqkv;    // qkv.weight [3C][C], qkv.bias [3C] or null
+  bf16* qkv_out; long ldq;                       // optional [nB_*128][3C] (q pre-scaled | k | v), window order
+  AttnArgs a;                                    // out / ldo, biasT, maskT, nB_, nW, heads, C, N, scale, bias_windows, bias_index
+};
+
+template <int NC, int CDIM>
+__global__ __launch_bounds__(512) void attn_qkv_fwd_kernel(AttnQkvArgs q) {
+  using T = bf16;
+  constexpr int NTOK = 128, HD = 128, ROWB = 256, KV = NTOK * ROWB, NSTG = 4;
+  constexpr int XB = 128 * 64, WB = 384 * 64, STAGE = XB + WB;               // ring stage: tokens [128][32 bf16] | weights [384][32 bf16]
+  using Cfg = AttnCfg<T, NTOK, HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const AttnArgs& a = q.a;
+  char* Qt = smem;                                   // the three tiles REUSE the ring's memory: they are written after the last chunk
+  char* Kt = smem + KV;                              // has been multiplied and are dead before the next problem's first copy
+  char* Vt = smem + 2 * KV;
+  char* ring = smem;
+  const int tid = threadIdx.x, l = tid & 63, w = wave_id();
+  constexpr int C = CDIM, nks = C / 32;
+  const long nprob = (long)a.nB_ * a.heads;
+  const int arow = tid >> 2, apiece = (tid & 3) ^ ((arow >> 2) & 3);         // token copy: physical piece tid & 3 of chunk row arow
+  const int fr = l & 15, fq = l >> 4;
+  // fragment read offsets inside a stage (64-byte rows, piece ^= (row >> 2) & 3): tokens 16 i + fr, weight rows 48 w + 16 j + fr
+  int xoff[8], woff[3];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const int row = 16 * i + fr; xoff[i] = row * 64 + ((fq ^ ((row >> 2) & 3)) << 4); }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { const int row = 48 * w + 16 * j + fr; woff[j] = XB + row * 64 + ((fq ^ ((row >> 2) & 3)) << 4); }
+  // DBG (tools/attn_qkv_timeline.py): a.dqkv_colsum = u64 [workgroups][8 waves][8] stamps (100 MHz) of every wave's SECOND problem
+  unsigned long long* ts = (unsigned long long*)a.dqkv_colsum;
+  int pcount = 0;
+  auto stamp = [&](int slot) {
+    if (ts && pcount == 1 && l == 0) ts[((long)blockIdx.x * 8 + w) * 8 + slot] = wall_clock64();
+  };
+  auto map_row = [&](long prob) -> int {             // token row of this thread's chunk row in problem `prob`
+    const long rb = (prob / a.heads) * NTOK;
+    return q.rmap ? q.rmap[rb + arow] : (int)(rb + arow);
+  };
+  int srow_next = blockIdx.x < nprob ? map_row(blockIdx.x) : -1;
+  for (long prob = blockIdx.x; prob < nprob; prob += gridDim.x, ++pcount) {
+    const int b_ = (int)(prob / a.heads), head = (int)(prob - (long)b_ * a.heads);
+    const long rowbase = (long)b_ * NTOK;
+    stamp(0);
+    const int srow = srow_next;
+    // (the next problem's map entry is requested now: at its start the first copies no longer wait for a dependent load)
+    if (prob + gridDim.x < nprob) srow_next = map_row(prob + gridDim.x);
+    const T* asrc = srow >= 0 ? q.X + (long)srow * q.ldx + apiece * 8 : (const T*)g_stswin_zero;
+    const int astep = srow >= 0 ? 32 : 0;                                  // (padding rows keep reading the zero block)
+    const T* wsrc[3];                                                      // weight copy: pieces tid, tid + 512, tid + 1024 of the chunk
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int pc = tid + 512 * j, n = pc >> 2, part = n >> 7, within = n & 127;
+      wsrc[j] = q.W + ((long)part * C + head * HD + within) * q.ldw + (((pc & 3) ^ ((n >> 2) & 3)) << 3);
+    }
+    f32x4 acc[8][3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Every global -> LDS copy is raw ISA (glds16_raw: invisible to hipcc's waitcnt pass, which otherwise drains all outstanding
+    // copies in front of LDS reads and barriers) and the waits are counted by hand: a chunk = 4 copy instructions per thread
+    // (1 token piece + 3 weight pieces), chunks are requested 3 ahead, so chunk ks has landed when <= 8 copies are outstanding.
+    auto request = [&](int ks) {
+      char* st = ring + (ks % NSTG) * STAGE;
+      glds16_raw(asrc + (long)ks * astep, st + w * 1024);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) glds16_raw(wsrc[j] + ks * 32, st + XB + j * 8192 + w * 1024);
+    };
+    // Software pipeline: while the MFMAs of chunk ks run, the fragments of chunk ks + 1 are read from LDS into the other register
+    // set (22 KB of fragment reads per wave and chunk take as long as its 24 MFMAs: back to back they halved the rate), and chunk
+    // ks + 4 is requested into the stage chunk ks has just left.
+    request(0); request(1); request(2); request(3);
+    bf16x8 wf[2][3], xa[2][8];
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stamp(1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) wf[0][j] = *(const bf16x8*)(ring + woff[j]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xa[0][i] = *(const bf16x8*)(ring + xoff[i]);
+#pragma unroll
+    for (int ks = 0; ks < nks; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < nks) {
+        // chunk ks + 1 has landed when only the chunks requested after it (up to ks + 3) are outstanding
+        const int later = (ks + 3 < nks ? ks + 3 : nks - 1) - (ks + 1);
+        // (lgkmcnt(0): this wave's own fragment reads of chunk ks are complete - the barrier then frees that stage for a copy)
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // chunk ks + 1 visible; every wave has finished READING chunk ks (last step)
+        if (ks + 4 < nks) request(ks + 4);           // into the stage of chunk ks
+        const char* st = ring + ((ks + 1) % NSTG) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) wf[nxt][j] = *(const bf16x8*)(st + woff[j]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xa[nxt][i] = *(const bf16x8*)(st + xoff[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cur][j], xa[cur][i], acc[i][j], 0, 0, 0);
+    }
+    stamp(2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // every wave is done with the ring: its memory becomes the Q | K | V tiles
+    stamp(3);
+    // A': acc[i][j][r] = (token 16 i + fr, column 16 (3 w + j) + 4 fq + r of the head's q | k | v) -> LDS tiles
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int t = w * 3 + j, part = t >> 3, c0 = (t & 7) * 16 + 4 * fq;
+      char* tile = part == 0 ? Qt : (part == 1 ? Kt : Vt);
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (q.bqkv) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = q.bqkv[(long)part * C + head * HD + c0 + r];
+      }
+      const float mul = part == 0 ? a.scale : 1.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = 16 * i + fr;
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (bf16)((acc[i][j][r] + bv[r]) * mul);
+        *(bf16x4*)(tile + tile_off<ROWB>(row, c0 >> 3) + ((c0 & 7) << 1)) = v;
+      }
+    }
+    __syncthreads();
+    stamp(4);
+    if (w < 4) {
+      // B: attention core (attn_fwd_kernel) on the LDS tiles
+      const int lr = l & 31, half = l >> 5, q0 = w * 32;
+      bf16x8 qf[HD / 16];
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks) qf[ks] = frag_row<ROWB>(Qt, q0 + lr, ks, half);
+      f32x16 p[Cfg::KT];
+      scores_softmax<T, NTOK, HD, NC>(p, a, Kt, (const T*)nullptr, (const T*)nullptr, q0, head, b_ % a.nW, qf);
+      f32x16 o[Cfg::DT];
+#pragma unroll
+      for (int dt = 0; dt < Cfg::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          bf16x8 pa;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pa[e] = (bf16)p[kt][8 * m + e];
+#pragma unroll
+          for (int dt = 0; dt < Cfg::DT; ++dt)
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr_perm<ROWB>(Vt, kt * 32 + 16 * m, dt), o[dt], 0, 0, 0);
+        }
+      T* ob = (T*)a.out + (rowbase + q0) * a.ldo + head * HD;
+#pragma unroll
+      for (int dt = 0; dt < Cfg::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[(long)crow32(r, half) * a.ldo + dt * 32 + lr] = (bf16)o[dt][r];
+    } else if (q.qkv_out) {
+      // the rows the backward will read: 3 tiles x 128 rows x 16 pieces of 16 bytes, 24 per thread of waves 4-7
+      const int t4 = tid - 256;
+#pragma unroll 4
+      for (int pc = t4; pc < 3 * NTOK * 16; pc += 256) {
+        const int part = pc / (NTOK * 16), rem = pc - part * (NTOK * 16), row = rem >> 4, ch = rem & 15;
+        const char* tile = smem + part * KV;
+        const bf16x8 v = *(const bf16x8*)(tile + tile_off<ROWB>(row, ch));
+        *(bf16x8*)(q.qkv_out + (rowbase + row) * q.ldq + (long)part * C + head * HD + ch * 8) = v;
+      }
+    }
+    stamp(5);
+    __syncthreads();                                   // tiles and ring are reused by the next problem
+    stamp(6);
+  }
+}
+
+// ====================================================================================================
 // fp8 (OCP e4m3) forward for BASELINE.json configs[4] ("fp8 MFMA attention"): the same kernel with q, k, v and the
 // probabilities quantised in registers and both products on v_mfma_f32_32x32x16_fp8_fp8.  q / k / v stay bf16 in HBM (the
 // QKV GEMM writes them, the backward reads them), so this mode changes the arithmetic, not the traffic: per (window, head)
@@ -1233,6 +1427,39 @@ extern "C" int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const vo
              bias_windows | dbg, bias_index};
   a_scratch_floats = scratch_floats;
   return attn_common(dtype, a, T_frames, ws, true, stream);
+}
+
+extern "C" int stswin_win_attn_qkv_fwd(const void* x, long ldx, const int* rmap, const void* w, long ldw, const float* bqkv, void* qkv_out,
+                                       long ldq, void* out, long ldo, const float* biasT, int nB_, int nW, int T_frames, int ws, int heads,
+                                       int C, float scale, int bias_windows, const int* bias_index, void* stream) {
+  unsigned long long* dbg_ts = nullptr;               // DBG: bit 30 of bias_windows = qkv_out is a u64 [256][8][8] stamp buffer instead
+  if (bias_windows & (1 << 30)) { bias_windows &= ~(1 << 30); dbg_ts = (unsigned long long*)qkv_out; qkv_out = nullptr; }
+  if (T_frames * ws * ws != 128 || heads <= 0 || C != heads * 128 || C % 32) return -1206;     // the stage-1 shape only
+  if (nW <= 0 || nB_ % nW || (bias_windows != 1 && !bias_index && bias_windows != nW)) return -1204;
+  if (ldx % 8 || ldw % 8 || ldo % 8 || (qkv_out && ldq % 8)) return -1207;
+  AttnQkvArgs q;
+  q.X = (const bf16*)x; q.ldx = ldx; q.rmap = rmap; q.W = (const bf16*)w; q.ldw = ldw; q.bqkv = bqkv;
+  q.qkv_out = (bf16*)qkv_out; q.ldq = ldq;
+  q.a = AttnArgs{nullptr, 0, out, ldo, nullptr, 0, biasT, nullptr, nullptr, (float*)dbg_ts, nullptr, nB_, nW, heads, C, ws * ws, scale,
+                 bias_windows, bias_index};
+  constexpr int LDS = 4 * (128 * 64 + 384 * 64);     // 4-stage ring of token + weight chunks (128 KB); the Q | K | V tiles reuse it
+  hipStream_t st = (hipStream_t)stream;
+  const long probs = (long)nB_ * heads;
+  const int grid = (int)(probs < 256 ? probs : 256);
+#define QKV_LAUNCH(NCV, CV)                                                                                                            \
+  do {                                                                                                                                 \
+    static const int attr = (int)hipFuncSetAttribute((const void*)attn_qkv_fwd_kernel<NCV, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+    if (attr != 0) return -attr;                                                                                                       \
+    hipLaunchKernelGGL((attn_qkv_fwd_kernel<NCV, CV>), dim3(grid), dim3(512), LDS, st, q);                                             \
+  } while (0)
+  if (ws * ws == 64 && C == 512) QKV_LAUNCH(64, 512);
+  else if (C == 512) QKV_LAUNCH(0, 512);
+  else if (C == 256) QKV_LAUNCH(0, 256);
+  else if (C == 1024) QKV_LAUNCH(0, 1024);
+  else return -1206;
+#undef QKV_LAUNCH
+  STSWIN_CHECK_LAUNCH();
+  return 0;
 }
 
 template <int NTOK, int HD, int NC>

@@ -604,6 +604,29 @@ def win_attn_fwd(qkv, biasT, maskT, *, nB_, nW, T, ws, heads, C, bias_index=None
     return out
 
 
+def win_attn_qkv_fwd(x, rmap, w, bqkv, biasT, *, nB_, nW, T, ws, heads, C, scale, bias_index=None, want_qkv=True, debug_ts=None):
+    """QKV-fused window attention forward (include/stswin_hip.h: stswin_win_attn_qkv_fwd) -> (out [nB_*T*ws*ws][C], qkv or None)."""
+    rows = nB_ * T * ws * ws
+    if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
+        raise StswinHipError("win_attn_qkv_fwd is a bf16 kernel")
+    out = torch.empty(rows, C, dtype=x.dtype, device=x.device)
+    qkv = torch.empty(rows, 3 * C, dtype=x.dtype, device=x.device) if want_qkv else None
+    if debug_ts is not None:                     # tools/attn_qkv_timeline.py: int64 [256][8][8] stamp buffer in place of qkv_out
+        rc = load().stswin_win_attn_qkv_fwd(_p(x), _c_long(_ld(x)), _p(rmap), _p(w), _c_long(_ld(w)), _p(bqkv), _p(debug_ts), _c_long(0),
+                                            _p(out), _c_long(_ld(out)), _p(biasT), nB_, nW, T, ws, heads, C, _c_float(scale),
+                                            _bias_windows(biasT, None, nW, bias_index) | (1 << 30), _p(bias_index), _stream())
+        _check(rc, "win_attn_qkv_fwd")
+        return out, None
+    name = "attn_qkv_fwd_bf16"
+    with _Span(name, 2.0 * rows * 3 * C * C + 4.0 * nB_ * heads * (T * ws * ws) ** 2 * (C // heads)):
+        rc = load().stswin_win_attn_qkv_fwd(_p(x), _c_long(_ld(x)), _p(rmap), _p(w), _c_long(_ld(w)), _p(bqkv), _p(qkv),
+                                            _c_long(_ld(qkv) if qkv is not None else 0), _p(out), _c_long(_ld(out)), _p(biasT), nB_, nW, T,
+                                            ws, heads, C, _c_float(scale), _bias_windows(biasT, None, nW, bias_index), _p(bias_index),
+                                            _stream())
+    _check(rc, "win_attn_qkv_fwd")
+    return out, qkv
+
+
 def win_attn_bwd(qkv, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, scale, colsum_out=None, debug_ts=False,
                  bias_index=None):
     dqkv = torch.empty_like(qkv)

@@ -189,6 +189,15 @@ def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 _UNIQ_MASKS: Dict[int, tuple] = {}
 
 
+def _fused_qkv(need_bwd: bool) -> bool:
+    """Whether a stage-1 Swin block runs the QKV-fused attention forward (hip.win_attn_qkv_fwd) instead of the qkv GEMM + attention
+    kernel pair.  Default: in no-grad passes (momentum-key encoders, evaluation), where q | k | v then never reach memory and the
+    fused kernel measures 14 % faster than the pair; with a backward to feed it ties the pair (profiles/r03_attention_qkv_fused.txt)
+    and the pair stays.  STSWIN_FUSED_QKV=1 / 0 forces it on / off (read per call: A/B runs and tests switch it)."""
+    env = os.environ.get("STSWIN_FUSED_QKV")
+    return (env == "1") if env in ("0", "1") else not need_bwd
+
+
 def unique_windows(attn_mask: torch.Tensor):
     """(distinct window masks fp32 [U][N][N], int32 [nW] slot of every window) of an SW-MSA mask buffer; cached per buffer
     object (id + weak reference, like wcast; torch.unique syncs with the host, so this runs once per module)."""
@@ -230,8 +239,6 @@ class SwinBlockFn(torch.autograd.Function):
         dev = x.device
         rmap = window_rowmap(Bp, T, H, W, ws, shift, dev)
         scale = d ** -0.5
-        qkv = torch.empty(M, 3 * C, dtype=dt, device=dev)
-        hip.gemm_nt(X2, wcast(qkv_w, dt), qkv, M=M, a_rows=rmap, bias=_f32(qkv_b), scale=scale, scale_cols=C)
         # one [nW][heads][N][N] table = bias + SW-MSA mask (swin_512.py:122-131): the kernels then read one value per
         # score instead of two (the separate mask read cost +60 % on the stage-1 forward kernel)
         maskT = None
@@ -239,21 +246,33 @@ class SwinBlockFn(torch.autograd.Function):
         # table holds one slot per pattern (4 MB instead of 64 MB at stage 1: L2 resident) and a window -> slot index
         umask, bidx = unique_windows(attn_mask) if shift > 0 and attn_mask is not None else (None, None)
         biasT = hip.bias_expand(_f32(table), index.reshape(-1).contiguous(), umask, N, heads)
-        # STSWIN_FP8_ATTN=1 (BASELINE configs[4]): e4m3 q / k / v / P on the fp8 MFMA in the forward; the backward stays bf16
-        o = hip.win_attn_fwd(qkv, biasT, maskT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads, C=C, bias_index=bidx,
-                             fp8=(dt == torch.bfloat16 and os.environ.get("STSWIN_FP8_ATTN") == "1"))
+        need_bwd = any(ctx.needs_input_grad)
+        fp8 = dt == torch.bfloat16 and os.environ.get("STSWIN_FP8_ATTN") == "1"
+        if (_fused_qkv(need_bwd) and dt == torch.bfloat16 and not fp8 and T * N == 128 and d == 128 and C in (256, 512, 1024)
+                and (shift == 0 or attn_mask is not None)):
+            # stage-1 shape: window gather + QKV projection + attention core in ONE kernel; q | k | v reach memory only when a
+            # backward will read them (swin_512.py:115-141)
+            o, qkv = hip.win_attn_qkv_fwd(X2, rmap, wcast(qkv_w, dt), _f32(qkv_b), biasT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads,
+                                          C=C, scale=scale, bias_index=bidx, want_qkv=need_bwd)
+        else:
+            qkv = torch.empty(M, 3 * C, dtype=dt, device=dev)
+            hip.gemm_nt(X2, wcast(qkv_w, dt), qkv, M=M, a_rows=rmap, bias=_f32(qkv_b), scale=scale, scale_cols=C)
+            # STSWIN_FP8_ATTN=1 (BASELINE configs[4]): e4m3 q / k / v / P on the fp8 MFMA in the forward; the backward stays bf16
+            o = hip.win_attn_fwd(qkv, biasT, maskT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads, C=C, bias_index=bidx, fp8=fp8)
         x1 = torch.empty(M, C, dtype=dt, device=dev)
         hip.gemm_nt(o, wcast(proj_w, dt), x1, M=M, c_rows=rmap, bias=_f32(proj_b), resid=X2, r_rows=rmap,
                     flags=hip.GF_RESID)
         # no gradient wanted (the momentum-key passes of the contrastive step, evaluation): nothing is kept for a backward, and the
         # fc1 epilogue skips its second output (the GELU' tile: 268 MB and a third of the epilogue's polynomial work at stage 1)
-        need_bwd = any(ctx.needs_input_grad)
         n2, mean2, rstd2 = hip.layernorm_fwd(x1, _f32(n2_w), _f32(n2_b), M=M, save_stats=need_bwd)
         h = torch.empty(M, fc1_w.shape[0], dtype=dt, device=dev)
         h_pre = torch.empty_like(h) if need_bwd else None
         # out2 = gelu'(fc1 pre-activation): the backward epilogue is then a plain multiply (Phi is shared with the GELU here)
+        # (STSWIN_GELU_BWD=1, A/B switch for the round-2 verdict's question: store the pre-activation instead and evaluate gelu' in
+        #  the backward epilogue - one polynomial on each side instead of both here; measured slower, profiles/r03_gelu_split_ab.txt)
+        gelu_bwd = os.environ.get("STSWIN_GELU_BWD") == "1"
         hip.gemm_nt(n2, wcast(fc1_w, dt), h, M=M, bias=_f32(fc1_b), out2=h_pre,
-                    flags=(hip.GF_GELU | hip.GF_C2_DGELU) if need_bwd else hip.GF_GELU)
+                    flags=(hip.GF_GELU | (0 if gelu_bwd else hip.GF_C2_DGELU)) if need_bwd else hip.GF_GELU)
         y2 = torch.empty(M, C, dtype=dt, device=dev)
         hip.gemm_nt(h, wcast(fc2_w, dt), y2, M=M, bias=_f32(fc2_b), resid=x1, flags=hip.GF_RESID)
         out, mean1, rstd1 = hip.layernorm_fwd(y2, _f32(n1_w), _f32(n1_b), M=M, save_stats=need_bwd)
@@ -263,6 +282,7 @@ class SwinBlockFn(torch.autograd.Function):
         ctx.dt = dt
         ctx.in_dtype = x.dtype
         ctx.bidx = bidx
+        ctx.gelu_bwd = gelu_bwd
         ctx.save_for_backward(X2, rmap, qkv, biasT, maskT, o, x1, mean2, rstd2, n2, h_pre, h, y2, mean1, rstd1,
                               qkv_w, proj_w, n1_w, n2_w, fc1_w, fc2_w, index)
         return out.view(Bp, T, L, C)
@@ -291,7 +311,8 @@ class SwinBlockFn(torch.autograd.Function):
         # fc2 (+ GELU', + fc1's bias gradient from the epilogue)
         hip.gemm_tn(dy2, h, dfc2_w, Mk=M, overwrite=True)
         dh_pre = torch.empty(M, hid, dtype=dt, device=dev)
-        hip.gemm_nt(dy2, wcast(fc2_w, dt, True), dh_pre, M=M, resid=h_pre, flags=hip.GF_MUL_R, colsum_out=dfc1_b)
+        hip.gemm_nt(dy2, wcast(fc2_w, dt, True), dh_pre, M=M, resid=h_pre, flags=hip.GF_MUL_DGELU if ctx.gelu_bwd else hip.GF_MUL_R,
+                    colsum_out=dfc1_b)
         # fc1
         hip.gemm_tn(dh_pre, n2, dfc1_w, Mk=M, overwrite=True)
         dn2 = torch.empty(M, C, dtype=dt, device=dev)

@@ -125,3 +125,78 @@ def test_attention_fwd_fp8_mode(ws, C, heads):
     assert torch.isfinite(out8).all()
     assert rel16 < rel8 < 6e-2                               # really a different (coarser) arithmetic, and a bounded one
     assert float((out8 - ref).abs().max()) < 0.12 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("C,heads,shifted,want_qkv", [(512, 4, True, True), (512, 4, False, False), (256, 2, True, True), (1024, 8, False, True)])
+def test_qkv_fused_attention_forward_vs_reference_formulation(C, heads, shifted, want_qkv):
+    """stswin_win_attn_qkv_fwd (window gather + QKV projection + attention in one kernel, stage-1 shape: 8x8 windows over a
+    frame pair, head dim 128) against swin_512.py:115-141 evaluated in fp32 on the same bf16-rounded tokens and weights:
+    out, and the q*scale | k | v rows it hands to the backward; rows mapped to -1 (none in the model, possible in the ABI) read
+    as zero tokens."""
+    from stswincl_amd import ops
+    torch.manual_seed(C + heads)
+    BF = torch.bfloat16
+    ws, T, B, H, W = 8, 2, 2, 16, 24
+    N, d = ws * ws, C // heads
+    nW = (H // ws) * (W // ws)
+    nB_ = B * nW
+    rows = nB_ * T * N
+    x = (torch.randn(B * T * H * W, C) * 1.0).to(BF)
+    w = (torch.randn(3 * C, C) / C ** 0.5).to(BF)
+    bq = torch.randn(3 * C) * 0.1
+    bias = torch.randn(heads, N, N) * 0.5
+    shift = ws // 2 if shifted else 0
+    rmap = ops.window_rowmap(B, T, H, W, ws, shift, "cuda").clone()
+    rmap[5] = -1                                                     # one padding row
+    mask = O.shift_attn_mask(H, W, ws, shift) if shifted else None    # (nW, N, N)
+    # reference: gather, project, scale q, attention
+    rm = rmap.cpu().long()
+    xg = x.float()[rm.clamp(min=0)] * (rm >= 0).float()[:, None]
+    qkv = xg @ w.float().t() + bq
+    qkv[:, :C] *= d ** -0.5
+    ref = _ref(qkv, bias, mask, nB_, nW, T, N, heads, C)
+    if shifted:
+        umask, bidx = torch.unique(mask.reshape(nW, -1), dim=0, return_inverse=True)
+        tab = (bias[None] + umask.reshape(-1, 1, N, N)).transpose(2, 3).contiguous().cuda()      # [U][heads][key][query]
+        bidx = bidx.to(torch.int32).cuda()
+    else:
+        tab, bidx = bias.transpose(1, 2).contiguous().cuda(), None
+    out, qkv_g = hip.win_attn_qkv_fwd(x.cuda(), rmap, w.cuda(), bq.cuda(), tab, nB_=nB_, nW=nW, T=T, ws=ws, heads=heads, C=C,
+                                      scale=d ** -0.5, bias_index=bidx, want_qkv=want_qkv)
+    err = float((out.float().cpu() - ref).abs().max())
+    assert err <= 1.5e-2 * float(ref.abs().max()), f"out err {err} of {float(ref.abs().max())}"
+    r = float((out.float().cpu() - ref).norm() / ref.norm())
+    assert r < 6e-3, r
+    if want_qkv:
+        e = float((qkv_g.float().cpu() - qkv).abs().max())
+        assert e <= 6e-3 * float(qkv.abs().max()), f"qkv err {e}"
+    else:
+        assert qkv_g is None
+
+
+@pytest.mark.parametrize("shift", [0, 4])
+def test_swin_block_with_the_fused_qkv_kernel_equals_the_two_kernel_path(shift, monkeypatch):
+    """The production block (dim 512, 4 heads, 8x8 windows) forward + backward with STSWIN_FUSED_QKV=1 against the default qkv GEMM +
+    attention pair: same bf16 q | k | v up to the accumulation order of the projection, so outputs and gradients agree to bf16
+    rounding; and a no-grad pass (no q | k | v written) gives the same output as the grad pass."""
+    from stswincl_amd.net.Ours import swin_512 as S
+    torch.manual_seed(1)
+    blk = S.SwinTransformerBlock(512, (16, 16), 4, window_size=8, shift_size=shift).cuda()
+    x = torch.randn(2, 2, 256, 512, device="cuda").to(torch.bfloat16)
+    g = torch.randn(2, 2, 256, 512, device="cuda")
+    res = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("STSWIN_FUSED_QKV", fused)
+        blk.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        y = blk(xg)
+        (y.float() * g).sum().backward()
+        with torch.no_grad():
+            y_ng = blk(x)
+        res[fused] = (y.detach().float(), xg.grad.float(), {k: p.grad.clone() for k, p in blk.named_parameters()}, y_ng.float())
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))      # noqa: E731
+    assert rel(res["1"][0], res["0"][0]) < 4e-3
+    assert rel(res["1"][1], res["0"][1]) < 6e-3
+    for k in res["0"][2]:
+        assert rel(res["1"][2][k], res["0"][2][k]) < 8e-3, k
+    assert torch.equal(res["1"][3], res["1"][0]), "no-grad pass (no q | k | v written) must equal the grad pass bit for bit"
