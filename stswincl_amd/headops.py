@@ -380,12 +380,60 @@ def _sync_world(bn) -> int:
     return 1
 
 
+def rowmajor(t: torch.Tensor, dt) -> torch.Tensor:
+    """t as a [M][C] matrix the kernels can address (unit column stride, 16-byte aligned pitch and base) in dtype dt: a column
+    slice of a wider buffer (the gradient of a zero-copy concat part) is passed through as it is, anything else is compacted."""
+    t = t.detach()
+    if t.dtype != dt:
+        t = t.to(dt)
+    if (t.dim() == 2 and t.stride(1) == 1 and (t.stride(0) * t.element_size()) % 16 == 0 and t.data_ptr() % 16 == 0
+            and t.stride(0) >= t.shape[1]):
+        return t
+    return t.contiguous()
+
+
+class ConcatColsFn(torch.autograd.Function):
+    """torch.cat(parts, dim=1) of token matrices WITHOUT the copy (ASPP.py:48's 2560-channel concat, base18.py:104's 400-channel
+    one): the producers have already written the parts into column slices of `buf` (their `out=` argument), so the forward
+    only hands out the buffer and the backward hands every producer its column slice of the gradient as a strided view (the
+    backward kernels take a row pitch).  A cat kernel per concat and a split copy per part and step are gone."""
+
+    @staticmethod
+    def forward(ctx, buf, widths, *parts):
+        off = 0
+        for w_, p_ in zip(widths, parts):
+            assert p_.data_ptr() == buf.data_ptr() + off * buf.element_size() and p_.shape[1] == w_ and p_.stride(0) == buf.stride(0), \
+                "ConcatColsFn: a part does not live in its column slice of the buffer"
+            off += w_
+        assert off == buf.shape[1]
+        ctx.widths = widths
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for w_ in ctx.widths:
+            outs.append(g[:, off:off + w_])
+            off += w_
+        return (None, None, *outs)
+
+
+def concat_buffer(rows: int, widths, dt, device):
+    """-> (buffer [rows][sum widths], column-slice views for the producers' `out=`)."""
+    buf = torch.empty(rows, sum(widths), dtype=dt, device=device)
+    views, off = [], 0
+    for w_ in widths:
+        views.append(buf[:, off:off + w_])
+        off += w_
+    return buf, views
+
+
 class BNTokFn(torch.autograd.Function):
     """nn.BatchNorm2d (+ residual add + ReLU) on tokens with `groups` independent statistic groups."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, relu, resid, groups, lay, eps, momentum, world=1,
-                unit=0, stats=None, link=None):
+                unit=0, stats=None, link=None, out=None):
         ctx.link = link
         dt = compute_dtype(x)
         X = x.detach().to(dt)
@@ -446,7 +494,11 @@ class BNTokFn(torch.autograd.Function):
         else:
             mean = lay.pad_vec(running_mean).view(1, Cp).expand(groups, Cp).contiguous()
             rstd = torch.rsqrt(lay.pad_vec(running_var, 1.0) + eps).view(1, Cp).expand(groups, Cp).contiguous()
-        y = torch.empty(M, Cp, dtype=dt, device=x.device)
+        if out is not None:                              # a column slice of a concat buffer (ConcatColsFn): written in place
+            assert out.shape == (M, Cp) and out.dtype == dt and out.stride(1) == 1
+            y = out.view_as(out)
+        else:
+            y = torch.empty(M, Cp, dtype=dt, device=x.device)
         R = resid.detach().to(dt) if resid is not None else None
         hip.bn_apply(X, mean, rstd, gp, bp, y, resid=R, groups=groups, relu=relu, unit=unit)
         ctx.cfg = (training, relu, groups, lay, dt, x.dtype, resid is not None, world, rows_total)
@@ -460,7 +512,7 @@ class BNTokFn(torch.autograd.Function):
     def backward(ctx, dy):
         X, y, mean, rstd, gp, bp = ctx.saved_tensors
         training, relu, groups, lay, dt, in_dtype, has_res, world, rows_total = ctx.cfg
-        g = dy.detach().to(dt).contiguous()
+        g = rowmajor(dy, dt)
         dx = torch.empty_like(X)
         dres = torch.empty_like(X) if has_res else None
         if training and world > 1:
@@ -494,7 +546,7 @@ class BNTokFn(torch.autograd.Function):
         if dres is not None and ctx.link is not None:    # the shortcut's gradient travels to conv1's input-gradient GEMM
             ctx.link.put(dres)
             dres = None
-        return (dx.to(in_dtype), dgamma, dbeta, None, None, None, None, dres, None, None, None, None, None, None, None, None)
+        return (dx.to(in_dtype), dgamma, dbeta, None, None, None, None, dres, None, None, None, None, None, None, None, None, None)
 
 
 _NBT_PENDING = None
@@ -552,7 +604,7 @@ class deferred_bn_counters:
 
 
 def batchnorm_tokens(x, bn: torch.nn.BatchNorm2d, relu=True, resid=None, groups=1, lay: Optional[Layout] = None,
-                     il_frames: int = 0, stats=None, resid_link=None):
+                     il_frames: int = 0, stats=None, resid_link=None, out=None):
     """il_frames = F > 0: the rows are F frames stored clip-major and statistic group g = frames g, g + groups, ... (frame t
     of every clip); 0: `groups` contiguous row blocks."""
     lay = lay or Layout.dense(bn.num_features)
@@ -575,18 +627,22 @@ def batchnorm_tokens(x, bn: torch.nn.BatchNorm2d, relu=True, resid=None, groups=
     return BNTokFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, relu, resid, groups, lay,
                          bn.eps, bn.momentum if bn.momentum is not None else 0.1, world,
                          (x.shape[0] // il_frames) if (il_frames and groups > 1) else 0,
-                         stats if (training and world == 1) else None, resid_link if resid is not None else None)
+                         stats if (training and world == 1) else None, resid_link if resid is not None else None, out)
 
 
 class BilinearTokFn(torch.autograd.Function):
     """F.interpolate(mode='bilinear', align_corners=False) on tokens: [F*h*w][C] -> [F*H*W][C]."""
 
     @staticmethod
-    def forward(ctx, x, geom):
+    def forward(ctx, x, geom, out=None):
         frames, h, w, H, W = geom
         dt = compute_dtype(x)
         X = x.detach().to(dt).contiguous()
-        y = torch.empty(frames * H * W, X.shape[1], dtype=dt, device=x.device)
+        if out is not None:                              # a column slice of a concat buffer (ConcatColsFn)
+            assert out.shape == (frames * H * W, X.shape[1]) and out.dtype == dt and out.stride(1) == 1
+            y = out.view_as(out)
+        else:
+            y = torch.empty(frames * H * W, X.shape[1], dtype=dt, device=x.device)
         hip.bilinear(X, y, frames, h, w, H, W)
         ctx.geom, ctx.dt, ctx.in_dtype = geom, dt, x.dtype
         return y
@@ -594,10 +650,10 @@ class BilinearTokFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         frames, h, w, H, W = ctx.geom
-        g = dy.detach().to(ctx.dt).contiguous()
+        g = rowmajor(dy, ctx.dt)
         dx = torch.empty(frames * h * w, g.shape[1], dtype=ctx.dt, device=g.device)
         hip.bilinear(g, dx, frames, h, w, H, W, backward=True)
-        return dx.to(ctx.in_dtype), None
+        return dx.to(ctx.in_dtype), None, None
 
 
 class AvgPoolTokFn(torch.autograd.Function):
@@ -623,10 +679,14 @@ class BroadcastTokFn(torch.autograd.Function):
     """bilinear upsample of a 1x1 map = broadcast: [F][C] -> [F*HW][C]   (ASPP.py:46)."""
 
     @staticmethod
-    def forward(ctx, v, rows_per_frame):
+    def forward(ctx, v, rows_per_frame, out=None):
         dt = compute_dtype(v)
         frames, C = v.shape
-        y = torch.empty(frames * rows_per_frame, C, dtype=dt, device=v.device)
+        if out is not None:                              # a column slice of a concat buffer (ConcatColsFn)
+            assert out.shape == (frames * rows_per_frame, C) and out.dtype == dt and out.stride(1) == 1
+            y = out.view_as(out)
+        else:
+            y = torch.empty(frames * rows_per_frame, C, dtype=dt, device=v.device)
         hip.rows_broadcast(v.detach().float().contiguous(), y, frames)
         ctx.cfg = (frames, dt, v.dtype)
         return y
@@ -634,8 +694,8 @@ class BroadcastTokFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         frames, dt, in_dtype = ctx.cfg
-        s, _ = hip.colstats(dy.detach().to(dt).contiguous(), groups=frames, squares=False)
-        return s.to(in_dtype), None
+        s, _ = hip.colstats(rowmajor(dy, dt), groups=frames, squares=False)
+        return s.to(in_dtype), None, None
 
 
 class LogitsUpFn(torch.autograd.Function):
@@ -705,13 +765,14 @@ def pad_cols(t: torch.Tensor, width: int) -> torch.Tensor:
 
 
 def conv_bn_relu(x_tok, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, geom, lin=None, lout=None, relu=True, groups=1,
-                 resid=None):
-    """conv -> BatchNorm (-> + resid) (-> ReLU) on tokens; geom = (frames, Hin, Win).  Returns the output tokens."""
+                 resid=None, out=None):
+    """conv -> BatchNorm (-> + resid) (-> ReLU) on tokens; geom = (frames, Hin, Win).  Returns the output tokens (written into
+    `out`, a column slice of a concat buffer, when given)."""
     frames, Hh, Ww = geom
     lout = lout or Layout.dense(conv.out_channels)
     training = bn.training or bn.running_mean is None
     y, _, _, tab = conv_tokens(x_tok, conv, frames, Hh, Ww, lin, lout, stats=training and _sync_world(bn) == 1)
-    return batchnorm_tokens(y, bn, relu=relu, resid=resid, groups=groups, lay=lout, stats=tab)
+    return batchnorm_tokens(y, bn, relu=relu, resid=resid, groups=groups, lay=lout, stats=tab, out=out)
 
 
 def conv1x1_tokens(x_tok, conv: torch.nn.Conv2d, frames, Hh, Ww, lin=None, lout=None):

@@ -36,14 +36,18 @@ class ASPP(nn.Module):
         f, h, w = geom
         if self.training and f == 1:   # the reference's BatchNorm2d refuses a (1, C, 1, 1) map in train mode (ASPP.py:44-45)
             raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([1, 512, 1, 1])")
-        o1 = H.conv_bn_relu(x, self.conv_1x1_1, self.bn_conv_1x1_1, geom)
-        o2 = H.conv_bn_relu(x, self.conv_3x3_1, self.bn_conv_3x3_1, geom)
-        o3 = H.conv_bn_relu(x, self.conv_3x3_2, self.bn_conv_3x3_2, geom)
-        o4 = H.conv_bn_relu(x, self.conv_3x3_3, self.bn_conv_3x3_3, geom)
+        # the five branches write straight into their column slices of the 2560-wide concat (ASPP.py:48): no cat kernel, and the
+        # backward hands every branch a strided view of the concat's gradient instead of a split copy
+        nb = self.conv_1x1_1.out_channels
+        buf, (v1, v2, v3, v4, v5) = H.concat_buffer(x.shape[0], [nb] * 5, H.compute_dtype(x), x.device)
+        o1 = H.conv_bn_relu(x, self.conv_1x1_1, self.bn_conv_1x1_1, geom, out=v1)
+        o2 = H.conv_bn_relu(x, self.conv_3x3_1, self.bn_conv_3x3_1, geom, out=v2)
+        o3 = H.conv_bn_relu(x, self.conv_3x3_2, self.bn_conv_3x3_2, geom, out=v3)
+        o4 = H.conv_bn_relu(x, self.conv_3x3_3, self.bn_conv_3x3_3, geom, out=v4)
         img = H.AvgPoolTokFn.apply(x, f)
         img = H.conv_bn_relu(img, self.conv_1x1_2, self.bn_conv_1x1_2, (f, 1, 1))
-        img = H.BroadcastTokFn.apply(img, h * w)
-        cat = torch.cat([o1, o2, o3, o4, img.to(o1.dtype)], dim=1)
+        img = H.BroadcastTokFn.apply(img, h * w, v5)
+        cat = H.ConcatColsFn.apply(buf, (nb,) * 5, o1, o2, o3, o4, img)
         out = H.conv_bn_relu(cat, self.conv_1x1_3, self.bn_conv_1x1_3, geom)
         return H.conv1x1_tokens(out, self.conv_1x1_4, f, h, w)
 
