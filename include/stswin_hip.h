@@ -37,6 +37,9 @@ extern "C" {
 #define STSWIN_GF_CS_SQ 65536   /* with STSWIN_GF_CS_PARTIAL: `colsum` holds TWO planes [2][2*ceil(M/256)][N]; the second receives the column
                                   * sums of SQUARES of the same values: the BatchNorm statistics of a convolution output come out of
                                   * the convolution (stswin_cs_group_reduce + stswin_bn_finalize with x = NULL) */
+#define STSWIN_GF_TAPSKIP (1 << 29) /* tiled (non-ring) kernels, S > 1 with a_rows: a workgroup first scans its rows of the map and skips every
+                                    * segment (convolution tap) that is padding for ALL of them - pays when every row tile has such a tap (dilation >=
+                                    * half the map height: ASPP's dilation 18 on 32 x 32: 70 -> 53 us); the scan costs ~4 us per launch */
 #define STSWIN_GF_BIG 128       /* tuning: force the 256x256 4-stage-ring kernel (bf16) */
 #define STSWIN_GF_MID 512       /* tuning: 256x128x32 tile, 3-stage ring, 2 workgroups per CU (bf16) */
 #define STSWIN_GF_NOPIPE 1024   /* tuning: 256x256 ring kernel without software-pipelined LDS fragment reads */

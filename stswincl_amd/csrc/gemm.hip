@@ -39,6 +39,7 @@ enum {
   GF_STREAM = 1 << 25,    // tuning: persistent streaming 256x256 variant (measured no faster: both wave rows idle through each other's epilogue)
   GF_DUO = 1 << 24,       // tuning: 128x256 tiles, 4 waves, two workgroups per CU
   GF_CS_PARTIAL = 1 << 15,  // colsum is fp32 [2*ceil(M/256)][N]: row b = column sums of output rows 128b..128b+127, stored (not added)
+  GF_TAPSKIP = 1 << 29,     // tiled kernels: skip the segments (taps) whose row map has no row inside this tile (costs a 4 us map scan)
   GF_CS_SQ = 1 << 16,       // with GF_CS_PARTIAL: a second table plane (offset 2*ceil(M/256)*N floats) receives the column sums of
                             // SQUARES of the same values - the BatchNorm statistics of a convolution output without a pass over it
   GF_NOSTREAM = 1 << 23,  // tuning: 256x256 ring without the persistent streaming variant
@@ -241,7 +242,34 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
     }
   };
   const int kps = p.Kseg / BK;               // K tiles per segment
-  const int nt = p.S * kps;
+  // Tap skipping (flag GF_TAPSKIP; dilated 3x3 convolutions of ASPP.py:13-20 on small maps): a segment whose row map is -1 for EVERY row of this
+  // tile multiplies nothing but padding - with dilation 12 / 18 on a 32 x 32 map the three taps above (below) the image are all
+  // padding for 3/8 (1/2) of the row tiles.  The workgroup ORs a validity bit per segment over its rows (one pass over S x BM map
+  // entries, through the first word of the still unused ring memory) and walks only the segments that have a row.
+  unsigned segmask = 0xFFFFFFFFu;
+  if (p.S > 1 && p.S <= 32 && p.a_rows && (p.flags & GF_TAPSKIP)) {
+    unsigned* sm = (unsigned*)smem;
+    if (tid == 0) *sm = 0u;
+    __syncthreads();
+    unsigned mine = 0u;
+    if (tid < BM && m0 + tid < p.M)
+      for (int sg = 0; sg < p.S; ++sg) mine |= (p.a_rows[(long)sg * p.M + m0 + tid] >= 0 ? 1u : 0u) << sg;
+    if (mine) atomicOr(sm, mine);
+    __syncthreads();
+    segmask = *sm;
+    if (segmask == 0u) segmask = 1u;        // an all-padding tile: one segment of zeros keeps the pipeline's shape
+    __syncthreads();                         // (the word is ring memory: nobody reads it after the first copy lands)
+  } else if (p.S < 32) {
+    segmask = (1u << p.S) - 1u;
+  }
+  const int nact = p.S <= 32 ? __builtin_popcount(segmask) : p.S;
+  const int nt = nact * kps;
+  auto real_seg = [&](int v) -> int {        // v-th segment that has a row
+    if (nact == p.S) return v;
+    unsigned mk = segmask;
+    for (int i = 0; i < v; ++i) mk &= mk - 1u;
+    return __builtin_ctz(mk);
+  };
   auto stage = [&](int ktg, int kt, int buf) {
     char* Ab = smem + buf * STAGE;
     char* Bb = Ab + A_BYTES;
@@ -257,12 +285,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
     for (int j = 0; j < JN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  int seg = 0;
-  load_a_bases(0);
+  int seg = 0, rseg = real_seg(0);
+  load_a_bases(rseg);
   auto issue = [&](int tile) {                // K tiles are staged in order: `seg` follows the staging front
     const int nseg = tile / kps;
-    if (nseg != seg) { seg = nseg; load_a_bases(seg); }
-    stage(tile, tile - nseg * kps, tile % NST);
+    if (nseg != seg) { seg = nseg; rseg = real_seg(seg); load_a_bases(rseg); }
+    stage(rseg * kps + (tile - nseg * kps), tile - nseg * kps, tile % NST);
   };
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)

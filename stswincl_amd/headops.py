@@ -152,8 +152,10 @@ class ConvTokFn(torch.autograd.Function):
         # want_stats: the GEMM epilogue also leaves per-128-row-block column sums and sums of squares of y (the statistics
         # of the BatchNorm that follows: no colstats pass over y)
         tab = hip.stats_table(Mo, lout.width, x.device) if want_stats else None
+        # (dilation >= half the map: every row tile has taps that are padding for all of its rows - the kernel skips them)
+        ctx.tapskip = hip.GF_TAPSKIP if (k == 3 and stride == 1 and 2 * dil >= Hin + 3 and Mo <= 32768) else 0
         hip.gemm_nt(X, _conv_mats(weight, dt, lin, lout, False), y, M=Mo, a_rows=fmap, S=k * k,
-                    bias=lout.pad_vec(bias) if bias is not None else None, stats_out=tab)
+                    bias=lout.pad_vec(bias) if bias is not None else None, stats_out=tab, flags=ctx.tapskip)
         ctx.cfg = (k, lin, lout, dt, x.dtype, bias is not None, Mi, Mo)
         ctx.save_for_backward(X, weight, fmap, imap)
         if want_stats:
@@ -186,7 +188,7 @@ class ConvTokFn(torch.autograd.Function):
             # convolution reading x) rides in as the R operand of this GEMM's epilogue instead of an autograd add over the map
             pend = ctx.link.take(dt, dx.shape) if ctx.link is not None else None
             hip.gemm_nt(g, _conv_mats(weight, dt, lin, lout, True), dx, M=Mi, a_rows=imap, S=S, resid=pend,
-                        flags=hip.GF_RESID if pend is not None else 0)
+                        flags=(hip.GF_RESID if pend is not None else 0) | ctx.tapskip)
             dx = dx.to(in_dtype)
             if ctx.link is not None and not ctx.link.last():
                 ctx.link.put(dx)                          # a later consumer's backward adds it in; autograd gets no gradient from here

@@ -25,6 +25,7 @@ GF_NOSTREAM = 1 << 23
 GF_DUO = 1 << 24
 GF_STREAM = 1 << 25
 GF_NONARROW = 1 << 26
+GF_TAPSKIP = 1 << 29
 GF_NODEEP, GF_DEEP = 1 << 27, 1 << 28        # tuning: prefetch depth of the 128x64 / 128x128 / 256x64 kernels
 TN_OVERWRITE = 1 << 27
 
