@@ -538,9 +538,13 @@ def colsum(y: torch.Tensor, out_f32: torch.Tensor, M: Optional[int] = None):
 
 
 # ----------------------------------------------------------------------------------------------- LayerNorm
-def layernorm_fwd(x, gamma, beta, *, M, rows=None, S=1, Cseg=None, eps=1e-5, save_stats=True):
+def layernorm_fwd(x, gamma, beta, *, M, rows=None, S=1, Cseg=None, eps=1e-5, save_stats=True, out=None):
     Cseg = x.shape[1] if Cseg is None else Cseg
-    y = torch.empty(M, S * Cseg, dtype=x.dtype, device=x.device)
+    if out is not None:                       # caller-provided destination (a row block of a larger buffer)
+        assert out.shape == (M, S * Cseg) and out.dtype == x.dtype and out.stride(1) == 1
+        y = out
+    else:
+        y = torch.empty(M, S * Cseg, dtype=x.dtype, device=x.device)
     mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
     rc = load().stswin_layernorm_fwd(_dt(x), _p(x), _c_long(_ld(x)), _p(rows), S, Cseg, _p(y), _c_long(_ld(y)),

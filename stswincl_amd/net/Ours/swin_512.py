@@ -127,17 +127,20 @@ class SwinTransformerBlock(nn.Module):
         attn_mask = _shift_mask(H, W, self.window_size, self.shift_size) if self.shift_size > 0 else None
         self.register_buffer("attn_mask", attn_mask)
 
-    def forward(self, x_v):
-        B, T, L, C = x_v.shape
+    def forward(self, x_v, src=None, out=None):
+        """x_v (B, 2, L, C) -> (B, 2, L, C).  Extensions used by SwinTransformerLayerv5's zero-copy schedule: `src` (ops.PairSource):
+        x_v is a token matrix [rows][C] and src.xmap locates the frame pairs in it; `out`: [B*2*L][C] destination of the result."""
         H, W = self.input_resolution
-        assert L == H * W, "input feature has wrong size"
-        assert T == 2, "input feature has wrong size"
+        if src is None:
+            B, T, L, C = x_v.shape
+            assert L == H * W, "input feature has wrong size"
+            assert T == 2, "input feature has wrong size"
         a, m = self.attn, self.mlp
         return ops.SwinBlockFn.apply(
             x_v, a.qkv.weight, a.qkv.bias, a.relative_position_bias_table, a.proj.weight, a.proj.bias,
             self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias,
             m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, a.relative_position_index, self.attn_mask,
-            (H, W, self.window_size, self.shift_size, self.num_heads))
+            (H, W, self.window_size, self.shift_size, self.num_heads), src, out)
 
 
 class PatchMerging(nn.Module):
@@ -155,6 +158,7 @@ class PatchMerging(nn.Module):
 
 
 _FRAME_GRAD_LINK = os.environ.get("STSWIN_NO_FRAME_GRAD_LINK") != "1"      # (A/B switch)
+_ZERO_COPY_PAIRS = os.environ.get("STSWIN_NO_ZERO_COPY_PAIRS") != "1"      # (A/B switch: the slice / cat schedule of rounds 1-2)
 
 
 class _TakeFramesFn(torch.autograd.Function):
@@ -262,11 +266,32 @@ class SwinTransformerLayerv5(nn.Module):
         mid = layer(_TakeFramesFn.apply(x_v, p.start, p.stop, link))
         return _PutFramesFn.apply(x_v, mid.to(x_v.dtype), p.start, p.stop, link)
 
+    def _stage(self, x, first):
+        """Layers first, first + 1, first + 2 on clip tokens (B, 4, L, C): pairs (0,1),(2,3) -> middle pair (1,2) -> pairs (0,1),(2,3)
+        (swin_512.py:296-307) WITHOUT the reference's clones / cats of the clip: the first layer writes its output into rows
+        [0, 4BL) of one buffer, the middle-pair layer gathers its frames from there through a row map and writes its output into rows
+        [4BL, 6BL), and the last layer gathers frames 0, 3 from the first block of rows and frames 1, 2 from the second
+        (ops.pair_maps / ops.PairSource; the window gather of a Swin block is a row map anyway, so this is a composition of maps)."""
+        B, T, L, C = x.shape
+        la, lb, lc = self.layers[first], self.layers[first + 1], self.layers[first + 2]
+        dt = ops.compute_dtype(x)
+        Z = torch.empty(6 * B * L, C, dtype=dt, device=x.device)
+        xmap_mid, xmap_out = ops.pair_maps(B, L, x.device)
+        link = {} if torch.is_grad_enabled() else None
+        xa = la[1](la[0](x.reshape(B * 2, 2, L, C)), out=Z[:4 * B * L])                          # (2B, 2, L, C) = rows [0, 4BL) of Z
+        mid = lb[1](lb[0](xa.reshape(4 * B * L, C), src=ops.PairSource(xmap_mid, link, owner=False)), out=Z[4 * B * L:])
+        zj = ops.JoinRowsFn.apply(Z, xa, mid)
+        y = lc[1](lc[0](zj, src=ops.PairSource(xmap_out, link, owner=True, publish_rows=4 * B * L)))
+        return y.reshape(B, T, L, C)
+
     def forward_tokens(self, x):
         """(B, 4, L, C) tokens -> ((B, 4, L, C), (B, 4, L/4, 2C)) tokens."""
         B, T, L, C = x.shape
         assert T == 4, "input feature has wrong size"
         x = x.to(ops.compute_dtype(x))
+        if _ZERO_COPY_PAIRS:
+            out1 = self._stage(x, 0)
+            return out1, self._stage(self.downsample(out1), 3)
         for i in range(3):
             x = self._single_layer_forward(x, self.pairs[i], i, own_input=i > 0)       # (i > 0: x is the previous layer's output)
         out1 = x

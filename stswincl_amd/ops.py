@@ -139,6 +139,7 @@ def repack(params) -> int:
 
 def clear_caches() -> None:
     _ROWMAPS.clear()
+    _PAIR_MAPS.clear()
     _WCACHE.clear()
     _UNIQ_MASKS.clear()
     from . import headops
@@ -223,21 +224,125 @@ def expand_bias_T(table: torch.Tensor, index: torch.Tensor, N: int, heads: int) 
     return b.permute(2, 1, 0).contiguous()
 
 
+class PairSource:
+    """Where the frame pairs of a Swin block's input live: `xmap` int32 [Bp * 2 * L] = row of the source token matrix for every
+    virtual pair-token row (pair-major, then frame, then position).  `link` (a dict shared by the consumers of one source tensor)
+    carries ONE gradient buffer for that source: every consumer scatters its rows into it and only the first one to run returns it
+    to autograd (the others return None), so no consumer's gradient has to be zero-filled and added (swin_512.py:302-307: the
+    middle frame pair of layers 1 / 4 and the outer frames of layers 2 / 5 read the same layer output)."""
+
+    def __init__(self, xmap: torch.Tensor, link: Optional[dict] = None, owner: bool = True, publish_rows: int = 0):
+        self.xmap, self.link, self.owner, self.publish_rows = xmap, link, owner, publish_rows
+        self._composed = {}
+
+    def compose(self, rmap: torch.Tensor) -> torch.Tensor:
+        key = rmap.data_ptr()
+        m = self._composed.get(key)
+        if m is None:
+            idx = rmap.long()
+            m = torch.where(idx >= 0, self.xmap[idx.clamp(min=0)], torch.full_like(rmap, -1)).to(torch.int32).contiguous()
+            self._composed[key] = m
+        return m
+
+    def grad_buffer(self, shape, dt, dev):
+        """-> (gradient buffer of the source matrix [rows][C], whether THIS caller hands it to autograd).
+        owner (the consumer that reads the joined matrix: layers 2 / 5): allocates the buffer, scatters its rows and publishes the
+        leading `publish_rows` rows (the previous layer's output) through the link; the other consumer of those rows (the middle
+        pair of layers 1 / 4, which runs its backward later) scatters into that view and returns None to autograd.  Between them
+        every row is written exactly once, so the buffer is never zero-filled."""
+        if self.link is not None and not self.owner:
+            g = self.link.pop("g", None)
+            if g is not None:
+                assert tuple(g.shape) == tuple(shape) and g.dtype == dt
+                return g, False
+            return torch.zeros(shape, dtype=dt, device=dev), True          # (the owner never ran: the other rows get no gradient)
+        if self.link is None:
+            return torch.zeros(shape, dtype=dt, device=dev), True
+        g = torch.empty(shape, dtype=dt, device=dev)
+        self.link["g"] = g[:self.publish_rows]
+        return g, True
+
+
+_PAIR_MAPS: Dict[tuple, tuple] = {}
+
+
+def pair_maps(B: int, L: int, device):
+    """Row maps of the zero-copy temporal schedule for clips of 4 frames (swin_512.py:296-307).  The buffer Z holds the output of
+    layer a (pairs (0,1), (2,3): all four frames, rows [0, 4BL) in clip-major order) followed by the output of layer b (the middle
+    pair (1,2), rows [4BL, 6BL)).  -> (xmap_mid [B*2*L]: the middle pair inside the first 4BL rows;
+        xmap_out [2B*2*L]: pairs (0,1) and (2,3) with frames 1 and 2 taken from layer b's rows)."""
+    key = (B, L, str(device))
+    hit = _PAIR_MAPS.get(key)
+    if hit is None:
+        pos = torch.arange(L, device=device, dtype=torch.int64)
+        b = torch.arange(B, device=device, dtype=torch.int64)
+        t = torch.arange(2, device=device, dtype=torch.int64)
+        mid = ((b[:, None, None] * 4 + 1 + t[None, :, None]) * L + pos[None, None, :]).reshape(-1)
+        f = torch.arange(4, device=device, dtype=torch.int64)                       # frame of clip b -> row base
+        base_a = (b[:, None] * 4 + f[None, :]) * L                                  # in layer a's rows
+        base_b = 4 * B * L + (b[:, None] * 2 + (f[None, :] - 1)) * L                # in layer b's rows (frames 1, 2)
+        use_b = (f == 1) | (f == 2)
+        base = torch.where(use_b[None, :], base_b, base_a)                          # [B][4]
+        out = (base[:, :, None] + pos[None, None, :]).reshape(-1)                   # (b, frame, pos) = (pair 2b + f // 2, f % 2, pos)
+        hit = (mid.to(torch.int32).contiguous(), out.to(torch.int32).contiguous())
+        _PAIR_MAPS[key] = hit
+    return hit
+
+
+class JoinRowsFn(torch.autograd.Function):
+    """Row blocks written by their producers into one buffer (hip.layernorm_fwd(out=...)) become ONE token matrix without a cat
+    copy; the backward hands every producer its (contiguous) row block of the gradient."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        off = 0
+        rows = []
+        for p_ in parts:
+            n = p_.numel() // buf.shape[1]
+            assert p_.data_ptr() == buf.data_ptr() + off * buf.stride(0) * buf.element_size(), "JoinRowsFn: a part is not in its row block"
+            rows.append((n, tuple(p_.shape)))
+            off += n
+        assert off == buf.shape[0]
+        ctx.rows = rows
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for n, shp in ctx.rows:
+            outs.append(g[off:off + n].view(shp))
+            off += n
+        return (None, *outs)
+
+
 class SwinBlockFn(torch.autograd.Function):
     """One SwinTransformerBlock on a frame pair: (Bp, 2, L, C) -> (Bp, 2, L, C)   (swin_512.py:196-237)."""
 
     @staticmethod
     def forward(ctx, x, qkv_w, qkv_b, table, proj_w, proj_b, n1_w, n1_b, n2_w, n2_b, fc1_w, fc1_b, fc2_w, fc2_b,
-                index, attn_mask, geom):
+                index, attn_mask, geom, src=None, out=None):
+        """src (optional, PairSource): x is a token MATRIX [rows][C] that holds the frame pairs somewhere among its rows and
+        src.xmap[virtual pair-token row] says where - the block gathers its input (and the shortcut) through the composed row
+        map and scatters its input gradient back the same way, so the temporal schedule of swin_512.py:302-307 (middle frame pair,
+        then the outer pairs again) needs no slice / cat copies of the clip.  out (optional): [M][C] destination of the result."""
         H, W, ws, shift, heads = geom
         dt = compute_dtype(x)
-        Bp, T, L, C = x.shape
-        assert T == 2 and L == H * W, "input feature has wrong size"
-        M, N, d = Bp * T * L, ws * ws, C // heads
+        if src is None:
+            Bp, T, L, C = x.shape
+            assert T == 2 and L == H * W, "input feature has wrong size"
+            M = Bp * T * L
+            X2 = x.detach().to(dt).contiguous().view(M, C)
+        else:
+            C = x.shape[-1]
+            T, L = 2, H * W
+            M = src.xmap.numel()
+            Bp = M // (T * L)
+            X2 = x.detach().to(dt).contiguous().view(-1, C)
+        N, d = ws * ws, C // heads
         nW = (H // ws) * (W // ws)
-        X2 = x.detach().to(dt).contiguous().view(M, C)
         dev = x.device
         rmap = window_rowmap(Bp, T, H, W, ws, shift, dev)
+        rmap_in = rmap if src is None else src.compose(rmap)          # window row -> row of X2
         scale = d ** -0.5
         # one [nW][heads][N][N] table = bias + SW-MSA mask (swin_512.py:122-131): the kernels then read one value per
         # score instead of two (the separate mask read cost +60 % on the stage-1 forward kernel)
@@ -252,15 +357,16 @@ class SwinBlockFn(torch.autograd.Function):
                 and (shift == 0 or attn_mask is not None)):
             # stage-1 shape: window gather + QKV projection + attention core in ONE kernel; q | k | v reach memory only when a
             # backward will read them (swin_512.py:115-141)
-            o, qkv = hip.win_attn_qkv_fwd(X2, rmap, wcast(qkv_w, dt), _f32(qkv_b), biasT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads,
+            o, qkv = hip.win_attn_qkv_fwd(X2, rmap_in, wcast(qkv_w, dt), _f32(qkv_b), biasT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads,
                                           C=C, scale=scale, bias_index=bidx, want_qkv=need_bwd)
         else:
             qkv = torch.empty(M, 3 * C, dtype=dt, device=dev)
-            hip.gemm_nt(X2, wcast(qkv_w, dt), qkv, M=M, a_rows=rmap, bias=_f32(qkv_b), scale=scale, scale_cols=C)
+            hip.gemm_nt(X2, wcast(qkv_w, dt), qkv, M=M, a_rows=rmap_in, bias=_f32(qkv_b), scale=scale, scale_cols=C)
             # STSWIN_FP8_ATTN=1 (BASELINE configs[4]): e4m3 q / k / v / P on the fp8 MFMA in the forward; the backward stays bf16
             o = hip.win_attn_fwd(qkv, biasT, maskT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads, C=C, bias_index=bidx, fp8=fp8)
         x1 = torch.empty(M, C, dtype=dt, device=dev)
-        hip.gemm_nt(o, wcast(proj_w, dt), x1, M=M, c_rows=rmap, bias=_f32(proj_b), resid=X2, r_rows=rmap,
+        # (window row m lands on token row rmap[m] of x1; its shortcut is row rmap_in[m] of X2)
+        hip.gemm_nt(o, wcast(proj_w, dt), x1, M=M, c_rows=rmap, bias=_f32(proj_b), resid=X2, r_rows=rmap_in,
                     flags=hip.GF_RESID)
         # no gradient wanted (the momentum-key passes of the contrastive step, evaluation): nothing is kept for a backward, and the
         # fc1 epilogue skips its second output (the GELU' tile: 268 MB and a third of the epilogue's polynomial work at stage 1)
@@ -275,9 +381,10 @@ class SwinBlockFn(torch.autograd.Function):
                     flags=(hip.GF_GELU | (0 if gelu_bwd else hip.GF_C2_DGELU)) if need_bwd else hip.GF_GELU)
         y2 = torch.empty(M, C, dtype=dt, device=dev)
         hip.gemm_nt(h, wcast(fc2_w, dt), y2, M=M, bias=_f32(fc2_b), resid=x1, flags=hip.GF_RESID)
-        out, mean1, rstd1 = hip.layernorm_fwd(y2, _f32(n1_w), _f32(n1_b), M=M, save_stats=need_bwd)
+        out, mean1, rstd1 = hip.layernorm_fwd(y2, _f32(n1_w), _f32(n1_b), M=M, save_stats=need_bwd, out=out)
         if not need_bwd:
             return out.view(Bp, T, L, C)
+        ctx.src, ctx.x_shape = src, tuple(x.shape)
         ctx.geom = geom
         ctx.dt = dt
         ctx.in_dtype = x.dtype
@@ -294,7 +401,7 @@ class SwinBlockFn(torch.autograd.Function):
          qkv_w, proj_w, n1_w, n2_w, fc1_w, fc2_w, index) = ctx.saved_tensors
         H, W, ws, shift, heads = ctx.geom
         dt = ctx.dt
-        M, C = X2.shape
+        M, C = rmap.numel(), X2.shape[1]          # (X2 may be a larger source matrix: ctx.src)
         N, d = ws * ws, C // heads
         nW = (H // ws) * (W // ws)
         dev = X2.device
@@ -331,12 +438,21 @@ class SwinBlockFn(torch.autograd.Function):
                                 C=C, scale=d ** -0.5, colsum_out=dqkv_b, bias_index=ctx.bidx)
         hip.bias_scatter(dbiasT, index.reshape(-1).contiguous(), dtable, N, heads)
         # qkv
-        hip.gemm_tn(dqkv, X2, dqkv_w, Mk=M, bt_rows=rmap, overwrite=True)
-        dx = torch.empty(M, C, dtype=dt, device=dev)
-        hip.gemm_nt(dqkv, wcast(qkv_w, dt, True), dx, M=M, c_rows=rmap, resid=dx1, r_rows=rmap, flags=hip.GF_RESID)
-        Bp = M // (2 * H * W)
-        return (dx.view(Bp, 2, H * W, C).to(ctx.in_dtype), dqkv_w, dqkv_b, dtable, dproj_w, dproj_b, dn1_w, dn1_b,
-                dn2_w, dn2_b, dfc1_w, dfc1_b, dfc2_w, dfc2_b, None, None, None)
+        hip.gemm_tn(dqkv, X2, dqkv_w, Mk=M, bt_rows=rmap if ctx.src is None else ctx.src.compose(rmap), overwrite=True)
+        src = ctx.src
+        if src is None:
+            dx = torch.empty(M, C, dtype=dt, device=dev)
+            hip.gemm_nt(dqkv, wcast(qkv_w, dt, True), dx, M=M, c_rows=rmap, resid=dx1, r_rows=rmap, flags=hip.GF_RESID)
+            Bp = M // (2 * H * W)
+            dx_ret = dx.view(Bp, 2, H * W, C).to(ctx.in_dtype)
+        else:
+            # the input gradient is scattered to the rows of the source matrix this block read (src.xmap); the other rows of that
+            # gradient belong to the source's other consumers, which write them into the SAME buffer (src.grad_buffer)
+            dx, mine = src.grad_buffer(X2.shape, dt, dev)
+            hip.gemm_nt(dqkv, wcast(qkv_w, dt, True), dx, M=M, c_rows=src.compose(rmap), resid=dx1, r_rows=rmap, flags=hip.GF_RESID)
+            dx_ret = dx.view(ctx.x_shape).to(ctx.in_dtype) if mine else None
+        return (dx_ret, dqkv_w, dqkv_b, dtable, dproj_w, dproj_b, dn1_w, dn1_b,
+                dn2_w, dn2_b, dfc1_w, dfc1_b, dfc2_w, dfc2_b, None, None, None, None, None)
 
 
 class PatchMergeFn(torch.autograd.Function):
