@@ -277,7 +277,7 @@ def contrast_run(a, ctx, steps, warmup, profile_stride, batch=8, bank="sample"):
                                    ("all-gathered over the ranks)" if bank == "world" else "every sample of the rank)")) + f"; {opt_name}",
                       "bank_entries_per_key_map": visible,
                       "clips_per_gpu": 6 * B, "parallelism": f"dp{world}",
-                      "input_frames_per_s": world * 6 * B * 4 * steps / dt, "loss": float(loss),
+                      "input_frames_per_s": world * 6 * B * 4 * steps / dt, "loss": float(loss.detach()),
                       "launch": "hipGraph replay of the whole step" if graphed else "eager launches"},
            "dist": ctx.dist_info(reducer)}
     for name in ("contrast_fwd_bf16", "contrast_bank_fwd_bf16"):
@@ -330,8 +330,18 @@ def seg_run(a, ctx):
         opt.step()
         return loss
 
+    graph_note = None
+    if use_graph and world > 1 and ctx.backend != "nccl":
+        use_graph, graph_note = False, "hipGraph capture needs the RCCL backend (gloo collectives run on the host): eager launches"
     if use_graph:
-        step = capture(step, lambda: opt.zero_grad(set_to_none=True))
+        try:      # N > 1: the bucket all-reduces are enqueued on the reducer's side stream inside the capture (RCCL supports capture)
+            step_g = capture(step, lambda: opt.zero_grad(set_to_none=True))
+            step = step_g
+        except Exception as e:     # noqa: BLE001
+            if world == 1:
+                raise
+            use_graph, graph_note = False, f"hipGraph capture of the {world}-rank step failed ({type(e).__name__}): eager launches"
+            torch.cuda.synchronize()
     dt, prof, loss = timed_steps(ctx, step, a.steps, a.warmup, profile_stride)
     frames = world * B * 4 * a.steps
     res = {
@@ -343,8 +353,8 @@ def seg_run(a, ctx):
                                f"x 3x{S}x{S}, swin res ({S // 8},{S // 8}), OHEM-CE, Adam; T=4 because the reference "
                                f"asserts it (swin_512.py:313)",
                    "clips_per_gpu": B, "frames_per_clip": 4, "parallelism": f"dp{world}",
-                   "launch": "hipGraph replay of the whole step" if use_graph else "eager launches",
-                   "loss": float(loss)},
+                   "launch": "hipGraph replay of the whole step" if use_graph else (graph_note or "eager launches"),
+                   "loss": float(loss.detach())},
         "dist": ctx.dist_info(reducer),
     }
     if prof and a.dump_prof and rank == 0:

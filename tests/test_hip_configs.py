@@ -286,3 +286,24 @@ def test_contrastive_step_is_bitwise_reproducible():
     assert a[0] == b[0]
     for i, (u, v) in enumerate(zip(a[1], b[1])):
         assert torch.equal(u, v), f"parameter {i} differs between two runs"
+
+
+def test_bench_two_ranks_sharing_the_gpu_runs_the_data_parallel_path():
+    """The N > 1 code of bench.py (launcher -> 2 ranks -> process group -> weight broadcast -> GradBucketReducer with gradients
+    written straight into the all-reduce buckets -> max-over-ranks timing -> one JSON line) on the one GPU of the test box:
+    STSWIN_BENCH_SHARE_GPU=1 lets both ranks use device 0 over gloo.  The 8-GPU RCCL run is the driver's; this keeps the path
+    from rotting in between."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STSWIN_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                          "--size", "256", "--no-cpu-baseline", "--no-secondary"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["dist"]["rccl_ranks"] == 2 and d["dist"]["shared_gpu_functional_test"] is True
+    assert d["dist"]["allreduce_bytes_per_step_per_rank"] > 4e8         # ~125 M fp32 gradients
+    assert d["config"]["parallelism"] == "dp2" and d["value"] > 0 and d["config"]["loss"] == d["config"]["loss"]
