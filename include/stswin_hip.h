@@ -158,6 +158,12 @@ int stswin_last_variant(int family);
 int stswin_slab_fold(const float* ws, long slab_stride, long ws_batch_stride, int nslabs, int seg_len, int nseg, float* out0, float* out1,
                      float* out2, long out_batch_stride, int batch, int accumulate, void* stream);
 
+/* stswin_fold_defer(1): from now on (calling thread) the folds of the entry points are QUEUED instead of launched - each call must
+ * then get its own scratch region - and stswin_fold_flush launches them as one kernel; stswin_fold_defer(0) flushes and returns to
+ * immediate folds.  Legal when no folded output is read before the flush (the backward of a Swin block: all parameter gradients). */
+int stswin_fold_defer(int on, void* stream);
+int stswin_fold_flush(void* stream);
+
 /* out[n] += sum_m Y[m][n]  (bias gradients) */
 long stswin_colsum_scratch(int M, int N);
 int stswin_colsum(int dtype, const void* y, long ldy, float* out, int M, int N, float* scratch, void* stream);
@@ -185,9 +191,12 @@ int stswin_vec_gather(const float* v, const int* map, float* out, int n, float f
  * table / dtable fp32 [(2ws-1)^2][heads], index int64 [N*N] (the module's relative_position_index buffer). */
 int stswin_bias_expand(const float* table, const long* index, const float* mask, float* out, int N, int heads, int nW,
                        void* stream);
-/* scatter in gather form (one workgroup per table row adds its (i, j) pairs in a fixed order: no atomics); table_rows = (2ws-1)^2;
+/* scatter in gather form (no atomics: thread (table row e, head h) adds the pairs of row e in a fixed order).  order int32 [N*N] =
+ * the pairs i*N + j sorted by index[i*N + j] (stable), offs int32 [table_rows + 1] = start of every table row's range in it
+ * (table_rows = (2ws-1)^2); both are functions of the index buffer alone (stswincl_amd/hip.py caches them per buffer).
  * nslabs > 1: dbiasT is [nslabs][heads][N][N] and the slabs are added on the way. */
-int stswin_bias_scatter(const float* dbiasT, const long* index, float* dtable, int N, int heads, int table_rows, int nslabs, void* stream);
+int stswin_bias_scatter(const float* dbiasT, const int* order, const int* offs, float* dtable, int N, int heads, int table_rows, int nslabs,
+                        void* stream);
 
 /* ---- a6: windowed attention core (swin_512.py:117-138).  qkv [nB_*T*N][3C] = q (pre-scaled) | k | v in window
  * order; biasT [heads][N][N] and maskT [nW][N][N] are the expanded relative-position bias (:122-124) and the

@@ -388,18 +388,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, long ldx, const
 // q, q + 16, ... and the 16 lane sums are added in lane order.
 struct FoldArgs {
   const float* ws; long slab_stride, ws_batch_stride; int nslabs;
-  int len[3]; float* out[3]; long obs[3]; int accumulate;
+  int len[3]; float* out[3]; long obs[3]; int accumulate, cl;
 };
-// CL = float4 columns per workgroup (16: few slabs, 64 floats per workgroup; 4: many slabs - 64 slab lanes per column, four times
-// the workgroups); the association of the sum is fixed by (nslabs, CL) alone.
-template <int CL>
-__global__ __launch_bounds__(256) void slab_fold_kernel(FoldArgs f) {
-  constexpr int QL = 256 / CL;
-  __shared__ f32x4 fold[QL][CL];
+// cl = float4 columns per workgroup (16: few slabs, 64 floats per workgroup; 4: many slabs - 64 slab lanes per column, four times
+// the workgroups); the association of the sum is fixed by (nslabs, cl) alone.
+DEVI void slab_fold_body(const FoldArgs& f, int block_x, int batch) {
+  __shared__ f32x4 fold[256];
+  const int CL = f.cl, QL = 256 / CL;
   const int cl = threadIdx.x % CL, q = threadIdx.x / CL;
-  const int j = (blockIdx.x * CL + cl) * 4;
+  const int j = (block_x * CL + cl) * 4;
   const bool in = j < f.len[0] + f.len[1] + f.len[2];
-  const float* src = f.ws + (long)blockIdx.y * f.ws_batch_stride + j;
+  const float* src = f.ws + (long)batch * f.ws_batch_stride + j;
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
   if (in) {
     int p = q;
@@ -410,19 +409,53 @@ __global__ __launch_bounds__(256) void slab_fold_kernel(FoldArgs f) {
     }
     for (; p < f.nslabs; p += QL) a += *(const f32x4*)(src + (long)p * f.slab_stride);
   }
-  fold[q][cl] = a;
+  fold[q * CL + cl] = a;
   __syncthreads();
   if (q == 0 && in) {
-#pragma unroll 8
-    for (int k = 1; k < QL; ++k) a += fold[k][cl];
+    for (int k = 1; k < QL; ++k) a += fold[k * CL + cl];
     const int sgm = j < f.len[0] ? 0 : (j < f.len[0] + f.len[1] ? 1 : 2);
     const int jj = j - (sgm > 0 ? f.len[0] : 0) - (sgm > 1 ? f.len[1] : 0);
     float* out = f.out[sgm];
     if (out) {
-      f32x4* dst = (f32x4*)(out + (long)blockIdx.y * f.obs[sgm] + jj);
+      f32x4* dst = (f32x4*)(out + (long)batch * f.obs[sgm] + jj);
       *dst = f.accumulate ? *dst + a : a;
     }
   }
+}
+__global__ __launch_bounds__(256) void slab_fold_kernel(FoldArgs f) { slab_fold_body(f, blockIdx.x, blockIdx.y); }
+
+// Several folds in ONE launch (stswin_fold_defer / stswin_fold_flush): a backward pass of a Swin block queues the folds of its two
+// LayerNorm backward passes, its bias-gradient tables and the attention kernel's slabs - none of their results is read before the
+// pass ends - and launches them together (4 launches of ~5 us less per block and step).
+#define FOLD_QUEUE_MAX 12
+struct FoldBatch { FoldArgs f[FOLD_QUEUE_MAX]; int first_block[FOLD_QUEUE_MAX + 1]; int blocks_x[FOLD_QUEUE_MAX]; int count; };
+__global__ __launch_bounds__(256) void slab_fold_multi_kernel(FoldBatch b) {
+  int i = 0;
+  while (i + 1 < b.count && (int)blockIdx.x >= b.first_block[i + 1]) ++i;
+  const int local = blockIdx.x - b.first_block[i];
+  slab_fold_body(b.f[i], local % b.blocks_x[i], local / b.blocks_x[i]);
+}
+static thread_local int g_fold_defer = 0;
+static thread_local FoldBatch g_fold_batch;
+
+static int fold_flush(hipStream_t st) {
+  FoldBatch& b = g_fold_batch;
+  if (b.count > 0) {
+    hipLaunchKernelGGL(slab_fold_multi_kernel, dim3((unsigned)b.first_block[b.count]), dim3(256), 0, st, b);
+    b.count = 0;
+  }
+  return 0;
+}
+extern "C" int stswin_fold_defer(int on, void* stream) {          // on = 0 flushes what is queued
+  if (!on) { fold_flush((hipStream_t)stream); g_fold_defer = 0; STSWIN_CHECK_LAUNCH(); return 0; }
+  g_fold_defer = 1;
+  g_fold_batch.count = 0;
+  return 0;
+}
+extern "C" int stswin_fold_flush(void* stream) {
+  fold_flush((hipStream_t)stream);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
 }
 
 int stswin_fold3_launch(const float* ws, long slab_stride, long ws_batch_stride, int nslabs, const int* len, float* const* out,
@@ -437,10 +470,18 @@ int stswin_fold3_launch(const float* ws, long slab_stride, long ws_batch_stride,
   }
   if (nslabs <= 0 || tot <= 0 || batch <= 0) return 0;
   if (slab_stride % 4 || ws_batch_stride % 4) return -1110;
-  if (nslabs >= 96)
-    hipLaunchKernelGGL(slab_fold_kernel<4>, dim3((unsigned)((tot + 15) / 16), (unsigned)batch), dim3(256), 0, st, f);
-  else
-    hipLaunchKernelGGL(slab_fold_kernel<16>, dim3((unsigned)((tot + 63) / 64), (unsigned)batch), dim3(256), 0, st, f);
+  f.cl = nslabs >= 96 ? 4 : 16;
+  const int bx = (tot + 4 * f.cl - 1) / (4 * f.cl);
+  if (g_fold_defer) {
+    FoldBatch& b = g_fold_batch;
+    if (b.count == FOLD_QUEUE_MAX) fold_flush(st);
+    if (b.count == 0) b.first_block[0] = 0;
+    b.f[b.count] = f; b.blocks_x[b.count] = bx;
+    b.first_block[b.count + 1] = b.first_block[b.count] + bx * batch;
+    ++b.count;
+    return 0;
+  }
+  hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)bx, (unsigned)batch), dim3(256), 0, st, f);
   return 0;
 }
 
@@ -610,40 +651,23 @@ __global__ __launch_bounds__(256) void bias_expand_kernel(const float* table, co
     out[t] = v;
   }
 }
-// Gradient of the gather, in gather form (deterministic: no atomics): workgroup e owns table row e and adds, in a fixed order, the
-// dbiasT entries of the (query i, key j) pairs whose relative position is e (each thread scans N*N / 256 pairs of the index,
-// then a fixed shuffle / LDS tree).  nslabs > 1: dbiasT is [nslabs][heads][N][N] (per-workgroup partial slabs of the attention
-// backward) and the slabs are added on the way.
-__global__ __launch_bounds__(256) void bias_scatter_kernel(const float* dbiasT, const long* index, float* dtable, int N, int heads,
-                                                            int nslabs) {
-  __shared__ float red[4][8];
-  const int e = blockIdx.x, h0 = blockIdx.y * 8, nh = min(8, heads - h0);
+// Gradient of the gather, in gather form (deterministic: no atomics).  `order` lists the (query i, key j) pairs (as i * N + j) sorted
+// by their table row, `offs[e] .. offs[e + 1]` is row e's range (both built once per relative_position_index buffer by the
+// caller): thread (e, h) adds its <= N pairs in list order.  nslabs > 1: dbiasT is [nslabs][heads][N][N] and the slabs are added on
+// the way.
+__global__ __launch_bounds__(256) void bias_scatter_kernel(const float* dbiasT, const int* order, const int* offs, float* dtable, int N,
+                                                            int heads, int table_rows, int nslabs) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= table_rows * heads) return;
+  const int e = t / heads, h = t - e * heads;
   const long NN = (long)N * N;
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (long pr = threadIdx.x; pr < NN; pr += 256) {          // pr = i * N + j (the index buffer's order)
-    if (index[pr] != e) continue;
-    const int i = (int)(pr / N), j = (int)(pr % N);
-#pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      if (h < nh) {
-        const float* src = dbiasT + ((long)(h0 + h) * N + j) * N + i;  // dbiasT[h][key j][query i]
-        float t = 0.f;
-        for (int sl = 0; sl < nslabs; ++sl) t += src[(long)sl * heads * NN];
-        acc[h] += t;
-      }
-    }
+  float acc = 0.f;
+  for (int q = offs[e]; q < offs[e + 1]; ++q) {
+    const int pr = order[q], i = pr / N, j = pr - i * N;
+    const float* src = dbiasT + ((long)h * N + j) * N + i;        // dbiasT[h][key j][query i]
+    for (int sl = 0; sl < nslabs; ++sl) acc += src[(long)sl * heads * NN];
   }
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-#pragma unroll
-  for (int h = 0; h < 8; ++h) {
-    float v = acc[h];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    if (l == 0) red[w][h] = v;
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < nh)
-    dtable[(long)e * heads + h0 + threadIdx.x] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  dtable[(long)e * heads + h] += acc;
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -859,11 +883,11 @@ extern "C" int stswin_bias_expand(const float* table, const long* index, const f
   return 0;
 }
 
-extern "C" int stswin_bias_scatter(const float* dbiasT, const long* index, float* dtable, int N, int heads, int table_rows, int nslabs,
-                                   void* stream) {
-  if (N <= 0 || heads <= 0 || table_rows <= 0 || nslabs <= 0) return -1109;
-  hipLaunchKernelGGL(bias_scatter_kernel, dim3((unsigned)table_rows, (unsigned)((heads + 7) / 8)), dim3(256), 0, (hipStream_t)stream, dbiasT,
-                     index, dtable, N, heads, nslabs);
+extern "C" int stswin_bias_scatter(const float* dbiasT, const int* order, const int* offs, float* dtable, int N, int heads, int table_rows,
+                                   int nslabs, void* stream) {
+  if (N <= 0 || heads <= 0 || table_rows <= 0 || nslabs <= 0 || !order || !offs) return -1109;
+  hipLaunchKernelGGL(bias_scatter_kernel, dim3((unsigned)((table_rows * heads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dbiasT,
+                     order, offs, dtable, N, heads, table_rows, nslabs);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

@@ -153,19 +153,54 @@ def zeros(*shape, device) -> torch.Tensor:
 # fixed order (include/stswin_hip.h, "deterministic cross-workgroup sums").  One buffer per device: every use is write-then-read on
 # the launch stream and kernels of a stream run in order.  It only ever grows (warm-up steps size it before a hipGraph capture).
 _SCRATCH = {}
+_DEFER = [False, 0]          # [folds are being queued (deferred_folds), bump offset into the scratch buffer]
 
 
 def scratch(device, floats: int) -> torch.Tensor:
     device = torch.device(device)
     if device.type == "cuda" and device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
+    floats = (int(floats) + 63) // 64 * 64
     t = _SCRATCH.get(device)
-    if t is None or t.numel() < floats:
-        if t is not None and torch.cuda.is_current_stream_capturing():
-            raise StswinHipError("scratch buffer would have to grow during a hipGraph capture: run the step once before capturing")
-        t = torch.empty(max(int(floats), 1 << 22), dtype=torch.float32, device=device)
-        _SCRATCH[device] = t
+    off = _DEFER[1] if _DEFER[0] else 0
+    if t is None or t.numel() < off + floats:
+        if _DEFER[0] and off > 0:            # queued folds still read the regions handed out so far: run them, then start over
+            _check(load().stswin_fold_flush(_stream()), "fold_flush")
+            _DEFER[1] = off = 0
+        if t is None or t.numel() < floats:
+            if t is not None and torch.cuda.is_current_stream_capturing():
+                raise StswinHipError("scratch buffer would have to grow during a hipGraph capture: run the step once before capturing")
+            t = torch.empty(max(floats, 1 << 23), dtype=torch.float32, device=device)
+            _SCRATCH[device] = t
+    if _DEFER[0]:
+        _DEFER[1] = off + floats
+        return t[off:off + floats]
     return t
+
+
+class deferred_folds:
+    """with deferred_folds() as d: the fixed-order folds of the kernels called inside (LayerNorm / bias-gradient / attention partial
+    sums) are queued and launched together by d.flush() or at the end of the block - legal when none of their results is read
+    in between (a Swin block's backward: they are all parameter gradients).  Every call gets its own region of the scratch buffer."""
+
+    def __enter__(self):
+        _check(load().stswin_fold_defer(1, _stream()), "fold_defer")
+        _DEFER[0], _DEFER[1] = True, 0
+        return self
+
+    def flush(self):
+        _check(load().stswin_fold_flush(_stream()), "fold_flush")
+        _DEFER[1] = 0
+
+    def abort(self):
+        """Leave the deferred mode after an error inside the block (what was queued is still launched: its scratch is intact)."""
+        _DEFER[0], _DEFER[1] = False, 0
+        load().stswin_fold_defer(0, _stream())
+
+    def __exit__(self, *exc):
+        _DEFER[0], _DEFER[1] = False, 0
+        _check(load().stswin_fold_defer(0, _stream()), "fold_defer")
+        return False
 
 
 # ----------------------------------------------------------------------------------------------- live profiling
@@ -377,7 +412,7 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
         colsum_out = stats_out
     elif colsum_out is not None and M >= _CS_PARTIAL_MIN_M and N % 4 == 0 and not (flags & (1 << 19)):
         # >= 64 row tiles would each add into the same N addresses: per-block partial sums + one small reduce instead
-        cs_table = _cs_table(A.device, 2 * ((M + 255) // 256) * N)
+        cs_table = scratch(A.device, 2 * ((M + 255) // 256) * N)
         flags |= GF_CS_PARTIAL
     name = "gemm_nt_bf16" if A.dtype == torch.bfloat16 else "gemm_nt_f32"
     if _SHAPE_NAMES:
@@ -578,10 +613,23 @@ def bias_expand(table, index, mask, N, heads):
     return out
 
 
-def bias_scatter(dbiasT, index, dtable, N, heads):
+def scatter_lists(index: torch.Tensor, table_rows: int):
+    """(order, offs) of stswin_bias_scatter for an index buffer: the pairs i * N + j sorted (stably) by their table row and the start of
+    every row's range.  Three small torch kernels, no host sync; callers that scatter through the same index every step keep the
+    result (ops.py caches it per window size: relative_position_index is a function of the window size alone)."""
+    flat = index.reshape(-1)
+    order = torch.argsort(flat, stable=True).to(torch.int32).contiguous()
+    counts = torch.bincount(flat, minlength=table_rows)[:table_rows]
+    offs = torch.zeros(table_rows + 1, dtype=torch.int32, device=index.device)
+    offs[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return order, offs.contiguous()
+
+
+def bias_scatter(dbiasT, index, dtable, N, heads, lists=None):
     assert dbiasT.is_contiguous() and dtable.is_contiguous() and index.dtype == torch.int64 and index.is_contiguous()
     assert dtable.shape[0] * dtable.shape[1] == dtable.numel() and dtable.shape[1] == heads
-    _check(load().stswin_bias_scatter(_p(dbiasT), _p(index), _p(dtable), N, heads, dtable.shape[0], 1, _stream()), "bias_scatter")
+    order, offs = lists if lists is not None else scatter_lists(index, dtable.shape[0])
+    _check(load().stswin_bias_scatter(_p(dbiasT), _p(order), _p(offs), _p(dtable), N, heads, dtable.shape[0], 1, _stream()), "bias_scatter")
     return dtable
 
 

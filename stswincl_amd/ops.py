@@ -140,6 +140,8 @@ def repack(params) -> int:
 def clear_caches() -> None:
     _ROWMAPS.clear()
     _PAIR_MAPS.clear()
+    _COMPOSED.clear()
+    _SCATTER.clear()
     _WCACHE.clear()
     _UNIQ_MASKS.clear()
     from . import headops
@@ -233,15 +235,17 @@ class PairSource:
 
     def __init__(self, xmap: torch.Tensor, link: Optional[dict] = None, owner: bool = True, publish_rows: int = 0):
         self.xmap, self.link, self.owner, self.publish_rows = xmap, link, owner, publish_rows
-        self._composed = {}
 
     def compose(self, rmap: torch.Tensor) -> torch.Tensor:
-        key = rmap.data_ptr()
-        m = self._composed.get(key)
+        """window row -> source row (xmap o rmap); cached per pair of cached maps (both live in module-level caches)."""
+        key = (self.xmap.data_ptr(), rmap.data_ptr(), rmap.numel())
+        m = _COMPOSED.get(key)
         if m is None:
             idx = rmap.long()
             m = torch.where(idx >= 0, self.xmap[idx.clamp(min=0)], torch.full_like(rmap, -1)).to(torch.int32).contiguous()
-            self._composed[key] = m
+            if len(_COMPOSED) > 256:
+                _COMPOSED.clear()
+            _COMPOSED[key] = m
         return m
 
     def grad_buffer(self, shape, dt, dev):
@@ -263,7 +267,21 @@ class PairSource:
         return g, True
 
 
+_SCATTER: Dict[tuple, tuple] = {}
+
+
+def _scatter_lists_for(index: torch.Tensor, ws: int, table_rows: int):
+    """hip.scatter_lists of a module's relative_position_index buffer, kept per (window size, device): the buffer is a function of the
+    window size alone (swin_512.py:89-99), whatever module or checkpoint it came from."""
+    key = (ws, table_rows, str(index.device))
+    hit = _SCATTER.get(key)
+    if hit is None:
+        hit = _SCATTER[key] = hip.scatter_lists(index.reshape(-1).contiguous(), table_rows)
+    return hit
+
+
 _PAIR_MAPS: Dict[tuple, tuple] = {}
+_COMPOSED: Dict[tuple, torch.Tensor] = {}
 
 
 def pair_maps(B: int, L: int, device):
@@ -413,30 +431,39 @@ class SwinBlockFn(torch.autograd.Function):
         dfc2_w, dfc1_w, dproj_w, dqkv_w = (wgrad_buffer(fc2_w, (C, hid), dev), wgrad_buffer(fc1_w, (hid, C), dev),
                                            wgrad_buffer(proj_w, (C, C), dev), wgrad_buffer(qkv_w, (3 * C, C), dev))
         g = dout.detach().to(dt).contiguous().view(M, C)
-        # norm1 (its dx column sums are fc2's bias gradient)
-        dy2 = hip.layernorm_bwd(g, y2, _f32(n1_w), mean1, rstd1, dn1_w, dn1_b, M=M, dxsum=dfc2_b)
-        # fc2 (+ GELU', + fc1's bias gradient from the epilogue)
-        hip.gemm_tn(dy2, h, dfc2_w, Mk=M, overwrite=True)
-        dh_pre = torch.empty(M, hid, dtype=dt, device=dev)
-        hip.gemm_nt(dy2, wcast(fc2_w, dt, True), dh_pre, M=M, resid=h_pre, flags=hip.GF_MUL_DGELU if ctx.gelu_bwd else hip.GF_MUL_R,
-                    colsum_out=dfc1_b)
-        # fc1
-        hip.gemm_tn(dh_pre, n2, dfc1_w, Mk=M, overwrite=True)
-        dn2 = torch.empty(M, C, dtype=dt, device=dev)
-        hip.gemm_nt(dh_pre, wcast(fc1_w, dt, True), dn2, M=M)
-        del dh_pre
-        # norm2 ; dx1 = dy2 + LN'(dn2) accumulated in place into dy2; its column sums are proj's bias gradient
-        dx1 = hip.layernorm_bwd(dn2, x1, _f32(n2_w), mean2, rstd2, dn2_w, dn2_b, M=M, dx=dy2, accumulate=True,
-                                dxsum=dproj_b)
-        # proj (window order on the attention side)
-        hip.gemm_tn(dx1, o, dproj_w, Mk=M, at_rows=rmap, overwrite=True)
-        do = dn2  # reuse
-        # (dv third of the qkv bias gradient = column sums of dO: softmax rows sum to one; the dk third is exactly zero)
-        hip.gemm_nt(dx1, wcast(proj_w, dt, True), do, M=M, a_rows=rmap, colsum_out=dqkv_b[2 * C:])
-        # attention core (also yields the dq third of the qkv bias gradient)
-        dqkv = hip.win_attn_bwd(qkv, do, biasT, maskT, dbiasT, nB_=(M // (2 * N)), nW=nW, T=2, ws=ws, heads=heads,
-                                C=C, scale=d ** -0.5, colsum_out=dqkv_b, bias_index=ctx.bidx)
-        hip.bias_scatter(dbiasT, index.reshape(-1).contiguous(), dtable, N, heads)
+        # the folds of the partial sums below (LayerNorm / bias gradients, attention slabs) are all parameter gradients: queued and
+        # launched together in front of the bias scatter
+        folds = hip.deferred_folds()
+        folds.__enter__()
+        try:
+            # norm1 (its dx column sums are fc2's bias gradient)
+            dy2 = hip.layernorm_bwd(g, y2, _f32(n1_w), mean1, rstd1, dn1_w, dn1_b, M=M, dxsum=dfc2_b)
+            # fc2 (+ GELU', + fc1's bias gradient from the epilogue)
+            hip.gemm_tn(dy2, h, dfc2_w, Mk=M, overwrite=True)
+            dh_pre = torch.empty(M, hid, dtype=dt, device=dev)
+            hip.gemm_nt(dy2, wcast(fc2_w, dt, True), dh_pre, M=M, resid=h_pre, flags=hip.GF_MUL_DGELU if ctx.gelu_bwd else hip.GF_MUL_R,
+                        colsum_out=dfc1_b)
+            # fc1
+            hip.gemm_tn(dh_pre, n2, dfc1_w, Mk=M, overwrite=True)
+            dn2 = torch.empty(M, C, dtype=dt, device=dev)
+            hip.gemm_nt(dh_pre, wcast(fc1_w, dt, True), dn2, M=M)
+            del dh_pre
+            # norm2 ; dx1 = dy2 + LN'(dn2) accumulated in place into dy2; its column sums are proj's bias gradient
+            dx1 = hip.layernorm_bwd(dn2, x1, _f32(n2_w), mean2, rstd2, dn2_w, dn2_b, M=M, dx=dy2, accumulate=True,
+                                    dxsum=dproj_b)
+            # proj (window order on the attention side)
+            hip.gemm_tn(dx1, o, dproj_w, Mk=M, at_rows=rmap, overwrite=True)
+            do = dn2  # reuse
+            # (dv third of the qkv bias gradient = column sums of dO: softmax rows sum to one; the dk third is exactly zero)
+            hip.gemm_nt(dx1, wcast(proj_w, dt, True), do, M=M, a_rows=rmap, colsum_out=dqkv_b[2 * C:])
+            # attention core (also yields the dq third of the qkv bias gradient)
+            dqkv = hip.win_attn_bwd(qkv, do, biasT, maskT, dbiasT, nB_=(M // (2 * N)), nW=nW, T=2, ws=ws, heads=heads,
+                                    C=C, scale=d ** -0.5, colsum_out=dqkv_b, bias_index=ctx.bidx)
+        except BaseException:
+            folds.abort()
+            raise
+        folds.__exit__(None, None, None)
+        hip.bias_scatter(dbiasT, index.reshape(-1).contiguous(), dtable, N, heads, lists=_scatter_lists_for(index, ws, tsz))
         # qkv
         hip.gemm_tn(dqkv, X2, dqkv_w, Mk=M, bt_rows=rmap if ctx.src is None else ctx.src.compose(rmap), overwrite=True)
         src = ctx.src
