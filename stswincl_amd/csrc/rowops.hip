@@ -657,17 +657,21 @@ __global__ __launch_bounds__(256) void bias_expand_kernel(const float* table, co
 // the way.
 __global__ __launch_bounds__(256) void bias_scatter_kernel(const float* dbiasT, const int* order, const int* offs, float* dtable, int N,
                                                             int heads, int table_rows, int nslabs) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
+  // one WAVE per (table row e, head h): lane q adds the pairs q, q + 64, ... of the row (<= N of them for a real index), then a fixed
+  // butterfly over the lanes - the per-thread loop of dependent (order -> value) loads was latency-bound (17 us for 900 threads)
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
   if (t >= table_rows * heads) return;
   const int e = t / heads, h = t - e * heads;
   const long NN = (long)N * N;
   float acc = 0.f;
-  for (int q = offs[e]; q < offs[e + 1]; ++q) {
+  for (int q = offs[e] + l; q < offs[e + 1]; q += 64) {
     const int pr = order[q], i = pr / N, j = pr - i * N;
     const float* src = dbiasT + ((long)h * N + j) * N + i;        // dbiasT[h][key j][query i]
     for (int sl = 0; sl < nslabs; ++sl) acc += src[(long)sl * heads * NN];
   }
-  dtable[(long)e * heads + h] += acc;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+  if (l == 0) dtable[(long)e * heads + h] += acc;
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -886,7 +890,7 @@ extern "C" int stswin_bias_expand(const float* table, const long* index, const f
 extern "C" int stswin_bias_scatter(const float* dbiasT, const int* order, const int* offs, float* dtable, int N, int heads, int table_rows,
                                    int nslabs, void* stream) {
   if (N <= 0 || heads <= 0 || table_rows <= 0 || nslabs <= 0 || !order || !offs) return -1109;
-  hipLaunchKernelGGL(bias_scatter_kernel, dim3((unsigned)((table_rows * heads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dbiasT,
+  hipLaunchKernelGGL(bias_scatter_kernel, dim3((unsigned)((table_rows * heads + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dbiasT,
                      order, offs, dtable, N, heads, table_rows, nslabs);
   STSWIN_CHECK_LAUNCH();
   return 0;

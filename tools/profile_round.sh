@@ -52,4 +52,11 @@ grep '^{"metric"' $OUT/bench_b8.log | tail -1 > $OUT/${TAG}_bench_batch8_line.js
 python3 tools/bench_attn.py > $OUT/${TAG}_attention_kernels.txt 2>&1
 python3 tools/bench_contrast.py > $OUT/${TAG}_contrast_kernels.txt 2>&1
 python3 tools/attn_timeline8.py > $OUT/${TAG}_attn_bwd8_timeline.txt 2>&1
+python3 tools/bench_attn_qkv.py > $OUT/${TAG}_attention_qkv_fused_bench.txt 2>&1
+python3 tools/attn_qkv_timeline.py > $OUT/${TAG}_attention_qkv_fused_timeline.txt 2>&1
+python3 tools/bench_aspp_taps.py > $OUT/${TAG}_aspp_tap_skipping.txt 2>&1
+python3 tools/bench_bn.py > $OUT/${TAG}_batchnorm_kernels.txt 2>&1
+python3 tools/blas_compare.py > $OUT/${TAG}_vendor_blas_yardstick.txt 2>&1
+python3 tools/torch_ops.py > $OUT/${TAG}_torch_ops.txt 2>&1
+python3 -m pytest tests/test_hip_bf16_stages.py -q -s 2>&1 | grep -E "^\.?(swin|patch|conv|ASPP|eval)" > $OUT/${TAG}_bf16_stage_parity_table.txt
 ls -la $OUT
