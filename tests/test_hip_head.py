@@ -422,3 +422,28 @@ def test_single_frame_nchw_input_to_tokens():
     with torch.no_grad():
         out = net(fm)
     assert out.shape == (1, 256, 6, 6) and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("dil,hw", [(18, 32), (12, 16), (6, 8)])
+def test_dilated_conv_tap_skipping_is_bitwise_neutral(dil, hw):
+    """STSWIN_GF_TAPSKIP (set by ConvTokFn for 2 * dilation >= H + 3): the tiled gather GEMM skips the taps that are padding for every
+    row of a tile - a tap it skips only ever multiplied zeros, so forward and input gradient are bitwise those of the all-taps run."""
+    from stswincl_amd import hip
+    torch.manual_seed(dil)
+    f, cin, cout = 4, 128, 64
+    M = f * hw * hw
+    x = torch.randn(M, cin, device="cuda").to(torch.bfloat16)
+    wm = (torch.randn(cout, 9 * cin, device="cuda") / (9 * cin) ** 0.5).to(torch.bfloat16)
+    rmap = hip.conv_rowmap(f, hw, hw, hw, hw, 3, 1, dil, dil, False, "cuda")
+    assert float((rmap >= 0).float().mean()) < 0.75
+    ya, yb = torch.empty(M, cout, dtype=torch.bfloat16, device="cuda"), torch.empty(M, cout, dtype=torch.bfloat16, device="cuda")
+    hip.gemm_nt(x, wm, ya, M=M, a_rows=rmap, S=9)
+    hip.gemm_nt(x, wm, yb, M=M, a_rows=rmap, S=9, flags=hip.GF_TAPSKIP)
+    assert torch.equal(ya, yb)
+    ref = torch.zeros(M, cout)
+    xf, wf = x.float().cpu(), wm.float().cpu().view(cout, 9, cin)
+    rm = rmap.cpu().long()
+    for t in range(9):
+        ok = rm[t] >= 0
+        ref[ok] += xf[rm[t][ok]] @ wf[:, t].t()
+    assert float((yb.float().cpu() - ref).abs().max()) <= 1.5e-2 * float(ref.abs().max())

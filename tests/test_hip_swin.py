@@ -159,3 +159,61 @@ def test_middle_pair_gradient_link_equals_slice_and_cat(extra_use, monkeypatch):
     # frames outside the pair pass through: gradient = 1.5 * w (+ the extra use)
     exp = 1.5 * w[:, 0] * (1.5 if extra_use else 1.0)
     assert torch.allclose(xa[:, 0], exp, rtol=1e-6, atol=1e-6)
+
+
+def test_zero_copy_temporal_schedule_equals_the_slice_and_cat_schedule_bit_for_bit(monkeypatch):
+    """SwinTransformerLayerv5: the round-3 schedule (middle-pair layer gathers its frames through a composed row map, writes behind
+    the previous layer's rows, the next layer gathers from both row blocks; one gradient buffer written once per row) against the
+    round-2 schedule (slice + contiguous + cat with linked gradients).  Row maps only move data, and every kernel sums in a fixed
+    order, so outputs and ALL gradients must be bitwise equal - in bf16 and with gradient flowing into the input."""
+    torch.manual_seed(5)
+    net = S.SwinTransformerLayerv5(dim=128, input_resolution=(16, 16), num_heads=4).cuda()
+    x0 = torch.randn(3, 4, 128, 16, 16, device="cuda")
+    g1 = torch.randn(3, 4, 128, 16, 16, device="cuda")
+    g2 = torch.randn(3, 4, 256, 8, 8, device="cuda")
+    res = {}
+    for zero_copy in (True, False):
+        monkeypatch.setattr(S, "_ZERO_COPY_PAIRS", zero_copy)
+        net.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            o1, o2 = net(x)
+        ((o1.float() * g1).sum() + (o2.float() * g2).sum()).backward()
+        res[zero_copy] = (o1.detach().clone(), o2.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()})
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):       # the no-grad form of the same schedule
+            n1, n2 = net(x0)
+        assert torch.equal(n1, res[zero_copy][0]) and torch.equal(n2, res[zero_copy][1])
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "outputs differ"
+    assert torch.equal(a[2], b[2]), "input gradient differs"
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+
+
+def test_deferred_folds_of_a_block_backward_equal_immediate_folds(monkeypatch):
+    """hip.deferred_folds (the folds of a Swin block's backward queued and launched as ONE kernel, each with its own scratch region)
+    against immediate folds: the same partial sums are added in the same order, so every gradient is bitwise equal."""
+    from stswincl_amd import hip
+    torch.manual_seed(9)
+    blk = S.SwinTransformerBlock(256, (16, 16), 4, window_size=8, shift_size=4).cuda()
+    x0 = torch.randn(2, 2, 256, 256, device="cuda").to(torch.bfloat16)
+    g = torch.randn(2, 2, 256, 256, device="cuda")
+
+    class _NoDefer:
+        def __enter__(self): return self
+        def flush(self): pass
+        def abort(self): pass
+        def __exit__(self, *a): return False
+
+    res = {}
+    for mode in ("deferred", "immediate"):
+        if mode == "immediate":
+            monkeypatch.setattr(hip, "deferred_folds", _NoDefer)
+        blk.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y = blk(x)
+        (y.float() * g).sum().backward()
+        res[mode] = (x.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()})
+    assert torch.equal(res["deferred"][0], res["immediate"][0])
+    for k in res["deferred"][1]:
+        assert torch.equal(res["deferred"][1][k], res["immediate"][1][k]), k
