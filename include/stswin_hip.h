@@ -146,6 +146,9 @@ int stswin_tn_combine(const float* workspace, float* C, long ldc, int Ni, int Nj
 #define STSWIN_VAR_TN_128x128_W4 31
 #define STSWIN_VAR_TN_SLABS_F32 0x1000     /* split-K partial slabs + tn_reduce, fp32 partials */
 #define STSWIN_VAR_TN_SLABS_BF16 0x2000    /* ... bf16 partials */
+#define STSWIN_VAR_TN_TAPMINOR 0x4000      /* the combine stored the result tap-minor (STSWIN_TN_OUT_TAPMINOR was honoured) */
+#define STSWIN_TN_OUT_TAPMINOR (1 << 25)   /* bit of `splits` (with bseg > 0): store C[i][c * S + s] for GEMM column j = s * bseg + c, S = Nj / bseg - the [cout][cin][k][k]
+                                            * layout of a convolution weight gradient; only where split-K slabs are combined (check stswin_last_variant) */
 int stswin_last_variant(int family);
 
 /* ---- deterministic cross-workgroup sums.  No kernel of this library adds fp32 values with atomics any more: every kernel that sums

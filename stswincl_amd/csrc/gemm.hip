@@ -1764,8 +1764,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
 // bf16 partials: 8 outputs per thread (16-byte loads) and eight splits requested before the first is consumed - the pass is a
 // pure HBM stream (splits x Ni x Nj x 2 bytes in, 4 bytes per output out); with 8-byte loads issued one split at a time it
 // ran at 2.5 TB/s (14.5 us for the 16-split 512 x 2048 weight gradients, 1.4 ms per training step over its 80 launches).
+// perm > 0 (convolution weight gradients, STSWIN_TN_OUT_TAPMINOR): column j = (tap s, channel c) = (j / perm, j % perm) of the GEMM result is stored at
+// column c * S + s (S = Nj / perm taps): row i then IS conv.weight.grad[i] in its own [cin][k][k] layout - no permuting copy afterwards.
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, float* C, long ldc, int Ni, int Nj, int splits,
-                                                        int overwrite, int slab_bf16) {
+                                                        int overwrite, int slab_bf16, int perm) {
   if (slab_bf16) {
     const long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
     const long total = (long)Ni * Nj;
@@ -1788,6 +1790,13 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, floa
 #pragma unroll
       for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
     }
+    if (perm > 0) {
+      const int S = Nj / perm, sg = j / perm, c = j - sg * perm;
+      float* d = C + (long)i * ldc + (long)c * S + sg;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[(long)e * S] = overwrite ? a[e] : d[(long)e * S] + a[e];
+      return;
+    }
     float* dst = C + (long)i * ldc + j;
     if ((ldc & 3) == 0) {
       f32x4 lo = {a[0], a[1], a[2], a[3]}, hi = {a[4], a[5], a[6], a[7]};
@@ -1804,6 +1813,13 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, floa
   const int i = idx / Nj, j = idx % Nj;           // Nj % 4 == 0
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < splits; ++s) a += *(const f32x4*)(slabs + (long)s * Ni * Nj + idx);
+  if (perm > 0) {
+    const int S = Nj / perm, sg = j / perm, c = j - sg * perm;
+    float* d = C + (long)i * ldc + (long)c * S + sg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[(long)e * S] = overwrite ? a[e] : d[(long)e * S] + a[e];
+    return;
+  }
   float* dst = C + (long)i * ldc + j;
   if (overwrite) {
     if ((ldc & 3) == 0) *(f32x4*)dst = a;
@@ -2001,6 +2017,10 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   // the combine overlaps the next GEMM instead of standing between two launches); stswin_last_variant(1) tells it how many
   const int no_combine = (splits > 0 && (splits & (1 << 26))) ? 1 : 0;
   if (splits > 0) splits &= ~(1 << 26);
+  // bit 25 (STSWIN_TN_OUT_TAPMINOR, with bseg > 0): the split-K combine stores the result in [row][channel][tap] order (see
+  // tn_reduce_kernel); honoured only where partial slabs are combined - stswin_last_variant(1) says whether it was (0x4000)
+  const int perm = (splits > 0 && (splits & (1 << 25)) && bseg > 0 && !no_combine) ? bseg : 0;
+  if (splits > 0) splits &= ~(1 << 25);
   // bf16 operands: the split-K partials are stored as bf16 (each the fp32 sum of Mk / splits products, rounded once; the
   // combine pass adds them in fp32) - half the slab traffic of the weight gradients, the relative rounding error of a
   // gradient is 2^-9 / sqrt(splits) (a bf16 autocast GEMM rounds its whole result once, 2^-9).  STSWIN_TN_F32_SLABS=1: fp32.
@@ -2056,7 +2076,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
       (void)once_r;
       const dim3 grid((unsigned)(t256 * rs));
       g_last_variant[1] = (at_rows ? STSWIN_VAR_TN_RING_ATROWS : (bt_rows && bseg > 0) ? STSWIN_VAR_TN_RING_BSEG : bt_rows ? STSWIN_VAR_TN_RING_BTROWS : STSWIN_VAR_TN_RING_PLAIN) |
-                          (slabs ? (slab_bf16 ? STSWIN_VAR_TN_SLABS_BF16 : STSWIN_VAR_TN_SLABS_F32) : 0) | (rs << 16);
+                          (slabs ? (slab_bf16 ? STSWIN_VAR_TN_SLABS_BF16 : STSWIN_VAR_TN_SLABS_F32) : 0) | ((slabs && perm) ? 0x4000 : 0) | (rs << 16);
       if (at_rows) hipLaunchKernelGGL(gemm_tn_ring_kernel<1>, grid, dim3(512), 131072, (hipStream_t)stream, q);
       else if (bt_rows && bseg > 0) hipLaunchKernelGGL(gemm_tn_ring_kernel<3>, grid, dim3(512), 131072, (hipStream_t)stream, q);
       else if (bt_rows) hipLaunchKernelGGL(gemm_tn_ring_kernel<2>, grid, dim3(512), 131072, (hipStream_t)stream, q);
@@ -2064,7 +2084,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
       if (slabs && !no_combine) {
         const long n4 = slab_bf16 ? ((long)Ni * Nj + 7) / 8 : ((long)Ni * Nj + 3) / 4;
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, C, ldc,
-                           Ni, Nj, rs, overwrite, slab_bf16);
+                           Ni, Nj, rs, overwrite, slab_bf16, perm);
       }
       STSWIN_CHECK_LAUNCH();
       return 0;
@@ -2098,7 +2118,8 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   (void)once;
   const bool w8 = splits_flags_w4 == 0;
   g_last_variant[1] = ((w8 ? STSWIN_VAR_TN_128x128 : STSWIN_VAR_TN_128x128_W4) + (dtype ? STSWIN_VAR_F32 : 0)) |
-                      (use_slabs ? (slab_bf16 ? STSWIN_VAR_TN_SLABS_BF16 : STSWIN_VAR_TN_SLABS_F32) : 0) | (splits << 16);
+                      (use_slabs ? (slab_bf16 ? STSWIN_VAR_TN_SLABS_BF16 : STSWIN_VAR_TN_SLABS_F32) : 0) | ((use_slabs && perm) ? 0x4000 : 0) |
+                      (splits << 16);
   if (dtype == 0) {
     if (w8) hipLaunchKernelGGL((gemm_tn_kernel<bf16, 8>), grid, dim3(512), 65536, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_tn_kernel<bf16, 4>), grid, dim3(256), 65536, (hipStream_t)stream, p);
@@ -2109,7 +2130,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   if (use_slabs && !no_combine) {
     const long n4 = slab_bf16 ? ((long)Ni * Nj + 7) / 8 : ((long)Ni * Nj + 3) / 4;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, C, ldc,
-                       Ni, Nj, splits, overwrite, slab_bf16);
+                       Ni, Nj, splits, overwrite, slab_bf16, perm);
   }
   STSWIN_CHECK_LAUNCH();
   return 0;
@@ -2122,7 +2143,7 @@ extern "C" int stswin_tn_combine(const float* workspace, float* C, long ldc, int
   if (!workspace || !C || Ni <= 0 || Nj <= 0 || splits < 2) return -1007;
   const long n4 = slab_bf16 ? ((long)Ni * Nj + 7) / 8 : ((long)Ni * Nj + 3) / 4;
   hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, C, ldc, Ni, Nj,
-                     splits, overwrite, slab_bf16);
+                     splits, overwrite, slab_bf16, 0);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

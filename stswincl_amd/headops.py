@@ -175,12 +175,16 @@ class ConvTokFn(torch.autograd.Function):
         S = k * k
         g = dy.detach().to(dt).contiguous()
         # weight gradient first: its split-K combine then runs beside the input-gradient GEMM (hip.tn_deferred)
-        # (1x1 with dense layouts: the GEMM output IS the gradient - written straight into the data-parallel bucket slice)
+        # (dense layouts: the GEMM output IS the gradient - 1x1 as it is, k x k with the split-K combine storing [cout][cin][k][k]
+        #  (tap-minor) instead of the GEMM's [cout][tap][cin] - written straight into the data-parallel bucket slice)
         from .ops import wgrad_buffer
-        direct = lin.is_identity and lout.is_identity and S == 1
-        dwp = (wgrad_buffer(weight, (lout.width, lin.width), X.device) if direct
+        dense = lin.is_identity and lout.is_identity
+        direct = dense and S == 1
+        dwp = (wgrad_buffer(weight, (lout.width, S * lin.width), X.device) if dense
                else torch.empty(lout.width, S * lin.width, dtype=torch.float32, device=X.device))
-        hip.gemm_tn(g, X, dwp, Mk=Mo, bt_rows=fmap, bseg=lin.width if fmap is not None else 0, overwrite=True)
+        hip.gemm_tn(g, X, dwp, Mk=Mo, bt_rows=fmap, bseg=lin.width if fmap is not None else 0, overwrite=True,
+                    tapminor=dense and S > 1)
+        tapminor = dense and S > 1 and hip.last_tn_tapminor()
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(Mi, lin.width, dtype=dt, device=X.device)
@@ -194,10 +198,11 @@ class ConvTokFn(torch.autograd.Function):
                 ctx.link.put(dx)                          # a later consumer's backward adds it in; autograd gets no gradient from here
                 dx = None
         hip.tn_join()                                     # dwp is complete from here on (the layout copies below read it)
-        if lin.is_identity and lout.is_identity and S == 1:
-            dw = dwp                                      # 1x1: already [co][ci] with the strides autograd / DDP buckets expect
-        elif lin.is_identity and lout.is_identity:
-            dw = dwp.view(co, S, ci).permute(0, 2, 1)
+        if direct or tapminor:
+            dw = dwp                                      # already [co][ci] / [co][ci][k][k] with the strides autograd / DDP buckets expect
+        elif dense:
+            # (direct-store launch: the result is in GEMM order - and dwp may be the parameter's bucket slice, so permute out of place)
+            dw = dwp.clone().view(co, S, ci).permute(0, 2, 1)
         else:
             dw = torch.zeros(co, ci, S, dtype=torch.float32, device=X.device)
             d3 = dwp.view(lout.width, S, lin.width)
@@ -210,11 +215,14 @@ class ConvTokFn(torch.autograd.Function):
             hip.colsum(g, dbp)
             db = lout.unpad_vec(dbp)
         if dw is dwp:
-            dw = dw.view(co, ci, 1, 1)
+            dw = dw.view(co, ci, k, k)
         else:
             dw = dw.reshape(co, ci, k, k)                 # a strided view (tap-major GEMM output): autograd would clone it into the
             from .dp import grad_dest                     # parameter's layout anyway - make that copy land in the all-reduce bucket
-            dest = grad_dest(weight) if getattr(weight, "_stswin_grad_dest", None) is not None else None
+            if dense:                                     # (dwp was the bucket slice: the slot is ours already)
+                dest = dwp.view(co, ci, k, k) if getattr(weight, "_stswin_grad_dest", None) is not None and dwp.data_ptr() == weight._stswin_grad_dest[1].data_ptr() else None
+            else:
+                dest = grad_dest(weight) if getattr(weight, "_stswin_grad_dest", None) is not None else None
             if dest is not None:
                 dw = dest.copy_(dw)
         return dx, dw, db, None, None, None, None, None

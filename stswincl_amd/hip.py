@@ -502,12 +502,17 @@ def tn_join():
         _TN_PENDING = None
 
 
+TN_OUT_TAPMINOR, VAR_TN_TAPMINOR = 1 << 25, 0x4000
+
+
 def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: int, at_rows=None, bt_rows=None,
-            splits: int = 0, bseg: int = 0, atomics: bool = False, overwrite: bool = False, debug_ts: bool = False):
+            splits: int = 0, bseg: int = 0, atomics: bool = False, overwrite: bool = False, debug_ts: bool = False, tapminor: bool = False):
     """out_f32[i][j] += sum_m At[at_rows[m]][i] * Bt[bt_rows[m]][j]  (fp32); overwrite=True stores instead of adding, so
     out_f32 may come from torch.empty."""
     if overwrite:
         splits |= TN_OVERWRITE
+    if tapminor and bseg > 0:            # ask the combine for the [row][channel][tap] order; last_tn_tapminor() says whether it was honoured
+        splits |= TN_OUT_TAPMINOR
     Ni, Nj = out_f32.shape
     assert out_f32.dtype == torch.float32 and At.dtype == Bt.dtype
     ws = None if atomics or torch.cuda.is_current_stream_capturing() and At.device not in _TN_WS else _tn_workspace(At.device)
@@ -547,6 +552,12 @@ VAR_F32 = 100
 VAR_TN_RING_PLAIN, VAR_TN_RING_ATROWS, VAR_TN_RING_BTROWS, VAR_TN_RING_BSEG = 20, 21, 22, 23
 VAR_TN_128x128, VAR_TN_128x128_W4 = 30, 31
 VAR_TN_SLABS_F32, VAR_TN_SLABS_BF16 = 0x1000, 0x2000
+
+
+def last_tn_tapminor() -> bool:
+    """Whether the most recent gemm_tn(tapminor=True) of this thread stored its result tap-minor (it does where split-K slabs are
+    combined; a direct-store launch keeps the GEMM order and the caller permutes)."""
+    return bool(load().stswin_last_variant(1) & VAR_TN_TAPMINOR)
 
 
 def last_variant(family: int) -> dict:
