@@ -217,14 +217,17 @@ class ConvTokFn(torch.autograd.Function):
         if dw is dwp:
             dw = dw.view(co, ci, k, k)
         else:
-            dw = dw.reshape(co, ci, k, k)                 # a strided view (tap-major GEMM output): autograd would clone it into the
-            from .dp import grad_dest                     # parameter's layout anyway - make that copy land in the all-reduce bucket
-            if dense:                                     # (dwp was the bucket slice: the slot is ours already)
-                dest = dwp.view(co, ci, k, k) if getattr(weight, "_stswin_grad_dest", None) is not None and dwp.data_ptr() == weight._stswin_grad_dest[1].data_ptr() else None
-            else:
-                dest = grad_dest(weight) if getattr(weight, "_stswin_grad_dest", None) is not None else None
-            if dest is not None:
-                dw = dest.copy_(dw)
+            # a strided view of GEMM-ordered data: autograd would clone it into the parameter's layout anyway - make that copy land
+            # in the parameter's all-reduce bucket slice (dwp itself when the layouts are dense, else asked for now)
+            dw = dw.reshape(co, ci, k, k)
+            from .dp import grad_dest
+            slot = getattr(weight, "_stswin_grad_dest", None)
+            if dense and slot is not None and dwp.data_ptr() == slot[1].data_ptr():
+                dw = dwp.view(co, ci, k, k).copy_(dw)
+            elif not dense and slot is not None:
+                dest = grad_dest(weight)
+                if dest is not None:
+                    dw = dest.copy_(dw)
         return dx, dw, db, None, None, None, None, None
 
 
