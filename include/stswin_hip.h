@@ -90,6 +90,15 @@ int stswin_conv_pack_multi(int dtype, int count, const float* const* w, void* co
                            const int* const* imap, const int* ci, const int* S, const int* cop, const int* cip, void* stream);
 int stswin_maxpool3x3s2(int dtype, const void* in, long ldi, void* out, long ldo, unsigned char* arg, int frames, int H,
                         int W, int Ho, int Wo, int C, int backward, void* stream);
+/* 3x3 / stride 1 / pad 1 convolution of 64 -> 64 channels over bf16 NHWC tokens [frames*H*W][64] (torchvision resnet18.layer1 as
+ * used by resnet.py:104-105, basic blocks resnet.py:31-51) from an LDS-resident halo with the weights in registers: replaces the
+ * gather form of stswin_gemm_nt for these shapes.  wmat = the [64][9][64] matrices stswin_conv_pack makes; sign = +1 with the fwd
+ * matrix: the convolution; sign = -1 with the dgrad matrix: its input gradient (x = dy).  resid (or NULL): [frames*H*W][64] added
+ * before the store (a gradient another consumer of the input produced); stats (or NULL): the STSWIN_GF_CS_SQ table of the stored
+ * values ([2][2*ceil(M/256)][64]: per-128-row-block column sums | sums of squares).  W in {16, 32, 64, 128}, H*W % 256 == 0; other
+ * geometries return -1702 / -1701 and launch nothing (the caller keeps the gather GEMM). */
+int stswin_conv3x3_c64(const void* x, const void* wmat, void* y, const void* resid, float* stats, int frames, int H, int W, int sign,
+                       void* stream);
 
 /* ---- segmented gather GEMM: C[c_rows[m]][n] = epi( sum_s A[a_rows[s][m]][0:Kseg] . B[n][s*Kseg:(s+1)*Kseg] )
  * nn.Linear of swin_512.py:115 (qkv, with the window gather fused via a_rows and the q scaling via

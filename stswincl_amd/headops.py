@@ -134,6 +134,10 @@ def _conv_maps(frames, Hin, Win, k, stride, pad, dil, device):
     return Hout, Wout, hit[0], hit[1]
 
 
+_RESID_GRAD_LINK = os.environ.get("STSWIN_NO_RESID_GRAD_LINK") != "1"      # (A/B switch)
+_HALO_CONV = os.environ.get("STSWIN_NO_HALO_CONV") != "1"                  # (A/B switch)
+
+
 class ConvTokFn(torch.autograd.Function):
     """k x k convolution (any stride / padding / dilation) over NHWC tokens as segmented gather GEMM: forward gathers
     input pixels per tap, dgrad gathers output-gradient pixels through the inverse tap map, wgrad is ONE transposed GEMM
@@ -154,8 +158,15 @@ class ConvTokFn(torch.autograd.Function):
         tab = hip.stats_table(Mo, lout.width, x.device) if want_stats else None
         # (dilation >= half the map: every row tile has taps that are padding for all of its rows - the kernel skips them)
         ctx.tapskip = hip.GF_TAPSKIP if (k == 3 and stride == 1 and 2 * dil >= Hin + 3 and Mo <= 32768) else 0
-        hip.gemm_nt(X, _conv_mats(weight, dt, lin, lout, False), y, M=Mo, a_rows=fmap, S=k * k,
-                    bias=lout.pad_vec(bias) if bias is not None else None, stats_out=tab, flags=ctx.tapskip)
+        # (64 -> 64 channels, 3x3 / 1 / 1: the halo kernel - no row map, the input crosses HBM once)
+        ctx.halo = (_HALO_CONV and bias is None and lin.is_identity and lout.is_identity and X.is_contiguous()
+                    and hip.conv3x3_c64_ok(frames, Hin, Win, lin.width, lout.width, k, stride, pad, dil, dt))
+        if ctx.halo:
+            hip.conv3x3_c64(X, _conv_mats(weight, dt, lin, lout, False), y, frames, Hin, Win, 1, stats_out=tab)
+        else:
+            hip.gemm_nt(X, _conv_mats(weight, dt, lin, lout, False), y, M=Mo, a_rows=fmap, S=k * k,
+                        bias=lout.pad_vec(bias) if bias is not None else None, stats_out=tab, flags=ctx.tapskip)
+        ctx.geom = (frames, Hin, Win)
         ctx.cfg = (k, lin, lout, dt, x.dtype, bias is not None, Mi, Mo)
         ctx.save_for_backward(X, weight, fmap, imap)
         if want_stats:
@@ -191,8 +202,11 @@ class ConvTokFn(torch.autograd.Function):
             # GradLink: the gradient another consumer of x has already produced (the residual branch of the block, or the other
             # convolution reading x) rides in as the R operand of this GEMM's epilogue instead of an autograd add over the map
             pend = ctx.link.take(dt, dx.shape) if ctx.link is not None else None
-            hip.gemm_nt(g, _conv_mats(weight, dt, lin, lout, True), dx, M=Mi, a_rows=imap, S=S, resid=pend,
-                        flags=(hip.GF_RESID if pend is not None else 0) | ctx.tapskip)
+            if ctx.halo:
+                hip.conv3x3_c64(g, _conv_mats(weight, dt, lin, lout, True), dx, *ctx.geom, -1, resid=pend)
+            else:
+                hip.gemm_nt(g, _conv_mats(weight, dt, lin, lout, True), dx, M=Mi, a_rows=imap, S=S, resid=pend,
+                            flags=(hip.GF_RESID if pend is not None else 0) | ctx.tapskip)
             dx = dx.to(in_dtype)
             if ctx.link is not None and not ctx.link.last():
                 ctx.link.put(dx)                          # a later consumer's backward adds it in; autograd gets no gradient from here
@@ -256,7 +270,6 @@ class GradLink:
         return self.left <= 0
 
 
-_RESID_GRAD_LINK = os.environ.get("STSWIN_NO_RESID_GRAD_LINK") != "1"      # (A/B switch)
 _FUSED_BN_STATS = os.environ.get("STSWIN_NO_FUSED_BN_STATS") != "1"      # (A/B switch)
 
 

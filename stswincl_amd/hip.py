@@ -369,6 +369,23 @@ def maxpool3x3s2(src, dst, arg, frames, H, W, Ho, Wo, backward=False):
     return dst
 
 
+def conv3x3_c64_ok(frames, H, W, cin, cout, k, stride, pad, dil, dt) -> bool:
+    """Geometries stswin_conv3x3_c64 takes (everything else stays on the gather GEMM)."""
+    return (dt == torch.bfloat16 and cin == 64 and cout == 64 and k == 3 and stride == 1 and pad == 1 and dil == 1
+            and W in (16, 32, 64, 128) and (H * W) % 256 == 0 and frames > 0)
+
+
+def conv3x3_c64(x, wmat, y, frames, H, W, sign=1, resid=None, stats_out=None):
+    """y = conv3x3(x) (sign = +1, wmat = forward matrix) or its input gradient (sign = -1, x = dy, wmat = dgrad matrix)."""
+    M = frames * H * W
+    for t in (x, y, resid):
+        assert t is None or (t.dtype == torch.bfloat16 and t.shape == (M, 64) and t.is_contiguous())
+    assert wmat.dtype == torch.bfloat16 and wmat.shape == (64, 576) and wmat.is_contiguous()
+    assert stats_out is None or (stats_out.dtype == torch.float32 and stats_out.numel() == 2 * 2 * ((M + 255) // 256) * 64)
+    _check(load().stswin_conv3x3_c64(_p(x), _p(wmat), _p(y), _p(resid), _p(stats_out), frames, H, W, sign, _stream()), "conv3x3_c64")
+    return y
+
+
 # ----------------------------------------------------------------------------------------------- GEMMs
 def stats_table(M: int, N: int, device) -> torch.Tensor:
     """fp32 [2][2*ceil(M/256)][N] table for gemm_nt(stats_out=...): per-128-row-block column sums | sums of squares."""

@@ -447,3 +447,86 @@ def test_dilated_conv_tap_skipping_is_bitwise_neutral(dil, hw):
         ok = rm[t] >= 0
         ref[ok] += xf[rm[t][ok]] @ wf[:, t].t()
     assert float((yb.float().cpu() - ref).abs().max()) <= 1.5e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("f,h,w", [(2, 128, 128), (3, 64, 64), (5, 32, 32), (16, 16, 16), (1, 24, 32), (300, 16, 16)])
+@pytest.mark.parametrize("sign", [1, -1])
+def test_halo_conv3x3_c64_matches_gather_gemm_and_fp64(f, h, w, sign):
+    """stswin_conv3x3_c64 (resnet18.layer1 convolutions, resnet.py:31-51 via :104-105) against (a) an fp64 convolution of the same
+    bf16 operands - within bf16 rounding of the result - and (b) the gather GEMM it replaces, forward and input gradient, with the
+    residual operand and the BatchNorm statistics table."""
+    from stswincl_amd import hip
+    torch.manual_seed(f * 1000 + h + w + sign)
+    M = f * h * w
+    x = torch.randn(M, 64, device="cuda").to(torch.bfloat16)
+    wt = torch.randn(64, 64, 3, 3, device="cuda") / 24.0
+    ident = torch.arange(64, dtype=torch.int32, device="cuda")
+    fwd, dg = hip.conv_pack(wt, torch.bfloat16, ident, ident)
+    res = torch.randn(M, 64, device="cuda").to(torch.bfloat16)
+    mat = fwd if sign > 0 else dg
+    rmap = hip.conv_rowmap(f, h, w, h, w, 3, 1, 1, 1, sign < 0, "cuda")
+    tab_a, tab_b = hip.stats_table(M, 64, "cuda"), hip.stats_table(M, 64, "cuda")
+    ya, yb = torch.empty_like(x), torch.empty_like(x)
+    hip.gemm_nt(x, mat, ya, M=M, a_rows=rmap, S=9, resid=res, flags=hip.GF_RESID, stats_out=tab_a)
+    hip.conv3x3_c64(x, mat, yb, f, h, w, sign, resid=res, stats_out=tab_b)
+    torch.cuda.synchronize()
+    # fp64 reference from the bf16-rounded operands
+    xi = x.double().view(f, h, w, 64).permute(0, 3, 1, 2)
+    wb = wt.to(torch.bfloat16).double()
+    if sign > 0:
+        ref = F.conv2d(xi, wb, padding=1)
+    else:
+        ref = F.conv_transpose2d(xi, wb, padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(M, 64) + res.double()
+    scale = float(ref.abs().max())
+    assert float((yb.double() - ref).abs().max()) <= 2.0 ** -8 * scale * 1.01 + 1e-6
+    assert float((ya.double() - ref).abs().max()) <= 2.0 ** -8 * scale * 1.01 + 1e-6
+    # the two kernels: same fp32 sums up to summation order -> at most one bf16 step apart, almost everywhere equal
+    d = (ya.float() - yb.float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * scale
+    assert float((d > 0).float().mean()) < 0.02
+    # statistics tables: sums over 128-row blocks of the STORED values
+    nb = (M + 127) // 128
+    ta, tb = tab_a.view(2, -1, 64)[:, :nb], tab_b.view(2, -1, 64)[:, :nb]
+    want = torch.stack([yb.float().view(nb, -1, 64).sum(1), (yb.float() ** 2).view(nb, -1, 64).sum(1)]) if M % 128 == 0 else None
+    if want is not None:
+        assert float((tb - want).abs().max()) <= 2e-2 * float(want.abs().max())   # (sums of the fp32 values before the bf16 store)
+    if nb % 2 == 0:      # (the GEMM's tiles may leave the sum of a 256-row pair in its first row and zero in the second)
+        pa, pb = ta.reshape(2, nb // 2, 2, 64).sum(2), tb.reshape(2, nb // 2, 2, 64).sum(2)
+        assert float((pa - pb).abs().max()) <= 1e-3 * float(pa.abs().max())
+    # plain call: no residual, no table; bitwise reproducible
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    hip.conv3x3_c64(x, mat, y1, f, h, w, sign)
+    hip.conv3x3_c64(x, mat, y2, f, h, w, sign)
+    assert torch.equal(y1, y2)
+    assert float((y1.double() - (ref - res.double())).abs().max()) <= 2.0 ** -8 * scale * 1.01 + 1e-6
+
+
+def test_halo_conv_rejects_other_geometries_and_is_what_layer1_runs():
+    from stswincl_amd import hip
+    x = torch.zeros(2 * 20 * 24, 64, dtype=torch.bfloat16, device="cuda")
+    wm = torch.zeros(64, 576, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(hip.StswinHipError):
+        hip.conv3x3_c64(x, wm, torch.empty_like(x), 2, 20, 24)
+    assert not hip.conv3x3_c64_ok(2, 20, 24, 64, 64, 3, 1, 1, 1, torch.bfloat16)
+    assert hip.conv3x3_c64_ok(16, 128, 128, 64, 64, 3, 1, 1, 1, torch.bfloat16)
+    assert not hip.conv3x3_c64_ok(16, 128, 128, 64, 64, 3, 1, 1, 1, torch.float32)
+    # through the module path: forward + backward of a 64 -> 64 convolution under autocast equals the gather path within bf16 rounding
+    torch.manual_seed(3)
+    conv = nn.Conv2d(64, 64, 3, padding=1, bias=False).cuda()
+    xt = torch.randn(2 * 32 * 32, 64, device="cuda", requires_grad=True)
+    outs = []
+    for flag in (True, False):
+        H._HALO_CONV = flag
+        try:
+            conv.weight.grad = None
+            xt.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y, _, _ = H.conv_tokens(xt, conv, 2, 32, 32)
+            (y.float() * torch.linspace(-1, 1, 64, device="cuda")).sum().backward()
+            outs.append((y.detach().float().clone(), xt.grad.clone(), conv.weight.grad.clone()))
+        finally:
+            H._HALO_CONV = True
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max())
+    assert torch.equal(outs[0][2], outs[1][2])            # (the weight gradient does not go through the halo kernel)
