@@ -99,6 +99,14 @@ int stswin_maxpool3x3s2(int dtype, const void* in, long ldi, void* out, long ldo
  * geometries return -1702 / -1701 and launch nothing (the caller keeps the gather GEMM). */
 int stswin_conv3x3_c64(const void* x, const void* wmat, void* y, const void* resid, float* stats, int frames, int H, int W, int sign,
                        void* stream);
+/* Weight gradient of the same convolution from dy and x (both bf16 [frames*H*W][64]): dw fp32 [64][9][64] (the order of
+ * stswin_gemm_tn with bseg = 64: [cout][tap][cin]) or, tapminor != 0, [64][64][3][3] (nn.Conv2d.weight's own layout); accumulate != 0
+ * adds to dw instead of overwriting it.  Image rows of x pass through an LDS ring once, per-workgroup partials go to `scratch`
+ * (>= stswin_conv3x3_c64_wgrad_scratch(frames, H, W) floats) and are added in a fixed order: bitwise reproducible.  W in {32, 64,
+ * 128}, H*W % 128 == 0; else -1712 / -1711 and nothing is launched (the caller keeps stswin_gemm_tn).  resnet.py:31-51 backward. */
+long stswin_conv3x3_c64_wgrad_scratch(int frames, int H, int W);
+int stswin_conv3x3_c64_wgrad(const void* dy, const void* x, float* dw, int tapminor, int accumulate, float* scratch, long scratch_floats,
+                             int frames, int H, int W, void* stream);
 
 /* ---- segmented gather GEMM: C[c_rows[m]][n] = epi( sum_s A[a_rows[s][m]][0:Kseg] . B[n][s*Kseg:(s+1)*Kseg] )
  * nn.Linear of swin_512.py:115 (qkv, with the window gather fused via a_rows and the q scaling via

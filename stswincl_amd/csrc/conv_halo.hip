@@ -303,3 +303,236 @@ extern "C" int stswin_conv3x3_c64(const void* x, const void* wmat, void* y, cons
   }
   return -1702;                                   // (the caller keeps the gather GEMM for other widths)
 }
+
+// =====================================================================================================================
+// Weight gradient of the same convolution:  dW[co][tap][ci] = sum_p dy[p][co] * x[p + off(tap)][ci]   (resnet.py:31-51 backward).
+// The generic path (gemm_tn with a tap-segmented, row-map-gathered B operand) reads x nine times and runs at 235 TFLOP/s on
+// Mk = 262144, Ni = 64, Nj = 576.  Here a workgroup walks down consecutive 128-pixel units of a frame with the image rows in
+// an LDS RING (each row of x is copied once; rows y - 1 .. y + TYU of the current unit stay while the rows of the next unit
+// arrive) next to a double-buffered dy tile; both MFMA operands are read TRANSPOSED from their pixel-major tiles
+// (ds_read_b64_tr_b16: the contraction index is the pixel), the nine taps are nine address shifts of the x fragments.  Wave w
+// owns input-channel tile w (16 channels) of every tap: 9 x 4 accumulator tiles of 16 x 16 stay in registers for the whole run;
+// at the end the workgroup's 64 x 576 partial goes into its slab of the caller's workspace, and a fixed-order fold
+// (chw_fold_kernel) adds the slabs while it re-orders them: deterministic, no atomics.
+// =====================================================================================================================
+struct ConvHaloWgradArgs {
+  const bf16* X; const bf16* DY; float* ws;
+  int frames, H, tapminor; long per;            // units per workgroup
+  unsigned long long* ts;                       // tools/conv_halo_timeline.py --wgrad: [workgroup][16 units][4 slots] stamps of wave 0, or NULL
+};
+
+template <int LW>
+struct ChWg {
+  static constexpr int W = 1 << LW, TYU = 128 >> LW, HP = ch_hp(W), GPR = HP / 8;
+  static constexpr int RING = TYU == 1 ? 4 : TYU == 2 ? 8 : 16;             // image-row slots: >= 2 TYU + 2, power of two
+  static constexpr int ROWB = HP * CH_ROWB, XB = RING * ROWB, DYB = 128 * CH_ROWB, LDS = XB + 2 * DYB;
+  static constexpr int NPAD = HP - W;
+  static_assert(RING >= 2 * TYU + 2 && LW >= 5 && LW <= 7, "unit = 128 pixels of whole image rows, 32 <= W <= 128");
+  static_assert(LDS <= 160 * 1024, "ring + dy tiles must fit the LDS");
+};
+
+DEVI bf16x4 ch_tr4(const char* addr) {
+  short4v r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)addr);
+  return __builtin_bit_cast(bf16x4, r);
+}
+
+// One copy group (8 pixel records, 1 KB) of image row y of frame f into its ring slot, or - n past the x groups - of the dy tile
+// of `unit`.  n, y0, nrows are wave-uniform.  Rows outside the image copy zeros; the pad lanes of the first / last group of a
+// row are masked out (their LDS positions were zeroed once).
+template <int LW>
+DEVI void chw_issue(const ConvHaloWgradArgs& a, int n, int f, int ybase, int nrows, long unit, char* xr, char* dyt, unsigned voff) {
+  using C = ChWg<LW>;
+  const int NX = nrows * C::GPR;
+  if (n < NX) {
+    const int r = n / C::GPR, gx = n - r * C::GPR, y = ybase + r, slot = (y + 1) & (C::RING - 1);
+    const bool real = (unsigned)y < (unsigned)a.H;
+    const char* src = (const char*)ch_uniform((unsigned long)(real ? (const char*)(a.X + (((long)f * a.H + y) * C::W + gx * 8 - 1) * CH_C)
+                                                                    : (const char*)ch_zero));
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(xr + slot * C::ROWB + gx * 1024));
+    if (gx == 0)
+      asm volatile("s_mov_b32 m0, %2\n\ts_lshl_b64 exec, -1, 8\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(voff), "s"(src), "s"(dst)
+                   : "memory", "m0", "scc");
+    else if (gx == C::GPR - 1)
+      asm volatile("s_mov_b32 m0, %2\n\ts_lshr_b64 exec, -1, 56\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(voff), "s"(src), "s"(dst)
+                   : "memory", "m0", "scc");
+    else
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory", "m0");
+  } else if (n < NX + 16) {
+    const int gd = n - NX;
+    const char* src = (const char*)ch_uniform((unsigned long)(a.DY + (unit * 128 + gd * 8) * CH_C));
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(dyt + gd * 1024));
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory", "m0");
+  }
+}
+
+template <int LW>
+__global__ __launch_bounds__(512) void conv3x3_c64_wgrad_kernel(ConvHaloWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using C = ChWg<LW>;
+  constexpr int W = C::W, TYU = C::TYU, HP = C::HP;
+  const int tid = threadIdx.x, l = tid & 63, w = wave_id();
+  const int fr = l & 15, fq = l >> 4, q = fr >> 2, pq = fr & 3;
+  char* xr = smem;
+  char* dyb = smem + C::XB;
+  const long upf = ((long)a.H * W) >> 7, nunits = upf * a.frames;
+  const long u0 = blockIdx.x * a.per, u1 = u0 + a.per < nunits ? u0 + a.per : nunits;
+#define CHW_STAMP(unit, slot) \
+  if (a.ts && tid == 0 && (unit) < 16) a.ts[((long)blockIdx.x * 16 + (unit)) * 4 + (slot)] = wall_clock64()
+  CHW_STAMP(15, 0);
+  // Eight waves, two per SIMD: 0-3 multiply (wave w = input-channel tile w), 4-7 request the copies - an LDS-DMA request costs its
+  // wave 60-180 cycles of issue (plus its scalar address arithmetic), which a multiplying wave would pay in idle matrix cycles.
+  if (w >= 4) {
+    const int lw = w - 4;
+    const unsigned voff = (l >> 3) * CH_ROWB + (((l & 7) ^ (l >> 3)) << 4);
+    bool full = true;
+    for (long u = u0; u < u1; ++u) {
+      const int f = (int)(u / upf), y0 = (int)(u - (long)f * upf) * TYU;
+      if (full) {                                   // first unit of the run / of a frame: rows y0 - 1 .. y0 + TYU and the dy tile, not overlapped
+        if (u > u0) __syncthreads();                // (the previous frame's last unit is still being read)
+        for (int n = lw; n < (TYU + 2) * C::GPR + 16; n += 4) chw_issue<LW>(a, n, f, y0 - 1, TYU + 2, u, xr, dyb + (int)(u & 1) * C::DYB, voff);
+      }
+      wait_vm0();
+      __syncthreads();                              // unit u is in place; the multiplying waves are done with unit u - 1
+      const bool next = u + 1 < u1 && y0 + TYU < a.H;   // the next unit continues this frame: its TYU new rows + dy tile arrive during this one
+      full = u + 1 < u1 && !next;
+      if (next)
+        for (int n = lw; n < TYU * C::GPR + 16; n += 4) chw_issue<LW>(a, n, f, y0 + TYU + 1, TYU, u + 1, xr, dyb + (int)((u + 1) & 1) * C::DYB, voff);
+    }
+    return;
+  }
+  // pad columns of every ring slot: zero, once (nothing is copied there)
+  for (int idx = tid; idx < C::RING * C::NPAD * 8; idx += 256) {
+    const int c = idx & 7, k = (idx >> 3) % C::NPAD, row = (idx >> 3) / C::NPAD, hx = k == 0 ? 0 : W + k;
+    *(uint4*)(xr + row * C::ROWB + hx * CH_ROWB + c * 16) = uint4{0, 0, 0, 0};
+  }
+  // lane parts of the transposed fragment addresses (a 16-lane group reads 4 pixels x 16 channels; lane = pixel q, channels 4 pq ..):
+  // the 128-byte-row swizzle term depends on (pixel & 7) = (4 h + q [+ tap column]) & 7 only
+  int lb[3][2], la[4][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi)
+      lb[dxi][h] = (8 * fq + 4 * h + q + dxi) * CH_ROWB + ((((2 * w + (pq >> 1)) ^ ((4 * h + q + dxi) & 7)) & 7) << 4) + (pq & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      la[i][h] = (8 * fq + 4 * h + q) * CH_ROWB + ((((2 * i + (pq >> 1)) ^ ((4 * h + q) & 7)) & 7) << 4) + (pq & 1) * 8;
+  }
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int g = 0; g < 9; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bool full = false;
+  for (long u = u0; u < u1; ++u) {
+    const int y0 = (int)(u % upf) * TYU;
+    const char* dyt = dyb + (int)(u & 1) * C::DYB;
+    CHW_STAMP(u - u0, 0);
+    if (full) __syncthreads();
+    __syncthreads();                                // unit u is in place
+    CHW_STAMP(u - u0, 1);
+    full = u + 1 < u1 && !(y0 + TYU < a.H);
+    // ring offsets of the unit's image rows y0 - 1 + r
+    int rowoff[TYU + 2];
+#pragma unroll
+    for (int r = 0; r < TYU + 2; ++r) rowoff[r] = ((y0 + r) & (C::RING - 1)) * C::ROWB;
+    // 12 steps n = (pixel step ks = n / 3, tap row dyi = n % 3): the three x fragments of the step (tap columns) against the four dy
+    // fragments of ks (output-channel tiles): 12 MFMAs.  x fragments are requested two steps ahead, dy fragments one pixel step ahead.
+    bf16x8 af[2][4], bf[3][3];
+#define CHW_LOAD_A(ks)                                                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                  \
+    af[(ks) & 1][i] = cat4(ch_tr4(dyt + la[i][0] + (ks) * 32 * CH_ROWB), ch_tr4(dyt + la[i][1] + (ks) * 32 * CH_ROWB));
+#define CHW_LOAD_B(n)                                                                                                           \
+  {                                                                                                                              \
+    const char* base = xr + rowoff[((32 * ((n) / 3)) >> LW) + (n) % 3] + ((32 * ((n) / 3)) & (W - 1)) * CH_ROWB;                 \
+    _Pragma("unroll") for (int dxi = 0; dxi < 3; ++dxi) bf[(n) % 3][dxi] = cat4(ch_tr4(base + lb[dxi][0]), ch_tr4(base + lb[dxi][1])); \
+  }
+    CHW_LOAD_A(0)
+    CHW_LOAD_B(0)
+    CHW_LOAD_B(1)
+#pragma unroll
+    for (int n = 0; n < 12; ++n) {
+      const int ks = n / 3, dyi = n % 3;
+      if (n + 2 < 12) CHW_LOAD_B(n + 2)
+      if (dyi == 0 && ks + 1 < 4) { CHW_LOAD_A(ks + 1) }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dxi = 0; dxi < 3; ++dxi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[3 * dyi + dxi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks & 1][i], bf[n % 3][dxi], acc[3 * dyi + dxi][i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef CHW_LOAD_A
+#undef CHW_LOAD_B
+    CHW_STAMP(u - u0, 2);
+  }
+  CHW_STAMP(15, 1);
+  // the workgroup's partial -> its slab, straight from the registers, in the order [tap][ci][co]: a lane holds 4 consecutive
+  // output channels per (tap, tile), the four lanes of a column write one 64-byte segment; chw_fold_kernel re-orders while it adds
+  float* slab = a.ws + (long)blockIdx.x * (64 * 576);
+#pragma unroll
+  for (int g = 0; g < 9; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(f32x4*)(slab + (g * 64 + 16 * w + fr) * 64 + 16 * i + 4 * fq) = acc[g][i];
+  CHW_STAMP(15, 3);
+#undef CHW_STAMP
+}
+
+// out = [+] sum over slabs, re-ordered from the kernel's [tap][ci][co] to [co][tap][ci] or (tapminor) [co][ci][tap].  A workgroup owns
+// 16 float4 columns (256 contiguous bytes of every slab) and reads them with 16 slab lanes; lane sums meet in LDS and are added in
+// lane order: the association of every output's sum is fixed by the slab count alone.
+__global__ __launch_bounds__(256) void chw_fold_kernel(const float* ws, int nslabs, float* out, int tapminor, int accumulate) {
+  __shared__ f32x4 part[256];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int j = (blockIdx.x * 16 + cl) * 4;         // slab offset of the column: (tap * 64 + ci) * 64 + co, co % 4 == 0
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  int p = sl;
+  for (; p + 48 < nslabs; p += 64) {
+    const f32x4 v0 = *(const f32x4*)(ws + (long)p * 36864 + j), v1 = *(const f32x4*)(ws + (long)(p + 16) * 36864 + j);
+    const f32x4 v2 = *(const f32x4*)(ws + (long)(p + 32) * 36864 + j), v3 = *(const f32x4*)(ws + (long)(p + 48) * 36864 + j);
+    v += v0; v += v1; v += v2; v += v3;
+  }
+  for (; p < nslabs; p += 16) v += *(const f32x4*)(ws + (long)p * 36864 + j);
+  part[sl * 16 + cl] = v;
+  __syncthreads();
+  if (sl == 0) {
+    for (int k = 1; k < 16; ++k) v += part[k * 16 + cl];
+    const int co = j & 63, ci = (j >> 6) & 63, g = j >> 12;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* dst = out + (tapminor ? ((co + r) * 64 + ci) * 9 + g : (co + r) * 576 + g * 64 + ci);
+      *dst = accumulate ? *dst + v[r] : v[r];
+    }
+  }
+}
+
+template <int LW>
+static int chw_launch(const ConvHaloWgradArgs& a, int grid, hipStream_t st) {
+  static const int attr = (int)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<LW>, hipFuncAttributeMaxDynamicSharedMemorySize, ChWg<LW>::LDS);
+  if (attr != 0) return -attr;
+  hipLaunchKernelGGL(conv3x3_c64_wgrad_kernel<LW>, dim3(grid), dim3(512), ChWg<LW>::LDS, st, a);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" long stswin_conv3x3_c64_wgrad_scratch(int frames, int H, int W) {
+  const long nunits = (long)frames * H * W / 128;
+  return (nunits < 256 ? nunits : 256) * 64 * 576;
+}
+
+extern "C" int stswin_conv3x3_c64_wgrad(const void* dy, const void* x, float* dw, int tapminor, int accumulate, float* scratch, long scratch_floats,
+                                        int frames, int H, int W, void* stream) {
+  if (frames <= 0 || H <= 0 || ((long)H * W) % 128 || !dw) return -1711;
+  if (W != 32 && W != 64 && W != 128) return -1712;
+  const long nunits = (long)frames * H * W / 128;
+  const long g0 = nunits < 256 ? nunits : 256, per = (nunits + g0 - 1) / g0;
+  const int grid = (int)((nunits + per - 1) / per);             // every workgroup has at least one unit: every slab is written
+  if (!scratch || scratch_floats < (long)grid * 64 * 576) return -1713;
+  // (accumulate == 2: a tools run - dw is a stamp buffer of grid * 16 * 4 64-bit words, nothing is folded)
+  ConvHaloWgradArgs a{(const bf16*)x, (const bf16*)dy, scratch, frames, H, tapminor ? 1 : 0, per, accumulate == 2 ? (unsigned long long*)dw : nullptr};
+  int rc = W == 128 ? chw_launch<7>(a, grid, (hipStream_t)stream) : W == 64 ? chw_launch<6>(a, grid, (hipStream_t)stream) : chw_launch<5>(a, grid, (hipStream_t)stream);
+  if (rc || accumulate == 2) return rc;
+  hipLaunchKernelGGL(chw_fold_kernel, dim3(64 * 576 / 64), dim3(256), 0, (hipStream_t)stream, scratch, grid, dw, tapminor ? 1 : 0, accumulate ? 1 : 0);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}

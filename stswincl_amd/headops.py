@@ -136,6 +136,7 @@ def _conv_maps(frames, Hin, Win, k, stride, pad, dil, device):
 
 _RESID_GRAD_LINK = os.environ.get("STSWIN_NO_RESID_GRAD_LINK") != "1"      # (A/B switch)
 _HALO_CONV = os.environ.get("STSWIN_NO_HALO_CONV") != "1"                  # (A/B switch)
+_HALO_WGRAD = os.environ.get("STSWIN_NO_HALO_WGRAD") != "1"                # (A/B switch)
 
 
 class ConvTokFn(torch.autograd.Function):
@@ -193,9 +194,14 @@ class ConvTokFn(torch.autograd.Function):
         direct = dense and S == 1
         dwp = (wgrad_buffer(weight, (lout.width, S * lin.width), X.device) if dense
                else torch.empty(lout.width, S * lin.width, dtype=torch.float32, device=X.device))
-        hip.gemm_tn(g, X, dwp, Mk=Mo, bt_rows=fmap, bseg=lin.width if fmap is not None else 0, overwrite=True,
-                    tapminor=dense and S > 1)
-        tapminor = dense and S > 1 and hip.last_tn_tapminor()
+        if ctx.halo and _HALO_WGRAD and hip.conv3x3_c64_wgrad_ok(*ctx.geom):
+            # (x rows through an LDS ring once, dy and x fragments read transposed, taps as address shifts; stores nn.Conv2d's layout)
+            hip.conv3x3_c64_wgrad(g, X, dwp, *ctx.geom, tapminor=True)
+            tapminor = True
+        else:
+            hip.gemm_tn(g, X, dwp, Mk=Mo, bt_rows=fmap, bseg=lin.width if fmap is not None else 0, overwrite=True,
+                        tapminor=dense and S > 1)
+            tapminor = dense and S > 1 and hip.last_tn_tapminor()
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(Mi, lin.width, dtype=dt, device=X.device)

@@ -386,6 +386,23 @@ def conv3x3_c64(x, wmat, y, frames, H, W, sign=1, resid=None, stats_out=None):
     return y
 
 
+def conv3x3_c64_wgrad_ok(frames, H, W) -> bool:
+    return W in (32, 64, 128) and (H * W) % 128 == 0 and frames > 0
+
+
+def conv3x3_c64_wgrad(dy, x, dw, frames, H, W, tapminor=True, accumulate=False):
+    """dw (fp32, 64*576 values: [64][64][3][3] if tapminor else [64][9][64]) = weight gradient of the 64 -> 64 3x3 convolution."""
+    M = frames * H * W
+    for t in (dy, x):
+        assert t.dtype == torch.bfloat16 and t.shape == (M, 64) and t.is_contiguous()
+    assert dw.dtype == torch.float32 and dw.numel() == 64 * 576 and dw.is_contiguous()
+    need = load().stswin_conv3x3_c64_wgrad_scratch(frames, H, W)
+    ws = scratch(x.device, need)
+    _check(load().stswin_conv3x3_c64_wgrad(_p(dy), _p(x), _p(dw), 1 if tapminor else 0, 1 if accumulate else 0, _p(ws), _c_long(ws.numel()),
+                                           frames, H, W, _stream()), "conv3x3_c64_wgrad")
+    return dw
+
+
 # ----------------------------------------------------------------------------------------------- GEMMs
 def stats_table(M: int, N: int, device) -> torch.Tensor:
     """fp32 [2][2*ceil(M/256)][N] table for gemm_nt(stats_out=...): per-128-row-block column sums | sums of squares."""

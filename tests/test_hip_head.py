@@ -517,7 +517,7 @@ def test_halo_conv_rejects_other_geometries_and_is_what_layer1_runs():
     xt = torch.randn(2 * 32 * 32, 64, device="cuda", requires_grad=True)
     outs = []
     for flag in (True, False):
-        H._HALO_CONV = flag
+        H._HALO_CONV = H._HALO_WGRAD = flag
         try:
             conv.weight.grad = None
             xt.grad = None
@@ -526,7 +526,44 @@ def test_halo_conv_rejects_other_geometries_and_is_what_layer1_runs():
             (y.float() * torch.linspace(-1, 1, 64, device="cuda")).sum().backward()
             outs.append((y.detach().float().clone(), xt.grad.clone(), conv.weight.grad.clone()))
         finally:
-            H._HALO_CONV = True
-    for a, b in zip(*outs):
+            H._HALO_CONV = H._HALO_WGRAD = True
+    for a, b in list(zip(*outs))[:2]:
         assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max())
-    assert torch.equal(outs[0][2], outs[1][2])            # (the weight gradient does not go through the halo kernel)
+    # (weight gradients: fp32 slabs here, bf16 split-K slabs on the gemm_tn path)
+    assert float((outs[0][2] - outs[1][2]).abs().max()) <= 5e-3 * float(outs[1][2].abs().max())
+
+
+@pytest.mark.parametrize("f,h,w", [(2, 128, 128), (16, 128, 128), (3, 64, 64), (5, 32, 32), (1, 12, 32), (40, 8, 32), (7, 64, 128)])
+def test_halo_wgrad_c64_matches_fp64_and_gemm_tn(f, h, w):
+    """stswin_conv3x3_c64_wgrad against an fp64 weight gradient of the same bf16 operands and against the gemm_tn path it replaces;
+    both output layouts, accumulate, and bitwise reproducibility (fixed-order fold of the workgroup slabs)."""
+    from stswincl_amd import hip
+    torch.manual_seed(f * 100 + h + w)
+    M = f * h * w
+    x = torch.randn(M, 64, device="cuda").to(torch.bfloat16)
+    dy = (torch.randn(M, 64, device="cuda") / 8).to(torch.bfloat16)
+    # fp64 reference: dW[co][ci][ky][kx]
+    xi = x.double().view(f, h, w, 64).permute(0, 3, 1, 2)
+    gi = dy.double().view(f, h, w, 64).permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(xi, (64, 64, 3, 3), gi, padding=1)
+    scale = float(ref.abs().max())
+    dw_t = torch.empty(64, 64, 3, 3, dtype=torch.float32, device="cuda")
+    hip.conv3x3_c64_wgrad(dy, x, dw_t, f, h, w, tapminor=True)
+    assert float((dw_t.double() - ref).abs().max()) <= 2e-5 * scale + 1e-6 * M ** 0.5      # fp32 accumulation of exact bf16 products
+    dw_g = torch.empty(64, 576, dtype=torch.float32, device="cuda")
+    hip.conv3x3_c64_wgrad(dy, x, dw_g, f, h, w, tapminor=False)
+    assert torch.equal(dw_g.view(64, 9, 64).permute(0, 2, 1).reshape(64, 64, 3, 3), dw_t)
+    # the path it replaces
+    fmap = hip.conv_rowmap(f, h, w, h, w, 3, 1, 1, 1, False, "cuda")
+    old = torch.empty(64, 576, dtype=torch.float32, device="cuda")
+    hip.gemm_tn(dy, x, old, Mk=M, bt_rows=fmap, bseg=64, overwrite=True)
+    hip.tn_join()
+    torch.cuda.synchronize()
+    assert float((old - dw_g).abs().max()) <= 5e-3 * scale           # (its split-K slabs are bf16)
+    # accumulate and reproducibility
+    again = dw_t.clone()
+    hip.conv3x3_c64_wgrad(dy, x, again, f, h, w, tapminor=True, accumulate=True)
+    assert torch.equal(again, dw_t + dw_t)
+    rep = torch.empty_like(dw_t)
+    hip.conv3x3_c64_wgrad(dy, x, rep, f, h, w, tapminor=True)
+    assert torch.equal(rep, dw_t)

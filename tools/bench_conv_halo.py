@@ -50,6 +50,11 @@ def main():
         ("dgrad+resid gather GEMM", lambda: hip.gemm_nt(x, dg, y, M=M, a_rows=imap, S=9, resid=res, flags=hip.GF_RESID)),
         ("dgrad+resid halo", lambda: hip.conv3x3_c64(x, dg, y, f, h, w, -1, resid=res)),
     ]
+    dw = torch.empty(64, 576, dtype=torch.float32, device="cuda")
+    rows += [
+        ("wgrad gemm_tn + combine", lambda: (hip.gemm_tn(res, x, dw, Mk=M, bt_rows=fmap, bseg=64, overwrite=True, tapminor=True), hip.tn_join())),
+        ("wgrad halo + fold", lambda: hip.conv3x3_c64_wgrad(res, x, dw, f, h, w, tapminor=True)),
+    ]
     for name, fn in rows:
         us = timeit(fn)
         print(f"{name:28s} {us:8.1f} us   {flops / us * 1e-6:7.1f} TFLOP/s   {byts / us * 1e-3:7.1f} GB/s (in + out)")
