@@ -71,6 +71,14 @@ int stswin_conv_rowmap(int* map, int frames, int Hin, int Win, int Hout, int Wou
  * patches [F*Ho*Wo][ld] with column (ky*7+kx)*3 + c, zero padded to ld. */
 int stswin_stem_im2col(int dtype, const float* img, void* patches, long ld, int frames, int H, int W, int Ho, int Wo,
                        void* stream);
+/* stem input as a 2 x 2 space-to-depth image (torchvision conv1 7x7/2 pad 3 = a 4 x 4 / stride 1 convolution over 12-channel
+ * superpixels; resnet.py:98-102): NCHW fp32 images [F][3][H][W] -> records [F][Ho + 3][Wo + 3][16] (Ho = (H-1)/2 + 1; 2 records of
+ * zero padding before, 1 after, in both directions), record (sy, sx)[(dy*2 + dx)*3 + c] = img[c][2(sy-2) + dy][2(sx-2) + dx],
+ * positions 12..15 zero.  Output pixel (oy, ox) contracts, per tap row s = 0..3, the 64 contiguous values of records
+ * (oy + s, ox .. ox + 3) with W[co][c][2s + dy - 1][2t + dx - 1] (t = record in the segment; taps outside 0..6 are zero):
+ * stswin_gemm_nt / stswin_gemm_tn with a row map [4][M], Kseg = bseg = 64 and lda = 16.  The buffer must extend 48 values past
+ * the last record (the last segment reads on). */
+int stswin_stem_s2d(int dtype, const float* img, void* out, int frames, int H, int W, void* stream);
 /* nn.MaxPool2d(3, 2, 1) on tokens [F][H][W][C] -> [F][Ho][Wo][C]; arg (uint8 [F*Ho*Wo][C]) = winning tap (first max in
  * (ky,kx) scan order, like torch); backward gathers dy through arg (no atomics). */
 /* (Cout, Cin, k, k) fp32 nn.Conv2d weight -> the bf16 / fp32 GEMM operand matrices of the token convolutions in one launch:

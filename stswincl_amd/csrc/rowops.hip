@@ -137,6 +137,42 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* img, T* p
   }
 }
 
+// Stem input as a 2 x 2 SPACE-TO-DEPTH image (torchvision conv1 7x7 / 2 / 3 of resnet.py:98-102 as a 4 x 4 convolution of stride 1
+// over 12-channel superpixels): record (f, sy, sx) of the padded [F][Ho + 3][Wo + 3] grid (2 records of padding before, 1 after)
+// holds the 2 x 2 x 3 input values img[f][c][2 (sy - 2) + dy][2 (sx - 2) + dx] at position (dy * 2 + dx) * 3 + c, then 4 zeros.
+// Output pixel (oy, ox) reads the FOUR records (oy + s, ox .. ox + 3) of each tap row s = 0..3: 64 contiguous values - a segment
+// the row-map gather of gemm_nt / gemm_tn takes as it is (row pitch 16 < segment length 64: overlapping rows), so neither the
+// forward GEMM nor the weight gradient needs the 147-wide patch matrix (403 MB at 16 frames of 512 x 512; this image: 34 MB).
+template <typename T>
+__global__ __launch_bounds__(256) void stem_s2d_kernel(const float* img, T* out, int frames, int H, int W, int Hs, int Ws) {
+  const long n = (long)blockIdx.x * 256 + threadIdx.x, total = (long)frames * Hs * Ws;
+  if (n >= total) return;
+  const int sx = (int)(n % Ws), sy = (int)((n / Ws) % Hs), f = (int)(n / ((long)Ws * Hs));
+  const int iy = 2 * (sy - 2), ix = 2 * (sx - 2);
+  float v[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) v[e] = 0.f;
+  const float* base = img + (long)f * 3 * H * W;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int y = iy + dy, x = ix + dx;
+      if (y >= 0 && y < H && x >= 0 && x < W) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[(dy * 2 + dx) * 3 + c] = base[((long)c * H + y) * W + x];
+      }
+    }
+  constexpr int PACK = TT<T>::PACK;
+#pragma unroll
+  for (int h = 0; h < 16 / PACK; ++h) {
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < PACK; ++e) o.set(e, v[h * PACK + e]);
+    *(decltype(o.v)*)(out + n * 16 + h * PACK) = o.v;
+  }
+}
+
 // conv weight packing: (Cout, Cin, k, k) fp32 parameter -> the two GEMM operand matrices of the token convolutions in one
 // launch: fwd [Cout_p][S][Cin_p] (B operand of y = X W^T, tap-major K) and dgrad [Cin_p][S][Cout_p].  omap / imap give the
 // source channel of every padded channel position (-1 = zero padding; concatenated layouts have gaps).  Replaces, per
@@ -737,6 +773,18 @@ extern "C" int stswin_stem_im2col(int dtype, const float* img, void* patches, lo
   dim3 grid((unsigned)want);
   if (dtype == 0) hipLaunchKernelGGL(stem_im2col_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, img, (bf16*)patches, ld, frames, H, W, Ho, Wo);
   else hipLaunchKernelGGL(stem_im2col_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, img, (float*)patches, ld, frames, H, W, Ho, Wo);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_stem_s2d(int dtype, const float* img, void* out, int frames, int H, int W, void* stream) {
+  if (frames <= 0 || H <= 0 || W <= 0) return -1112;
+  const int Hs = (H - 1) / 2 + 1 + 3, Ws = (W - 1) / 2 + 1 + 3;
+  const long total = (long)frames * Hs * Ws;
+  if (total > 0x7fffffffL * 64) return -1112;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == 0) hipLaunchKernelGGL(stem_s2d_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, img, (bf16*)out, frames, H, W, Hs, Ws);
+  else hipLaunchKernelGGL(stem_s2d_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, img, (float*)out, frames, H, W, Hs, Ws);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

@@ -11,6 +11,7 @@ import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
+import torch.nn.functional as F
 
 from . import hip
 from .ops import compute_dtype, _f32
@@ -299,26 +300,54 @@ def conv_tokens(x_tok, conv: torch.nn.Conv2d, frames, Hin, Win, lin=None, lout=N
     return (y, Hout, Wout) if stats is None else (y, Hout, Wout, tab)
 
 
+_STEM_MAPS: dict = {}
+
+
+def _stem_rowmap(frames, Ho, Wo, Hs, Ws, device):
+    """[4][frames*Ho*Wo] int32: first record of tap row s of every output pixel in the padded space-to-depth image; cached."""
+    key = (frames, Ho, Wo, Hs, Ws, str(device))
+    hit = _STEM_MAPS.get(key)
+    if hit is None:
+        f, oy, ox = torch.meshgrid(torch.arange(frames, device=device), torch.arange(Ho, device=device),
+                                   torch.arange(Wo, device=device), indexing="ij")
+        hit = torch.stack([((f * Hs + oy + s) * Ws + ox).reshape(-1) for s in range(4)]).to(torch.int32).contiguous()
+        if len(_STEM_MAPS) > 16:
+            _STEM_MAPS.clear()
+        _STEM_MAPS[key] = hit
+    return hit
+
+
+def _stem_pack(weight, dt):
+    """(64, 3, 7, 7) -> [64][4 tap rows][4 records][16]: W[co][c][2s + dy - 1][2t + dx - 1] at (s, t, (dy*2 + dx)*3 + c), zero elsewhere."""
+    w8 = F.pad(weight.detach().float(), (1, 0, 1, 0))
+    w8 = w8.view(-1, 3, 4, 2, 4, 2).permute(0, 2, 4, 3, 5, 1).reshape(-1, 4, 4, 12)
+    return F.pad(w8, (0, 4)).reshape(-1, 256).to(dt)
+
+
+def _stem_unpack(dw):
+    """the inverse of _stem_pack for the fp32 weight gradient [64][256] -> (64, 3, 7, 7) (a view)."""
+    co = dw.shape[0]
+    return dw.view(co, 4, 4, 16)[..., :12].reshape(co, 4, 4, 2, 2, 3).permute(0, 5, 1, 3, 2, 4).reshape(co, 3, 8, 8)[:, :, 1:, 1:]
+
+
 class StemConvFn(torch.autograd.Function):
-    """torchvision resnet18.conv1 (7x7 / stride 2 / pad 3, Cin = 3; reference resnet.py:98-102) = im2col + GEMM.
-    The 147-wide patches (padded to 192) are kept for the weight gradient when they are <= 2 GB (403 MB at B = 4 clips of
-    512x512: nothing on a 288 GB part, and rebuilding them costs as much as the GEMM that uses them); larger ones are
-    rebuilt in backward."""
+    """torchvision resnet18.conv1 (7x7 / stride 2 / pad 3, Cin = 3; reference resnet.py:98-102) as a 4 x 4 / stride 1 convolution over
+    the 2 x 2 space-to-depth image (hip.stem_s2d): per output pixel four 64-value segments, gathered by the GEMM's row map.  The
+    34 MB image replaces the 147-wide patch matrix (403 MB at B = 4 clips of 512x512, 175 us to build) for forward and weight
+    gradient alike."""
 
     @staticmethod
     def forward(ctx, img, weight, dt, want_stats=False):
         F_, _, Hh, Ww = img.shape
         Ho, Wo = (Hh + 6 - 7) // 2 + 1, (Ww + 6 - 7) // 2 + 1
         im = img.detach().float().contiguous()
-        patches = hip.stem_im2col(im, dt, Ho, Wo)
-        wm = torch.zeros(64, 192, dtype=torch.float32, device=img.device)
-        wm[:, :147] = weight.detach().float().permute(0, 2, 3, 1).reshape(64, 147)
+        A, Hs, Ws = hip.stem_s2d(im, dt)
+        rmap = _stem_rowmap(F_, Ho, Wo, Hs, Ws, img.device)
         y = torch.empty(F_ * Ho * Wo, 64, dtype=dt, device=img.device)
         tab = hip.stats_table(y.shape[0], 64, img.device) if want_stats else None    # BatchNorm statistics of y (see ConvTokFn)
-        hip.gemm_nt(patches, wm.to(dt), y, M=y.shape[0], stats_out=tab)
-        keep = patches.numel() * patches.element_size() <= (2 << 30)
-        ctx.cfg = (dt, Ho, Wo, keep)
-        ctx.save_for_backward(patches if keep else im, weight)
+        hip.gemm_nt(A, _stem_pack(weight, dt), y, M=y.shape[0], a_rows=rmap, S=4, stats_out=tab)
+        ctx.dt = dt
+        ctx.save_for_backward(A, rmap, weight)
         if want_stats:
             ctx.mark_non_differentiable(tab)
             ctx.set_materialize_grads(False)
@@ -330,17 +359,14 @@ class StemConvFn(torch.autograd.Function):
     def backward(ctx, dy, _dtab=None):
         if dy is None:
             return None, None, None, None
-        saved, weight = ctx.saved_tensors
-        dt, Ho, Wo, keep = ctx.cfg
-        patches = saved if keep else hip.stem_im2col(saved, dt, Ho, Wo)
-        im = saved
-        dw = torch.empty(64, 192, dtype=torch.float32, device=im.device)
-        hip.gemm_tn(dy.detach().to(dt).contiguous(), patches, dw, Mk=patches.shape[0], overwrite=True)
+        A, rmap, weight = ctx.saved_tensors
+        dw = torch.empty(64, 256, dtype=torch.float32, device=A.device)
+        hip.gemm_tn(dy.detach().to(ctx.dt).contiguous(), A, dw, Mk=rmap.shape[1], bt_rows=rmap, bseg=64, overwrite=True)
         hip.tn_join()
-        dwv = dw[:, :147].reshape(64, 7, 7, 3).permute(0, 3, 1, 2)
+        dwv = _stem_unpack(dw)
         from .dp import grad_dest
         dest = grad_dest(weight) if getattr(weight, "_stswin_grad_dest", None) is not None else None
-        return None, (dest.copy_(dwv) if dest is not None else dwv), None, None
+        return None, (dest.copy_(dwv) if dest is not None else dwv.contiguous()), None, None
 
 
 def stem_conv_tokens(img, weight, dt, stats=False):

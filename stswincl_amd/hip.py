@@ -362,6 +362,19 @@ def stem_im2col(img: torch.Tensor, dtype: torch.dtype, Ho: int, Wo: int, ld: int
     return out
 
 
+def stem_s2d(img: torch.Tensor, dtype: torch.dtype):
+    """img fp32 NCHW [F][3][H][W] -> (A, Hs, Ws): A = the [F*Hs*Ws][64] row view (row pitch 16: every row is the 4-record segment
+    starting at its record) of the padded 2 x 2 space-to-depth image; see include/stswin_hip.h."""
+    F_, c, H, W = img.shape
+    assert c == 3 and img.dtype == torch.float32 and img.is_contiguous()
+    Hs, Ws = (H - 1) // 2 + 4, (W - 1) // 2 + 4
+    n = F_ * Hs * Ws
+    flat = torch.empty(n * 16 + 64, dtype=dtype, device=img.device)
+    flat[n * 16:].zero_()
+    _check(load().stswin_stem_s2d(_dt(flat), _p(img), _p(flat), F_, H, W, _stream()), "stem_s2d")
+    return torch.as_strided(flat, (n, 64), (16, 1)), Hs, Ws
+
+
 def maxpool3x3s2(src, dst, arg, frames, H, W, Ho, Wo, backward=False):
     C = src.shape[1]
     _check(load().stswin_maxpool3x3s2(_dt(src), _p(src), _c_long(_ld(src)), _p(dst), _c_long(_ld(dst)), _p(arg), frames, H,

@@ -172,3 +172,33 @@ def test_stem_im2col_matches_unfold(dtype, frames, H, W):
     ref = ref.to(dtype).float()
     assert got.shape == (frames * Ho * Wo, 192)
     assert torch.equal(got[:, :147], ref) and float(got[:, 147:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("frames,H,W", [(2, 36, 28), (1, 35, 29), (3, 16, 64)])
+def test_stem_space_to_depth_image_and_segments(dtype, frames, H, W):
+    """hip.stem_s2d: every record of the padded 2 x 2 space-to-depth image, and the 64-value segments the GEMM row map reads, against a
+    direct restatement; the convolution they define equals F.conv2d(7, 2, 3) (resnet.py:98-102) - odd image sizes included."""
+    import torch.nn.functional as F
+    from stswincl_amd import headops as Hd
+    torch.manual_seed(H + W)
+    img = torch.randn(frames, 3, H, W)
+    A, Hs, Ws = hip.stem_s2d(img.cuda(), dtype)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    assert (Hs, Ws) == (Ho + 3, Wo + 3) and A.shape == (frames * Hs * Ws, 64) and A.stride() == (16, 1)
+    rec = A[:, :16].float().cpu().view(frames, Hs, Ws, 16)
+    want = torch.zeros(frames, Hs, Ws, 16)
+    pad = F.pad(img.to(dtype).float(), (0, 2 * Wo - W, 0, 2 * Ho - H))
+    want[:, 2:2 + Ho, 2:2 + Wo, :12] = pad.view(frames, 3, Ho, 2, Wo, 2).permute(0, 2, 4, 3, 5, 1).reshape(frames, Ho, Wo, 12)
+    assert torch.equal(rec, want)
+    assert torch.equal(A[5, 16:32], A[6, :16])                      # a row is the 4-record segment starting at its record
+    w = torch.randn(64, 3, 7, 7) / 10
+    rmap = Hd._stem_rowmap(frames, Ho, Wo, Hs, Ws, "cuda")
+    wm = Hd._stem_pack(w.cuda(), torch.float32).cpu()
+    seg = torch.stack([A.float().cpu()[rmap[s].cpu().long()] for s in range(4)], 1).reshape(frames * Ho * Wo, 256)
+    y = seg @ wm.t()
+    ref = F.conv2d(img.to(dtype).float(), w, stride=2, padding=3).permute(0, 2, 3, 1).reshape(-1, 64)
+    assert float((y - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    g = torch.randn(64, 256)
+    assert torch.equal(Hd._stem_unpack(Hd._stem_pack(w, torch.float32)), w)
+    assert Hd._stem_unpack(g).shape == (64, 3, 7, 7)
