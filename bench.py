@@ -196,7 +196,9 @@ def timed_steps(ctx, step, steps, warmup, profile_stride):
     if profile_stride and ctx.rank == 0:
         hip.profile_begin(profile_stride)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for k in range(steps):
+        if profile_stride and ctx.rank == 0:
+            hip.profile_step(k)               # which launches are timed rotates with the step: every site once per `stride` steps
         loss = step()
     ctx.barrier()
     dt = time.perf_counter() - t0
@@ -311,6 +313,10 @@ def seg_run(a, ctx):
                 dist.broadcast(t, 0)
                 p.data.copy_(t)
     profile_stride = 0 if a.no_profile else a.profile_stride
+    if profile_stride > 1:                     # a stride that divides the step count times every launch site equally often
+        div = [d for d in range(5, 13) if a.steps % d == 0]
+        if div:
+            profile_stride = min(div, key=lambda d: abs(d - profile_stride))
     use_graph = a.graph == 1 or (a.graph == -1 and world == 1 and not profile_stride)
     opt = FusedAdam(model.parameters(), 1e-4)          # == torch.optim.Adam (tests/test_hip_optim.py), 8 launches per step
     crit = OhemCELoss2D(S * S // 16)
@@ -390,8 +396,10 @@ def seg_run(a, ctx):
                            "algorithmic_flops_per_launch": q["work"] / q["sampled"],
                            "launches_per_step": q["launches"] / a.steps,
                            "launches_timed": q["sampled"],
-                           "timing": f"HIP events on the launch stream around one launch in {a.profile_stride} (seeded random "
-                                     f"choice per launch) inside the timed region; averages are over the timed launches",
+                           "timing": f"HIP events on the launch stream around one launch in {profile_stride} inside the timed region; "
+                                     f"which ones rotates with the step, so every launch site of the step is timed "
+                                     f"{a.steps // profile_stride if profile_stride and a.steps % profile_stride == 0 else '~' + str(round(a.steps / max(profile_stride, 1), 1))} "
+                                     f"time(s); averages are over the timed launches",
                            "avg_launch_ms": q["ms_avg"], "ms_per_step": q["ms_avg"] * q["launches"] / a.steps,
                            "other_kernels": {n: {"ms_per_step": v["ms_avg"] * v["launches"] / a.steps,
                                                  "tflops": v["work"] / (v["ms_total"] * 1e-3) / 1e12}

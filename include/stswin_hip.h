@@ -79,6 +79,13 @@ int stswin_stem_im2col(int dtype, const float* img, void* patches, long ld, int 
  * stswin_gemm_nt / stswin_gemm_tn with a row map [4][M], Kseg = bseg = 64 and lda = 16.  The buffer must extend 48 values past
  * the last record (the last segment reads on). */
 int stswin_stem_s2d(int dtype, const float* img, void* out, int frames, int H, int W, void* stream);
+/* Weight gradient of the stem convolution from dy (bf16 [F*Ho*Wo][64]) and the space-to-depth image `rec` of stswin_stem_s2d (bf16):
+ * dw fp32 [64][4][4][16] = [cout][tap row][record][position], the order stswin_gemm_tn produces over the row map (accumulate != 0 adds).
+ * Record rows pass through an LDS ring once; per-workgroup partials go to `scratch` (>= stswin_stem_wgrad_scratch floats) and are added
+ * in a fixed order.  Wo = (W-1)/2 + 1 must be a multiple of 128, else -1722 and nothing is launched.  resnet.py:98-102 backward. */
+long stswin_stem_wgrad_scratch(int frames, int Ho, int Wo);
+int stswin_stem_wgrad(const void* dy, const void* rec, float* dw, int accumulate, float* scratch, long scratch_floats, int frames, int H, int W,
+                      void* stream);
 /* nn.MaxPool2d(3, 2, 1) on tokens [F][H][W][C] -> [F][Ho][Wo][C]; arg (uint8 [F*Ho*Wo][C]) = winning tap (first max in
  * (ky,kx) scan order, like torch); backward gathers dy through arg (no atomics). */
 /* (Cout, Cin, k, k) fp32 nn.Conv2d weight -> the bf16 / fp32 GEMM operand matrices of the token convolutions in one launch:

@@ -478,29 +478,30 @@ __global__ __launch_bounds__(512) void conv3x3_c64_wgrad_kernel(ConvHaloWgradArg
 #undef CHW_STAMP
 }
 
-// out = [+] sum over slabs, re-ordered from the kernel's [tap][ci][co] to [co][tap][ci] or (tapminor) [co][ci][tap].  A workgroup owns
+// out = [+] sum over slabs, re-ordered from the kernels' [column][co] (column = tap * 64 + ci; ncol of them) to [co][column] or (tapminor) [co][ci][tap].  A workgroup owns
 // 16 float4 columns (256 contiguous bytes of every slab) and reads them with 16 slab lanes; lane sums meet in LDS and are added in
 // lane order: the association of every output's sum is fixed by the slab count alone.
-__global__ __launch_bounds__(256) void chw_fold_kernel(const float* ws, int nslabs, float* out, int tapminor, int accumulate) {
+__global__ __launch_bounds__(256) void chw_fold_kernel(const float* ws, int nslabs, int ncol, float* out, int tapminor, int accumulate) {
+  const long slab = 64L * ncol;
   __shared__ f32x4 part[256];
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int j = (blockIdx.x * 16 + cl) * 4;         // slab offset of the column: (tap * 64 + ci) * 64 + co, co % 4 == 0
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   int p = sl;
   for (; p + 48 < nslabs; p += 64) {
-    const f32x4 v0 = *(const f32x4*)(ws + (long)p * 36864 + j), v1 = *(const f32x4*)(ws + (long)(p + 16) * 36864 + j);
-    const f32x4 v2 = *(const f32x4*)(ws + (long)(p + 32) * 36864 + j), v3 = *(const f32x4*)(ws + (long)(p + 48) * 36864 + j);
+    const f32x4 v0 = *(const f32x4*)(ws + (long)p * slab + j), v1 = *(const f32x4*)(ws + (long)(p + 16) * slab + j);
+    const f32x4 v2 = *(const f32x4*)(ws + (long)(p + 32) * slab + j), v3 = *(const f32x4*)(ws + (long)(p + 48) * slab + j);
     v += v0; v += v1; v += v2; v += v3;
   }
-  for (; p < nslabs; p += 16) v += *(const f32x4*)(ws + (long)p * 36864 + j);
+  for (; p < nslabs; p += 16) v += *(const f32x4*)(ws + (long)p * slab + j);
   part[sl * 16 + cl] = v;
   __syncthreads();
   if (sl == 0) {
     for (int k = 1; k < 16; ++k) v += part[k * 16 + cl];
-    const int co = j & 63, ci = (j >> 6) & 63, g = j >> 12;
+    const int co = j & 63, col = j >> 6, ci = col & 63, g = col >> 6;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float* dst = out + (tapminor ? ((co + r) * 64 + ci) * 9 + g : (co + r) * 576 + g * 64 + ci);
+      float* dst = out + (tapminor ? ((co + r) * 64 + ci) * 9 + g : (co + r) * ncol + col);
       *dst = accumulate ? *dst + v[r] : v[r];
     }
   }
@@ -532,7 +533,145 @@ extern "C" int stswin_conv3x3_c64_wgrad(const void* dy, const void* x, float* dw
   ConvHaloWgradArgs a{(const bf16*)x, (const bf16*)dy, scratch, frames, H, tapminor ? 1 : 0, per, accumulate == 2 ? (unsigned long long*)dw : nullptr};
   int rc = W == 128 ? chw_launch<7>(a, grid, (hipStream_t)stream) : W == 64 ? chw_launch<6>(a, grid, (hipStream_t)stream) : chw_launch<5>(a, grid, (hipStream_t)stream);
   if (rc || accumulate == 2) return rc;
-  hipLaunchKernelGGL(chw_fold_kernel, dim3(64 * 576 / 64), dim3(256), 0, (hipStream_t)stream, scratch, grid, dw, tapminor ? 1 : 0, accumulate ? 1 : 0);
+  hipLaunchKernelGGL(chw_fold_kernel, dim3(576), dim3(256), 0, (hipStream_t)stream, scratch, grid, 576, dw, tapminor ? 1 : 0, accumulate ? 1 : 0);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+
+// =====================================================================================================================
+// Weight gradient of the stem convolution over the space-to-depth image (stem_s2d_kernel of rowops.hip; resnet.py:98-102 backward):
+//   dW[co][s][t][ch] = sum_p dy[p][co] * rec[(oy + s, ox + t)][ch]        s, t = 0..3 tap row / record, ch = 0..15
+// The gemm_tn path gathers 4 x 128 bytes per output pixel (537 MB for 16 frames of 512 x 512; 150 us).  Here a workgroup walks
+// down a 128-pixel-wide strip of output rows: per unit ONE new row segment of records (131 x 32 bytes) enters an 8-slot LDS ring
+// and one dy tile (128 x 128 bytes) a double buffer - 168 MB in all.  Wave w owns tap row s = w: 4 records x 4 output-channel
+// tiles of accumulators; both operands are read transposed (the contraction index is the pixel; lane group fq takes pixels
+// 4 fq .. 4 fq + 3 and 16 + 4 fq .. of a 32-pixel step - any assignment is legal if both operands agree, and this one makes the
+// 32-lane halves of a record read contiguous); waves 4-7 request the copies.  Partials go to slabs [s][t][ch][co], chw_fold_kernel
+// adds them in a fixed order into [co][s][t][ch].
+// =====================================================================================================================
+struct StemWgradArgs {
+  const bf16* REC; const bf16* DY; float* ws;
+  int frames, Ho, Wo, Hs, Ws; long per;
+};
+
+constexpr int SW_ROWP = 136 * 32;                       // ring slot pitch: 131 records used
+constexpr int SW_XB = 8 * SW_ROWP, SW_DYB = 128 * CH_ROWB, SW_LDS = SW_XB + 2 * SW_DYB;
+
+// copy n of a unit: n < 5 nrows: part n % 5 of padded record row row0 + n / 5 (columns x0 .. x0 + 130); then the 16 groups of the dy tile
+DEVI void sw_issue(const StemWgradArgs& a, int n, int nrows, int f, int row0, int x0, long pix0, char* xr, char* dyt, int l) {
+  if (n < 5 * nrows) {
+    const int r = n / 5, part = n - 5 * r, y = row0 + r, slot = y & 7;
+    const char* src = (const char*)ch_uniform((unsigned long)(a.REC + (((long)f * a.Hs + y) * a.Ws + x0) * 16 + part * 512));
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(xr + slot * SW_ROWP + part * 1024));
+    const unsigned voff = l * 16;
+    if (part < 4)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory", "m0");
+    else                                            // records 128 .. 130: 6 lanes
+      asm volatile("s_mov_b32 m0, %2\n\ts_lshr_b64 exec, -1, 58\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(voff), "s"(src), "s"(dst)
+                   : "memory", "m0", "scc");
+  } else if (n < 5 * nrows + 16) {
+    const int gd = n - 5 * nrows;
+    const char* src = (const char*)ch_uniform((unsigned long)(a.DY + (pix0 + gd * 8) * CH_C));
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(dyt + gd * 1024));
+    const unsigned voff = (l >> 3) * CH_ROWB + (((l & 7) ^ (l >> 3)) << 4);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory", "m0");
+  }
+}
+
+__global__ __launch_bounds__(512) void stem_wgrad_kernel(StemWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63, w = wave_id();
+  const int fr = l & 15, fq = l >> 4, q = fr >> 2, pq = fr & 3;
+  char* xr = smem;
+  char* dyb = smem + SW_XB;
+  const int nxh = a.Wo >> 7;
+  const long nunits = (long)a.frames * nxh * a.Ho;
+  const long u0 = blockIdx.x * a.per, u1 = u0 + a.per < nunits ? u0 + a.per : nunits;
+  // unit u = (strip = u / Ho -> frame strip / nxh, column block strip % nxh; output row oy = u % Ho)
+  if (w >= 4) {
+    const int lw = w - 4;
+    bool full = true;
+    for (long u = u0; u < u1; ++u) {
+      const int strip = (int)(u / a.Ho), oy = (int)(u - (long)strip * a.Ho), f = strip / nxh, x0 = (strip - f * nxh) << 7;
+      const long pix0 = ((long)f * a.Ho + oy) * a.Wo + x0;
+      if (full) {
+        if (u > u0) __syncthreads();
+        for (int n = lw; n < 5 * 4 + 16; n += 4) sw_issue(a, n, 4, f, oy, x0, pix0, xr, dyb + (int)(u & 1) * SW_DYB, l);
+      }
+      wait_vm0();
+      __syncthreads();
+      const bool next = u + 1 < u1 && oy + 1 < a.Ho;
+      full = u + 1 < u1 && !next;
+      if (next)
+        for (int n = lw; n < 5 + 16; n += 4) sw_issue(a, n, 1, f, oy + 4, x0, pix0 + a.Wo, xr, dyb + (int)((u + 1) & 1) * SW_DYB, l);
+    }
+    return;
+  }
+  // lane parts of the transposed fragment addresses: pixel 4 fq + q (+ 16 h + 32 ks), channels 4 pq ..
+  int la[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) la[i] = (4 * fq + q) * CH_ROWB + ((((2 * i + (pq >> 1)) ^ ((4 * (fq & 1) + q) & 7)) & 7) << 4) + (pq & 1) * 8;
+  const int lbB = (4 * fq + q) * 32 + pq * 8;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bool full = false;
+  for (long u = u0; u < u1; ++u) {
+    const int oy = (int)(u % a.Ho);
+    const char* dyt = dyb + (int)(u & 1) * SW_DYB;
+    if (full) __syncthreads();
+    __syncthreads();                                // unit u is in place
+    full = u + 1 < u1 && !(oy + 1 < a.Ho);
+    const char* xrow = xr + ((oy + w) & 7) * SW_ROWP + lbB;      // this wave's tap row
+    bf16x8 af[2][4], bf[2][4];
+#define SW_LOAD(ks)                                                                                                              \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                                   \
+    af[(ks) & 1][i] = cat4(ch_tr4(dyt + la[i] + (ks) * 32 * CH_ROWB), ch_tr4(dyt + la[i] + ((ks) * 32 + 16) * CH_ROWB));          \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                                   \
+    bf[(ks) & 1][t] = cat4(ch_tr4(xrow + ((ks) * 32 + t) * 32), ch_tr4(xrow + ((ks) * 32 + 16 + t) * 32));
+    SW_LOAD(0)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) { SW_LOAD(ks + 1) }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks & 1][i], bf[ks & 1][t], acc[t][i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef SW_LOAD
+  }
+  float* slab = a.ws + (long)blockIdx.x * (64 * 256);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(f32x4*)(slab + ((w * 4 + t) * 16 + fr) * 64 + 16 * i + 4 * fq) = acc[t][i];
+}
+
+extern "C" long stswin_stem_wgrad_scratch(int frames, int Ho, int Wo) {
+  const long nunits = (long)frames * (Wo / 128) * Ho;
+  return (nunits < 256 ? nunits : 256) * 64 * 256;
+}
+
+extern "C" int stswin_stem_wgrad(const void* dy, const void* rec, float* dw, int accumulate, float* scratch, long scratch_floats, int frames,
+                                 int H, int W, void* stream) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  if (frames <= 0 || H <= 0 || W <= 0 || !dw) return -1721;
+  if (Wo % 128) return -1722;                                   // (the caller keeps stswin_gemm_tn over the row map)
+  const long nunits = (long)frames * (Wo / 128) * Ho;
+  const long g0 = nunits < 256 ? nunits : 256, per = (nunits + g0 - 1) / g0;
+  const int grid = (int)((nunits + per - 1) / per);
+  if (!scratch || scratch_floats < (long)grid * 64 * 256) return -1723;
+  StemWgradArgs a{(const bf16*)rec, (const bf16*)dy, scratch, frames, Ho, Wo, Ho + 3, Wo + 3, per};
+  static const int attr = (int)hipFuncSetAttribute((const void*)stem_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS);
+  if (attr != 0) return -attr;
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(512), SW_LDS, (hipStream_t)stream, a);
+  STSWIN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(chw_fold_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, scratch, grid, 256, dw, 0, accumulate ? 1 : 0);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

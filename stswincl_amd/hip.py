@@ -207,20 +207,32 @@ class deferred_folds:
 # bench.py brackets every launch of the dominant kernels with HIP events recorded on the launch stream (torch's
 # current stream IS the stream the kernels are launched on) and reads them back after the timed region.
 # Two event records per launch cost ~1.7 ms of host time per training step (480 spans), which would make the timed
-# region launch-bound; `stride` > 1 brackets each launch with probability 1 / stride (a seeded generator: every launch
-# site is equally likely whatever the number of launches per step - a fixed stride that divides the launches per step
-# would time the same sites every step), the others are only counted.
+# region launch-bound; `stride` > 1 brackets one launch in `stride`.  WHICH ones rotates with the step (profile_step(k), called by
+# the caller before step k): launch number n of a kernel family inside step k is timed iff (n + k) % stride == 0, so over `stride`
+# steps every launch site of the step is timed exactly once and the average is the exact per-site average - not a sample whose
+# composition changes whenever a launch is added or removed elsewhere (a seeded random choice moved the reported gemm_nt
+# fraction by +-0.01 between trees with identical gemm_nt launches).  Without profile_step the choice is the seeded random one.
 _PROFILE = None
 _PROFILE_STRIDE = 1
 _PROFILE_COUNT = {}
+_PROFILE_STEP_COUNT = None            # per-step launch numbers (rotating mode) or None (random mode)
+_PROFILE_OFFSET = 0
 _PROFILE_RNG = None
 _PROFILE_ALWAYS = ("contrast_",)      # kernels launched once per step: every launch is timed
 
 
 def profile_begin(stride: int = 1):
-    global _PROFILE, _PROFILE_STRIDE, _PROFILE_COUNT, _PROFILE_RNG
+    global _PROFILE, _PROFILE_STRIDE, _PROFILE_COUNT, _PROFILE_RNG, _PROFILE_STEP_COUNT, _PROFILE_OFFSET
     import random
     _PROFILE, _PROFILE_STRIDE, _PROFILE_COUNT, _PROFILE_RNG = {}, max(1, int(stride)), {}, random.Random(12345)
+    _PROFILE_STEP_COUNT, _PROFILE_OFFSET = None, 0
+
+
+def profile_step(k: int):
+    """Start of timed step k: switch to (or stay in) the rotating choice of timed launches."""
+    global _PROFILE_STEP_COUNT, _PROFILE_OFFSET
+    if _PROFILE is not None:
+        _PROFILE_STEP_COUNT, _PROFILE_OFFSET = {}, int(k) % _PROFILE_STRIDE
 
 
 def profile_end():
@@ -249,7 +261,13 @@ class _Span:
         if _PROFILE is not None:
             n = _PROFILE_COUNT.get(self.name, 0)
             _PROFILE_COUNT[self.name] = n + 1
-            if _PROFILE_STRIDE == 1 or self.name.startswith(_PROFILE_ALWAYS) or _PROFILE_RNG.random() * _PROFILE_STRIDE < 1.0:
+            if _PROFILE_STEP_COUNT is not None:
+                m = _PROFILE_STEP_COUNT.get(self.name, 0)
+                _PROFILE_STEP_COUNT[self.name] = m + 1
+                pick = (m + _PROFILE_OFFSET) % _PROFILE_STRIDE == 0
+            else:
+                pick = _PROFILE_RNG.random() * _PROFILE_STRIDE < 1.0
+            if _PROFILE_STRIDE == 1 or self.name.startswith(_PROFILE_ALWAYS) or pick:
                 self.a = torch.cuda.Event(enable_timing=True)
                 self.a.record()
         return self
@@ -375,6 +393,23 @@ def stem_s2d(img: torch.Tensor, dtype: torch.dtype):
     return torch.as_strided(flat, (n, 64), (16, 1)), Hs, Ws
 
 
+def stem_wgrad_ok(H, W, dtype) -> bool:
+    return dtype == torch.bfloat16 and ((W - 1) // 2 + 1) % 128 == 0
+
+
+def stem_wgrad(dy, A, dw, frames, H, W, accumulate=False):
+    """dw fp32 [64][256] (= [cout][tap row][record][16]) from dy [F*Ho*Wo][64] and the hip.stem_s2d view A of the same images."""
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    assert dy.dtype == torch.bfloat16 and dy.shape == (frames * Ho * Wo, 64) and dy.is_contiguous()
+    assert A.dtype == torch.bfloat16 and A.stride() == (16, 1) and A.shape[0] == frames * (Ho + 3) * (Wo + 3)
+    assert dw.dtype == torch.float32 and dw.numel() == 64 * 256 and dw.is_contiguous()
+    ws = scratch(dy.device, load().stswin_stem_wgrad_scratch(frames, Ho, Wo))
+    with _Span("stem_wgrad_bf16", 2.0 * frames * Ho * Wo * 64 * 147):
+        rc = load().stswin_stem_wgrad(_p(dy), _p(A), _p(dw), 1 if accumulate else 0, _p(ws), _c_long(ws.numel()), frames, H, W, _stream())
+    _check(rc, "stem_wgrad")
+    return dw
+
+
 def maxpool3x3s2(src, dst, arg, frames, H, W, Ho, Wo, backward=False):
     C = src.shape[1]
     _check(load().stswin_maxpool3x3s2(_dt(src), _p(src), _c_long(_ld(src)), _p(dst), _c_long(_ld(dst)), _p(arg), frames, H,
@@ -395,7 +430,9 @@ def conv3x3_c64(x, wmat, y, frames, H, W, sign=1, resid=None, stats_out=None):
         assert t is None or (t.dtype == torch.bfloat16 and t.shape == (M, 64) and t.is_contiguous())
     assert wmat.dtype == torch.bfloat16 and wmat.shape == (64, 576) and wmat.is_contiguous()
     assert stats_out is None or (stats_out.dtype == torch.float32 and stats_out.numel() == 2 * 2 * ((M + 255) // 256) * 64)
-    _check(load().stswin_conv3x3_c64(_p(x), _p(wmat), _p(y), _p(resid), _p(stats_out), frames, H, W, sign, _stream()), "conv3x3_c64")
+    with _Span("conv3x3_c64_bf16", 2.0 * M * 64 * 576):
+        rc = load().stswin_conv3x3_c64(_p(x), _p(wmat), _p(y), _p(resid), _p(stats_out), frames, H, W, sign, _stream())
+    _check(rc, "conv3x3_c64")
     return y
 
 
@@ -411,8 +448,10 @@ def conv3x3_c64_wgrad(dy, x, dw, frames, H, W, tapminor=True, accumulate=False):
     assert dw.dtype == torch.float32 and dw.numel() == 64 * 576 and dw.is_contiguous()
     need = load().stswin_conv3x3_c64_wgrad_scratch(frames, H, W)
     ws = scratch(x.device, need)
-    _check(load().stswin_conv3x3_c64_wgrad(_p(dy), _p(x), _p(dw), 1 if tapminor else 0, 1 if accumulate else 0, _p(ws), _c_long(ws.numel()),
-                                           frames, H, W, _stream()), "conv3x3_c64_wgrad")
+    with _Span("conv3x3_c64_wgrad_bf16", 2.0 * M * 64 * 576):
+        rc = load().stswin_conv3x3_c64_wgrad(_p(dy), _p(x), _p(dw), 1 if tapminor else 0, 1 if accumulate else 0, _p(ws), _c_long(ws.numel()),
+                                             frames, H, W, _stream())
+    _check(rc, "conv3x3_c64_wgrad")
     return dw
 
 

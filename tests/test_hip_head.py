@@ -567,3 +567,37 @@ def test_halo_wgrad_c64_matches_fp64_and_gemm_tn(f, h, w):
     rep = torch.empty_like(dw_t)
     hip.conv3x3_c64_wgrad(dy, x, rep, f, h, w, tapminor=True)
     assert torch.equal(rep, dw_t)
+
+
+@pytest.mark.parametrize("f,hh,ww", [(2, 64, 256), (1, 37, 255), (3, 16, 512), (16, 512, 512)])
+def test_stem_wgrad_ring_kernel_matches_fp64_and_gemm_tn(f, hh, ww):
+    """stswin_stem_wgrad against the fp64 weight gradient of the 7x7 / 2 / 3 convolution on the same bf16 operands, and against the
+    gemm_tn path over the row map; bitwise reproducible; accumulate."""
+    from stswincl_amd import hip
+    torch.manual_seed(f + hh + ww)
+    img = torch.randn(f, 3, hh, ww, device="cuda")
+    ho, wo = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+    M = f * ho * wo
+    dy = (torch.randn(M, 64, device="cuda") / 8).to(torch.bfloat16)
+    A, hs, ws = hip.stem_s2d(img, torch.bfloat16)
+    assert hip.stem_wgrad_ok(hh, ww, torch.bfloat16)
+    dw = torch.empty(64, 256, dtype=torch.float32, device="cuda")
+    hip.stem_wgrad(dy, A, dw, f, hh, ww)
+    got = H._stem_unpack(dw).double()
+    gi = dy.double().view(f, ho, wo, 64).permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(img.to(torch.bfloat16).double(), (64, 3, 7, 7), gi, stride=2, padding=3)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-5 * scale + 1e-6 * M ** 0.5
+    # the structural zeros of the packed layout (taps outside the 7x7 window, positions 12..15) stay exactly zero
+    full = dw.view(64, 4, 4, 16)
+    assert float(full[..., 12:].abs().max()) == 0.0
+    rmap = H._stem_rowmap(f, ho, wo, hs, ws, "cuda")
+    old = torch.empty_like(dw)
+    hip.gemm_tn(dy, A, old, Mk=M, bt_rows=rmap, bseg=64, overwrite=True)
+    hip.tn_join()
+    assert float((old - dw).abs().max()) <= 5e-3 * scale
+    rep = torch.empty_like(dw)
+    hip.stem_wgrad(dy, A, rep, f, hh, ww)
+    assert torch.equal(rep, dw)
+    hip.stem_wgrad(dy, A, rep, f, hh, ww, accumulate=True)
+    assert torch.equal(rep, dw + dw)

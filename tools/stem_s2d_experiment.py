@@ -76,6 +76,9 @@ def main():
     dw1 = torch.empty(64, 256, dtype=torch.float32, device="cuda")
     print(f"gemm_tn patches             {timeit(lambda: (hip.gemm_tn(dy, patches, dw0, Mk=M, overwrite=True), hip.tn_join())):8.1f} us")
     print(f"gemm_tn s2d gather          {timeit(lambda: (hip.gemm_tn(dy, A, dw1, Mk=M, bt_rows=rmap, bseg=64, overwrite=True), hip.tn_join())):8.1f} us")
+    dw2 = torch.empty(64, 256, dtype=torch.float32, device="cuda")
+    print(f"stem_wgrad ring + fold      {timeit(lambda: hip.stem_wgrad(dy, A, dw2, Fr, H, W)):8.1f} us")
+    print("ring vs gather max diff", float((dw2 - dw1).abs().max()))
     g0 = dw0[:, :147].reshape(64, 7, 7, 3).permute(0, 3, 1, 2)
     g1 = dw1.view(64, 4, 4, 16)[..., :12].reshape(64, 4, 4, 2, 2, 3).permute(0, 5, 1, 3, 2, 4).reshape(64, 3, 8, 8)[:, :, 1:, 1:]
     print("wgrad max diff / max", float((g0 - g1).abs().max()), float(g0.abs().max()))
