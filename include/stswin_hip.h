@@ -313,6 +313,13 @@ int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx,
                   float* scratch /* phases 0 / 1: >= stswin_bn_bwd_scratch(...) floats (per-chunk partial sums, folded into s1 / s2) */,
                   void* stream);
 long stswin_bn_bwd_scratch(int dtype, int M, int C, int groups, int unit_rows);
+/* BatchNorm + ReLU + nn.MaxPool2d(3, 2, 1) in one pass (torchvision resnet18 conv1 -> bn1 -> relu -> maxpool, resnet.py:98-102):
+ * x [frames*H*W][C] = the BatchNorm's input, out [frames*Hp*Wp][C] (Hp = (H-1)/2 + 1), arg (uint8, same shape) = winning tap per
+ * value (first maximum in (ky, kx) scan order).  Candidates are stswin_bn_apply's values rounded to the compute dtype, so out and
+ * arg equal those of stswin_bn_apply + stswin_maxpool3x3s2 (whose backward form takes arg).  Statistic groups as in stswin_bn_apply
+ * (whole frames per group). */
+int stswin_bn_relu_pool(int dtype, const void* x, long ldx, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        void* out, long ldo, unsigned char* arg, int frames, int H, int W, int C, int groups, int unit_rows, void* stream);
 /* out[r][c] (+)= v[r / (M/groups)][c] * scale : image-pool broadcast (ASPP.py:46) and avg-pool backward */
 int stswin_rows_broadcast(int dtype, const float* v, void* out, long ldo, int M, int C, int groups, float scale,
                           int accumulate, void* stream);

@@ -630,6 +630,102 @@ extern "C" int stswin_bn_bwd(int dtype, const void* dy, long lddy, const void* x
   return 0;
 }
 
+// BatchNorm (batch or running statistics of `groups` statistic groups) + ReLU + nn.MaxPool2d(3, 2, 1) in one pass over the
+// BatchNorm's input: out [frames*Hp*Wp][C], arg = winning tap per value (first maximum in (ky, kx) scan order, like torch and
+// like maxpool_fwd_kernel).  Each candidate is bn_apply_kernel's expression rounded to T before it is compared, so output and
+// taps are those of the two-pass form.  torchvision resnet18 conv1 -> bn1 -> relu -> maxpool, resnet.py:98-102.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const T* x, long ldx, const float* mean, const float* rstd, const float* gamma,
+                                                            const float* beta, T* out, long ldo, unsigned char* arg, int frames, int H,
+                                                            int W, int Hp, int Wp, int C, int G, int group_rows, int unit) {
+  // A thread owns a 2 x 2 block of pooled pixels of one 16-byte channel chunk: their windows share a 5 x 5 patch of the input
+  // (25 loads and BatchNorm evaluations instead of 36), scanned row by row so every output meets its taps in (ky, kx) order.
+  constexpr int PACK = TT<T>::PACK;
+  const int ppr = C / PACK, Hb = (Hp + 1) >> 1, Wb = (Wp + 1) >> 1;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)frames * Hb * Wb * ppr) return;
+  const int c = (int)(idx % ppr) * PACK;
+  const long pb = idx / ppr;
+  const int xb = (int)(pb % Wb), yb = (int)((pb / Wb) % Hb);
+  const long f = pb / ((long)Wb * Hb);
+  const long row0 = f * H * W;
+  const int g = unit > 0 ? (int)((row0 / unit) % G) : (int)(row0 / group_rows);
+  float sc[8], sh[8], best[4][8];
+  unsigned char ba[4][8];
+#pragma unroll
+  for (int e = 0; e < PACK; ++e) {
+    const float rs = rstd[(long)g * C + c + e] * gamma[c + e];
+    sc[e] = rs;
+    sh[e] = beta[c + e] - mean[(long)g * C + c + e] * rs;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { best[o][e] = -3.0e38f; ba[o][e] = 255; }
+  }
+  const int y0 = 4 * yb - 1, x0 = 4 * xb - 1;           // input coordinates of the patch origin (pooled (2 yb, 2 xb), tap (0, 0))
+#pragma unroll
+  for (int iy = 0; iy < 5; ++iy) {
+    const int yy = y0 + iy;
+    if (yy < 0 || yy >= H) continue;
+#pragma unroll
+    for (int ix = 0; ix < 5; ++ix) {
+      const int xx = x0 + ix;
+      if (xx < 0 || xx >= W) continue;
+      Vec16<T> v, z;
+      v.v = *(const decltype(v.v)*)(x + (row0 + (long)yy * W + xx) * ldx + c);
+#pragma unroll
+      for (int e = 0; e < PACK; ++e) z.set(e, fmaxf(v.get(e) * sc[e] + sh[e], 0.f));
+#pragma unroll
+      for (int oy = 0; oy < 2; ++oy) {
+        const int ky = iy - 2 * oy;                      // tap row of this input row in output row 2 yb + oy
+        if (ky < 0 || ky > 2) continue;
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox) {
+          const int kx = ix - 2 * ox;
+          if (kx < 0 || kx > 2) continue;
+          const int o = oy * 2 + ox;
+          const unsigned char t = (unsigned char)(ky * 3 + kx);
+#pragma unroll
+          for (int e = 0; e < PACK; ++e) {
+            const float u = z.get(e);
+            if (u > best[o][e] || ba[o][e] == 255) { best[o][e] = u; ba[o][e] = t; }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+    for (int ox = 0; ox < 2; ++ox) {
+      const int yo = 2 * yb + oy, xo = 2 * xb + ox, o = oy * 2 + ox;
+      if (yo >= Hp || xo >= Wp) continue;
+      const long px = (f * Hp + yo) * Wp + xo;
+      Vec16<T> r;
+      unsigned a[2] = {0, 0};
+#pragma unroll
+      for (int e = 0; e < PACK; ++e) { r.set(e, best[o][e]); a[e >> 2] |= (unsigned)ba[o][e] << (8 * (e & 3)); }
+      if (PACK == 8) *(uint2*)(arg + px * C + c) = uint2{a[0], a[1]};
+      else *(unsigned*)(arg + px * C + c) = a[0];
+      *(decltype(r.v)*)(out + px * ldo + c) = r.v;
+    }
+}
+
+extern "C" int stswin_bn_relu_pool(int dtype, const void* x, long ldx, const float* mean, const float* rstd, const float* gamma,
+                                   const float* beta, void* out, long ldo, unsigned char* arg, int frames, int H, int W, int C, int groups,
+                                   int unit_rows, void* stream) {
+  const int pk = PACK_OF(dtype);
+  const long M = (long)frames * H * W;
+  if (frames <= 0 || H <= 0 || W <= 0 || C % pk || ldx % pk || ldo % pk || groups <= 0 || M % groups) return -1408;
+  if (unit_rows > 0 ? (unit_rows % ((long)H * W) != 0 || M % ((long)groups * unit_rows)) : ((M / groups) % ((long)H * W) != 0)) return -1408;
+  const int Hp = (H - 1) / 2 + 1, Wp = (W - 1) / 2 + 1;
+  const long n = (long)frames * ((Hp + 1) / 2) * ((Wp + 1) / 2) * (C / pk);
+  dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_pool_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, ldx, mean, rstd, gamma, beta, (bf16*)out, ldo, arg, frames, H, W, Hp, Wp, C, groups, (int)(M / groups), unit_rows),
+             hipLaunchKernelGGL(bn_relu_pool_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, mean, rstd, gamma, beta, (float*)out, ldo, arg, frames, H, W, Hp, Wp, C, groups, (int)(M / groups), unit_rows));
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int stswin_rows_broadcast(int dtype, const float* v, void* out, long ldo, int M, int C, int groups, float scale,
                                      int accumulate, void* stream) {
   const int pk = PACK_OF(dtype);

@@ -342,17 +342,26 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dout, long ld
   const long px = idx / ppr;
   const int x = px % W, y = (px / W) % H, f = px / ((long)W * H);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int t = 0; t < 9; ++t) {       // output pixel (yo,xo) reads (y,x) through tap t iff 2yo-1+t/3 == y
-    const int ny = y + 1 - t / 3, nx = x + 1 - t % 3;
-    if (ny < 0 || nx < 0 || (ny & 1) || (nx & 1)) continue;
-    const int yo = ny >> 1, xo = nx >> 1;
-    if (yo >= Ho || xo >= Wo) continue;
-    const long po = ((long)f * Ho + yo) * Wo + xo;
-    Vec16<T> d;
-    d.v = *(const decltype(d.v)*)(dout + po * ldo + c);
+  // output pixel (yo, xo) reads (y, x) through tap (ty, tx) iff 2 yo - 1 + ty == y: an odd coordinate has the candidates ty = 0 and
+  // ty = 2, an even one only ty = 1 - at most four output pixels, visited in tap order; their winning-tap bytes come in one load
+  const int ny = (y & 1) ? 2 : 1, nx = (x & 1) ? 2 : 1;
+  for (int iy = 0; iy < ny; ++iy) {
+    const int ty = (y & 1) ? 2 * iy : 1, yo = (y + 1 - ty) >> 1;
+    if (yo >= Ho) continue;
+    for (int ix = 0; ix < nx; ++ix) {
+      const int tx = (x & 1) ? 2 * ix : 1, xo = (x + 1 - tx) >> 1;
+      if (xo >= Wo) continue;
+      const unsigned t = (unsigned)(ty * 3 + tx);
+      const long po = ((long)f * Ho + yo) * Wo + xo;
+      Vec16<T> d;
+      d.v = *(const decltype(d.v)*)(dout + po * ldo + c);
+      unsigned a[2] = {0, 0};
+      if (PACK == 8) { const uint2 w = *(const uint2*)(arg + po * C + c); a[0] = w.x; a[1] = w.y; }
+      else a[0] = *(const unsigned*)(arg + po * C + c);
 #pragma unroll
-    for (int e = 0; e < PACK; ++e)
-      if (arg[po * C + c + e] == t) acc[e] += d.get(e);
+      for (int e = 0; e < PACK; ++e)
+        if (((a[e >> 2] >> (8 * (e & 3))) & 0xFFu) == t) acc[e] += d.get(e);
+    }
   }
   Vec16<T> o;
 #pragma unroll

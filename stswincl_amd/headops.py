@@ -693,6 +693,79 @@ def batchnorm_tokens(x, bn: torch.nn.BatchNorm2d, relu=True, resid=None, groups=
                          stats if (training and world == 1) else None, resid_link if resid is not None else None, out)
 
 
+class BNReluPoolFn(torch.autograd.Function):
+    """nn.BatchNorm2d + ReLU + nn.MaxPool2d(3, 2, 1) on tokens as ONE pass forward (the normalised map is never stored): the tail of
+    the torchvision stem, resnet.py:98-102.  Backward: the max-pool scatter (gather form, through the winning-tap bytes) and the two
+    BatchNorm passes with the ReLU mask recomputed from the input.  Values, taps and gradients are those of BNTokFn followed by
+    MaxPoolTokFn.  (A variant whose BatchNorm passes gathered the pooled gradient themselves - no max-pool backward pass - measured
+    SLOWER, 253 us against 68 + 146 us: the gather then runs twice, and it breaks the four-rows-in-flight load batching of those passes.)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, groups, eps, momentum, unit, stats, geom):
+        frames, Hh, Ww = geom
+        dt = compute_dtype(x)
+        X = x.detach().to(dt)
+        M, C = X.shape
+        if training:
+            raw = stats is not None and groups <= 32 and ((unit % 256 == 0) if unit > 0 else ((M // groups) % 256 == 0))
+            if raw:
+                mean, rstd = hip.bn_table_finalize(stats, M, running_mean, running_var, groups, eps, momentum, unit=unit)
+            else:
+                s, ss = hip.colstats(X, groups=groups, unit=unit)
+                mean, rstd = hip.bn_finalize(X, s, ss, running_mean, running_var, groups, eps, momentum, unit=unit)
+        else:
+            mean = running_mean.float().view(1, C).expand(groups, C).contiguous()
+            rstd = torch.rsqrt(running_var.float() + eps).view(1, C).expand(groups, C).contiguous()
+        gp, bp = _f32(gamma), _f32(beta)
+        y, arg = hip.bn_relu_pool(X, mean, rstd, gp, bp, frames, Hh, Ww, groups=groups, unit=unit)
+        ctx.cfg = (training, groups, unit, geom, x.dtype)
+        ctx.save_for_backward(X, arg, mean, rstd, gp, bp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        X, arg, mean, rstd, gp, bp = ctx.saved_tensors
+        training, groups, unit, (frames, Hh, Ww), in_dtype = ctx.cfg
+        g = rowmajor(dy, X.dtype).contiguous()
+        Hp, Wp = (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1
+        dz = torch.empty_like(X)
+        hip.maxpool3x3s2(g, dz, arg, frames, Hh, Ww, Hp, Wp, backward=True)
+        dx = torch.empty_like(X)
+        gs = torch.empty(2, X.shape[1], dtype=torch.float32, device=X.device) if groups > 1 else None
+        s1, s2 = hip.bn_bwd(dz, X, None, mean, rstd, gp, dx, None, groups, True, training, beta=bp, unit=unit, group_sums=gs)
+        if gs is not None:
+            s1, s2 = gs[0:1], gs[1:2]
+        return (dx.to(in_dtype), s2[0], s1[0]) + (None,) * 9
+
+
+_FUSED_STEM_TAIL = os.environ.get("STSWIN_NO_FUSED_STEM_TAIL") != "1"      # (A/B switch)
+
+
+def batchnorm_relu_maxpool_tokens(x, bn: torch.nn.BatchNorm2d, geom, groups=1, il_frames: int = 0, stats=None):
+    """bn -> relu -> MaxPool2d(3, 2, 1) of a token map [frames*H*W][C] (geom = (frames, H, W)); one fused pass each way where the
+    BatchNorm is local (no SyncBatchNorm) - else the two separate operators."""
+    frames, Hh, Ww = geom
+    training = bn.training or bn.running_mean is None
+    world = _sync_world(bn) if training else 1
+    if not _FUSED_STEM_TAIL or world > 1 or bn.running_mean is None or x.shape[1] % 8:
+        return MaxPoolTokFn.apply(batchnorm_tokens(x, bn, relu=True, groups=groups, il_frames=il_frames, stats=stats), geom)
+    if _BN_VIEWS is not None and training:                 # (view batching: as batchnorm_tokens)
+        views, clips = _BN_VIEWS
+        if il_frames:
+            groups = groups * views
+        else:
+            assert groups == 1, "view batching: contiguous multi-group BatchNorm inside an encoder is not supported"
+            groups, il_frames = views, clips
+    if training and bn.num_batches_tracked is not None:
+        if _NBT_PENDING is not None:
+            _NBT_PENDING.append((bn.num_batches_tracked, groups))
+        else:
+            bn.num_batches_tracked += groups
+    unit = (x.shape[0] // il_frames) if (il_frames and groups > 1) else 0
+    return BNReluPoolFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, groups, bn.eps,
+                              bn.momentum if bn.momentum is not None else 0.1, unit, stats if training else None, geom)
+
+
 class BilinearTokFn(torch.autograd.Function):
     """F.interpolate(mode='bilinear', align_corners=False) on tokens: [F*h*w][C] -> [F*H*W][C]."""
 

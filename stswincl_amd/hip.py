@@ -850,6 +850,17 @@ def bn_bwd(dy, x, y, mean, rstd, gamma, dx, dresid=None, groups=1, relu=True, tr
     return s1, s2
 
 
+def bn_relu_pool(x, mean, rstd, gamma, beta, frames, H, W, groups=1, unit=0):
+    """-> (pooled [frames*Hp*Wp][C], arg uint8): BatchNorm + ReLU + MaxPool2d(3, 2, 1) of x [frames*H*W][C] in one pass."""
+    C = x.shape[1]
+    Hp, Wp = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty(frames * Hp * Wp, C, dtype=x.dtype, device=x.device)
+    arg = torch.empty(frames * Hp * Wp, C, dtype=torch.uint8, device=x.device)
+    _check(load().stswin_bn_relu_pool(_dt(x), _p(x), _c_long(_ld(x)), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(out), _c_long(_ld(out)),
+                                      _p(arg), frames, H, W, C, groups, unit, _stream()), "bn_relu_pool")
+    return out, arg
+
+
 def rows_broadcast(v, out, groups, scale=1.0, accumulate=False, M=None):
     M = out.shape[0] if M is None else M
     _check(load().stswin_rows_broadcast(_dt(out), _p(v), _p(out), _c_long(_ld(out)), M, v.shape[1], groups,

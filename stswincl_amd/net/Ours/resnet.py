@@ -112,8 +112,7 @@ class ResNet_BasicBlock_OS8(nn.Module):
         dt = compute_dtype(img)
         x, tab = H.stem_conv_tokens(img, self.resnet[0].weight, dt, stats=self.resnet[1].training and H._sync_world(self.resnet[1]) == 1)
         h, w = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
-        x = H.batchnorm_tokens(x, self.resnet[1], relu=True, groups=groups, il_frames=f if il else 0, stats=tab)
-        x = H.MaxPoolTokFn.apply(x, (f, h, w))
+        x = H.batchnorm_relu_maxpool_tokens(x, self.resnet[1], (f, h, w), groups=groups, il_frames=f if il else 0, stats=tab)
         h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         for layer in (self.resnet[4], self.resnet[5], self.layer4, self.layer5):
             for blk in layer:

@@ -601,3 +601,49 @@ def test_stem_wgrad_ring_kernel_matches_fp64_and_gemm_tn(f, hh, ww):
     assert torch.equal(rep, dw)
     hip.stem_wgrad(dy, A, rep, f, hh, ww, accumulate=True)
     assert torch.equal(rep, dw + dw)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("f,hh,ww,groups,il,train", [(4, 16, 16, 1, False, True), (8, 32, 16, 4, True, True), (4, 17, 13, 1, False, True),
+                                                     (4, 32, 32, 2, False, True), (3, 16, 24, 1, False, False)])
+def test_fused_bn_relu_maxpool_equals_the_two_operators(mode, f, hh, ww, groups, il, train):
+    """BNReluPoolFn (stswin_bn_relu_pool; the stem tail conv1 -> bn1 -> relu -> maxpool of resnet.py:98-102) against
+    BNTokFn + MaxPoolTokFn: pooled values, running statistics and every gradient are bitwise the same (same expressions, same
+    rounding points, same summation order); and against torch on the CPU."""
+    torch.manual_seed(f * hh + ww)
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    x0 = torch.randn(f * hh * ww, 64, device="cuda")
+    res = []
+    for fused in (True, False):
+        H._FUSED_STEM_TAIL = fused
+        try:
+            bn = nn.BatchNorm2d(64).cuda()
+            with torch.no_grad():
+                bn.weight.copy_(torch.linspace(0.5, 1.5, 64))
+                bn.bias.copy_(torch.linspace(-0.3, 0.3, 64))
+                bn.running_mean.copy_(torch.linspace(-0.1, 0.1, 64))
+                bn.running_var.copy_(torch.linspace(0.8, 1.2, 64))
+            bn.train(train)
+            x = x0.clone().to(dt).requires_grad_(True)
+            y = H.batchnorm_relu_maxpool_tokens(x, bn, (f, hh, ww), groups=groups, il_frames=f if il else 0)
+            w = torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)
+            (y.float() * w).sum().backward()
+            res.append((y.detach().clone(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(),
+                        bn.running_var.clone(), int(bn.num_batches_tracked)))
+        finally:
+            H._FUSED_STEM_TAIL = True
+    for a, b in zip(*res):
+        assert (a == b) if isinstance(a, int) else torch.equal(a, b)
+    if groups == 1 and mode == "fp32":
+        bn = nn.BatchNorm2d(64)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, 64)); bn.bias.copy_(torch.linspace(-0.3, 0.3, 64))
+            bn.running_mean.copy_(torch.linspace(-0.1, 0.1, 64)); bn.running_var.copy_(torch.linspace(0.8, 1.2, 64))
+        bn.train(train)
+        xc = x0.cpu().view(f, hh, ww, 64).permute(0, 3, 1, 2).clone().requires_grad_(True)
+        yc = F.max_pool2d(F.relu(bn(xc)), 3, 2, 1)
+        wc = torch.linspace(-1, 1, yc.numel()).view(f, yc.shape[2], yc.shape[3], 64).permute(0, 3, 1, 2)
+        (yc * wc).sum().backward()
+        assert rel(H.from_tokens(res[0][0], f, yc.shape[2], yc.shape[3]), yc) < 1e-5
+        assert rel(H.from_tokens(res[0][1], f, hh, ww), xc.grad) < 1e-4
+        assert rel(res[0][2], bn.weight.grad) < 1e-4 and rel(res[0][3], bn.bias.grad) < 1e-4
