@@ -83,6 +83,11 @@ int stswin_stem_s2d(int dtype, const float* img, void* out, int frames, int H, i
  * dw fp32 [64][4][4][16] = [cout][tap row][record][position], the order stswin_gemm_tn produces over the row map (accumulate != 0 adds).
  * Record rows pass through an LDS ring once; per-workgroup partials go to `scratch` (>= stswin_stem_wgrad_scratch floats) and are added
  * in a fixed order.  Wo = (W-1)/2 + 1 must be a multiple of 128, else -1722 and nothing is launched.  resnet.py:98-102 backward. */
+/* The stem convolution over the space-to-depth image `rec` of stswin_stem_s2d (bf16): y bf16 [F*Ho*Wo][64] = conv(7, 2, 3) with
+ * wmat bf16 [64][4][4][16] (= [cout][tap row][record][position], zeros where the 7 x 7 window has no tap); stats (or NULL): the
+ * STSWIN_GF_CS_SQ table of y.  Record rows pass through an LDS ring once, the weights live in registers: replaces stswin_gemm_nt
+ * over the row map for this M = F*Ho*Wo, N = 64, K = 256 shape.  Wo % 128 != 0: -1732, nothing launched.  resnet.py:98-102. */
+int stswin_stem_conv(const void* rec, const void* wmat, void* y, float* stats, int frames, int H, int W, void* stream);
 long stswin_stem_wgrad_scratch(int frames, int Ho, int Wo);
 int stswin_stem_wgrad(const void* dy, const void* rec, float* dw, int accumulate, float* scratch, long scratch_floats, int frames, int H, int W,
                       void* stream);

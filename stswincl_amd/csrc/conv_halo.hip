@@ -675,3 +675,164 @@ extern "C" int stswin_stem_wgrad(const void* dy, const void* rec, float* dw, int
   STSWIN_CHECK_LAUNCH();
   return 0;
 }
+
+// =====================================================================================================================
+// The stem convolution itself over the space-to-depth image (resnet.py:98-102 forward):
+//   y[p][co] = sum_{s, t, ch} rec[(oy + s, ox + t)][ch] * W[co][s][t][ch]          K = 4 * 4 * 16 = 256 (147 of them non-zero)
+// The gather GEMM reads 4 x 128 bytes per output pixel through its row map and runs this M = 1 M, N = 64 shape at 230-315 TFLOP/s.
+// Same skeleton as stem_wgrad_kernel: a workgroup walks down a 128-pixel-wide strip, one new row of records per unit through the
+// 8-slot LDS ring (requested by waves 4-7); waves 0-3 own 32 pixels each, hold the whole 64 x 256 weight matrix in 128 registers
+// and read pixel fragments as plain 16-byte LDS loads (a record is 32 bytes: the k group picks the record and its half).  Weights
+// are the first MFMA operand with permuted rows, so a lane ends up with 16 consecutive channels of its pixel.  Column sums and
+// sums of squares go to the BatchNorm statistics table once per run of units (reducing them over lanes for every unit cost 26 of
+// 70 us): the table row of a run's first 128-row block holds the run's sums, the rows of its other blocks are zero.
+// =====================================================================================================================
+struct StemConvArgs {
+  const bf16* REC; const bf16* Wm; bf16* Y; float* stats;
+  int frames, Ho, Wo, Hs, Ws; long per, M;
+};
+
+constexpr int SC_EX = 4 * 2 * 64 * 4;                   // statistics exchange: [wave][sum | squares][64] floats
+constexpr int SC_LDS = SW_XB + SC_EX;
+
+__global__ __launch_bounds__(512) void stem_conv_kernel(StemConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63, w = wave_id();
+  const int fr = l & 15, fq = l >> 4;
+  char* xr = smem;
+  float* ex = (float*)(smem + SW_XB);
+  const int nxh = a.Wo >> 7;
+  const long nunits = (long)a.frames * nxh * a.Ho;
+  const long u0 = blockIdx.x * a.per, u1 = u0 + a.per < nunits ? u0 + a.per : nunits;
+  if (w >= 4) {                                        // loader waves: the record rows
+    const int lw = w - 4;
+    bool full = true;
+    StemWgradArgs ia{a.REC, nullptr, nullptr, a.frames, a.Ho, a.Wo, a.Hs, a.Ws, a.per};
+    for (long u = u0; u < u1; ++u) {
+      const int strip = (int)(u / a.Ho), oy = (int)(u - (long)strip * a.Ho), f = strip / nxh, x0 = (strip - f * nxh) << 7;
+      if (full) {
+        if (u > u0) __syncthreads();
+        for (int n = lw; n < 5 * 4; n += 4) sw_issue(ia, n, 4, f, oy, x0, 0, xr, nullptr, l);
+      }
+      wait_vm0();
+      __syncthreads();
+      const bool next = u + 1 < u1 && oy + 1 < a.Ho;
+      full = u + 1 < u1 && !next;
+      if (next)
+        for (int n = lw; n < 5; n += 4) sw_issue(ia, n, 1, f, oy + 4, x0, 0, xr, nullptr, l);
+      if (a.stats && !next) __syncthreads();           // (end of a run inside one strip: the multiplying waves exchange their sums)
+    }
+    return;
+  }
+  // weights -> registers: MFMA row m of channel tile j = channel 16 (m / 4) + 4 j + (m % 4), k group fq of step ks
+  bf16x8 wf[8][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bf16* wr = a.Wm + (long)(16 * (fr >> 2) + 4 * j + (fr & 3)) * 256 + fq * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) wf[ks][j] = *(const bf16x8*)(wr + ks * 32);
+  }
+  // pixel fragment address: record (tap row s = ks / 2 -> ring slot; column pixel + t, t = 2 (ks & 1) + fq / 2), half fq & 1
+  const int lane_off = (32 * w + fr + (fq >> 1)) * 32 + (fq & 1) * 16;
+  // BatchNorm statistics: a lane keeps the column sums | sums of squares of its pixels over a whole RUN (consecutive units of one
+  // strip of one frame); they are reduced over lanes and waves once per run and stored in the table row of the run's first
+  // 128-row block, the rows of its other blocks are zero - the table's readers add the rows of whole frames.
+  float s1[16], s2[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+  const long nblk = 2 * ((a.M + 255) >> 8);
+  long run_blk = -1;
+  bool full = false;
+  for (long u = u0; u < u1; ++u) {
+    const int strip = (int)(u / a.Ho), oy = (int)(u - (long)strip * a.Ho), f = strip / nxh, x0 = (strip - f * nxh) << 7;
+    const long pix0 = ((long)f * a.Ho + oy) * a.Wo + x0;
+    if (full) __syncthreads();
+    __syncthreads();                                   // unit u is in place
+    const bool next = u + 1 < u1 && oy + 1 < a.Ho;
+    full = u + 1 < u1 && !next;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[2][2];
+#define SC_LOAD(ks)                                                                                                               \
+  {                                                                                                                                \
+    const char* rb = xr + ((oy + ((ks) >> 1)) & 7) * SW_ROWP + lane_off + ((ks) & 1) * 2 * 32;                                       \
+    xf[(ks) & 1][0] = *(const bf16x8*)rb;                                                                                          \
+    xf[(ks) & 1][1] = *(const bf16x8*)(rb + 16 * 32);                                                                              \
+  }
+    SC_LOAD(0)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks + 1 < 8) SC_LOAD(ks + 1)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], xf[ks & 1][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef SC_LOAD
+    // epilogue: acc[i][j][r] = (pixel 32 w + 16 i + fr, channel 16 fq + 4 j + r)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long row = pix0 + 32 * w + 16 * i + fr;
+      bf16x8 o0, o1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[i][j][r];
+          const int c = 4 * j + r;
+          if (c < 8) o0[c] = (bf16)v; else o1[c - 8] = (bf16)v;
+          s1[c] += v;
+          s2[c] += v * v;
+        }
+      *(bf16x8*)(a.Y + row * CH_C + 16 * fq) = o0;
+      *(bf16x8*)(a.Y + row * CH_C + 16 * fq + 8) = o1;
+    }
+    if (a.stats) {
+      NO_IFCVT;
+      const long blk = pix0 >> 7;
+      if (run_blk < 0) run_blk = blk;
+      else if ((int)(u & 3) == w) {                    // not the run's first block: a row of zeros
+        a.stats[(0 * nblk + blk) * 64 + l] = 0.f;
+        a.stats[(1 * nblk + blk) * 64 + l] = 0.f;
+      }
+      if (!next) {                                     // end of the run: lanes -> waves -> the table row of its first block
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const float t1 = sum16(s1[c]), t2 = sum16(s2[c]);
+          if (fr == 0) { ex[(w * 2 + 0) * 64 + 16 * fq + c] = t1; ex[(w * 2 + 1) * 64 + 16 * fq + c] = t2; }
+          s1[c] = 0.f;
+          s2[c] = 0.f;
+        }
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float t = ex[(0 * 2 + h) * 64 + l] + ex[(1 * 2 + h) * 64 + l] + ex[(2 * 2 + h) * 64 + l] + ex[(3 * 2 + h) * 64 + l];
+            a.stats[(h * nblk + run_blk) * 64 + l] = t;
+          }
+        }
+        run_blk = -1;
+      }
+    }
+  }
+}
+
+extern "C" int stswin_stem_conv(const void* rec, const void* wmat, void* y, float* stats, int frames, int H, int W, void* stream) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  if (frames <= 0 || H <= 0 || W <= 0 || !y) return -1731;
+  if (Wo % 128) return -1732;                                   // (the caller keeps stswin_gemm_nt over the row map)
+  const long nunits = (long)frames * (Wo / 128) * Ho;
+  const long g0 = nunits < 256 ? nunits : 256, per = (nunits + g0 - 1) / g0;
+  const int grid = (int)((nunits + per - 1) / per);
+  StemConvArgs a{(const bf16*)rec, (const bf16*)wmat, (bf16*)y, stats, frames, Ho, Wo, Ho + 3, Wo + 3, per, (long)frames * Ho * Wo};
+  static const int attr = (int)hipFuncSetAttribute((const void*)stem_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LDS);
+  if (attr != 0) return -attr;
+  hipLaunchKernelGGL(stem_conv_kernel, dim3(grid), dim3(512), SC_LDS, (hipStream_t)stream, a);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}

@@ -139,6 +139,7 @@ _RESID_GRAD_LINK = os.environ.get("STSWIN_NO_RESID_GRAD_LINK") != "1"      # (A/
 _HALO_CONV = os.environ.get("STSWIN_NO_HALO_CONV") != "1"                  # (A/B switch)
 _HALO_WGRAD = os.environ.get("STSWIN_NO_HALO_WGRAD") != "1"                # (A/B switch)
 _STEM_WGRAD = os.environ.get("STSWIN_NO_STEM_WGRAD") != "1"                # (A/B switch)
+_STEM_CONV = os.environ.get("STSWIN_NO_STEM_CONV") != "1"                  # (A/B switch)
 
 
 class ConvTokFn(torch.autograd.Function):
@@ -346,7 +347,10 @@ class StemConvFn(torch.autograd.Function):
         rmap = _stem_rowmap(F_, Ho, Wo, Hs, Ws, img.device)
         y = torch.empty(F_ * Ho * Wo, 64, dtype=dt, device=img.device)
         tab = hip.stats_table(y.shape[0], 64, img.device) if want_stats else None    # BatchNorm statistics of y (see ConvTokFn)
-        hip.gemm_nt(A, _stem_pack(weight, dt), y, M=y.shape[0], a_rows=rmap, S=4, stats_out=tab)
+        if _STEM_CONV and hip.stem_wgrad_ok(Hh, Ww, dt):   # (same geometry rule: bf16, output rows of whole 128-pixel units)
+            hip.stem_conv(A, _stem_pack(weight, dt), y, F_, Hh, Ww, stats_out=tab)
+        else:
+            hip.gemm_nt(A, _stem_pack(weight, dt), y, M=y.shape[0], a_rows=rmap, S=4, stats_out=tab)
         ctx.dt, ctx.geom = dt, (F_, Hh, Ww)
         ctx.save_for_backward(A, rmap, weight)
         if want_stats:

@@ -393,6 +393,20 @@ def stem_s2d(img: torch.Tensor, dtype: torch.dtype):
     return torch.as_strided(flat, (n, 64), (16, 1)), Hs, Ws
 
 
+def stem_conv(A, wmat, y, frames, H, W, stats_out=None):
+    """y [F*Ho*Wo][64] = the stem convolution of the hip.stem_s2d view A with the packed weights wmat [64][256] (bf16; Wo % 128 == 0)."""
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    M = frames * Ho * Wo
+    assert A.dtype == torch.bfloat16 and A.stride() == (16, 1) and A.shape[0] == frames * (Ho + 3) * (Wo + 3)
+    assert wmat.dtype == torch.bfloat16 and wmat.shape == (64, 256) and wmat.is_contiguous()
+    assert y.dtype == torch.bfloat16 and y.shape == (M, 64) and y.is_contiguous()
+    assert stats_out is None or (stats_out.dtype == torch.float32 and stats_out.numel() == 2 * 2 * ((M + 255) // 256) * 64)
+    with _Span("stem_conv_bf16", 2.0 * M * 64 * 147):
+        rc = load().stswin_stem_conv(_p(A), _p(wmat), _p(y), _p(stats_out), frames, H, W, _stream())
+    _check(rc, "stem_conv")
+    return y
+
+
 def stem_wgrad_ok(H, W, dtype) -> bool:
     return dtype == torch.bfloat16 and ((W - 1) // 2 + 1) % 128 == 0
 

@@ -647,3 +647,38 @@ def test_fused_bn_relu_maxpool_equals_the_two_operators(mode, f, hh, ww, groups,
         assert rel(H.from_tokens(res[0][0], f, yc.shape[2], yc.shape[3]), yc) < 1e-5
         assert rel(H.from_tokens(res[0][1], f, hh, ww), xc.grad) < 1e-4
         assert rel(res[0][2], bn.weight.grad) < 1e-4 and rel(res[0][3], bn.bias.grad) < 1e-4
+
+
+@pytest.mark.parametrize("f,hh,ww", [(2, 64, 256), (1, 37, 255), (3, 16, 512), (16, 512, 512)])
+def test_stem_conv_ring_kernel_matches_fp64_and_gemm_nt(f, hh, ww):
+    """stswin_stem_conv against the fp64 7x7 / 2 / 3 convolution of the same bf16 operands and against gemm_nt over the row map, with
+    the BatchNorm statistics table; bitwise reproducible."""
+    from stswincl_amd import hip
+    torch.manual_seed(f + hh + ww)
+    img = torch.randn(f, 3, hh, ww, device="cuda")
+    wt = torch.randn(64, 3, 7, 7, device="cuda") / 12
+    ho, wo = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+    M = f * ho * wo
+    A, hs, ws = hip.stem_s2d(img, torch.bfloat16)
+    wm = H._stem_pack(wt, torch.bfloat16)
+    y, y2, y3 = (torch.empty(M, 64, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    tab, tab2 = hip.stats_table(M, 64, "cuda"), hip.stats_table(M, 64, "cuda")
+    hip.stem_conv(A, wm, y, f, hh, ww, stats_out=tab)
+    ref = F.conv2d(img.to(torch.bfloat16).double(), wt.to(torch.bfloat16).double(), stride=2, padding=3).permute(0, 2, 3, 1).reshape(M, 64)
+    scale = float(ref.abs().max())
+    assert float((y.double() - ref).abs().max()) <= 2.0 ** -8 * scale * 1.01 + 1e-6
+    rmap = H._stem_rowmap(f, ho, wo, hs, ws, "cuda")
+    hip.gemm_nt(A, wm, y2, M=M, a_rows=rmap, S=4, stats_out=tab2)
+    d = (y.float() - y2.float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * scale and float((d > 0).float().mean()) < 0.02
+    # the statistics table is read per FRAME (whole statistic groups): the ring kernel keeps the sums of a run of units in the row of the
+    # run's first block and zero rows for the others, the GEMM may keep a 256-row pair in its first row - frame sums agree
+    nb = M // 128
+    bpf = nb // f
+    want = torch.stack([y.float().view(f, -1, 64).sum(1), (y.float() ** 2).view(f, -1, 64).sum(1)])
+    got = tab.view(2, -1, 64)[:, :nb].reshape(2, f, bpf, 64).sum(2)
+    assert float((got - want).abs().max()) <= 2e-3 * float(want.abs().max())
+    ref_t = tab2.view(2, -1, 64)[:, :nb].reshape(2, f, bpf, 64).sum(2)
+    assert float((got - ref_t).abs().max()) <= 1e-4 * float(ref_t.abs().max())
+    hip.stem_conv(A, wm, y3, f, hh, ww)
+    assert torch.equal(y3, y)

@@ -71,6 +71,10 @@ def main():
     A2, _, _ = hip.stem_s2d(img, torch.bfloat16)
     assert torch.equal(A2[:, :16], A[:, :16])
     print(f"gemm_nt s2d gather (K=256)  {timeit(lambda: hip.gemm_nt(A, wm, y, M=M, a_rows=rmap, S=4, stats_out=tab)):8.1f} us")
+    y5 = torch.empty_like(y)
+    print(f"stem_conv ring kernel       {timeit(lambda: hip.stem_conv(A, wm, y5, Fr, H, W, stats_out=tab)):8.1f} us")
+    print(f"stem_conv ring, no stats    {timeit(lambda: hip.stem_conv(A, wm, y5, Fr, H, W)):8.1f} us")
+    print("ring vs gather fwd max diff", float((y5.float() - y.float()).abs().max()))
     dy = torch.randn(M, 64, device="cuda").to(torch.bfloat16)
     dw0 = torch.empty(64, 192, dtype=torch.float32, device="cuda")
     dw1 = torch.empty(64, 256, dtype=torch.float32, device="cuda")
