@@ -56,6 +56,12 @@ python3 tools/bench_attn_qkv.py > $OUT/${TAG}_attention_qkv_fused_bench.txt 2>&1
 python3 tools/attn_qkv_timeline.py > $OUT/${TAG}_attention_qkv_fused_timeline.txt 2>&1
 python3 tools/bench_aspp_taps.py > $OUT/${TAG}_aspp_tap_skipping.txt 2>&1
 python3 tools/bench_bn.py > $OUT/${TAG}_batchnorm_kernels.txt 2>&1
+python3 tools/bench_conv_halo.py > $OUT/${TAG}_conv_halo_bench.txt 2>&1
+python3 tools/conv_halo_timeline.py > $OUT/${TAG}_conv_halo_timeline_fwd.txt 2>&1
+python3 tools/conv_halo_timeline.py --dgrad > $OUT/${TAG}_conv_halo_timeline_dgrad.txt 2>&1
+python3 tools/conv_halo_timeline.py --wgrad > $OUT/${TAG}_conv_halo_timeline_wgrad.txt 2>&1
+python3 tools/stem_s2d_experiment.py > $OUT/${TAG}_stem_kernels.txt 2>&1
+python3 tools/bench_stem_tail.py > $OUT/${TAG}_stem_tail.txt 2>&1
 python3 tools/blas_compare.py > $OUT/${TAG}_vendor_blas_yardstick.txt 2>&1
 python3 tools/torch_ops.py > $OUT/${TAG}_torch_ops.txt 2>&1
 python3 -m pytest tests/test_hip_bf16_stages.py -q -s 2>&1 | grep -E "^\.?(swin|patch|conv|ASPP|eval)" > $OUT/${TAG}_bf16_stage_parity_table.txt
