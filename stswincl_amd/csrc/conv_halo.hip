@@ -836,3 +836,4 @@ extern "C" int stswin_stem_conv(const void* rec, const void* wmat, void* y, floa
   STSWIN_CHECK_LAUNCH();
   return 0;
 }
+

@@ -682,3 +682,4 @@ def test_stem_conv_ring_kernel_matches_fp64_and_gemm_nt(f, hh, ww):
     assert float((got - ref_t).abs().max()) <= 1e-4 * float(ref_t.abs().max())
     hip.stem_conv(A, wm, y3, f, hh, ww)
     assert torch.equal(y3, y)
+
