@@ -402,8 +402,70 @@ def fuzz_consistency():
     check("consistency/loss", abs(float(lg) - float(lo)) / abs(float(lo)), 2e-3, info + f" ref={float(lo):.5f} got={float(lg):.5f}")
 
 
+def fuzz_resnet_feeder():
+    """The dedicated kernels of the ResNet18 feeder (conv_halo.hip, stem_s2d, bn_relu_pool; bf16 only) through the module-level
+    entry points, on random geometries that the dispatch accepts - and neighbours it must turn away - against torch fp32 on the CPU."""
+    which = rng.choice(["c64", "c64", "stem", "tail", "tail32"])
+    tol = 0.03
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=which != "tail32"):
+        if which == "c64":
+            w = rng.choice([16, 32, 64, 128, 24, 48])
+            h = rng.choice([q for q in range(2, 70) if (q * w) % 128 == 0] or [8])
+            f = rng.randint(1, 6)
+            info = f"feeder c64 f={f} h={h} w={w}"
+            globals()["LAST"] = info
+            conv = nn.Conv2d(64, 64, 3, padding=1, bias=False)
+            x = torch.randn(f, 64, h, w, requires_grad=True)
+            y = conv(x); g = torch.randn_like(y); (y * g).sum().backward()
+            convg = nn.Conv2d(64, 64, 3, padding=1, bias=False).cuda(); convg.load_state_dict(conv.state_dict())
+            xt = H.to_tokens(x.detach().cuda()).requires_grad_(True)
+            yt, ho, wo = H.conv_tokens(xt, convg, f, h, w)
+            check("feeder/c64 y", rel(H.from_tokens(yt, f, ho, wo), y), tol, info)
+            (yt.float() * H.to_tokens(g.cuda())).sum().backward()
+            check("feeder/c64 dx", rel(H.from_tokens(xt.grad, f, h, w), x.grad), tol, info)
+            check("feeder/c64 dw", rel(convg.weight.grad, conv.weight.grad), tol, info)
+        elif which == "stem":
+            hh, ww = rng.choice([(32, 256), (64, 255), (40, 512), (33, 100), (18, 258), (64, 64)])
+            f = rng.randint(1, 4)
+            info = f"feeder stem f={f} h={hh} w={ww}"
+            globals()["LAST"] = info
+            conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+            img = torch.randn(f, 3, hh, ww)
+            y = conv(img); g = torch.randn_like(y); (y * g).sum().backward()
+            convg = nn.Conv2d(3, 64, 7, 2, 3, bias=False).cuda(); convg.load_state_dict(conv.state_dict())
+            yt = H.StemConvFn.apply(img.cuda(), convg.weight, torch.bfloat16)
+            check("feeder/stem y", rel(H.from_tokens(yt, f, *y.shape[2:]), y), tol, info)
+            (yt.float() * H.to_tokens(g.cuda())).sum().backward()
+            check("feeder/stem dw", rel(convg.weight.grad, conv.weight.grad), tol, info)
+        else:
+            f, hh, ww = rng.randint(1, 6), rng.randint(3, 40), rng.randint(3, 40)
+            groups = rng.choice([1, 1, f]) if f > 1 else 1
+            info = f"feeder tail f={f} h={hh} w={ww} groups={groups}"
+            globals()["LAST"] = info
+            bn = nn.BatchNorm2d(64)
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+            x = torch.randn(f, 64, hh, ww, requires_grad=True)
+            if groups == 1:
+                yb = bn(x)
+            else:                                   # one statistic group per frame
+                yb = torch.cat([F.batch_norm(x[i:i + 1], None, None, bn.weight, bn.bias, True, 0.1, bn.eps) for i in range(f)])
+            y = F.max_pool2d(F.relu(yb), 3, 2, 1)
+            g = torch.randn_like(y); (y * g).sum().backward()
+            bng = nn.BatchNorm2d(64).cuda(); bng.load_state_dict(bn.state_dict())
+            xt = H.to_tokens(x.detach().cuda()).requires_grad_(True)
+            yt = H.batchnorm_relu_maxpool_tokens(xt, bng, (f, hh, ww), groups=groups)
+            # bf16: rounding creates ties the fp32 reference does not have, and a flipped arg-max moves a whole gradient value (the fused
+            # path is bitwise the two-operator path, tests/test_hip_head.py); fp32: the same taps as torch
+            t_y, t_g = (tol, 0.15) if which == "tail" else (1e-5, 2e-4)
+            check("feeder/tail y", rel(H.from_tokens(yt, f, *y.shape[2:]), y), t_y, info + " " + which)
+            (yt.float() * H.to_tokens(g.cuda())).sum().backward()
+            check("feeder/tail dx", rel(H.from_tokens(xt.grad, f, hh, ww), x.grad), t_g, info + " " + which)
+            check("feeder/tail dgamma", rel(bng.weight.grad, bn.weight.grad), t_g, info + " " + which)
+
+
 FAMILIES = [fuzz_consistency, fuzz_window_attention, fuzz_ohem_edges, fuzz_optim_groups, fuzz_conv, fuzz_bn, fuzz_swin_block, fuzz_patch_merge, fuzz_pool_bilinear, fuzz_ohem, fuzz_regression_loss, fuzz_optim,
-            fuzz_bank, fuzz_argmax, fuzz_conv_bn_stats, fuzz_tswinplus]
+            fuzz_bank, fuzz_argmax, fuzz_conv_bn_stats, fuzz_resnet_feeder, fuzz_tswinplus]
 only = os.environ.get("FUZZ_ONLY")
 skip = [t for t in os.environ.get("FUZZ_SKIP", "").split(",") if t]
 for fam in FAMILIES:

@@ -27,3 +27,7 @@ def test_fuzz_ops_slice():
 
 def test_fuzz_whole_model_slice():
     _run("fuzz_ops.py", "2", "8", FUZZ_ONLY="tswinplus")
+
+
+def test_fuzz_resnet_feeder_slice():
+    _run("fuzz_ops.py", "24", "11", FUZZ_ONLY="resnet_feeder")
