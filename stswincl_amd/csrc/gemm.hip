@@ -1956,6 +1956,21 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     STSWIN_CHECK_LAUNCH();
     return 0;
   }
+  // narrow AND short (the decode head's 1x1 convolutions to 48 / 64 channels: M = 4096 .. 16384): 256-row tiles would be 16 .. 64
+  // workgroups on 256 CUs - 128x64 tiles double them and two fit a CU
+  if (dtype == 0 && N <= 64 && M >= 128 && w8 && !(flags & GF_NONARROW) && (M + 255) / 256 <= 128) {
+    static int once_ns = (int)hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16, 8, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152) |
+                         (int)hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16, 8, 128, 64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    (void)once_ns;
+    const int nb = ((M + 127) / 128) * ((N + 63) / 64);
+    g_last_variant[0] = STSWIN_VAR_NT_128x64;
+    if (!(flags & GF_NODEEP) && (long)S * Kseg >= 1024)
+      hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8, 128, 64, 4>), dim3(nb), dim3(512), 98304, (hipStream_t)stream, p);
+    else
+      hipLaunchKernelGGL((gemm_nt_kernel<bf16, 8, 128, 64>), dim3(nb), dim3(512), 49152, (hipStream_t)stream, p);
+    STSWIN_CHECK_LAUNCH();
+    return 0;
+  }
   // narrow outputs (ResNet stem / layer1: N = 64): 256x64 tiles instead of 128x128 ones whose second half multiplies zeros
   if (N <= 64 && M >= 256 && w8 && !(flags & GF_NONARROW)) {
     static int once_n = (int)hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16, 8, 256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920) |
