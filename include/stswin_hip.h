@@ -175,12 +175,14 @@ int stswin_tn_combine(const float* workspace, float* C, long ldc, int Ni, int Nj
 #define STSWIN_VAR_NT_128x64 9
 #define STSWIN_VAR_NT_128x128 10
 #define STSWIN_VAR_NT_128x128_W4 11
+#define STSWIN_VAR_NT_ROWS 12          /* M <= 8 rows: one wave per output column (ASPP.py:43-46 image-pool branch) */
 #define STSWIN_VAR_TN_RING_PLAIN 20        /* gemm_tn_ring_kernel<0> */
 #define STSWIN_VAR_TN_RING_ATROWS 21       /* <1> */
 #define STSWIN_VAR_TN_RING_BTROWS 22       /* <2> */
 #define STSWIN_VAR_TN_RING_BSEG 23         /* <3>: tap-segmented convolution weight gradient */
 #define STSWIN_VAR_TN_128x128 30
 #define STSWIN_VAR_TN_128x128_W4 31
+#define STSWIN_VAR_TN_ROWS 32          /* Mk <= 8: a sum of outer products, no split-K slabs */
 #define STSWIN_VAR_TN_SLABS_F32 0x1000     /* split-K partial slabs + tn_reduce, fp32 partials */
 #define STSWIN_VAR_TN_SLABS_BF16 0x2000    /* ... bf16 partials */
 #define STSWIN_VAR_TN_TAPMINOR 0x4000      /* the combine stored the result tap-minor (STSWIN_TN_OUT_TAPMINOR was honoured) */

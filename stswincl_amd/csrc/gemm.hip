@@ -1851,6 +1851,53 @@ extern "C" int stswin_cs_reduce(const float* partials, int M, int N, float* out,
   return 0;
 }
 
+// ---- a handful of rows (nn.Conv2d 1x1 behind AdaptiveAvgPool2d(1), ASPP.py:43-46: M = frames of the batch) -------------------
+// The tiled kernels run a 4-row product as one workgroup walking K alone (24 us for 4 x 512 x 1024).  Here a wave owns one output
+// column: lanes split K in 16-byte pieces, up to 8 row accumulators, one wave reduction per row.  bf16, plain epilogue (bias, ReLU).
+__global__ __launch_bounds__(256) void gemm_nt_rows_kernel(GemmNT p) {
+  const int l = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= p.N) return;
+  const bf16* A = (const bf16*)p.A;
+  const bf16* Bn = (const bf16*)p.B + (long)n * p.ldb;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k = l * 8; k < p.Kseg; k += 512) {
+    const bf16x8 b = *(const bf16x8*)(Bn + k);
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+      if (m < p.M) {
+        const bf16x8 a = *(const bf16x8*)(A + (long)m * p.lda + k);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[m] += (float)a[e] * (float)b[e];
+      }
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+    if (m < p.M) {
+      float v = wave_sum(acc[m]);
+      if (l == 0) {
+        if (p.bias) v += p.bias[n];
+        if (p.flags & GF_RELU) v = fmaxf(v, 0.f);
+        ((bf16*)p.C)[(long)m * p.ldc + n] = (bf16)v;
+      }
+    }
+}
+// the matching weight gradient: C[i][j] (+)= sum over <= 8 rows m of At[m][i] * Bt[m][j] - a sum of outer products, one 16-byte
+// piece of a C row per thread
+__global__ __launch_bounds__(256) void gemm_tn_rows_kernel(const bf16* At, long lda, const bf16* Bt, long ldb, float* C, long ldc, int Mk, int Ni,
+                                                           int Nj, int overwrite) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int pj = Nj / 4;
+  if (idx >= (long)Ni * pj) return;
+  const int i = (int)(idx / pj), j = (int)(idx % pj) * 4;
+  f32x4 v = overwrite ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(C + (long)i * ldc + j);
+  for (int m = 0; m < Mk; ++m) {
+    const float a = (float)At[(long)m * lda + i];
+    const bf16x4 b = *(const bf16x4*)(Bt + (long)m * ldb + j);
+    v += f32x4{a * (float)b[0], a * (float)b[1], a * (float)b[2], a * (float)b[3]};
+  }
+  *(f32x4*)(C + (long)i * ldc + j) = v;
+}
+
 extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_rows, const void* B, long ldb,
                               void* C, long ldc, const int* c_rows, void* C2, long ldc2, const float* bias,
                               const void* R, long ldr, const int* r_rows, int M, int N, int Kseg, int S,
@@ -1867,6 +1914,13 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
       (void)hipMemsetAsync(colsum + (long)(4 * ((M + 255) / 256) - 1) * N, 0, sizeof(float) * N, (hipStream_t)stream);
   }
   GemmNT p{A, lda, a_rows, B, ldb, C, ldc, c_rows, C2, ldc2, bias, R, ldr, r_rows, M, N, Kseg, S, scale, scale_cols, flags, colsum};
+  if (dtype == 0 && M <= 8 && S == 1 && !a_rows && !c_rows && !C2 && !R && !colsum && !(flags & ~GF_RELU) && scale_cols == 0 && Kseg % 8 == 0 &&
+      lda % 8 == 0 && ldb % 8 == 0) {
+    g_last_variant[0] = STSWIN_VAR_NT_ROWS;
+    hipLaunchKernelGGL(gemm_nt_rows_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    STSWIN_CHECK_LAUNCH();
+    return 0;
+  }
   const int nblk = ((M + 127) / 128) * ((N + 127) / 128);
   static int once = set_lds_once((const void*)gemm_nt_kernel<bf16, 4>) | set_lds_once((const void*)gemm_nt_kernel<float, 4>) |
                     set_lds_once((const void*)gemm_nt_kernel<bf16, 8>) | set_lds_once((const void*)gemm_nt_kernel<float, 8>);
@@ -2048,6 +2102,14 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   const int pack = dtype == 0 ? 8 : 4;
   if (Ni % pack || Nj % pack || lda % pack || ldb % pack) return -1003;
   if (bseg < 0 || (bseg > 0 && (bseg % pack || !bt_rows || Nj % bseg))) return -1004;
+  if (dtype == 0 && Mk <= 8 && !at_rows && !bt_rows && bseg == 0 && ldc % 4 == 0) {            // a sum of <= 8 outer products
+    g_last_variant[1] = STSWIN_VAR_TN_ROWS;
+    const long nthr = (long)Ni * (Nj / 4);
+    hipLaunchKernelGGL(gemm_tn_rows_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)At, lda, (const bf16*)Bt,
+                       ldb, C, ldc, Mk, Ni, Nj, overwrite);
+    STSWIN_CHECK_LAUNCH();
+    return 0;
+  }
   if (bseg > 0)                                            // the kernel keeps two tap index rows per 128-column tile
     for (int j0 = 0; j0 < Nj; j0 += 128)
       if ((j0 + 127 < Nj ? j0 + 127 : Nj - 1) / bseg - j0 / bseg > 1) return -1005;

@@ -648,9 +648,9 @@ def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: in
 # kernel-variant codes of stswin_last_variant (include/stswin_hip.h)
 VAR_F32 = 100
 (VAR_NT_RING256_REGEPI, VAR_NT_RING256_LDSEPI, VAR_NT_RING256_NOPIPE, VAR_NT_STREAM, VAR_NT_DUO, VAR_NT_RING256x128_PP,
- VAR_NT_MID, VAR_NT_256x64, VAR_NT_128x64, VAR_NT_128x128, VAR_NT_128x128_W4) = range(1, 12)
+ VAR_NT_MID, VAR_NT_256x64, VAR_NT_128x64, VAR_NT_128x128, VAR_NT_128x128_W4, VAR_NT_ROWS) = range(1, 13)
 VAR_TN_RING_PLAIN, VAR_TN_RING_ATROWS, VAR_TN_RING_BTROWS, VAR_TN_RING_BSEG = 20, 21, 22, 23
-VAR_TN_128x128, VAR_TN_128x128_W4 = 30, 31
+VAR_TN_128x128, VAR_TN_128x128_W4, VAR_TN_ROWS = 30, 31, 32
 VAR_TN_SLABS_F32, VAR_TN_SLABS_BF16 = 0x1000, 0x2000
 
 

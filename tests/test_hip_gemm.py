@@ -328,3 +328,29 @@ def test_gemm_tn_ragged_contraction_no_empty_split(mk, ni, nj, ow):
     ref = at.float().t() @ bt.float() + (0.0 if ow else 1.0)
     assert torch.isfinite(c).all()
     assert float((c - ref).abs().max()) < 1e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,relu,bias", [(4, 512, 1024, False, False), (4, 1024, 512, True, True), (1, 64, 64, False, True), (8, 260, 1088, True, False)])
+def test_few_row_products_take_the_row_kernels(M, N, K, relu, bias):
+    """M <= 8 rows (the 1x1 convolution behind AdaptiveAvgPool2d(1), ASPP.py:43-46, forward / input gradient / weight gradient):
+    one wave per output column, and a sum of <= 8 outer products - against fp64 products of the same bf16 operands."""
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    b = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
+    bv = torch.randn(N, device="cuda") if bias else None
+    c = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm_nt(a, b, c, M=M, bias=bv, flags=hip.GF_RELU if relu else 0)
+    assert hip.last_variant(0)["kernel"] == hip.VAR_NT_ROWS
+    ref = a.double() @ b.double().t() + (bv.double() if bias else 0)
+    ref = ref.clamp(min=0) if relu else ref
+    assert float((c.double() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-6
+    # weight gradient of the same layer: dW[n][k] = sum_m dy[m][n] * x[m][k]
+    N8 = N // 8 * 8
+    dy = torch.randn(M, N8, device="cuda").to(torch.bfloat16)
+    dw = torch.full((N8, K), 0.5, dtype=torch.float32, device="cuda")
+    hip.gemm_tn(dy, a, dw, Mk=M)
+    assert hip.last_variant(1)["kernel"] == hip.VAR_TN_ROWS
+    want = 0.5 + dy.double().t() @ a.double()
+    assert float((dw.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    hip.gemm_tn(dy, a, dw, Mk=M, overwrite=True)
+    assert float((dw.double() - (want - 0.5)).abs().max()) <= 1e-5 * float(want.abs().max())

@@ -22,7 +22,7 @@ def timeit(fn, n=100):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for M, N, K in [(16384, 64, 512), (4096, 64, 1024), (16384, 64, 256), (16384, 48, 256), (32768, 64, 512), (65536, 64, 512), (8192, 64, 2048)]:
+for M, N, K in [(4, 512, 1024), (4, 1024, 512), (16384, 64, 512), (4096, 64, 1024), (16384, 64, 256), (16384, 48, 256), (32768, 64, 512), (65536, 64, 512), (8192, 64, 2048)]:
     a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     b = torch.randn(N, K, device="cuda").to(torch.bfloat16)
     c = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
