@@ -3,9 +3,8 @@
 // and input gradient; the 16-frame batch of a 4-clip step is 262144 pixels of 128x128 maps).
 //
 // The generic gather GEMM (gemm.hip) stages the A operand tap by tap: nine row-map-driven copies of the same 256 x 64 input
-// tile per 256 x 64 output tile, 288 KB through L2 for 33 KB of distinct data - 300 MB per launch - and a wave tile of
-// 64 x 64 reads as many LDS bytes per MFMA as the LDS can deliver at the full matrix rate.  Both bound the N = 64
-// convolutions at 350-390 TFLOP/s (~50 us per launch).  Here
+// tile per 256 x 64 output tile, 288 KB through L2 for 33 KB of distinct data - 300 MB per launch, with a row-map lookup and
+// a copy request per 1 KB of it - which holds the N = 64 convolutions at 350-420 TFLOP/s (~50 us per launch).  Here
 //   * a workgroup owns 256 consecutive pixels of one frame (256 / W image rows) and loads their HALO once: (rows + 2) x
 //     (W + 2) pixel records of 128 bytes, zeros outside the image; every tap reads its pixel fragments straight from the
 //     halo at a shifted address - no global traffic inside the multiply loop, input and output cross HBM once (plus the
