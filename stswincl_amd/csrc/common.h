@@ -115,19 +115,6 @@ DEVI float dgelu_erf(float x) {
 // lane per 256x256 tile that was as long as the tile's whole main loop.  GELU' adds one v_exp_f32 for the density.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define STSWIN_PHI_COEFFS 1.579097463e+00f, -4.098180595e+00f, 9.285439338e+00f, -1.537328732e+01f, 1.769340906e+01f, -1.318582850e+01f, 5.639688737e+00f, -1.040338190e+00f
-#ifdef STSWIN_SCALAR_GELU
-DEVI float phi_poly1(float x) {
-  constexpr float C[8] = {STSWIN_PHI_COEFFS};
-  float z = x * 0.2525381361380527f;
-  z = fminf(fmaxf(z, -1.f), 1.f);
-  const float s = z * z;
-  float q = C[7];
-#pragma unroll
-  for (int i = 6; i >= 0; --i) q = __builtin_fmaf(q, s, C[i]);
-  return __builtin_fmaf(z, q, 0.5f);
-}
-DEVI f32x2 phi_poly2(f32x2 x) { return (f32x2){phi_poly1(x[0]), phi_poly1(x[1])}; }
-#else
 DEVI f32x2 phi_poly2(f32x2 x) {
   constexpr float C[8] = {STSWIN_PHI_COEFFS};
   f32x2 z = x * 0.2525381361380527f;
@@ -138,7 +125,6 @@ DEVI f32x2 phi_poly2(f32x2 x) {
   for (int i = 6; i >= 0; --i) q = __builtin_elementwise_fma(q, s, (f32x2){C[i], C[i]});
   return __builtin_elementwise_fma(z, q, (f32x2){0.5f, 0.5f});
 }
-#endif
 DEVI f32x2 gelu_fast2(f32x2 x) { return x * phi_poly2(x); }
 DEVI f32x2 dgelu_fast2(f32x2 x) {
   const f32x2 h = x * x * -0.72134752044448170368f;          // -x^2/2 * log2(e)
