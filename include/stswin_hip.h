@@ -148,7 +148,15 @@ int stswin_cs_reduce(const float* partials, int M, int N, float* out, void* stre
  * uninitialised; saves the caller's zero fill); bits 28-30 are tuning overrides (forbid / force the 256x256 ring kernel,
  * 4-wave 128x128 variant) used by tools/tn_sweep.py; the low bits are the split count, 0 = automatic. */
 #define STSWIN_TN_OVERWRITE (1 << 27)
-#define STSWIN_TN_NO_COMBINE (1 << 26)   /* with a workspace: leave the partials there; the caller runs stswin_tn_combine */
+#define STSWIN_TN_NO_COMBINE (1 << 26)   /* gemm_nt for few output tiles and a long K (ASPP.py:13-20,37-40: dilated 3x3 convolutions on 32x32 maps; M = 4096, N = 512,
+ * K = 9 x 1024): the 256x256 ring kernel over tiles x K-splits with fp32 partial slabs in `workspace`, then a fixed-order combine
+ * (+ bias, ReLU) into C (bf16, pitch ldc).  bf16 only, plain epilogue only.  stswin_gemm_nt_splitk_scratch returns the floats of
+ * workspace needed, or 0 when the shape is not a candidate (<= 32 tiles of 256x256, >= 64 stages of 32: call stswin_gemm_nt).
+ * Environment STSWIN_SPLITK_BF16=1 (tuning, read per call): bf16 partial slabs - 20 % faster, the partials rounded once more. */
+long stswin_gemm_nt_splitk_scratch(int M, int N, int Kseg, int S);
+int stswin_gemm_nt_splitk(const void* A, long lda, const int* a_rows, const void* B, long ldb, void* C, long ldc, const float* bias, int M, int N,
+                          int Kseg, int S, int relu, float* workspace, long workspace_floats, void* stream);
+/* with a workspace: leave the partials there; the caller runs stswin_tn_combine */
 int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, const void* Bt, long ldb, const int* bt_rows,
                    float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg,
                    float* workspace /* optional caller-owned scratch: split-K partials are stored there and combined by a
@@ -175,6 +183,7 @@ int stswin_tn_combine(const float* workspace, float* C, long ldc, int Ni, int Nj
 #define STSWIN_VAR_NT_128x64 9
 #define STSWIN_VAR_NT_128x128 10
 #define STSWIN_VAR_NT_128x128_W4 11
+#define STSWIN_VAR_NT_SPLITK 13        /* 256x256 ring on tiles x splits + fp32 slab combine (stswin_gemm_nt_splitk); splits in bits 16.. */
 #define STSWIN_VAR_NT_ROWS 12          /* M <= 8 rows: one wave per output column (ASPP.py:43-46 image-pool branch) */
 #define STSWIN_VAR_TN_RING_PLAIN 20        /* gemm_tn_ring_kernel<0> */
 #define STSWIN_VAR_TN_RING_ATROWS 21       /* <1> */

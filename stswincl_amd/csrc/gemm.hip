@@ -60,6 +60,7 @@ struct GemmNT {
   float scale; int scale_cols;
   int flags;
   float* colsum;                 // optional fp32 [N]: += column sums of the values written to C
+  int qsplit;                    // ring kernels, split-K launches (stswin_gemm_nt_splitk): 32-deep stages per blockIdx.y slice, 0 = whole K
 };
 
 // Column sum `v` of output rows [128*blk, 128*blk + 128*nblk) of column gn.  Default: one fp32 atomic per (tile, column) -
@@ -495,18 +496,22 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     }
   };
   const int kps = p.Kseg / BK;
-  const int nt = p.S * kps;
+  // split-K launch: workgroup row blockIdx.y owns stages [qbase, qbase + nt) of the K loop and the fp32 slab blockIdx.y of C
+  const int qbase = p.qsplit > 0 ? (int)blockIdx.y * p.qsplit : 0;
+  const int nt = p.qsplit > 0 ? min(p.qsplit, p.S * kps - qbase) : p.S * kps;
+  if (p.qsplit > 0) p.C = (char*)p.C + (long)blockIdx.y * p.M * p.ldc * ((p.flags & GF_OUT_F32) ? 4 : 2);
   int seg = -1;
   auto issue = [&](int q) {
-    int sg = 0, kt = q;
-    if (p.S > 1) { sg = q / kps; kt = q - sg * kps; }
+    const int Q = q + qbase;
+    int sg = 0, kt = Q;
+    if (p.S > 1) { sg = Q / kps; kt = Q - sg * kps; }
     if (sg != seg) { seg = sg; load_a_bases(sg); }
     char* Ab = smem + (q % NST) * STAGE;
     char* Bb = Ab + A_BYTES;
 #pragma unroll
     for (int i = 0; i < NIA; ++i) glds16_buf(p.A, aoff[i], kt * (BK * (int)sizeof(T)), Ab + (w * NIA + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < NIB; ++i) glds16_buf(p.B, boff[i], q * (BK * (int)sizeof(T)), Bb + (w * NIB + i) * 1024);
+    for (int i = 0; i < NIB; ++i) glds16_buf(p.B, boff[i], Q * (BK * (int)sizeof(T)), Bb + (w * NIB + i) * 1024);
   };
 
   f32x4 acc[FI][FJ];                                 // zeroed AFTER the prologue copies are requested (below)
@@ -1896,6 +1901,101 @@ __global__ __launch_bounds__(256) void gemm_tn_rows_kernel(const bf16* At, long 
     v += f32x4{a * (float)b[0], a * (float)b[1], a * (float)b[2], a * (float)b[3]};
   }
   *(f32x4*)(C + (long)i * ldc + j) = v;
+}
+
+// ---- split-K form of gemm_nt for FEW output tiles and a long K (ASPP's dilated 3x3 convolutions: M = 4096, N = 512, K = 9 x 1024 -
+// 32 tiles of 256 x 256 on 256 CUs; the 128x64-tile kernel that filled the CUs ran them at 500 TFLOP/s): the 256x256 ring kernel on
+// a grid of tiles x splits, every split writing its fp32 partial tile into its own slab of the caller's workspace, and one pass
+// that adds the slabs in split order (+ bias, ReLU) and stores the compute dtype.  Deterministic; same result as the unsplit
+// kernel up to the association of the fp32 sum.
+__global__ __launch_bounds__(256) void nt_splitk_combine_kernel(const float* ws, int splits, long slab, int M, int N, bf16* C, long ldc, const float* bias,
+                                                                int relu) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int pn = N / 8;
+  if (idx >= (long)M * pn) return;
+  const int m = (int)(idx / pn), n = (int)(idx % pn) * 8;
+  const float* src = ws + (long)m * N + n;
+  f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+  for (int j = 1; j < splits; ++j) {
+    a += *(const f32x4*)(src + j * slab);
+    b += *(const f32x4*)(src + j * slab + 4);
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = (e < 4 ? a[e] : b[e - 4]) + (bias ? bias[n + e] : 0.f);
+    if (relu) v = fmaxf(v, 0.f);
+    o[e] = (bf16)v;
+  }
+  *(bf16x8*)(C + (long)m * ldc + n) = o;
+}
+
+__global__ __launch_bounds__(256) void nt_splitk_combine16_kernel(const bf16* ws, int splits, long slab, int M, int N, bf16* C, long ldc, const float* bias,
+                                                                  int relu) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int pn = N / 8;
+  if (idx >= (long)M * pn) return;
+  const int m = (int)(idx / pn), n = (int)(idx % pn) * 8;
+  const bf16* src = ws + (long)m * N + n;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int j = 0; j < splits; ++j) {
+    const bf16x8 v = *(const bf16x8*)(src + j * slab);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = a[e] + (bias ? bias[n + e] : 0.f);
+    if (relu) v = fmaxf(v, 0.f);
+    o[e] = (bf16)v;
+  }
+  *(bf16x8*)(C + (long)m * ldc + n) = o;
+}
+
+static int nt_splitk_plan(int M, int N, int Kseg, int S, int* qsplit_o) {
+  if (M < 256 || N < 256 || N % 8 || Kseg % 32) return 0;
+  const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+  const int nt = S * (Kseg / 32);
+  if (tiles > 32 || nt < 64) return 0;                   // (at 64 tiles = 4 splits the tiled kernels measured faster: 57 vs 62 us)
+  int splits = (int)(256 / tiles);
+  if (splits > nt / 16) splits = nt / 16;                // >= 16 stages per split
+  if (splits < 2) return 0;
+  const int qs = (nt + splits - 1) / splits;
+  *qsplit_o = qs;
+  return (nt + qs - 1) / qs;
+}
+/* floats of workspace stswin_gemm_nt_splitk needs, 0 = the shape is not a split-K candidate (use stswin_gemm_nt) */
+extern "C" long stswin_gemm_nt_splitk_scratch(int M, int N, int Kseg, int S) {
+  int qs = 0;
+  const int splits = nt_splitk_plan(M, N, Kseg, S, &qs);
+  return splits ? (long)splits * M * N : 0;
+}
+extern "C" int stswin_gemm_nt_splitk(const void* A, long lda, const int* a_rows, const void* B, long ldb, void* C, long ldc, const float* bias, int M,
+                                     int N, int Kseg, int S, int relu, float* workspace, long workspace_floats, void* stream) {
+  int qs = 0;
+  const int splits = nt_splitk_plan(M, N, Kseg, S, &qs);
+  if (!splits) return -1008;
+  if (!workspace || workspace_floats < (long)splits * M * N) return -1009;
+  if ((a_rows ? false : (long)M * lda * 2 > 0xFFFF0000L) || (long)N * ldb * 2 > 0xFFFF0000L) return -1008;
+  const char* e16 = getenv("STSWIN_SPLITK_BF16");
+  const int b16 = e16 && atoi(e16) ? 1 : 0;
+  GemmNT p{A, lda, a_rows, B, ldb, workspace, N, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, M, N, Kseg, S, 1.0f, 0, b16 ? 0 : GF_OUT_F32, nullptr, qs};
+  static const int attr = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
+                          (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  if (attr != 0) return -attr;
+  const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+  g_last_variant[0] = STSWIN_VAR_NT_SPLITK | (splits << 16);
+  if (b16) hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>), dim3((unsigned)tiles, (unsigned)splits), dim3(512), 131072, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true>), dim3((unsigned)tiles, (unsigned)splits), dim3(512), 131072, (hipStream_t)stream, p);
+  STSWIN_CHECK_LAUNCH();
+  const long n = (long)M * (N / 8);
+  if (b16) hipLaunchKernelGGL(nt_splitk_combine16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)workspace, splits, (long)M * N, M, N,
+                     (bf16*)C, ldc, bias, relu);
+  else hipLaunchKernelGGL(nt_splitk_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, splits, (long)M * N, M, N,
+                     (bf16*)C, ldc, bias, relu);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_rows, const void* B, long ldb,

@@ -517,6 +517,17 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
     name = "gemm_nt_bf16" if A.dtype == torch.bfloat16 else "gemm_nt_f32"
     if _SHAPE_NAMES:
         name += f" M={M} N={N} K={Kseg} S={S} a={int(a_rows is not None)} c={int(c_rows is not None)} fl={flags}"
+    # few output tiles, long K (ASPP's dilated convolutions, the 448-channel classifier convolution): ring kernel over tiles x K-splits
+    if (_NT_SPLITK and A.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and c_rows is None and resid is None and out2 is None
+            and colsum_out is None and scale == 1.0 and scale_cols == 0 and not (flags & ~GF_RELU)):
+        need = load().stswin_gemm_nt_splitk_scratch(M, N, Kseg, S)
+        if need > 0:
+            ws = scratch(A.device, need)
+            with _Span(name, 2.0 * M * N * Ktot):
+                rc = load().stswin_gemm_nt_splitk(_p(A), _c_long(_ld(A)), _p(a_rows), _p(Bw), _c_long(_ld(Bw)), _p(out), _c_long(_ld(out)),
+                                                  _p(bias), M, N, Kseg, S, 1 if (flags & GF_RELU) else 0, _p(ws), _c_long(ws.numel()), _stream())
+            _check(rc, "gemm_nt_splitk")
+            return out
     with _Span(name, 2.0 * M * N * Ktot):
         rc = load().stswin_gemm_nt(
             _dt(A), _p(A), _c_long(_ld(A)), _p(a_rows), _p(Bw), _c_long(_ld(Bw)), _p(out), _c_long(_ld(out)),
@@ -529,6 +540,7 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
     return out
 
 
+_NT_SPLITK = os.environ.get("STSWIN_NO_NT_SPLITK") != "1"                 # (A/B switch)
 _CS_PARTIAL_MIN_M = int(os.environ.get("STSWIN_CS_PARTIAL_MIN_M", "1"))   # (the table + fold path is the deterministic one: always)
 _CS_TABLES = {}
 
@@ -648,7 +660,7 @@ def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: in
 # kernel-variant codes of stswin_last_variant (include/stswin_hip.h)
 VAR_F32 = 100
 (VAR_NT_RING256_REGEPI, VAR_NT_RING256_LDSEPI, VAR_NT_RING256_NOPIPE, VAR_NT_STREAM, VAR_NT_DUO, VAR_NT_RING256x128_PP,
- VAR_NT_MID, VAR_NT_256x64, VAR_NT_128x64, VAR_NT_128x128, VAR_NT_128x128_W4, VAR_NT_ROWS) = range(1, 13)
+ VAR_NT_MID, VAR_NT_256x64, VAR_NT_128x64, VAR_NT_128x128, VAR_NT_128x128_W4, VAR_NT_ROWS, VAR_NT_SPLITK) = range(1, 14)
 VAR_TN_RING_PLAIN, VAR_TN_RING_ATROWS, VAR_TN_RING_BTROWS, VAR_TN_RING_BSEG = 20, 21, 22, 23
 VAR_TN_128x128, VAR_TN_128x128_W4, VAR_TN_ROWS = 30, 31, 32
 VAR_TN_SLABS_F32, VAR_TN_SLABS_BF16 = 0x1000, 0x2000

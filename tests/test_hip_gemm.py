@@ -354,3 +354,50 @@ def test_few_row_products_take_the_row_kernels(M, N, K, relu, bias):
     assert float((dw.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
     hip.gemm_tn(dy, a, dw, Mk=M, overwrite=True)
     assert float((dw.double() - (want - 0.5)).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("M,N,Kseg,S,relu,bias,gather", [(4096, 512, 1024, 9, False, False, True), (2048, 1024, 512, 9, True, True, True),
+                                                         (8192, 256, 448, 9, False, False, True), (2048, 512, 4096, 1, True, False, False),
+                                                         (3000, 264, 1024, 3, False, True, True)])
+def test_split_k_gemm_nt_matches_unsplit_and_fp64(M, N, Kseg, S, relu, bias, gather):
+    """stswin_gemm_nt_splitk (few 256x256 tiles, long K: ASPP.py:13-20 dilated convolutions) against fp64 products of the same bf16
+    operands and against the unsplit kernels; bitwise reproducible."""
+    torch.manual_seed(M + N + S)
+    rows = M + 37
+    a = torch.randn(rows, Kseg, device="cuda").to(torch.bfloat16)
+    b = (torch.randn(N, S * Kseg, device="cuda") / (S * Kseg) ** 0.5).to(torch.bfloat16)
+    bv = torch.randn(N, device="cuda") if bias else None
+    rmap = None
+    if gather:
+        rmap = torch.randint(-1, rows, (S, M), device="cuda", dtype=torch.int32)
+    assert hip.load().stswin_gemm_nt_splitk_scratch(M, N, Kseg, S) > 0
+    c = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm_nt(a, b, c, M=M, a_rows=rmap, S=S, bias=bv, flags=hip.GF_RELU if relu else 0)
+    v = hip.last_variant(0)
+    assert v["kernel"] == hip.VAR_NT_SPLITK and v["splits"] >= 2
+    ref = torch.zeros(M, N, dtype=torch.float64, device="cuda")
+    for s_ in range(S):
+        if gather:
+            idx = rmap[s_].long()
+            seg = torch.where((idx >= 0)[:, None], a.double()[idx.clamp(min=0)], torch.zeros((), dtype=torch.float64, device="cuda"))
+        else:
+            seg = a.double()[:M]
+        ref += seg @ b.double()[:, s_ * Kseg:(s_ + 1) * Kseg].t()
+    if bias:
+        ref += bv.double()
+    if relu:
+        ref = ref.clamp(min=0)
+    scale = float(ref.abs().max())
+    assert float((c.double() - ref).abs().max()) <= 2.0 ** -8 * scale * 1.01 + 1e-6
+    c2 = torch.empty_like(c)
+    hip._NT_SPLITK = False
+    try:
+        hip.gemm_nt(a, b, c2, M=M, a_rows=rmap, S=S, bias=bv, flags=hip.GF_RELU if relu else 0)
+    finally:
+        hip._NT_SPLITK = True
+    assert hip.last_variant(0)["kernel"] != hip.VAR_NT_SPLITK
+    d = (c.float() - c2.float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * scale and float((d > 0).float().mean()) < 0.02
+    c3 = torch.empty_like(c)
+    hip.gemm_nt(a, b, c3, M=M, a_rows=rmap, S=S, bias=bv, flags=hip.GF_RELU if relu else 0)
+    assert torch.equal(c3, c)

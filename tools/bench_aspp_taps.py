@@ -32,8 +32,14 @@ for cin, cout, tag in ((1024, 512, "forward 1024->512"), (512, 1024, "input grad
         valid = float((rmap >= 0).float().mean())
         t_on = timeit(lambda: hip.gemm_nt(x, wmat, y, M=M, a_rows=rmap, S=9, flags=hip.GF_TAPSKIP))
         y_on = y.clone()
+        hip._NT_SPLITK = False
         t_off = timeit(lambda: hip.gemm_nt(x, wmat, y, M=M, a_rows=rmap, S=9))
+        hip._NT_SPLITK = True
         same = torch.equal(y_on, y)
+        if hip.load().stswin_gemm_nt_splitk_scratch(M, cout, cin, 9) > 0:
+            t_sk = timeit(lambda: hip.gemm_nt(x, wmat, y, M=M, a_rows=rmap, S=9))
+            print(f"{tag:28s} dilation {d:2d}: split-K ring (stswin_gemm_nt_splitk, {hip.last_variant(0)['splits']} splits) {t_sk:6.1f} us; "
+                  f"max |difference| {float((y.float() - y_on.float()).abs().max()):.3g}")
         fl = 2.0 * M * cout * 9 * cin
         print(f"{tag:28s} dilation {d:2d}: {t_off:6.1f} us all taps -> {t_on:6.1f} us with tap skipping ({100 * valid:.0f} % of the tap rows are "
               f"inside the image); {fl / t_on / 1e6:6.0f} TF/s dense-equivalent; bitwise equal: {same}")

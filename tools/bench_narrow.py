@@ -30,3 +30,16 @@ for M, N, K in [(4, 512, 1024), (4, 1024, 512), (16384, 64, 512), (4096, 64, 102
     ref = a.float() @ b.float().t()
     err = float((c.float() - ref).abs().max() / ref.abs().max())
     print(f"M={M:6d} N={N:3d} K={K:5d}  {us:7.1f} us  {2.0 * M * N * K / us * 1e-6:7.1f} TFLOP/s  variant {hip.last_variant(0)['kernel']}  err {err:.1e}")
+
+
+print("few tiles, long K (tap-segmented gather): split-K ring vs the tiled kernels")
+for M, N, Kseg, S in [(4096, 512, 1024, 9), (4096, 1024, 512, 9), (16384, 256, 448, 9)]:
+    a = torch.randn(M, Kseg, device="cuda").to(torch.bfloat16)
+    b = (torch.randn(N, S * Kseg, device="cuda") / (S * Kseg) ** 0.5).to(torch.bfloat16)
+    rmap = torch.randint(-1, M, (S, M), device="cuda", dtype=torch.int32)
+    c = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    for on in (True, False):
+        hip._NT_SPLITK = on
+        us = timeit(lambda: hip.gemm_nt(a, b, c, M=M, a_rows=rmap, S=S), n=30)
+        print(f"M={M:6d} N={N:4d} K={Kseg:5d} x {S}  split-K {'on ' if on else 'off'} {us:7.1f} us  {2.0 * M * N * Kseg * S / us * 1e-6:7.1f} TFLOP/s  {hip.last_variant(0)}")
+    hip._NT_SPLITK = True
