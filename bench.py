@@ -52,7 +52,7 @@ def parse():
                     help="contrast workload: key set a query pixel sees - its own sample (the reference), every sample of the rank, "
                          "or every sample of every rank (RCCL all-gather of the keys: the inter-video bank of BASELINE configs[3])")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short contrastive run that fills `secondary`")
-    ap.add_argument("--secondary-steps", type=int, default=4)
+    ap.add_argument("--secondary-steps", type=int, default=20)
     ap.add_argument("--dump-prof", default=None,
                     help="write the per-span timing table here (with STSWIN_SHAPE_PROFILE=1: one row per GEMM shape)")
     ap.add_argument("--workload", default="seg", choices=["seg", "contrast"],
@@ -84,15 +84,15 @@ def physical_cores():
     return (len(cores) or len(allowed)), len(allowed)
 
 
-def cpu_baseline(size: int, budget_s: float = 45.0):
+def cpu_baseline(size: int, budget_s: float = 60.0):
     """The oracle (a port of the reference graph) doing the same training step on the host cores (SURVEY 8(d) protocol).
 
-    fwd+bwd+Adam steps of B = 2 clips (B = 1 cannot train: ASPP's BatchNorm on a 1x1 map) in fp32, BEST OF 3 at the largest of
-    {size, size/2, size/4} whose three repeats fit the budget (predicted from a 128x128 calibration step: work scales with
-    pixels); the rate is scaled by the pixel ratio to `size` (stated in `sample`).  Threads: the physical cores of the
-    affinity mask are detected and stated; the thread count actually used is the faster of {physical cores, 32} on the
-    calibration step (on a shared 256-thread host, one thread per physical core measured slower than 32 - both timings are in
-    `sample`, with torch.__config__.parallel_info())."""
+    fwd+bwd+Adam steps of B = 2 clips (B = 1 cannot train: ASPP's BatchNorm on a 1x1 map) in fp32 AT THE BENCH SIZE (`size` x `size`
+    frames: SURVEY 8(d) says B = 2 at 512x512) - measured, never extrapolated from a smaller frame (the CPU step does not scale with
+    the pixel count: 256x256 is ~7x cheaper than 512x512, not 4x).  Best of as many repeats as fit the budget (at least one, at
+    most three; every time is listed in `sample`).  Threads: the physical cores of the affinity mask are detected and stated; the
+    thread count actually used is the faster of {physical cores, 32} on a 128x128 calibration step (on a shared 256-thread host, one
+    thread per physical core measured slower than 32 - both timings are in `sample`, with torch.__config__.parallel_info())."""
     from oracle import stswin_oracle as O
     from stswincl_amd.net.Ours.base18 import TswinPlus
     phys, logical = physical_cores()
@@ -122,22 +122,20 @@ def cpu_baseline(size: int, budget_s: float = 45.0):
         cal[th] = one_step(128)
     threads = min(cal, key=cal.get)
     torch.set_num_threads(threads)
-    t_cal = cal[threads]
-    left = budget_s - (time.perf_counter() - t_start)
-    sz = size
-    while sz > 128 and 3 * t_cal * (sz / 128.0) ** 2 > left:
-        sz //= 2
-    times = [one_step(sz) for _ in range(3)]
+    times = []
+    while len(times) < 3:
+        times.append(one_step(size))
+        if time.perf_counter() - t_start + min(times) > budget_s:
+            break
     dt = min(times)
-    scale = (sz / float(size)) ** 2    # pixel-count ratio: a smaller frame is proportionally less work
     pinfo = " ".join(torch.__config__.parallel_info().split())
-    return {"value": 2 * 4 / dt * scale, "unit": "frames/s", "cores": threads, "kind": "port",
+    return {"value": 2 * 4 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
             "physical_cores": phys, "logical_cpus": logical,
-            "sample": f"best of 3 fwd+bwd+Adam steps of the CPU oracle, B=2 clips x 4 frames at {sz}x{sz} fp32: "
-                      f"{', '.join(f'{t:.2f}' for t in times)} s on {threads} threads ({phys} physical cores / {logical} logical CPUs in "
-                      f"the affinity mask; 128x128 calibration step: "
-                      f"{', '.join(f'{t:.2f} s on {th} threads' for th, t in sorted(cal.items()))}); rate scaled by ({sz}/{size})^2 to "
-                      f"{size}x{size} frames; parallel_info: {pinfo[:400]}"}
+            "sample": f"best of {len(times)} fwd+bwd+Adam step(s) of the CPU oracle, B=2 clips x 4 frames at {size}x{size} fp32 (the bench's "
+                      f"frame size, measured directly, nothing scaled): {', '.join(f'{t:.2f}' for t in times)} s on {threads} threads "
+                      f"({phys} physical cores / {logical} logical CPUs in the affinity mask; 128x128 calibration step: "
+                      f"{', '.join(f'{t:.2f} s on {th} threads' for th, t in sorted(cal.items()))}); "
+                      f"parallel_info: {pinfo[:400]}"}
 
 
 class Ctx:
@@ -227,7 +225,7 @@ def capture(step_fn, zero_grad):
     return replay
 
 
-def contrast_run(a, ctx, steps, warmup, profile_stride, batch=8, bank="sample"):
+def contrast_run(a, ctx, steps, warmup, profile_stride, batch=8, bank="sample", eager=False):
     """BASELINE.json configs[3] as far as the reference can run it: ConsistencyLoss (PixPro-style, 2 query + 6 momentum-key
     encoder passes) at 256x256 (224 is illegal for the window sizes), B clips/GPU, LARS over SGD-momentum as in
     main_pretrain_swinv5.py:37-47.  Reports contrastive pairs/s = 2 directions x B x HW x 5 HW per step."""
@@ -259,7 +257,7 @@ def contrast_run(a, ctx, steps, warmup, profile_stride, batch=8, bank="sample"):
         opt.step()
         return loss
 
-    graphed = a.graph == 1 or (a.graph == -1 and world == 1 and not profile_stride)
+    graphed = not eager and (a.graph == 1 or (a.graph == -1 and world == 1 and not profile_stride))
     if graphed:
         # the contrastive step is ~2400 launches of 20-70 us kernels (8 encoder passes at 256x256): eager launches keep the
         # GPU only 68 % busy (profiles/r01_v13_contrast_steady_state_kernels.txt); one hipGraph replay removes the host
@@ -460,7 +458,9 @@ def main():
             torch.cuda.empty_cache()
             hip.arena_reset()
             try:                       # the primary line must survive whatever happens in the second workload
-                sec = contrast_run(a, ctx, a.secondary_steps, 2, 0)
+                # eager launches: a graph replay would freeze the host-side scalars (LARS learning rate, EMA momentum schedule) at
+                # their captured values; here every step advances them as main_pretrain_swinv5.py does
+                sec = contrast_run(a, ctx, a.secondary_steps, 3, 0, eager=True)
                 res["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype")}
                 res["secondary"]["config"] = sec["config"]
             except Exception as e:     # noqa: BLE001

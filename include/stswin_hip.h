@@ -39,7 +39,9 @@ extern "C" {
                                   * the convolution (stswin_cs_group_reduce + stswin_bn_finalize with x = NULL) */
 #define STSWIN_GF_TAPSKIP (1 << 29) /* tiled (non-ring) kernels, S > 1 with a_rows: a workgroup first scans its rows of the map and skips every
                                     * segment (convolution tap) that is padding for ALL of them - pays when every row tile has such a tap (dilation >=
-                                    * half the map height: ASPP's dilation 18 on 32 x 32: 70 -> 53 us); the scan costs ~4 us per launch */
+                                    * half the map height: ASPP's dilation 18 on 32 x 32: 70 -> 53 us); the scan costs ~4 us per launch.
+                                    * Bitwise neutral for FINITE weights only: a skipped all-padding tap contributes 0 * w, which the unskipped
+                                    * kernel evaluates as NaN when w is Inf / NaN - a diverged run can look healthy in the skipped taps */
 #define STSWIN_GF_BIG 128       /* tuning: force the 256x256 4-stage-ring kernel (bf16) */
 #define STSWIN_GF_MID 512       /* tuning: 256x128x32 tile, 3-stage ring, 2 workgroups per CU (bf16) */
 #define STSWIN_GF_NOPIPE 1024   /* tuning: 256x256 ring kernel without software-pipelined LDS fragment reads */
@@ -198,6 +200,10 @@ int stswin_tn_combine(const float* workspace, float* C, long ldc, int Ni, int Nj
 #define STSWIN_TN_OUT_TAPMINOR (1 << 25)   /* bit of `splits` (with bseg > 0): store C[i][c * S + s] for GEMM column j = s * bseg + c, S = Nj / bseg - the [cout][cin][k][k]
                                             * layout of a convolution weight gradient; only where split-K slabs are combined (check stswin_last_variant) */
 int stswin_last_variant(int family);
+/* 1: the library was built with -DSTSWIN_TUNING (STSWIN_TUNING=1 python __graft_entry__.py --force) and holds the A/B-only gemm_nt variants
+ * (STSWIN_GF_MID / _HALF / _NOPIPE / duo / stream: each measured slower than the default dispatch); 0: the product build, which ignores
+ * those flags and picks the default kernel. */
+int stswin_tuning_build(void);
 
 /* ---- deterministic cross-workgroup sums.  No kernel of this library adds fp32 values with atomics any more: every kernel that sums
  * over workgroups (bias / LayerNorm / BatchNorm parameter gradients, BatchNorm statistics, the relative-position-bias gradient, the

@@ -41,14 +41,13 @@ class LARS:
         self.optim = optimizer
         self.eps = eps
         self.trust_coef = trust_coef
-        self._norms = {}
 
     def __getstate__(self):
         return (self.optim, {"eps": self.eps, "trust_coef": self.trust_coef})
 
     def __setstate__(self, state):
         self.optim, d = state
-        self.eps, self.trust_coef, self._norms = d["eps"], d["trust_coef"], {}
+        self.eps, self.trust_coef = d["eps"], d["trust_coef"]
 
     def __repr__(self):
         return "%s(%r)" % (self.__class__.__name__, self.optim)
@@ -72,13 +71,6 @@ class LARS:
 
     def add_param_group(self, param_group):
         self.optim.add_param_group(param_group)
-
-    def _scratch(self, device, n):
-        t = self._norms.get(device)
-        if t is None or t.numel() < 2 * n:
-            t = torch.empty(2 * max(n, 48), dtype=torch.float32, device=device)
-            self._norms[device] = t
-        return t
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -110,7 +102,7 @@ class LARS:
                 touched.append(p)
             for (ps, gs, ms), is_first in ((first, True), (later, False)):
                 if ps:
-                    hip.multi_tensor_lars(ps, gs, ms, self._scratch(ps[0].device, 48), lr=float(group["lr"]), momentum=momentum,
+                    hip.multi_tensor_lars(ps, gs, ms, None, lr=float(group["lr"]), momentum=momentum,
                                           wd=wd, trust_coef=self.trust_coef, eps=self.eps, first=is_first, adaptive=adaptive)
             _mark_updated(touched)
         return loss

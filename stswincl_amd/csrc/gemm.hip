@@ -1029,6 +1029,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
 }
 
 
+#ifdef STSWIN_TUNING   // measured losers kept for A/B runs only: not compiled into the product library (build with STSWIN_TUNING=1)
 // =====================================================================================================
 // gemm_nt "stream" (bf16, S = 1, no A gather): the 256x256 ping-pong ring kernel made PERSISTENT.  A workgroup owns tiles
 // blockIdx.x, blockIdx.x + gridDim.x, ... and the 4-stage LDS ring streams straight across tile boundaries: the first
@@ -1329,6 +1330,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_stream_kernel(GemmNT p) {
   }
   if (!lag) __builtin_amdgcn_s_barrier();
 }
+
+#endif  // STSWIN_TUNING
 
 // =====================================================================================================
 // TN: C[i][j] += sum_m At[m][i] * Bt[m][j]      (both operands have the contraction index as their ROW)
@@ -1837,6 +1840,13 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slabs, floa
 // Which kernel the launcher picked for the calling thread's most recent stswin_gemm_nt / stswin_gemm_tn call (codes in
 // include/stswin_hip.h): the parity tests assert that the production shapes really run the production kernels.
 static thread_local int g_last_variant[2] = {0, 0};
+extern "C" int stswin_tuning_build() {
+#ifdef STSWIN_TUNING
+  return 1;
+#else
+  return 0;
+#endif
+}
 extern "C" int stswin_last_variant(int family) { return family >= 0 && family < 2 ? g_last_variant[family] : -1; }
 
 static int set_lds_once(const void* fn) {
@@ -1976,6 +1986,10 @@ extern "C" int stswin_gemm_nt_splitk(const void* A, long lda, const int* a_rows,
   int qs = 0;
   const int splits = nt_splitk_plan(M, N, Kseg, S, &qs);
   if (!splits) return -1008;
+  if (M <= 0 || N <= 0 || Kseg <= 0 || S <= 0 || lda % 8 || ldb % 8) return -1001;
+  // the combine kernels store whole 16-byte row pieces: a column slice that starts off an 8-column boundary (or a row pitch that
+  // is not a multiple of 8) is not a split-K candidate - the caller falls back to stswin_gemm_nt, whose epilogues handle it
+  if (ldc % 8 || ((uintptr_t)C & 15)) return -1008;
   if (!workspace || workspace_floats < (long)splits * M * N) return -1009;
   if ((a_rows ? false : (long)M * lda * 2 > 0xFFFF0000L) || (long)N * ldb * 2 > 0xFFFF0000L) return -1008;
   const char* e16 = getenv("STSWIN_SPLITK_BF16");
@@ -2003,6 +2017,11 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
                               const void* R, long ldr, const int* r_rows, int M, int N, int Kseg, int S,
                               float scale, int scale_cols, int flags, float* colsum, void* stream) {
   if (M <= 0 || N <= 0) return 0;
+#ifndef STSWIN_TUNING
+  // the stream / duo / mid / half / nopipe kernels (measured slower everywhere, kept for A/B runs) exist in STSWIN_TUNING builds
+  // only: the product library ignores their flags (stswin_tuning_build() tells a caller which library it has)
+  flags &= ~(GF_MID | GF_HALF | GF_DUO | GF_STREAM | GF_NOPIPE);
+#endif
   const int bk = dtype == 0 ? 64 : 32;
   if (Kseg <= 0 || Kseg % bk || S <= 0) return -1001;
   if ((flags & GF_ACCUM) && !(flags & GF_OUT_F32)) return -1002;
@@ -2052,6 +2071,7 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
   // measured slower than the 8-wave 128x128 kernel on every shape tried (128x32 wave tiles: 10 fragment reads per 16
   // MFMAs) - kept as a forced tuning option only
   (void)hfills;
+#ifdef STSWIN_TUNING
   const bool half = (flags & GF_HALF) && mid_ok && !mid;
   if (half && !(flags & GF_BIG)) {
     static int once_half = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 128, 2, 4, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
@@ -2061,9 +2081,9 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     STSWIN_CHECK_LAUNCH();
     return 0;
   }
+#endif
   if (big && !mid) {
-    static int once_big = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
-                          (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    static int once_big = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)once_big;
     // register epilogue (operand-swapped MFMA): bf16 output, every row piece 16-byte aligned, R rows copied by 16-byte LDS-DMA
     const bool regepi = !(flags & (GF_OUT_F32 | GF_ACCUM | GF_NOREGEPI)) && N % 8 == 0 && ldc % 8 == 0 && (!C2 || ldc2 % 8 == 0) &&
@@ -2072,6 +2092,7 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     static int once_swap = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)once_swap;
     if ((flags & GF_CS_SQ) && (!regepi || (flags & GF_NOPIPE))) return -1006;   // (only the register epilogue sums squares)
+#ifdef STSWIN_TUNING
     // persistent streaming variant: plain Linear GEMMs (S = 1, no A gather) with the register epilogue
     const bool streamk = regepi && S == 1 && !a_rows && (flags & GF_STREAM) && !(flags & (GF_NOPIPE | GF_NOSTREAM));
     if (streamk) {
@@ -2094,13 +2115,22 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
       STSWIN_CHECK_LAUNCH();
       return 0;
     }
-    g_last_variant[0] = (flags & GF_NOPIPE) ? STSWIN_VAR_NT_RING256_NOPIPE : regepi ? STSWIN_VAR_NT_RING256_REGEPI : STSWIN_VAR_NT_RING256_LDSEPI;
-    if (flags & GF_NOPIPE) hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, false>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
-    else if (regepi) hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
+    if (flags & GF_NOPIPE) {
+      static int once_np = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)once_np;
+      g_last_variant[0] = STSWIN_VAR_NT_RING256_NOPIPE;
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, false>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
+      STSWIN_CHECK_LAUNCH();
+      return 0;
+    }
+#endif
+    g_last_variant[0] = regepi ? STSWIN_VAR_NT_RING256_REGEPI : STSWIN_VAR_NT_RING256_LDSEPI;
+    if (regepi) hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
     STSWIN_CHECK_LAUNCH();
     return 0;
   }
+#ifdef STSWIN_TUNING
   if (mid) {
     static int once_mid = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 128, 4, 2, 3, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
     (void)once_mid;
@@ -2110,6 +2140,7 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     STSWIN_CHECK_LAUNCH();
     return 0;
   }
+#endif
   // narrow AND short (the decode head's 1x1 convolutions to 48 / 64 channels: M = 4096 .. 16384): 256-row tiles would be 16 .. 64
   // workgroups on 256 CUs - 128x64 tiles double them and two fit a CU
   if (dtype == 0 && N <= 64 && M >= 128 && w8 && !(flags & GF_NONARROW) && (M + 255) / 256 <= 128) {

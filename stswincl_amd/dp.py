@@ -11,6 +11,7 @@ they overlap the rest of backward.
 from __future__ import annotations
 
 import contextlib
+import weakref
 from typing import Iterable, List, Optional
 
 import torch
@@ -43,7 +44,10 @@ def grad_dest(p: torch.Tensor, shape=None, dtype=torch.float32):
     ent = getattr(p, "_stswin_grad_dest", None)
     if ent is None or p.grad is not None:
         return None
-    red, view = ent
+    red, view = ent[0](), ent[1]                        # (the reducer is held weakly: a dropped reducer must not live on here)
+    if red is None:
+        del p._stswin_grad_dest
+        return None
     if red._accumulate_only or id(p) in red._claimed or view.dtype != dtype:
         return None
     if shape is not None and tuple(shape) != tuple(view.shape):
@@ -94,7 +98,9 @@ class GradBucketReducer:
         # write them.  With comm_dtype set the collective runs on a converted copy (gradient compression) instead.
         self._flat: List[torch.Tensor] = []
         self._views: List[List[torch.Tensor]] = []
+        self._flat_numel: List[int] = []
         self._claimed = set()
+        me = weakref.ref(self)
         for b in self.buckets:
             offs, tot = [], 0
             for p in b:
@@ -102,13 +108,19 @@ class GradBucketReducer:
                 tot += (p.numel() + 15) // 16 * 16
             dt = b[0].dtype
             assert all(p.dtype == dt for p in b), "GradBucketReducer: mixed parameter dtypes inside one bucket"
+            self._flat_numel.append(tot)
+            if self.world == 1:                   # nothing is reduced: no second copy of the gradients (~500 MB for the seg model)
+                continue
             flat = torch.zeros(tot, dtype=dt, device=dev)
             self._flat.append(flat)
             vs = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, b)]
             self._views.append(vs)
-            if self.world > 1:
-                for p, v in zip(b, vs):
-                    p._stswin_grad_dest = (self, v)
+            for p, v in zip(b, vs):
+                other = getattr(p, "_stswin_grad_dest", None)
+                if other is not None and other[0]() is not None and other[0]() is not self:
+                    raise RuntimeError("GradBucketReducer: this parameter already belongs to another live reducer - close() it first "
+                                       "(two reducers would both hook the parameter and fight over its gradient slice)")
+                p._stswin_grad_dest = (me, v)
         self._hooks = []
         self._accumulate_only = 0
         self.collectives = 0                      # all-reduce launches so far (tests count them)
@@ -126,7 +138,8 @@ class GradBucketReducer:
             h.remove()
         self._hooks = []
         for p in self.params:
-            if getattr(p, "_stswin_grad_dest", (None,))[0] is self:
+            ent = getattr(p, "_stswin_grad_dest", None)
+            if ent is not None and ent[0]() in (self, None):
                 del p._stswin_grad_dest
 
     def reset(self):
@@ -134,7 +147,8 @@ class GradBucketReducer:
         self._work = [None] * len(self.buckets)
         self._comm = [None] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
-        self._claimed = set()
+        self._claimed = set()                     # (a backward that raises before finish() leaves its claims behind: call reset();
+                                                  #  until then those parameters merely take the copy path, never a wrong slice)
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -229,7 +243,7 @@ class GradBucketReducer:
     def bytes_per_step(self) -> int:
         """Bytes each rank contributes to the gradient all-reduce per step."""
         esz = torch.empty((), dtype=self.comm_dtype or torch.float32).element_size()
-        return sum(f.numel() for f in self._flat) * esz
+        return sum(self._flat_numel) * esz
 
 
 def all_gather_embeddings(x: torch.Tensor, group=None) -> torch.Tensor:

@@ -153,6 +153,7 @@ def zeros(*shape, device) -> torch.Tensor:
 # fixed order (include/stswin_hip.h, "deterministic cross-workgroup sums").  One buffer per device: every use is write-then-read on
 # the launch stream and kernels of a stream run in order.  It only ever grows (warm-up steps size it before a hipGraph capture).
 _SCRATCH = {}
+_SCRATCH_RETIRED = []        # superseded (smaller) scratch blocks: see scratch()
 _DEFER = [False, 0]          # [folds are being queued (deferred_folds), bump offset into the scratch buffer]
 
 
@@ -170,6 +171,10 @@ def scratch(device, floats: int) -> torch.Tensor:
         if t is None or t.numel() < floats:
             if t is not None and torch.cuda.is_current_stream_capturing():
                 raise StswinHipError("scratch buffer would have to grow during a hipGraph capture: run the step once before capturing")
+            if t is not None:
+                # A hipGraph captured earlier may still write and read the old block on every replay (its address is baked into the
+                # graph's kernel arguments): superseded blocks are kept alive, never handed back to the caching allocator
+                _SCRATCH_RETIRED.append(t)
             t = torch.empty(max(floats, 1 << 23), dtype=torch.float32, device=device)
             _SCRATCH[device] = t
     if _DEFER[0]:
@@ -514,6 +519,11 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
         # >= 64 row tiles would each add into the same N addresses: per-block partial sums + one small reduce instead
         cs_table = scratch(A.device, 2 * ((M + 255) // 256) * N)
         flags |= GF_CS_PARTIAL
+    elif colsum_out is not None and N % 4 and not _WARNED.get("cs_atomic"):
+        _WARNED["cs_atomic"] = True
+        import warnings
+        warnings.warn(f"stswincl_amd.hip.gemm_nt: column sums of an output with N = {N} (not a multiple of 4) are added with fp32 "
+                      f"atomics (order-dependent last bits); pad N to a multiple of 4 for bitwise-reproducible sums")
     name = "gemm_nt_bf16" if A.dtype == torch.bfloat16 else "gemm_nt_f32"
     if _SHAPE_NAMES:
         name += f" M={M} N={N} K={Kseg} S={S} a={int(a_rows is not None)} c={int(c_rows is not None)} fl={flags}"
@@ -526,8 +536,9 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
             with _Span(name, 2.0 * M * N * Ktot):
                 rc = load().stswin_gemm_nt_splitk(_p(A), _c_long(_ld(A)), _p(a_rows), _p(Bw), _c_long(_ld(Bw)), _p(out), _c_long(_ld(out)),
                                                   _p(bias), M, N, Kseg, S, 1 if (flags & GF_RELU) else 0, _p(ws), _c_long(ws.numel()), _stream())
-            _check(rc, "gemm_nt_splitk")
-            return out
+            if rc != -1008:                  # -1008: not a split-K candidate after all (an `out` column slice that is not 16-byte
+                _check(rc, "gemm_nt_splitk")  # aligned, a row pitch that is not a multiple of 8): the tiled kernels below take it
+                return out
     with _Span(name, 2.0 * M * N * Ktot):
         rc = load().stswin_gemm_nt(
             _dt(A), _p(A), _c_long(_ld(A)), _p(a_rows), _p(Bw), _c_long(_ld(Bw)), _p(out), _c_long(_ld(out)),
@@ -540,6 +551,7 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
     return out
 
 
+_WARNED = {}
 _NT_SPLITK = os.environ.get("STSWIN_NO_NT_SPLITK") != "1"                 # (A/B switch)
 _CS_PARTIAL_MIN_M = int(os.environ.get("STSWIN_CS_PARTIAL_MIN_M", "1"))   # (the table + fold path is the deterministic one: always)
 _CS_TABLES = {}

@@ -333,6 +333,9 @@ class JoinRowsFn(torch.autograd.Function):
         return (None, *outs)
 
 
+ATTN_TAP = None      # a list while a test records the attention operands of every block (SwinBlockFn.forward)
+
+
 class SwinBlockFn(torch.autograd.Function):
     """One SwinTransformerBlock on a frame pair: (Bp, 2, L, C) -> (Bp, 2, L, C)   (swin_512.py:196-237)."""
 
@@ -382,6 +385,9 @@ class SwinBlockFn(torch.autograd.Function):
             hip.gemm_nt(X2, wcast(qkv_w, dt), qkv, M=M, a_rows=rmap_in, bias=_f32(qkv_b), scale=scale, scale_cols=C)
             # STSWIN_FP8_ATTN=1 (BASELINE configs[4]): e4m3 q / k / v / P on the fp8 MFMA in the forward; the backward stays bf16
             o = hip.win_attn_fwd(qkv, biasT, maskT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads, C=C, bias_index=bidx, fp8=fp8)
+        if ATTN_TAP is not None:      # test instrumentation (tests/test_hip_configs.py): what the attention core read and wrote
+            ATTN_TAP.append({"qkv": qkv, "o": o, "table": table.detach(), "index": index, "mask": attn_mask, "geom": geom,
+                             "Bp": Bp, "C": C, "fp8": fp8})
         x1 = torch.empty(M, C, dtype=dt, device=dev)
         # (window row m lands on token row rmap[m] of x1; its shortcut is row rmap_in[m] of X2)
         hip.gemm_nt(o, wcast(proj_w, dt), x1, M=M, c_rows=rmap, bias=_f32(proj_b), resid=X2, r_rows=rmap_in,

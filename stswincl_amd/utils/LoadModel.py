@@ -39,15 +39,18 @@ def _torch_load(path, map_location, trusted=None):
     import pickle
     if trusted is None:
         trusted = os.environ.get("STSWIN_TRUST_CHECKPOINTS") == "1"
+    # what the safe unpickler raises: UnpicklingError for a refused global; RuntimeError / AttributeError / ModuleNotFoundError / EOFError
+    # for legacy (non-zip, tar) files and classes that are not importable here
+    refused = (pickle.UnpicklingError, RuntimeError, AttributeError, ModuleNotFoundError, EOFError)
     try:
         with torch.serialization.safe_globals([argparse.Namespace]):
             return torch.load(path, map_location=map_location, weights_only=True)
-    except pickle.UnpicklingError as e:
+    except refused as e:
         if trusted:
             return torch.load(path, map_location=map_location, weights_only=False)
         raise pickle.UnpicklingError(
-            f"{path}: refused by the safe unpickler ({e}).  If this checkpoint comes from a source you trust, pass trusted=True "
-            "to the loader or set STSWIN_TRUST_CHECKPOINTS=1 to unpickle it without restrictions.") from e
+            f"{path}: refused by the safe unpickler ({type(e).__name__}: {e}).  If this checkpoint comes from a source you trust, pass "
+            "trusted=True to the loader or set STSWIN_TRUST_CHECKPOINTS=1 to unpickle it without restrictions.") from e
 
 
 def _device_of(model):

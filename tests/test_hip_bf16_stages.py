@@ -244,3 +244,50 @@ def test_tswinplus_eval_mode_bf16_logits_within_2e2_of_the_fp32_oracle(hw, B):
     assert r32 < 1e-3
     assert r16_ < 2e-2, r16_
     assert agree > 0.99
+
+
+def test_tswinplus_eval_mode_bf16_weight_gradients_vs_the_fp32_oracle():
+    """Whole-model bf16 GRADIENT check on the conditioned fixture (round-3 verdict, weak #1): eval-mode BatchNorm (running statistics
+    loaded), OHEM-CE on the logits, every parameter gradient of the bf16 HIP path against the fp32 CPU oracle's - the oracle evaluated
+    on the bf16-rounded GEMM weights the kernels multiply, like every other row of this file.  One backward through ResNet18 -> 12
+    Swin blocks -> ASPP -> head: a mis-scaled or mis-indexed term anywhere in a backward kernel is O(0.1 .. 1) on the weights behind
+    it; bf16 rounding is the measured 1e-3 .. 2e-2 (printed).  Bound: 3e-2 rel-L2 on EVERY weight gradient (matrices, convolutions,
+    norm scales, bias table); bias-type vectors whose gradient is a small difference of large sums get 6e-2."""
+    from stswincl_amd.net.Ours.base18 import TswinPlus
+    from stswincl_amd.utils.losses import OhemCELoss2D
+    hw, B = 128, 2
+    m = TswinPlus(12, (hw // 8, hw // 8))
+    sd = _round_weights(gu.det_fill(m.state_dict(), salt=9))
+    m.load_state_dict(sd)
+    x = gu.det_tensor("stages/x", (B, 4, 3, hw, hw))
+    g = torch.Generator().manual_seed(11)
+    lab = torch.randint(0, 12, (B, hw, hw), generator=g)
+    names = [k for k, _ in m.named_parameters()]
+    sdo = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in sd.items()}
+    ref_loss = O.ohem_ce(O.tswin_plus(x, sdo, training=False), lab, hw * hw // 16)
+    ref_loss.backward()
+    m = m.cuda().eval()
+    with torch.autocast("cuda", dtype=BF):
+        loss = OhemCELoss2D(hw * hw // 16)(m(x.cuda()), lab.cuda())
+    loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 5e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    rows, bad, worst = [], [], {}
+    for k, p in m.named_parameters():
+        want = sdo[k].grad
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        if want is None or float(want.norm()) == 0.0:          # (value_transform-style unused parameters: none in TswinPlus)
+            assert float(p.grad.abs().max()) == 0.0, k
+            continue
+        r = rel(p.grad, want)
+        vec = p.dim() == 1 and k.endswith(".bias")
+        bound = 6e-2 if vec else 3e-2
+        fam = k.split(".")[0] + (" bias" if vec else "")
+        worst[fam] = max(worst.get(fam, 0.0), r)
+        rows.append(f"{k:60s} {r:.3e}")
+        if not r < bound:
+            bad.append((k, r, bound))
+    print(f"eval-mode TswinPlus {hw}x{hw} B={B}: loss {float(loss):.5f} vs oracle {float(ref_loss):.5f}; worst bf16-vs-fp32-oracle gradient "
+          f"rel-L2 per family: " + ", ".join(f"{f} {v:.2e}" for f, v in sorted(worst.items())))
+    if bad:
+        print("\n".join(rows))
+    assert not bad, bad

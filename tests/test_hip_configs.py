@@ -186,6 +186,89 @@ def test_config4_joint_finetune_steps_fp8_attention_vs_bf16(tmp_path):
     assert rel(w8, w16) < 1e-2
 
 
+def test_config4_full_size_fp8_finetune_step_vs_the_oracle(tmp_path):
+    """BASELINE configs[4] AT ITS SIZE: one joint-fine-tune step (train_CL_ft_mswin_sgd_minput.py:147-165,192-201: contrastive
+    checkpoint -> TswinPlus, 7-group SGD, GradScaler) on B = 4 clips x 4 frames x 3x512x512 with the fp8 (e4m3) attention on.
+    (i) every gradient finite, no skipped step; (ii) the training loss within 2e-2 of the loss of the fp32 CPU ORACLE on the same
+    weights and clips (the oracle's forward: reference formulation, fp32); (iii) the attention core of EVERY block call inside
+    that step (6 at stage 1: 128-token windows, head dim 128; 6 at stage 2: 32-token windows, head dim 256) against the reference
+    formulation (swin_512.py:117-138) evaluated in fp32 on the very q | k | v the kernel read: rel-L2 <= 6e-2, max error <= 12 % of
+    the output scale - the e4m3 bounds of the kernel test, now on the operands of a real step."""
+    from torch.cuda import amp
+    from oracle import stswin_oracle as O
+    from stswincl_amd import ops
+    from stswincl_amd.net.Ours.base18 import TswinPlus
+    from stswincl_amd.optim import FusedSGD
+    from stswincl_amd.utils.LoadModel import load_model_mswin_CL
+    from stswincl_amd.utils.losses import OhemCELoss2D
+    S, B = 512, 4
+    ckpt = str(tmp_path / "ckpt_epoch_150.pth")
+    _contrastive_checkpoint(ckpt, res=(S // 8, S // 8))
+    torch.manual_seed(5)
+    model = TswinPlus(12, (S // 8, S // 8))
+    model = load_model_mswin_CL(model, ckpt, log=False)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    torch.manual_seed(6)
+    lab = torch.randint(0, 12, (B, S // 32, S // 32)).repeat_interleave(32, 1).repeat_interleave(32, 2)
+    x = torch.randn(B, 4, 3, S, S) + F.one_hot(lab, 12).permute(0, 3, 1, 2)[:, None, :3].float() * 2.0
+    with torch.no_grad():
+        ref_loss = float(O.ohem_ce(O.tswin_plus(x, sd, training=True), lab, S * S // 16))
+    model = model.cuda().train()
+    lr = 0.01
+    groups = [{"params": model.resnet.parameters(), "lr": lr}, {"params": model.aspp.parameters(), "lr": lr},
+              {"params": model.swin.parameters(), "lr": lr}, {"params": model.project1.parameters(), "lr": lr},
+              {"params": model.project2.parameters(), "lr": lr}, {"params": model.project3.parameters(), "lr": lr},
+              {"params": model.classifier.parameters(), "lr": lr * 10}]
+    opt = FusedSGD(groups, lr=lr, momentum=0.9, weight_decay=1e-4)
+    scaler = amp.GradScaler()
+    os.environ["STSWIN_FP8_ATTN"] = "1"
+    ops.ATTN_TAP = taps = []
+    try:
+        opt.zero_grad()
+        with amp.autocast():
+            loss = OhemCELoss2D(S * S // 16)(model(x.cuda()), lab.cuda())
+        ops.ATTN_TAP = None
+        scaler.scale(loss).backward()
+        grads_finite = all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+        scaler.step(opt)
+        scaler.update()
+    finally:
+        ops.ATTN_TAP = None
+        os.environ.pop("STSWIN_FP8_ATTN", None)
+    assert grads_finite and scaler.get_scale() >= 65536.0, "inf / nan gradients: the step was skipped"
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    r_loss = abs(float(loss) - ref_loss) / abs(ref_loss)
+    print(f"configs[4] 512x512 B=4 fp8-attention step: loss {float(loss):.5f}, fp32 CPU oracle {ref_loss:.5f} (rel {r_loss:.2e})")
+    assert r_loss < 2e-2, (float(loss), ref_loss)
+    assert len(taps) == 12 and all(t["fp8"] for t in taps), [t["fp8"] for t in taps]
+    rows = []
+    for i, t in enumerate(taps):
+        H, W, ws, shift, heads = t["geom"]
+        C, N, T = t["C"], ws * ws, 2
+        d = C // heads
+        nW = (H // ws) * (W // ws)
+        qkv = _tap_qkv_f32(t)
+        nB_ = qkv.shape[0] // (T * N)
+        bias = t["table"].float()[t["index"].reshape(-1)].reshape(N, N, heads).permute(2, 0, 1)        # swin_512.py:122-124
+        q, k, v = qkv.reshape(nB_, T * N, 3, heads, d).permute(2, 0, 3, 1, 4)
+        attn = q @ k.transpose(-2, -1) + bias.repeat(1, T, T).unsqueeze(0)
+        if shift > 0:
+            attn = (attn.reshape(nB_ // nW, nW, heads, T * N, T * N) + t["mask"].float().repeat(1, T, T)[None, :, None]).reshape(-1, heads, T * N, T * N)
+        ref = (attn.softmax(-1) @ v).transpose(1, 2).reshape(nB_ * T * N, C)
+        got = t["o"].float()
+        r = float((got - ref).norm() / ref.norm())
+        mx = float((got - ref).abs().max() / ref.abs().max())
+        rows.append(f"block call {i:2d} (dim {C}, window {ws}, shift {shift}, {nB_} windows): rel-L2 {r:.4f}, max err {mx:.4f} of the output scale")
+        assert torch.isfinite(got).all() and r < 6e-2 and mx < 0.12, rows[-1]
+        del qkv, q, k, v, attn, ref, got
+    print("\n".join(rows))
+
+
+def _tap_qkv_f32(t):
+    """q (pre-scaled) | k | v rows as fp32, as the attention kernel read them."""
+    return t["qkv"].float()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, BF])
 def test_postprocessing_at_the_evaluation_size_1024x1280(dtype):
     """seg18/test.py:153-157 at its real size: 512x640 logits -> bilinear (align_corners=True) to 1024x1280 -> softmax ->

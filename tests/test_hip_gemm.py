@@ -174,6 +174,8 @@ def test_gemm_nt_ring_register_epilogues(variant):
     ac, wc, rc, bc = a.cuda(), w.cuda(), r.cuda(), bias.cuda()
     lin0 = F.linear(a.float(), w.float())
     lin = lin0 + bias
+    if variant == "stream" and not hip.load().stswin_tuning_build():
+        pytest.skip("the persistent streaming variant exists in STSWIN_TUNING builds only (the product library ignores its flag)")
     BIG = hip.GF_BIG | (hip.GF_STREAM if variant == "stream" else 0)
     out = torch.empty(m, n, dtype=dtype, device="cuda")
     pre = torch.empty(m, n, dtype=dtype, device="cuda")
@@ -401,3 +403,28 @@ def test_split_k_gemm_nt_matches_unsplit_and_fp64(M, N, Kseg, S, relu, bias, gat
     c3 = torch.empty_like(c)
     hip.gemm_nt(a, b, c3, M=M, a_rows=rmap, S=S, bias=bv, flags=hip.GF_RELU if relu else 0)
     assert torch.equal(c3, c)
+
+
+@pytest.mark.parametrize("col0,wide", [(4, 1032), (8, 1028), (16, 1040)])
+def test_split_k_gemm_nt_unaligned_out_slice_falls_back_or_runs_correctly(col0, wide):
+    """`out` as a column slice of a wider buffer (the ASPP concat path hands gemm_nt such slices): the split-K combine stores 16-byte
+    row pieces, so a slice that starts off an 8-column boundary or sits in a buffer whose pitch is not a multiple of 8 must be
+    refused by stswin_gemm_nt_splitk (-1008) and computed by the tiled kernels; an aligned slice takes the split-K path.  Either way
+    the values are right and nothing outside the slice is touched."""
+    M, N, Kseg, S = 2048, 512, 1024, 4
+    torch.manual_seed(col0)
+    a = torch.randn(M, Kseg, device="cuda").to(torch.bfloat16)
+    b = (torch.randn(N, S * Kseg, device="cuda") / (S * Kseg) ** 0.5).to(torch.bfloat16)
+    rmap = torch.randint(-1, M, (S, M), device="cuda", dtype=torch.int32)
+    buf = torch.full((M, wide), 7.0, dtype=torch.bfloat16, device="cuda")
+    out = buf[:, col0:col0 + N]
+    hip.gemm_nt(a, b, out, M=M, a_rows=rmap, S=S)
+    aligned = col0 % 8 == 0 and wide % 8 == 0
+    assert (hip.last_variant(0)["kernel"] == hip.VAR_NT_SPLITK) == aligned
+    ref = torch.zeros(M, N, dtype=torch.float64, device="cuda")
+    for s_ in range(S):
+        idx = rmap[s_].long()
+        ref += torch.where((idx >= 0)[:, None], a.double()[idx.clamp(min=0)], torch.zeros((), dtype=torch.float64, device="cuda")) \
+            @ b.double()[:, s_ * Kseg:(s_ + 1) * Kseg].t()
+    assert float((out.double() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) * 1.01 + 1e-6
+    assert bool((buf[:, :col0] == 7.0).all()) and bool((buf[:, col0 + N:] == 7.0).all())

@@ -53,8 +53,10 @@ def test_tswinplus_bf16_autocast():
     # Yardstick: the REFERENCE graph itself under CPU bf16 autocast on this fixture deviates by rel_logits_128 (7.8 %) from its
     # own fp32 run (tests/golden/bf16_yardstick.npz, tools/gen_golden.py --only bf16_yardstick): untrained weights and
     # train-mode BN on 16x16 / B = 2 maps amplify bf16 rounding.  The HIP bf16 path keeps more in bf16 than autocast does
-    # (BatchNorm / LayerNorm outputs, residual streams) and differs from run to run (fp32 atomics in the BatchNorm statistics change
-    # the bf16 rounding of a few activations: 0.078 ... 0.093 over eight runs), so it is held to 1.5 x the yardstick on the logits.
+    # (BatchNorm / LayerNorm outputs, residual streams); it is deterministic since round 3 (no fp32 atomics: the same value in
+    # every run, tests/test_hip_configs.py::test_bf16_training_step_is_bitwise_reproducible) and held to 1.5 x the yardstick on
+    # the logits.  The tight whole-model checks are on the conditioned fixture: tests/test_hip_bf16_stages.py (eval-mode logits
+    # 2e-2, every weight gradient 3e-2 against the fp32 oracle).
     yard = gu.load("bf16_yardstick.npz")
     r_log = rel(y.float()[:, :, ::2, ::2], g["y_train_sub"])
     r_loss = abs(float(loss) - float(g["loss_train"])) / float(g["loss_train"])
@@ -68,10 +70,11 @@ def test_tswinplus_bf16_weight_gradients_vs_reference_autocast_yardstick():
     """Weight gradients of the bf16 path against the fp32 path on the golden fixture (128x128, B = 2).  Yardstick = what the
     reference's own bf16-autocast backward loses on the same fixture (bf16_yardstick.npz: 0.14 classifier, 0.23 ASPP, 0.58-0.79 for
     the Swin / ResNet weights).  The decode-head weights are well conditioned and held to 1.3 x the yardstick.  The deep weights
-    are NOT reproducible in 16-bit arithmetic on this untrained fixture - neither by the reference's autocast (above) nor from run to
-    run here (BatchNorm-statistic atomics change the bf16 rounding of a few activations, ~50 layers amplify it: 0.45 ... 1.99 over
-    ten runs, same spread on the round-1 tree) - so they only get a sanity bound; the full-size step test
-    (tests/test_hip_production_dispatch.py) carries their check at a batch size where the gradients are stable."""
+    sit behind ~50 untrained layers with train-mode BatchNorm over 2 samples: a flipped bf16 rounding of one normalised activation
+    changes them by O(1) (the reference's own autocast run is 0.58-0.79 away from its fp32 run) - on THIS fixture they are a
+    chaos indicator, not a parity measure, and only get a sanity bound here.  Their parity is asserted where it is well posed:
+    tests/test_hip_bf16_stages.py::test_tswinplus_eval_mode_bf16_weight_gradients_vs_the_fp32_oracle (every weight gradient of the
+    whole model <= 3e-2 of the fp32 oracle's with the BatchNorm statistics loaded) and the per-stage table of that file."""
     yard = gu.load("bf16_yardstick.npz")
     names = [k[len("rel_grad/"):] for k in yard.files if k.startswith("rel_grad/")]
     head = ("aspp.conv_3x3_2.weight", "classifier.0.weight")
