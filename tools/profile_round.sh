@@ -22,7 +22,7 @@ rocprofv3 --output-format csv --kernel-trace --stats -d /tmp/prof_kt -o kt -- py
 KT=$(find /tmp/prof_kt -name "*kernel_trace.csv" | head -1)
 ST=$(find /tmp/prof_kt -name "*kernel_stats.csv" | head -1)
 [ -n "$ST" ] && head -60 "$ST" > $OUT/${TAG}_rocprofv3_kernel_stats.csv
-[ -n "$KT" ] && python3 tools/prof_summary.py "$KT" --last-ms 150 --top 60 > $OUT/${TAG}_bench_steady_state_kernels.txt 2>&1
+[ -n "$KT" ] && python3 tools/prof_summary.py "$KT" --last-ms 150 --top 60 --gaps 25 > $OUT/${TAG}_bench_steady_state_kernels.txt 2>&1
 grep '^{"metric"' $OUT/bench_under_rocprof.log | tail -1 > $OUT/${TAG}_bench_line_under_rocprof.json
 # 2. clean bench line + per-shape table
 python3 bench.py --steps 20 --warmup 3 > $OUT/bench_clean.log 2>&1
@@ -43,7 +43,7 @@ grep '^{"metric"' $OUT/bench_contrast.log | tail -1 > $OUT/${TAG}_bench_contrast
 rm -rf /tmp/prof_ktc
 rocprofv3 --output-format csv --kernel-trace --stats -d /tmp/prof_ktc -o kt -- python3 bench.py --workload contrast --steps 4 --warmup 2 --no-profile --graph 0 > $OUT/bench_contrast_under_rocprof.log 2>&1
 KTC=$(find /tmp/prof_ktc -name "*kernel_trace.csv" | head -1)
-[ -n "$KTC" ] && python3 tools/prof_summary.py "$KTC" --last-ms 120 --top 50 > $OUT/${TAG}_contrast_steady_state_kernels.txt 2>&1
+[ -n "$KTC" ] && python3 tools/prof_summary.py "$KTC" --last-ms 120 --top 50 --gaps 15 > $OUT/${TAG}_contrast_steady_state_kernels.txt 2>&1
 python3 bench.py --workload contrast --bank batch --steps 6 --warmup 2 > $OUT/bench_contrast_bank.log 2>&1
 grep '^{"metric"' $OUT/bench_contrast_bank.log | tail -1 > $OUT/${TAG}_bench_contrast_bank_line.json
 python3 bench.py --batch 8 --steps 8 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_b8.log 2>&1
