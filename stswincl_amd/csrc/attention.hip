@@ -41,19 +41,25 @@ template <int ROWB> DEVI int tile_off(int row, int chunk) {   // byte offset of 
 
 // LDS-DMA a [ROWS][ROWB bytes] tile (rows `row0..` of a row-major global matrix with pitch ld_bytes) using
 // `nwaves` waves (this wave is number `wv` of them).  Destination image: tile_off().
-template <int ROWS, int ROWB>
-DEVI void stage_tile(char* lds, const char* g, long ld_bytes, int wv, int nwaves) {
+// lane: the caller's lane id when it wants the per-lane address arithmetic re-derived at the call (an `asm volatile("" : "+v"(lane))`
+// inside its loop): hipcc otherwise hoists the 64-bit lane offsets of every call site out of a persistent loop and keeps them live.
+// RAW: the copies are issued as raw ISA (glds16_raw), invisible to hipcc's waitcnt pass - behind a BUILTIN LDS-DMA it drains vmcnt(0) in
+// front of every ds_read_b64_tr_b16 (and every LDS store), i.e. the transposed products of the backward waited for the prefetch of
+// the next problem's tiles and for their own output stores; the caller then owns every wait (wait_vm0 + barrier before a tile is read).
+template <int ROWS, int ROWB, bool RAW = false>
+DEVI void stage_tile(char* lds, const char* g, long ld_bytes, int wv, int nwaves, int lane = -1) {
   constexpr int CPR = ROWB / 16;
   constexpr int RPI = (1024 / ROWB) > 0 ? (1024 / ROWB) : 1;       // rows per wave instruction
   constexpr int IPR = ROWB > 1024 ? ROWB / 1024 : 1;               // instructions per row (rows > 1 KiB)
   constexpr int NINST = ROWS * ROWB / 1024;
-  const int l = threadIdx.x & 63;
+  const int l = lane >= 0 ? lane : (int)(threadIdx.x & 63);
   for (int ins = wv; ins < NINST; ins += nwaves) {
     int row, cphys;
     if constexpr (IPR == 1) { row = ins * RPI + l / CPR; cphys = l % CPR; }
     else { row = ins / IPR; cphys = (ins % IPR) * 64 + l; }
     const int csrc = (cphys & ~15) | ((cphys ^ swz_cpr<CPR>(row)) & 15);
-    glds16(g + row * ld_bytes + csrc * 16, lds + ins * 1024);
+    if constexpr (RAW) glds16_raw(g + row * ld_bytes + csrc * 16, lds + ins * 1024);
+    else glds16(g + row * ld_bytes + csrc * 16, lds + ins * 1024);
   }
 }
 
@@ -973,7 +979,20 @@ DEVI bf16x8 lds_tr_pair(const char* tile, int off0, int off1, int imm) {
   return cat4(__builtin_bit_cast(bf16x4, t0), __builtin_bit_cast(bf16x4, t1));
 }
 
-template <int NC>
+// QPF (round 4, the default): ALL of the next problem's q | k | v tiles are prefetched half a problem ahead, and its bias-table values
+// at the end of the current one.
+//  * The scores start right after the top-of-problem barrier with the Q row pieces read from LDS.  Before, V was prefetched instead of
+//    Q and the Q row pieces came from global memory at the top of the problem: a first-touch HBM round trip of ~3 us per problem in
+//    front of the first MFMA (profiles/r03_attn_bwd8_timeline.txt: 3.4 of 12.9 us).  Only dO is requested at the top; it lands
+//    behind the scores + softmax.  P overwrites V once dP is done; Q is never re-staged.
+//  * product 1 = dV (waves 0-3) and dK (waves 4-7), product 2 = the two halves of dQ: after product 1 the buffers of dO, P and Q are all
+//    dead and take the next K, Q and V; every wave multiplies 4 + 2 tiles and issues 64 + 32 stores (before: 4 + 2 against 2 + 4 with
+//    the stores of one group queueing behind the other's, 1.6 us of end-of-problem wait on waves 0-3).
+//  * Buffer roles (five 32 KB buffers): K | Q | V -> P | dO | dS; rotation at the end: K <- dO's, Q <- P's, V <- Q's, dO <- K's buffer.
+//  * The copies are raw ISA and the lane-constant LDS offsets are formed at their use (see stage_tile, ld_row, tro): at the 256-register
+//    cap every spilled constant and every scratch-resident table came back through s_waitcnt vmcnt(0), i.e. behind the output stores
+//    and the prefetch in flight - that, not the arithmetic, was most of the "latency-bound" phases of the round-2/3 timelines.
+template <int NC, bool QPF = false>
 __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
   using T = bf16;
   constexpr int NTOK = 128, HD = 128, ROWB = 256;          // K / V / Q / dO tiles and the P / dS tiles all have 256-byte rows
@@ -1000,54 +1019,49 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
   const int N = NC ? NC : a.N;
   const int q0 = qt * 32, qn = (q0 + lr) % N;
   // ---- lane constants of the LDS images (tile_off<256>: byte = row * 256 + ((chunk ^ swz256(row)) & 15) * 16)
-  // row fragments of rows X + lr (X a multiple of 32: swz256 sees lr only): rowc[ks] + X * 256 = offset of k-step ks
-  int rowc[8];
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) rowc[ks] = lr * ROWB + ((((2 * ks + half) ^ swz256(lr)) & 15) << 4);
-  // transposed fragments (frag_tr): rows 16 ks + 8 (l >> 5) + 4 e + q, columns 32 ct + 16 ((l >> 4) & 1) + 4 p
-  int troff[4][2];
+  // row fragments of rows X + lr (X a multiple of 32: swz256 sees lr only): offset of k-step ks = rbase + (((2 ks) ^ rsx) & 15) * 16 + X * 256
+  // (two lane constants and two VALU instructions per read instead of eight constants: the kernel sits at its 256-register cap and
+  // every spilled constant comes back through a scratch load + s_waitcnt vmcnt(0), i.e. behind the output stores in flight)
+  const int rbase = lr * ROWB, rsx = half ^ swz256(lr);
+  // transposed fragments (frag_tr): rows 16 ks + 8 (l >> 5) + 4 e + q, columns 32 ct + 16 ((l >> 4) & 1) + 4 p.  The byte offset of column
+  // tile ct is trb[e] + (((4 ct) ^ trx[e]) << 4): two lane constants per row pair instead of a [4][2] table - indexed with a run-time
+  // column tile (qt, hw) hipcc put that table into SCRATCH memory, and every scratch read is followed by s_waitcnt vmcnt(0): the
+  // products waited for their own output stores and for the tile prefetch of the next problem (profiles/r04_attn_bwd8_timeline.txt).
+  int trb[2], trx[2];
   {
     const int q = (l & 15) >> 2, pp = l & 3;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int row = 8 * half + 4 * e + q;
-        const int chunk = 4 * ct + 2 * ((l >> 4) & 1) + (pp >> 1);
-        troff[ct][e] = row * ROWB + (((chunk ^ swz256(row)) & 15) << 4) + (pp & 1) * 8;
-      }
+    for (int e = 0; e < 2; ++e) {
+      const int row = 8 * half + 4 * e + q;
+      trb[e] = row * ROWB + (pp & 1) * 8;
+      trx[e] = (2 * ((l >> 4) & 1) + (pp >> 1)) ^ swz256(row);
+    }
   }
-  auto ld_row = [&](const char* tile, int X, int ks) -> bf16x8 { return *(const bf16x8*)(tile + X * ROWB + rowc[ks]); };
-  auto ld_tr = [&](const char* tile, int ks, int ct) -> bf16x8 { return lds_tr_pair(tile, troff[ct][0], troff[ct][1], ks * 16 * ROWB); };
+  auto tro = [&](int ct, int e) -> int {
+    int tx = trx[e];
+    asm("" : "+v"(tx));
+    return trb[e] + ((((4 * ct) ^ tx) & 15) << 4);
+  };
+  auto ld_row = [&](const char* tile, int X, int ks) -> bf16x8 {
+    int sx = rsx;
+    asm("" : "+v"(sx));                            // (opaque: the offset is formed here, not hoisted out of the persistent loop)
+    return *(const bf16x8*)(tile + X * ROWB + rbase + ((((2 * ks) ^ sx) & 15) << 4));
+  };
+  auto ld_tr = [&](const char* tile, int ks, int ct) -> bf16x8 { return lds_tr_pair(tile, tro(ct, 0), tro(ct, 1), ks * 16 * ROWB); };
   {
     const long rb0 = (long)(blockIdx.x / a.heads) * NTOK;
     const T* q0b = (const T*)a.qkv + rb0 * a.ld + head * HD;
-    stage_tile<NTOK, ROWB>(smem, (const char*)(q0b + a.C), a.ld * sizeof(T), w, 8);
-    stage_tile<NTOK, ROWB>(smem + KV, (const char*)(q0b + 2 * a.C), a.ld * sizeof(T), w, 8);
+    stage_tile<NTOK, ROWB, QPF>(smem, (const char*)(q0b + a.C), a.ld * sizeof(T), w, 8);
+    stage_tile<NTOK, ROWB, QPF>(smem + KV, (const char*)(QPF ? q0b : q0b + 2 * a.C), a.ld * sizeof(T), w, 8);
+    if constexpr (QPF) stage_tile<NTOK, ROWB, QPF>(smem + 2 * KV, (const char*)(q0b + 2 * a.C), a.ld * sizeof(T), w, 8);   // V (buffer xb)
   }
-  const int out_voff = (4 * half * (int)a.ldo + lr) * 2;                 // per-lane part of every dqkv store address
-  const bool dbg_ts = (a.bias_windows & (1 << 30)) != 0;   // DBG (tools/attn_timeline.py): dqkv_colsum = u64 [workgroups][32] stamps
-  auto stamp = [&](int slot) {
-    if (dbg_ts && (threadIdx.x & 255) == 0) ((unsigned long long*)a.dqkv_colsum)[(long)blockIdx.x * 32 + hw * 16 + slot] = wall_clock64();
-  };
-  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int b_ = (int)(grp / a.heads);
-    const long rowbase = (long)b_ * NTOK;
-    const T* qbase = (const T*)a.qkv + rowbase * a.ld + head * HD;
-    const T* dobase = (const T*)a.dout + rowbase * a.lddo + head * HD;
-    char* Kt = smem + kb * KV;
-    char* Vt = smem + vb * KV;                     // V, later Q
-    char* Xt = smem + xb * KV;                     // dO, later the next problem's K
-    char* Pt = smem + pb * KV;                     // P, later the next problem's V
-    const bool has_next = grp + gridDim.x < ngroups;
-    const T* nqbase = (const T*)a.qkv + (long)((grp + gridDim.x) / a.heads) * NTOK * a.ld + head * HD;
-    stamp(0);
-    bf16x8 qf[HD / 16];
-    load_row_frags<T, HD>(qf, qbase, a.ld, q0 + lr);
-    // ---- bias (+ mask) values of this wave's 2 x 16 (key, query) entries per lane: requested BEFORE the tile wait
+  // bias (+ mask) values of a problem's 2 x 16 (key, query) entries per lane
+  float tb[2][16];
+  auto load_tb = [&](int b_) {
     const int widx = b_ % a.nW;
-    const int slot = (a.bias_windows & 0xffffff) > 1 ? (a.bias_index ? a.bias_index[widx] : widx) : 0;
-    float tb[2][16];
+    // (scalar load: a vector load of the wave-uniform slot index would be followed by s_waitcnt vmcnt(0) - at the end of a problem
+    //  that is a wait for the 64 output stores and the next problem's tile copies)
+    const int slot = (a.bias_windows & 0xffffff) > 1 ? (a.bias_index ? sload(a.bias_index, widx) : widx) : 0;
     if constexpr (NC == 64) {                      // key n = (kt & 1) * 32 + crow32(r, half): no wrap inside a 32-key tile
       const int tvoff = (4 * half * NC + qn) * 4;
       const int tsoff = (slot * a.heads + head) * NC * NC * 4;
@@ -1069,19 +1083,75 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) tb[kk][r] += mt[(((2 * hw + kk) * 32 + crow32(r, half)) % N) * N];
     }
+  };
+  if constexpr (QPF) load_tb((int)(blockIdx.x / a.heads));
+  // Output stores are two-byte stores.  Round 4 re-measured the alternatives now that no other stall hides them: a 4 x 4 register
+  // transpose (DPP + v_perm, 10 VALU per 4 registers) to 8-byte stores - a quarter of the instructions, each touching 8 rows x 64 B -
+  // ran 7 % SLOWER (134.8 vs 126.1 us): the cost follows the row pieces touched, not the instruction count.  See store_pair below.
+  const int out_voff = l * 2;                      // per-lane part of every dqkv store address: 64 consecutive columns of one row
+  const bool dbg_ts = (a.bias_windows & (1 << 30)) != 0;   // DBG (tools/attn_timeline.py): dqkv_colsum = u64 [workgroups][32] stamps
+  bool stamp_on = true;                            // (the timeline shows a STEADY-STATE problem: the last one, which requests nothing, is skipped)
+  auto stamp = [&](int slot) {
+    if (dbg_ts && stamp_on && (threadIdx.x & 255) == 0)
+      ((unsigned long long*)a.dqkv_colsum)[(long)blockIdx.x * 32 + hw * 16 + slot] = wall_clock64();
+  };
+  stamp(12);                                       // (workgroup start: slot 12 is written once)
+  for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int b_ = (int)(grp / a.heads);
+    const long rowbase = (long)b_ * NTOK;
+    const T* qbase = (const T*)a.qkv + rowbase * a.ld + head * HD;
+    const T* dobase = (const T*)a.dout + rowbase * a.lddo + head * HD;
+    char* Kt = smem + kb * KV;
+    char* Vt = smem + (QPF ? xb : vb) * KV;        // V, later Q                  (QPF: V, later P, later the next problem's Q)
+    char* Xt = smem + (QPF ? pb : xb) * KV;        // dO, later the next problem's K
+    char* Pt = QPF ? Vt : smem + pb * KV;          // P, later the next problem's V
+    char* Qt = smem + vb * KV;                     // QPF: Q (prefetched)
+    const bool has_next = grp + gridDim.x < ngroups;
+    const T* nqbase = (const T*)a.qkv + (long)((grp + gridDim.x) / a.heads) * NTOK * a.ld + head * HD;
+    stamp_on = has_next || ngroups <= (long)gridDim.x;
+    stamp(0);
+    bf16x8 qf[HD / 16];
+    if constexpr (!QPF) {
+      load_row_frags<T, HD>(qf, qbase, a.ld, q0 + lr);
+      // ---- bias (+ mask) values: requested BEFORE the tile wait
+      load_tb(b_);
+    }
     wait_vm0();
-    __syncthreads();                               // K, V (requested half a problem ago) and the Q row pieces have landed
+    __syncthreads();                               // K and V | Q (requested half a problem ago) have landed (+ the Q row pieces)
     stamp(1);
-    stage_tile<NTOK, ROWB>(Xt, (const char*)dobase, a.lddo * sizeof(T), w, 8);
+    if constexpr (QPF) {
+      // the table values were requested one problem ago and are complete behind the wait above; as asm outputs hipcc no longer treats
+      // them as pending loads (it would otherwise wait vmcnt(0) at their first use - with the V / dO copies below in flight)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(tb[kk][r]));
+      int lv = l;                                  // (re-derive the copies' lane offsets here: see stage_tile)
+      asm volatile("" : "+v"(lv));
+      stage_tile<NTOK, ROWB, QPF>(Xt, (const char*)dobase, a.lddo * sizeof(T), w, 8, lv);   // (V was prefetched with K and Q)
+    } else {
+      stage_tile<NTOK, ROWB, QPF>(Xt, (const char*)dobase, a.lddo * sizeof(T), w, 8);
+    }
     // ---- S^T for this wave's two key tiles: lane = query column, registers = keys
     f32x16 p[2], dp[2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) p[kk][r] = 0.f;
+    if constexpr (QPF) {                           // the Q row pieces come from LDS one k-step at a time: no 32-register fragment set
 #pragma unroll
-      for (int ks = 0; ks < HD / 16; ++ks)
-        p[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Kt, (2 * hw + kk) * 32, ks), qf[ks], p[kk], 0, 0, 0);
+      for (int ks = 0; ks < HD / 16; ++ks) {
+        const bf16x8 qk = ld_row(Qt, q0, ks);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          p[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Kt, (2 * hw + kk) * 32, ks), qk, p[kk], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks)
+          p[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Kt, (2 * hw + kk) * 32, ks), qf[ks], p[kk], 0, 0, 0);
     }
     float mx = -3.0e38f;
 #pragma unroll
@@ -1102,13 +1172,16 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
         sum += e;
       }
     sum += __shfl_xor(sum, 32);
-    if (half == 0) ex1[hw * NTOK + q0 + lr] = make_float2(mx, sum);
+    int le = l;                                    // (QPF: exchange indices re-derived, not kept live over the loop)
+    if constexpr (QPF) asm volatile("" : "+v"(le));
+    const int exi = q0 + (le & 31);
+    if ((le >> 5) == 0) ex1[hw * NTOK + exi] = make_float2(mx, sum);
     stamp(2);
     wait_vm0();                                    // this wave's pieces of the dO tile
     __syncthreads();                               // partner statistics + dO tile visible
     stamp(3);
     {
-      const float2 o = ex1[(hw ^ 1) * NTOK + q0 + lr];
+      const float2 o = ex1[(hw ^ 1) * NTOK + exi];
       const float m = fmaxf(mx, o.x);
       const float mine = __expf(mx - m);
       const float inv = mine / (sum * mine + o.y * __expf(o.x - m));
@@ -1119,14 +1192,25 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
     }
     // ---- dP^T = V dO^T on the same key tiles (the dO row pieces replace Q's in qf)
 #pragma unroll
-    for (int ks = 0; ks < HD / 16; ++ks) qf[ks] = ld_row(Xt, q0, ks);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dp[kk][r] = 0.f;
+    if constexpr (QPF) {
 #pragma unroll
-      for (int ks = 0; ks < HD / 16; ++ks)
-        dp[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Vt, (2 * hw + kk) * 32, ks), qf[ks], dp[kk], 0, 0, 0);
+      for (int ks = 0; ks < HD / 16; ++ks) {
+        const bf16x8 ok = ld_row(Xt, q0, ks);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          dp[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Vt, (2 * hw + kk) * 32, ks), ok, dp[kk], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks) qf[ks] = ld_row(Xt, q0, ks);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks)
+          dp[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Vt, (2 * hw + kk) * 32, ks), qf[ks], dp[kk], 0, 0, 0);
     }
     float delta = 0.f;
 #pragma unroll
@@ -1134,10 +1218,10 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) delta += p[kk][r] * dp[kk][r];
     delta += __shfl_xor(delta, 32);
-    if (half == 0) ex2[hw * NTOK + q0 + lr] = delta;
+    if ((le >> 5) == 0) ex2[hw * NTOK + exi] = delta;
     stamp(4);
     __syncthreads();
-    delta += ex2[(hw ^ 1) * NTOK + q0 + lr];
+    delta += ex2[(hw ^ 1) * NTOK + exi];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -1148,6 +1232,10 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
     stamp(5);
     __syncthreads();                               // every wave has read the exchange area: P / dS may overwrite it
     // P and dS tiles [query row][key] (bf16): this wave's 32 query rows x 64 keys
+    // (QPF: the eight store offsets are re-derived here instead of living in registers across the whole persistent loop)
+    int lq = l;
+    if constexpr (QPF) asm volatile("" : "+v"(lq));
+    const int lrq = lq & 31, halfq = lq >> 5;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -1155,13 +1243,13 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
         bf16x4 vp, vs;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { vp[e] = (bf16)p[kk][4 * g + e]; vs[e] = (bf16)dp[kk][4 * g + e]; }
-        const int off = (q0 + lr) * ROWB + (((((2 * hw + kk) * 4 + g) ^ swz256(lr)) & 15) << 4) + half * 8;
+        const int off = (q0 + lrq) * ROWB + (((((2 * hw + kk) * 4 + g) ^ swz256(lrq)) & 15) << 4) + halfq * 8;
         *(bf16x4*)(Pt + off) = vp;
         *(bf16x4*)(St + off) = vs;
       }
     __syncthreads();                               // P, dS complete; every wave is done with V
     stamp(6);
-    stage_tile<NTOK, ROWB>(Vt, (const char*)qbase, a.ld * sizeof(T), w, 8);      // V is dead: Q (for dK)
+    if constexpr (!QPF) stage_tile<NTOK, ROWB, QPF>(Vt, (const char*)qbase, a.ld * sizeof(T), w, 8);      // V is dead: Q (for dK)
     // dqkv row rowbase + .., columns head * HD + ..: scalar byte offsets of the three thirds
     const int so_q = (int)((rowbase * a.ldo + head * HD) * 2), so_k = so_q + a.C * 2, so_v = so_k + a.C * 2;
     const int k0 = qt * 32;
@@ -1172,12 +1260,23 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
     };
+    // Two neighbouring 32-column tiles hold, per register, rows r' (lanes 0-31) and r' + 4 (lanes 32-63) of their columns.  ONE
+    // v_permlane32_swap per register pair (upper half of tile A's register <-> lower half of tile B's) leaves register A with row r'
+    // and register B with row r' + 4, each across all 64 lanes = 64 consecutive columns: every store instruction then writes ONE whole
+    // 128-byte line instead of two 64-byte halves of two different lines.
+    auto store_pair = [&](float va, float vb, int soff) {       // soff: byte offset of (row r', first column of tile A)
+      const bf16 oa = (bf16)va, ob = (bf16)vb;
+      const unsigned ua = (unsigned)__builtin_bit_cast(unsigned short, oa), ub = (unsigned)__builtin_bit_cast(unsigned short, ob);
+      const auto sw = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
+      buf_store_b16(a.out, __builtin_bit_cast(bf16, (unsigned short)sw[0]), out_voff, soff);
+      buf_store_b16(a.out, __builtin_bit_cast(bf16, (unsigned short)sw[1]), out_voff, soff + 4 * (int)a.ldo * 2);
+    };
     auto store4 = [&](int sbase, int row0) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
+      for (int dt = 0; dt < 4; dt += 2)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          buf_store_b16(a.out, (bf16)acc[dt][r], out_voff, sbase + ((row0 + crow32(r, 0)) * (int)a.ldo + dt * 32) * 2);
+          store_pair(acc[dt][r], acc[dt + 1][r], sbase + ((row0 + crow32(r, 0)) * (int)a.ldo + dt * 32) * 2);
     };
     // acc[0..3] += A^T(tile at, column tile qt) x B(tile bt) over the 128 contraction rows: dV (P, dO) and dK (dS, Q).
     // (the operands of step ks + 1 are requested before the MFMAs of step ks; the scheduling barrier keeps hipcc from
@@ -1230,43 +1329,71 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
       for (int dd = 0; dd < 2; ++dd) {
         float csum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const T o = (bf16)(acc[dd][r] * a.scale);
-          buf_store_b16(a.out, o, out_voff, so_q + ((q0 + crow32(r, 0)) * (int)a.ldo + (2 * hw + dd) * 32) * 2);
-          csum += (float)o;
-        }
+        for (int r = 0; r < 16; ++r) csum += (float)(bf16)(acc[dd][r] * a.scale);        // (sums of the ROUNDED values, own column)
         csacc[dd] += csum;
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        store_pair(acc[0][r] * a.scale, acc[1][r] * a.scale, so_q + ((q0 + crow32(r, 0)) * (int)a.ldo + 2 * hw * 32) * 2);
     };
-    if (hw == 0) {                                 // dV[key][d] = sum_q P[q][key] dO[q][d]
+    if constexpr (QPF) {
+      // product 1: dV (waves 0-3: P, dO) and dK (waves 4-7: dS, Q) - four tile products each; after it P, dO AND Q are dead, so the
+      // next problem's K, Q and V all go out here (into dO's, P's and Q's buffers): only dO is left to request at the next top.
+      // product 2: both wave groups multiply their half of dQ (dS, K).  Same work and the same number of stores in every wave.
       zero4();
-      tr_product(Pt, Xt);
-    } else {
-      dq_half();
-    }
-    stamp(7);
-    wait_vm0();                                    // Q has landed (waited for BEFORE this phase's stores are issued)
-    __syncthreads();                               // ... and every wave is done with the dO tile
-    stamp(8);
-    if (hw == 0) store4(so_v, k0);
-    else dq_store();
-    if (has_next) {                                // the next problem's K and V into the buffers dO and P just left
-      stage_tile<NTOK, ROWB>(Xt, (const char*)(nqbase + a.C), a.ld * sizeof(T), w, 8);
-      stage_tile<NTOK, ROWB>(Pt, (const char*)(nqbase + 2 * a.C), a.ld * sizeof(T), w, 8);
-    }
-    stamp(9);
-    if (hw == 0) {
+      if (hw == 0) tr_product(Pt, Xt);             // dV[key][d] = sum_q P[q][key] dO[q][d]
+      else tr_product(St, Qt);                     // dK[key][d] = sum_q dS[q][key] q_s[q][d]
+      stamp(7);
+      __syncthreads();                             // every wave is done with dO, P and Q
+      stamp(8);
+      store4(hw == 0 ? so_v : so_k, k0);
+      if (has_next) {
+        int lv = l;
+        asm volatile("" : "+v"(lv));
+        stage_tile<NTOK, ROWB, true>(Xt, (const char*)(nqbase + a.C), a.ld * sizeof(T), w, 8, lv);       // next K
+        stage_tile<NTOK, ROWB, true>(Pt, (const char*)nqbase, a.ld * sizeof(T), w, 8, lv);               // next Q
+        stage_tile<NTOK, ROWB, true>(Qt, (const char*)(nqbase + 2 * a.C), a.ld * sizeof(T), w, 8, lv);   // next V
+      }
+      stamp(9);
       dq_half();
       dq_store();
-    } else {                                       // dK[key][d] = sum_q dS[q][key] q_s[q][d]
-      zero4();
-      tr_product(St, Vt);
-      store4(so_k, k0);
+      __builtin_amdgcn_sched_barrier(0);           // (not hoisted above the products: 32 more live registers there would spill)
+      if (has_next) load_tb((int)((grp + gridDim.x) / a.heads));   // next problem's table values: complete long before its top
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      if (hw == 0) {                               // dV[key][d] = sum_q P[q][key] dO[q][d]
+        zero4();
+        tr_product(Pt, Xt);
+      } else {
+        dq_half();
+      }
+      stamp(7);
+      wait_vm0();                                  // Q has landed (waited for BEFORE this phase's stores are issued)
+      __syncthreads();                             // ... and every wave is done with the dO tile
+      stamp(8);
+      if (hw == 0) store4(so_v, k0);
+      else dq_store();
+      if (has_next) {                              // the next problem's K and V into the buffers dO and P just left
+        stage_tile<NTOK, ROWB, false>(Xt, (const char*)(nqbase + a.C), a.ld * sizeof(T), w, 8);
+        stage_tile<NTOK, ROWB, false>(Pt, (const char*)(nqbase + 2 * a.C), a.ld * sizeof(T), w, 8);
+      }
+      stamp(9);
+      if (hw == 0) {
+        dq_half();
+        dq_store();
+      } else {                                     // dK[key][d] = sum_q dS[q][key] q_s[q][d]
+        zero4();
+        tr_product(St, Vt);
+        store4(so_k, k0);
+      }
     }
     stamp(10);
     __syncthreads();                               // the next problem's tiles overwrite Q / K / dS
     stamp(11);
-    { const int t0 = kb, t1 = vb; kb = xb; vb = pb; xb = t0; pb = t1; }     // next K sits in xb, next V in pb
+    stamp_on = true;
+    stamp(14);                                     // (end of the workgroup's latest problem, whichever it is)
+    if constexpr (QPF) { const int t0 = kb, t1 = vb; kb = pb; vb = xb; xb = t1; pb = t0; }   // K <- dO's, Q <- P's, V <- Q's, dO <- K's buffer
+    else { const int t0 = kb, t1 = vb; kb = xb; vb = pb; xb = t0; pb = t1; }     // next K sits in xb, next V in pb
   }
   // ---- deterministic hand-over (see attn_bwd_kernel): wave (qt, hw) parks its 64 key rows x 32 queries + its 64 dq columns in a
   // private LDS plane; fixed-order sums of the T x T entries per table cell and of the four query tiles per dq column; one slab per
@@ -1303,6 +1430,8 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
       slab[(long)N * N + c] = t;
     }
   }
+  stamp_on = true;
+  stamp(13);                                       // (workgroup end, after the hand-over)
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -1336,16 +1465,21 @@ static int launch_attn(const AttnArgs& a, bool bwd, hipStream_t st) {
     const int no8 = e4 && atoi(e4) ? 1 : 0;
     const bool fits = (long)a.nB_ * NTOK * a.ldo * 2 < 0x7FFF0000L;          // 32-bit buffer offsets of the dqkv stores
     if (bwd && !no8 && fits) {
-      static const int attr8 = (int)hipFuncSetAttribute((const void*)attn_bwd8_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      static const int attr8 = (int)hipFuncSetAttribute((const void*)attn_bwd8_kernel<NC, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        Cfg::BWD_LDS) |
+                               (int)hipFuncSetAttribute((const void*)attn_bwd8_kernel<NC, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         Cfg::BWD_LDS);
       if (attr8 != 0) return -attr8;
+      const char* eq = getenv("STSWIN_ATTN_BWD_QPF");                        // A/B switch (read per call): 0 = the round-3 schedule
+      const bool qpf = !(eq && atoi(eq) == 0);
       int g = 256;
       if (g > grid) g = grid;
       g = (g / a.heads) * a.heads;
       if (g < a.heads) g = a.heads;
       if (grid % a.heads == 0 && g >= a.heads) {
         if (a.slabs && (long)g * (a.N * a.N + HD) > a_scratch_floats) return -1205;
-        hipLaunchKernelGGL((attn_bwd8_kernel<NC>), dim3(g), dim3(512), Cfg::BWD_LDS, st, a);
+        if (qpf) hipLaunchKernelGGL((attn_bwd8_kernel<NC, true>), dim3(g), dim3(512), Cfg::BWD_LDS, st, a);
+        else hipLaunchKernelGGL((attn_bwd8_kernel<NC, false>), dim3(g), dim3(512), Cfg::BWD_LDS, st, a);
         const int rf = attn_bwd_fold(a, g, HD, st);
         if (rf) return rf;
         STSWIN_CHECK_LAUNCH();

@@ -1,4 +1,5 @@
-mkdir -p gpurun_out/r04b
-python -m pytest tests/test_hip_bf16_stages.py::test_tswinplus_eval_mode_bf16_weight_gradients_vs_the_fp32_oracle -x -q -s -m gpu > gpurun_out/r04b/test_grad.log 2>&1
-python -m pytest tests/test_hip_configs.py::test_config4_full_size_fp8_finetune_step_vs_the_oracle tests/test_hip_gemm.py tests/test_hip_model.py tests/test_hip_abi.py -q -s -m gpu > gpurun_out/r04b/tests2.log 2>&1
-tail -5 gpurun_out/r04b/tests2.log
+mkdir -p gpurun_out/r04c
+python -m pytest tests/test_hip_attention.py tests/test_hip_swin.py -x -q -m gpu 2>&1 | tail -2
+python tools/bench_attn.py 2>&1 | grep "stage1"
+STSWIN_ATTN_BWD_QPF=0 python tools/bench_attn.py 2>&1 | grep "stage1 bwd"
+python tools/attn_timeline8.py > gpurun_out/r04c/timeline_qpf.txt 2>&1

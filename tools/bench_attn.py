@@ -36,6 +36,14 @@ def main():
         cs = torch.zeros(3 * C, device=dev)
         probs = nB_ * heads
         f_fwd, f_bwd = 4.0 * ntok * ntok * hd * probs, 10.0 * ntok * ntok * hd * probs
+        # what the shifted blocks of the model pass: bias + mask pre-summed into one slot per distinct window pattern + a window -> slot index
+        tab4 = torch.randn(4, heads, N, N, device=dev)
+        bidx = (torch.arange(nW, device=dev) % 4).to(torch.int32)
+        t = timeit(lambda: hip.win_attn_fwd(qkv, tab4, None, nB_=nB_, nW=nW, T=T, ws=ws, heads=heads, C=C, bias_index=bidx))
+        print(f"{name} fwd table+index {t:8.1f} us {f_fwd / t / 1e6:7.1f} TF/s")
+        t = timeit(lambda: hip.win_attn_bwd(qkv, do, tab4, None, dbiasT, nB_=nB_, nW=nW, T=T, ws=ws, heads=heads, C=C,
+                                            scale=hd ** -0.5, colsum_out=cs, bias_index=bidx))
+        print(f"{name} bwd table+index {t:8.1f} us {f_bwd / t / 1e6:7.1f} TF/s   (the shifted blocks of the training step)", flush=True)
         for mname, m in (("mask", maskT), ("nomask", None)):
             t = timeit(lambda: hip.win_attn_fwd(qkv, biasT, m, nB_=nB_, nW=nW, T=T, ws=ws, heads=heads, C=C))
             print(f"{name} fwd {mname:7s} {t:8.1f} us {f_fwd / t / 1e6:7.1f} TF/s")
