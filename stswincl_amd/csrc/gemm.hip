@@ -733,9 +733,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
         for (int j = 0; j < FJ; ++j) asm volatile("" : "+v"(bj[j]));
       }
     }
-    f32x4 cs[FJ], cs2[FJ];
-#pragma unroll
-    for (int j = 0; j < FJ; ++j) { cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; cs2[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     // R (residual / GELU' factor): the whole [BM][BN] tile comes in by LDS-DMA, straight into the image positions that
     // the results will overwrite (same row-major layout, same chunk ^ row swizzle, so a lane reads its 8-byte piece and
     // later writes its 8-byte result to the very same address).  16 bytes per lane and whole 512-byte rows per request
@@ -764,64 +761,79 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
       wait_vmcnt<0>();
       __syncthreads();
     }
-#pragma unroll
-    for (int i = 0; i < FI; ++i) {
+    // one fragment: activation / R operand / ReLU on the accumulators, the result into the bf16 image; its column sums into csj / cs2j
+    auto fragment = [&](int i, int j, f32x4& csj, f32x4& cs2j) __attribute__((always_inline)) {
       const bool row_ok = m0 + wr * TM + i * 16 + fr < p.M;
+      f32x4 v = pre_act(i, j);
+      if constexpr (FUSED_C2D) {
+        // the two volatile asms pin this fragment between its neighbours: without them the polynomials of all 32
+        // fragments are hoisted ahead of the first store and 340 registers spill
+        asm volatile("" : "+v"(v));
+        f32x2 glo, ghi, dlo, dhi;
+        gelu_dgelu_fast2((f32x2){v[0], v[1]}, glo, dlo);
+        gelu_dgelu_fast2((f32x2){v[2], v[3]}, ghi, dhi);
+        bf16x4 dq = {(bf16)dlo[0], (bf16)dlo[1], (bf16)dhi[0], (bf16)dhi[1]};
+        asm volatile("" : "+v"(dq));
+        dpk[i][j] = dq;
+        v = (f32x4){glo[0], glo[1], ghi[0], ghi[1]};
+      } else if (do_gelu) {
+        const f32x2 lo = gelu_fast2((f32x2){v[0], v[1]}), hi = gelu_fast2((f32x2){v[2], v[3]});
+        v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
+      }
+      if (has_r) {
+        const bf16x4 rb = *(const bf16x4*)(img + (wr * TM + i * 16 + fr) * PITCH +
+                                           (((((wc * TN + j * 16 + 4 * fq) >> 3) ^ fr) & (CPRW - 1)) << 4) + (fq & 1) * 8);
+        const f32x4 r = {(float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]};
+        if (do_resid) v += r;
+        else if (do_mulr) v *= r;
+        else {
+          const f32x2 lo = dgelu_fast2((f32x2){r[0], r[1]}), hi = dgelu_fast2((f32x2){r[2], r[3]});
+          v *= (f32x4){lo[0], lo[1], hi[0], hi[1]};
+        }
+      }
+      if (do_relu) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
+      if (do_cs) { if (row_ok) { csj += v; if (do_sq) cs2j += v * v; } }
+      put(i, j, v);
+      if (do_gelu || do_dgelu) __builtin_amdgcn_sched_barrier(0);   // one fragment's polynomial temporaries at a time
+    };
+    constexpr bool CS_BODY = MD < 0 || (MD & E_COLSUM) != 0;
+    if constexpr (CS_BODY) {
+      // Bodies that sum columns walk the fragments COLUMN GROUP by column group (j outer, i inner) and emit each group's four sums
+      // (+ four sums of squares) as soon as its eight fragments are through: one f32x4 (two) of accumulators live instead of
+      // FJ = 4 (8) of them.  With all of them live beside the 128 accumulator registers hipcc spilled the sums to scratch and
+      // brought them back one at a time, each reload behind an s_waitcnt vmcnt(0): 16 dependent scratch round trips per tile in
+      // front of the C stores - on the fc2 input gradient (mul_r + column sums) a third of the epilogue (round 4, from the ISA).
+      // The sums still leave BEFORE the C stores are issued (stores count in vmcnt: a later wait would sit out their drain).
 #pragma unroll
       for (int j = 0; j < FJ; ++j) {
-        f32x4 v = pre_act(i, j);
-        if constexpr (FUSED_C2D) {
-          // the two volatile asms pin this fragment between its neighbours: without them the polynomials of all 32
-          // fragments are hoisted ahead of the first store and 340 registers spill
-          asm volatile("" : "+v"(v));
-          f32x2 glo, ghi, dlo, dhi;
-          gelu_dgelu_fast2((f32x2){v[0], v[1]}, glo, dlo);
-          gelu_dgelu_fast2((f32x2){v[2], v[3]}, ghi, dhi);
-          bf16x4 dq = {(bf16)dlo[0], (bf16)dlo[1], (bf16)dhi[0], (bf16)dhi[1]};
-          asm volatile("" : "+v"(dq));
-          dpk[i][j] = dq;
-          v = (f32x4){glo[0], glo[1], ghi[0], ghi[1]};
-        } else if (do_gelu) {
-          const f32x2 lo = gelu_fast2((f32x2){v[0], v[1]}), hi = gelu_fast2((f32x2){v[2], v[3]});
-          v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
-        }
-        if (has_r) {
-          const bf16x4 rb = *(const bf16x4*)(img + (wr * TM + i * 16 + fr) * PITCH +
-                                             (((((wc * TN + j * 16 + 4 * fq) >> 3) ^ fr) & (CPRW - 1)) << 4) + (fq & 1) * 8);
-          const f32x4 r = {(float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]};
-          if (do_resid) v += r;
-          else if (do_mulr) v *= r;
-          else {
-            const f32x2 lo = dgelu_fast2((f32x2){r[0], r[1]}), hi = dgelu_fast2((f32x2){r[2], r[3]});
-            v *= (f32x4){lo[0], lo[1], hi[0], hi[1]};
+        f32x4 csj = {0.f, 0.f, 0.f, 0.f}, cs2j = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < FI; ++i) fragment(i, j, csj, cs2j);
+        if (do_cs) {                                   // fold the 16 rows (fr) of each lane group, then one value per column
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = sum16(csj[e]);
+            const int gn = colb + j * 16 + e;
+            if (fr == 0 && gn < p.N) {                 // (register epilogue = SWAP kernels only: TM is 128 there)
+              if (TM % 128 == 0) cs_emit(p, (m0 + wr * TM) / 128, TM / 128, gn, t);
+              else atomicAdd(p.colsum + gn, t);
+            }
+            if (do_sq) {
+              const float t2 = sum16(cs2j[e]);
+              if (fr == 0 && gn < p.N && TM % 128 == 0) cs_emit_sq(p, (m0 + wr * TM) / 128, TM / 128, gn, t2);
+            }
           }
         }
-        if (do_relu) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
-        if (do_cs) { if (row_ok) { cs[j] += v; if (do_sq) cs2[j] += v * v; } }
-        put(i, j, v);
-        if (do_gelu || do_dgelu) __builtin_amdgcn_sched_barrier(0);   // one fragment's polynomial temporaries at a time
+        __builtin_amdgcn_sched_barrier(0);            // keep the column groups apart
       }
-      __builtin_amdgcn_sched_barrier(0);              // keep fragment rows apart: interleaved they spill
-    }
-    // Column sums leave BEFORE the C stores are issued: stores count in vmcnt, so any later wait on a load (a scratch
-    // reload of cs[], the index of an atomic) would sit out the whole store drain of the tile (7 us per tile measured).
-    if (do_cs) {                                       // fold the 16 rows (fr) of each lane group, then one value per column
+    } else {
+      f32x4 none = {0.f, 0.f, 0.f, 0.f}, none2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < FJ; ++j)
+      for (int i = 0; i < FI; ++i) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = cs[j][e];
-          t = sum16(t);
-          const int gn = colb + j * 16 + e;
-          if (fr == 0 && gn < p.N) {                   // (register epilogue = SWAP kernels only: TM is 128 there)
-            if (TM % 128 == 0) cs_emit(p, (m0 + wr * TM) / 128, TM / 128, gn, t);
-            else atomicAdd(p.colsum + gn, t);
-          }
-          if (do_sq) {
-            const float t2 = sum16(cs2[j][e]);
-            if (fr == 0 && gn < p.N && TM % 128 == 0) cs_emit_sq(p, (m0 + wr * TM) / 128, TM / 128, gn, t2);
-          }
-        }
+        for (int j = 0; j < FJ; ++j) fragment(i, j, none, none2);
+        __builtin_amdgcn_sched_barrier(0);            // keep fragment rows apart: interleaved they spill
+      }
     }
     stamp(5);
     readback(p.C, p.ldc);

@@ -1,5 +1,5 @@
-mkdir -p gpurun_out/r04c
-python -m pytest tests/test_hip_attention.py tests/test_hip_swin.py -x -q -m gpu 2>&1 | tail -2
-python tools/bench_attn.py 2>&1 | grep "stage1"
-STSWIN_ATTN_BWD_QPF=0 python tools/bench_attn.py 2>&1 | grep "stage1 bwd"
-python tools/attn_timeline8.py > gpurun_out/r04c/timeline_qpf.txt 2>&1
+mkdir -p gpurun_out/r04d
+python -m pytest tests/test_hip_gemm.py tests/test_hip_production_dispatch.py -x -q -m gpu 2>&1 | tail -2
+python tools/epi_decomp.py > gpurun_out/r04d/epi_decomp.txt 2>&1
+python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > gpurun_out/r04d/bench.log 2>&1
+grep -o '"value": [0-9.]*' gpurun_out/r04d/bench.log | head -1; grep -o '"frac": [0-9.]*' gpurun_out/r04d/bench.log
