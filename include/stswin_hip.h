@@ -196,6 +196,7 @@ int stswin_tn_combine(const float* workspace, float* C, long ldc, int Ni, int Nj
 #define STSWIN_VAR_TN_ROWS 32          /* Mk <= 8: a sum of outer products, no split-K slabs */
 #define STSWIN_VAR_TN_SLABS_F32 0x1000     /* split-K partial slabs + tn_reduce, fp32 partials */
 #define STSWIN_VAR_TN_SLABS_BF16 0x2000    /* ... bf16 partials */
+#define STSWIN_VAR_TN_FUSED 0x8000         /* the split-K partials were combined inside the GEMM launch (no tn_reduce pass) */
 #define STSWIN_VAR_TN_TAPMINOR 0x4000      /* the combine stored the result tap-minor (STSWIN_TN_OUT_TAPMINOR was honoured) */
 #define STSWIN_TN_OUT_TAPMINOR (1 << 25)   /* bit of `splits` (with bseg > 0): store C[i][c * S + s] for GEMM column j = s * bseg + c, S = Nj / bseg - the [cout][cin][k][k]
                                             * layout of a convolution weight gradient; only where split-K slabs are combined (check stswin_last_variant) */

@@ -1358,6 +1358,9 @@ struct GemmTN {
   int bseg;                                       // >0: Bt column j reads source column j % bseg of row bt_rows[(j / bseg)*Mk + m]
   float* slabs;                                   // optional [splits][Ni][Nj] partial results (plain stores) instead of atomics
   int slab_bf16;                                  // the partials are stored as bf16 (half the slab traffic; see stswin_gemm_tn)
+  // fused split-K combine (gemm_tn_ring_kernel<MODE, true>): arrival / departure counters of the output tiles [2][tiles], zero
+  // before and after every launch; overwrite / perm as tn_reduce_kernel's
+  unsigned* tile_cnt; int overwrite; int perm;
 };
 
 template <typename T, int NW>
@@ -1556,7 +1559,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(GemmTN p) {
 // else (both maps, Mk not a multiple of 32 with maps) to the 128x128 kernel: with the map handling resolved at compile time a
 // stage costs one or two scalar index loads, a dozen scalar multiplies / selects and 2 VALU per copy; written with runtime
 // tests it was 18 scalar branches and ~150 SALU instructions per stage, longer than the partner row's MFMA phase.
-template <int MODE>
+// FUSE (round 4): the split-K combine runs INSIDE this launch.  The MFMA operands are swapped (a lane then holds 4 consecutive output
+// COLUMNS of one row), the bf16 partial tile goes through one [256][256] LDS image and leaves as whole 16-byte row pieces - written
+// THROUGH the caches (sc1) - every wave drains its stores, one lane adds 1 to the tile's arrival counter (agent scope) and polls it
+// until all `splits` workgroups of the tile have arrived; then each of them adds rows [split * 256 / splits, ...) of the tile's
+// `splits` partial tiles in split order (sc1 loads: no acquire fence needed, MI355X_MICROARCH.md "Valid forms", row 1) and stores the
+// fp32 result.  Same values bit for bit as tn_reduce_kernel (same fp32 additions in the same order).  It replaces a 9.6 us
+// all-chip pass and a kernel boundary per weight gradient (69 of them per training step), and the 128 two-byte stores per lane
+// of the unfused epilogue.  Progress: the launcher only fuses when the whole grid is resident at once (<= one workgroup per CU),
+// so no arrival can wait for a workgroup that has not started; the poll is bounded and traps instead of hanging.
+template <int MODE, bool FUSE = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
   constexpr bool MAPS = MODE != 0, MAP_A = MODE == 1, MAP_B = MODE >= 2, TAPS = MODE == 3;
   using T = bf16;
@@ -1692,7 +1704,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
 #pragma unroll
     for (int i = 0; i < FI; ++i)
 #pragma unroll
-      for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < FJ; ++j) {
+        if constexpr (FUSE) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // C^T fragment: 4 columns per lane
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
     __builtin_amdgcn_s_setprio(0);
   };
   auto wait_tile = [&](int kt) {
@@ -1761,6 +1776,104 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
   if (MAPS && ixmax > (MAP_A ? limA : limB)) __builtin_trap();   // gathered operand beyond the 4 GB a 32-bit offset reaches
   stamp(3);
   if (p.ldc < 0) return;                               // debug / timing runs: no result
+  if constexpr (FUSE) {
+    typedef int v4i32 __attribute__((ext_vector_type(4)));
+    char* img = smem;                                  // [256 rows][512 B] bf16, 16-byte chunk ^= row & 15 (conflict-free both ways)
+    __syncthreads();                                   // every wave is done with the ring stages
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) {
+        const int row = wr * 128 + i * 16 + fr, chunk = (wc * 64 + j * 16 + 4 * fq) >> 3;
+        const bf16x4 o = {(bf16)acc[i][j][0], (bf16)acc[i][j][1], (bf16)acc[i][j][2], (bf16)acc[i][j][3]};
+        *(bf16x4*)(img + row * 512 + (((chunk ^ fr) & 31) << 4) + (fq & 1) * 8) = o;
+      }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)p.slabs, (short)0, (int)0xFFFFFFFE, 0x00020000);
+    const int rb_row = tid >> 5, rb_chunk = tid & 31;
+    const int gj = j0 + rb_chunk * 8;                  // this thread's 8 columns (Nj % 8 == 0: all or none exist)
+    const long plane = (long)p.Ni * p.Nj;
+    if (gj < p.Nj) {
+#pragma unroll
+      for (int ps = 0; ps < 16; ++ps) {
+        const int row = ps * 16 + rb_row, gi = i0 + row;
+        if (gi < p.Ni) {
+          const v4i32 val = *(const v4i32*)(img + row * 512 + (((rb_chunk ^ (row & 15)) & 31) << 4));
+          __builtin_amdgcn_raw_buffer_store_b128(val, rsS, (int)((((long)split_id * plane) + (long)gi * p.Nj + gj) * 2), 0, 16);   // sc1
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores ...
+    __syncthreads();                                   // ... before the one lane that signals for all of them
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    gu32* arrive = (gu32*)p.tile_cnt + tile_id;
+    gu32* depart = (gu32*)p.tile_cnt + gridDim.x / p.splits + tile_id;
+    if (tid == 0) {
+      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.splits) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 26)) __builtin_trap();    // (~10 s: a workgroup of this tile never arrived - fail loudly, do not hang)
+      }
+    }
+    __syncthreads();                                   // the other waves load behind the barrier the polling wave joins
+    stamp(4);
+    const int per = (256 + p.splits - 1) / p.splits;   // rows of the tile this workgroup combines
+    const int r_end = min(256, (split_id + 1) * per);
+    if (gj < p.Nj) {
+      for (int row = split_id * per + rb_row; row < r_end; row += 16) {
+        const int gi = i0 + row;
+        if (gi >= p.Ni) break;
+        const int off0 = (int)(((long)gi * p.Nj + gj) * 2);
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int sp = 0;
+        for (; sp + 8 <= p.splits; sp += 8) {          // eight partial rows in flight, added in split order
+          v4i32 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsS, off0, (int)((long)(sp + u) * plane * 2), 16);   // sc1
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const bf16x8 h = __builtin_bit_cast(bf16x8, v[u]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s8[e] += (float)h[e];
+          }
+        }
+        for (; sp < p.splits; ++sp) {
+          const bf16x8 h = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsS, off0, (int)((long)sp * plane * 2), 16));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s8[e] += (float)h[e];
+        }
+        if (p.perm > 0) {                              // tap-minor output (see tn_reduce_kernel)
+          const int S = p.Nj / p.perm, sg = gj / p.perm, c = gj - sg * p.perm;
+          float* d = p.C + (long)gi * p.ldc + (long)c * S + sg;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d[(long)e * S] = p.overwrite ? s8[e] : d[(long)e * S] + s8[e];
+        } else {
+          float* dst = p.C + (long)gi * p.ldc + gj;
+          if ((p.ldc & 3) == 0) {
+            f32x4 lo = {s8[0], s8[1], s8[2], s8[3]}, hi = {s8[4], s8[5], s8[6], s8[7]};
+            if (!p.overwrite) { lo += *(const f32x4*)dst; hi += *(const f32x4*)(dst + 4); }
+            *(f32x4*)dst = lo;
+            *(f32x4*)(dst + 4) = hi;
+          } else {
+            for (int e = 0; e < 8; ++e) dst[e] = p.overwrite ? s8[e] : dst[e] + s8[e];
+          }
+        }
+      }
+    }
+    // departure: the last workgroup of the tile to finish its share zeroes both counters for the next launch (every load of the
+    // tile's partials has returned by then: the sums above consumed them)
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned d = __hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d == (unsigned)p.splits - 1) {
+        __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    stamp(5);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < FI; ++i)
 #pragma unroll
@@ -2220,6 +2333,39 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
   return 0;
 }
 
+// Workgroups of gemm_tn_ring_kernel (128 KB of LDS: one per CU) that are resident at the same time = compute units of the device.
+static long tn_resident_workgroups() {
+  static thread_local int dev_cached = -1;
+  static thread_local long cus = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev != dev_cached) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cus = n;
+    dev_cached = dev;
+  }
+  return cus;
+}
+// Arrival / departure counters of the fused split-K combine: [2][tiles] unsigned per launch, zero when a launch starts and zeroed
+// again by its last workgroups.  16 regions per device, handed out round-robin (a captured hipGraph node keeps the region it was
+// captured with; launches that share a region are ordered by their stream).  Allocated and cleared once per device, outside
+// any stream capture (the first fused launch of a process is a warm-up launch; if it is not, the unfused path is taken).
+static unsigned* tn_tile_counters(int tiles) {
+  constexpr int REGIONS = 16, PER = 2 * 1024;
+  static unsigned* bufs[64] = {nullptr};
+  static unsigned next[64] = {0};
+  int dev = 0;
+  if (tiles > 1024 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!bufs[dev]) {
+    unsigned* b = nullptr;
+    if (hipMalloc((void**)&b, sizeof(unsigned) * REGIONS * PER) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemset(b, 0, sizeof(unsigned) * REGIONS * PER) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(b); return nullptr; }
+    bufs[dev] = b;
+  }
+  return bufs[dev] + (size_t)(next[dev]++ % REGIONS) * PER;
+}
+
 extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, const void* Bt, long ldb,
                               const int* bt_rows, float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg,
                               float* workspace, long workspace_floats, void* stream) {
@@ -2288,15 +2434,36 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
     if (ring) {
       const bool slabs = workspace && rs > 1 && (long)rs * Ni * Nj <= workspace_floats;
       if (overwrite && !slabs) (void)hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)Nj * sizeof(float), (size_t)Ni, (hipStream_t)stream);
-      GemmTN q{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, rs, bseg, slabs ? workspace : nullptr, slab_bf16};
+      // Fused split-K combine (gemm_tn_ring_kernel<MODE, true>): bf16 partials, the whole grid resident at once (one workgroup per
+      // CU: a workgroup polls for the other splits of its tile), byte offsets of the partials within 31 bits.
+      // STSWIN_TN_FUSED=0: the separate tn_reduce pass (A/B switch, read per call).
+      unsigned* tile_cnt = nullptr;
+      if (slabs && slab_bf16 && !no_combine && ldc >= 0 && (long)t256 * rs <= tn_resident_workgroups() && (long)rs * Ni * Nj * 2 < 0x7FFFFFF0L) {
+        const char* ef = getenv("STSWIN_TN_FUSED");
+        if (!(ef && atoi(ef) == 0)) tile_cnt = tn_tile_counters(t256);
+      }
+      GemmTN q{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, rs, bseg, slabs ? workspace : nullptr, slab_bf16, tile_cnt, overwrite, perm};
       static int once_r = (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
                           (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
                           (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
-                          (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                          (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
+                          (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
+                          (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
+                          (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
+                          (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       (void)once_r;
       const dim3 grid((unsigned)(t256 * rs));
       g_last_variant[1] = (at_rows ? STSWIN_VAR_TN_RING_ATROWS : (bt_rows && bseg > 0) ? STSWIN_VAR_TN_RING_BSEG : bt_rows ? STSWIN_VAR_TN_RING_BTROWS : STSWIN_VAR_TN_RING_PLAIN) |
-                          (slabs ? (slab_bf16 ? STSWIN_VAR_TN_SLABS_BF16 : STSWIN_VAR_TN_SLABS_F32) : 0) | ((slabs && perm) ? 0x4000 : 0) | (rs << 16);
+                          (slabs ? (slab_bf16 ? STSWIN_VAR_TN_SLABS_BF16 : STSWIN_VAR_TN_SLABS_F32) : 0) | ((slabs && perm) ? 0x4000 : 0) | (rs << 16) |
+                          (tile_cnt ? STSWIN_VAR_TN_FUSED : 0);
+      if (tile_cnt) {
+        if (at_rows) hipLaunchKernelGGL((gemm_tn_ring_kernel<1, true>), grid, dim3(512), 131072, (hipStream_t)stream, q);
+        else if (bt_rows && bseg > 0) hipLaunchKernelGGL((gemm_tn_ring_kernel<3, true>), grid, dim3(512), 131072, (hipStream_t)stream, q);
+        else if (bt_rows) hipLaunchKernelGGL((gemm_tn_ring_kernel<2, true>), grid, dim3(512), 131072, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL((gemm_tn_ring_kernel<0, true>), grid, dim3(512), 131072, (hipStream_t)stream, q);
+        STSWIN_CHECK_LAUNCH();
+        return 0;
+      }
       if (at_rows) hipLaunchKernelGGL(gemm_tn_ring_kernel<1>, grid, dim3(512), 131072, (hipStream_t)stream, q);
       else if (bt_rows && bseg > 0) hipLaunchKernelGGL(gemm_tn_ring_kernel<3>, grid, dim3(512), 131072, (hipStream_t)stream, q);
       else if (bt_rows) hipLaunchKernelGGL(gemm_tn_ring_kernel<2>, grid, dim3(512), 131072, (hipStream_t)stream, q);
@@ -2331,7 +2498,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   { const int per = (ntile + splits - 1) / splits; splits = (ntile + per - 1) / per; }
   const bool use_slabs = workspace && splits > 1 && (long)splits * Ni * Nj <= workspace_floats;
   if (overwrite && !use_slabs) (void)hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)Nj * sizeof(float), (size_t)Ni, (hipStream_t)stream);
-  GemmTN p{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, splits, bseg, use_slabs ? workspace : nullptr, slab_bf16};
+  GemmTN p{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, splits, bseg, use_slabs ? workspace : nullptr, slab_bf16, nullptr, 0, 0};
   dim3 grid(((Ni + 127) / 128) * ((Nj + 127) / 128) * splits);
   static int once = set_lds_once((const void*)gemm_tn_kernel<bf16, 4>) | set_lds_once((const void*)gemm_tn_kernel<float, 4>) |
                     set_lds_once((const void*)gemm_tn_kernel<bf16, 8>) | set_lds_once((const void*)gemm_tn_kernel<float, 8>);

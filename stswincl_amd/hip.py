@@ -676,6 +676,7 @@ VAR_F32 = 100
 VAR_TN_RING_PLAIN, VAR_TN_RING_ATROWS, VAR_TN_RING_BTROWS, VAR_TN_RING_BSEG = 20, 21, 22, 23
 VAR_TN_128x128, VAR_TN_128x128_W4, VAR_TN_ROWS = 30, 31, 32
 VAR_TN_SLABS_F32, VAR_TN_SLABS_BF16 = 0x1000, 0x2000
+VAR_TN_FUSED = 0x8000        # the split-K partials were combined inside the GEMM launch
 
 
 def last_tn_tapminor() -> bool:
