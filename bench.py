@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--bank", default="sample", choices=["sample", "batch", "world"],
                     help="contrast workload: key set a query pixel sees - its own sample (the reference), every sample of the rank, "
                          "or every sample of every rank (RCCL all-gather of the keys: the inter-video bank of BASELINE configs[3])")
+    ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="N > 1: wire dtype of the gradient all-reduce buckets (bf16 halves the bytes on the xGMI links; the averaged "
+                         "gradients are converted back to fp32 behind the collective)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short contrastive run that fills `secondary`")
     ap.add_argument("--secondary-steps", type=int, default=20)
     ap.add_argument("--dump-prof", default=None,
@@ -91,8 +94,8 @@ def cpu_baseline(size: int, budget_s: float = 60.0):
     frames: SURVEY 8(d) says B = 2 at 512x512) - measured, never extrapolated from a smaller frame (the CPU step does not scale with
     the pixel count: 256x256 is ~7x cheaper than 512x512, not 4x).  Best of as many repeats as fit the budget (at least one, at
     most three; every time is listed in `sample`).  Threads: the physical cores of the affinity mask are detected and stated; the
-    thread count actually used is the faster of {physical cores, 32} on a 128x128 calibration step (on a shared 256-thread host, one
-    thread per physical core measured slower than 32 - both timings are in `sample`, with torch.__config__.parallel_info())."""
+    thread count actually used is the faster of {32, min(physical cores, 64)} on a 128x128 calibration step (both timings are in
+    `sample`, with torch.__config__.parallel_info())."""
     from oracle import stswin_oracle as O
     from stswincl_amd.net.Ours.base18 import TswinPlus
     phys, logical = physical_cores()
@@ -116,7 +119,10 @@ def cpu_baseline(size: int, budget_s: float = 60.0):
 
     t_start = time.perf_counter()
     cal = {}
-    for th in sorted({max(1, min(32, phys)), phys}):
+    # candidates: 32 and min(physical cores, 64).  One thread per physical core on the pool's 128-core hosts was measured in rounds
+    # 3-4 (this calibration step: 0.97 vs 5.20 s, 1.22 vs 17.50 s) - 5-14x SLOWER than 32 threads on the shared machine, and
+    # that one measurement ate the budget of the 512x512 repeats; it is no longer tried above 64
+    for th in sorted({max(1, min(32, phys)), max(1, min(64, phys))}):
         torch.set_num_threads(th)
         one_step(64)                   # thread-pool / allocator warm-up
         cal[th] = one_step(128)
@@ -180,6 +186,7 @@ class Ctx:
     def dist_info(self, reducer):
         return {"backend": ("rccl (torch.distributed 'nccl')" if self.backend == "nccl" else self.backend),
                 "rccl_ranks": self.ranks_seen,
+                "comm_dtype": (str(reducer.comm_dtype).replace("torch.", "") if (reducer is not None and reducer.comm_dtype is not None) else "float32"),
                 "allreduce_bytes_per_step_per_rank": reducer.bytes_per_step() if reducer is not None else 0,
                 "shared_gpu_functional_test": self.share}
 
@@ -242,7 +249,7 @@ def contrast_run(a, ctx, steps, warmup, profile_stride, batch=8, bank="sample", 
     model = ConsistencyLoss(args, input_resolution=(S // 8, S // 8)).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
     opt, opt_name = make_contrast_optimizer(params, batch_size=B * world)
-    reducer = GradBucketReducer(params, bucket_mb=32.0) if world > 1 else None
+    reducer = GradBucketReducer(params, bucket_mb=32.0, comm_dtype=torch.bfloat16 if a.comm_dtype == "bf16" else None) if world > 1 else None
     torch.manual_seed(1234 + rank)
     ims = [torch.randn(B, 4, 3, S, S, device=dev) for _ in range(6)]
     masks = [torch.randint(0, 12, (B, 1, S, S), device=dev).float() for _ in range(6)]
@@ -318,7 +325,8 @@ def seg_run(a, ctx):
     use_graph = a.graph == 1 or (a.graph == -1 and world == 1 and not profile_stride)
     opt = FusedAdam(model.parameters(), 1e-4)          # == torch.optim.Adam (tests/test_hip_optim.py), 8 launches per step
     crit = OhemCELoss2D(S * S // 16)
-    reducer = GradBucketReducer(model.parameters(), bucket_mb=32.0) if world > 1 else None
+    comm_dtype = torch.bfloat16 if a.comm_dtype == "bf16" else None
+    reducer = GradBucketReducer(model.parameters(), bucket_mb=32.0, comm_dtype=comm_dtype) if world > 1 else None
     torch.manual_seed(1234 + rank)            # each rank owns different clips (weak scaling)
     x = torch.randn(B, 4, 3, S, S, device=dev)
     y = torch.randint(0, 12, (B, S, S), device=dev)
@@ -335,8 +343,9 @@ def seg_run(a, ctx):
         return loss
 
     graph_note = None
+    graph_wanted = use_graph
     if use_graph and world > 1 and ctx.backend != "nccl":
-        use_graph, graph_note = False, "hipGraph capture needs the RCCL backend (gloo collectives run on the host): eager launches"
+        use_graph, graph_note = False, "eager launches (hipGraph capture needs the RCCL backend: gloo collectives run on the host)"
     if use_graph:
         try:      # N > 1: the bucket all-reduces are enqueued on the reducer's side stream inside the capture (RCCL supports capture)
             step_g = capture(step, lambda: opt.zero_grad(set_to_none=True))
@@ -344,7 +353,9 @@ def seg_run(a, ctx):
         except Exception as e:     # noqa: BLE001
             if world == 1:
                 raise
-            use_graph, graph_note = False, f"hipGraph capture of the {world}-rank step failed ({type(e).__name__}): eager launches"
+            use_graph, graph_note = False, f"eager launches (FALLBACK: hipGraph capture of the {world}-rank step failed: {type(e).__name__}: {str(e)[:120]})"
+            if os.environ.get("STSWIN_BENCH_STRICT_GRAPH") == "1":      # tests: a requested capture must not fall back silently
+                raise
             torch.cuda.synchronize()
     dt, prof, loss = timed_steps(ctx, step, a.steps, a.warmup, profile_stride)
     frames = world * B * 4 * a.steps
@@ -358,6 +369,7 @@ def seg_run(a, ctx):
                                f"asserts it (swin_512.py:313)",
                    "clips_per_gpu": B, "frames_per_clip": 4, "parallelism": f"dp{world}",
                    "launch": "hipGraph replay of the whole step" if use_graph else (graph_note or "eager launches"),
+                   "graph_requested": bool(graph_wanted),
                    "loss": float(loss.detach())},
         "dist": ctx.dist_info(reducer),
     }

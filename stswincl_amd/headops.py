@@ -616,6 +616,166 @@ class BNTokFn(torch.autograd.Function):
         return (dx.to(in_dtype), dgamma, dbeta, None, None, None, None, dres, None, None, None, None, None, None, None, None, None)
 
 
+class BNTokGroupFn(torch.autograd.Function):
+    """Several INDEPENDENT nn.SyncBatchNorm layers (+ ReLU) whose inputs are all known - the five ASPP branches, the three 1x1
+    projections of the decode head, conv1 / downsample of a ResNet block - with ONE all-gather for all their batch statistics in the
+    forward and ONE all-reduce for all their backward sums (PixPro_swin_v5.py:215-228 converts every BatchNorm of both encoders; the
+    reference pays one tiny collective pair per layer, ~90 latency-bound collectives per encoder pass).  Per layer the arithmetic is
+    BNTokFn's SyncBatchNorm branch, kernel for kernel: the values are identical to one exchange per layer.
+    args: n, then n configuration tuples (relu, groups, lay, eps, momentum, unit, out), then per layer x, gamma, beta, running_mean,
+    running_var."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        import torch.distributed as dist
+        cfgs, tens = args[:n], args[n:]
+        world = dist.get_world_size()
+        st, packs = [], []
+        for i in range(n):
+            relu, groups, lay, eps, momentum, unit, out = cfgs[i]
+            x, gamma, beta, rmean, rvar = tens[5 * i:5 * i + 5]
+            dt = compute_dtype(x)
+            X = x.detach().to(dt)
+            M, Cp = X.shape
+            assert Cp == lay.width
+            n_loc = M // groups
+            s, ss = hip.colstats(X, groups=groups, unit=unit)
+            pivot = (X.view(-1, unit, Cp)[:groups, 0, :] if unit > 0 else X.view(groups, n_loc, Cp)[:, 0, :]).float()
+            mean_l = pivot + s / n_loc
+            m2_l = ss - s * s / n_loc
+            packs.append(torch.stack([mean_l, m2_l, torch.full_like(mean_l, float(n_loc))]).reshape(3, groups * Cp))
+            st.append((X, dt, M, Cp, n_loc, x.dtype))
+        pack = torch.cat(packs, dim=1).contiguous()                      # [3][sum of groups_i * C_i]
+        allp = torch.empty(world * 3, pack.shape[1], dtype=pack.dtype, device=pack.device)
+        dist.all_gather_into_tensor(allp, pack)
+        COLLECTIVES["syncbn_all_gather"] = COLLECTIVES.get("syncbn_all_gather", 0) + 1
+        allp = allp.view(world, 3, -1)
+        outs, saved, meta, off = [], [], [], 0
+        for i in range(n):
+            relu, groups, lay, eps, momentum, unit, out = cfgs[i]
+            x, gamma, beta, rmean, rvar = tens[5 * i:5 * i + 5]
+            X, dt, M, Cp, n_loc, in_dtype = st[i]
+            blk = allp[:, :, off:off + groups * Cp].reshape(world, 3, groups, Cp)
+            off += groups * Cp
+            n_r = blk[:, 2, 0, 0]
+            mean, var, n_tot = combine_bn_stats(blk[:, 0], blk[:, 1], n_r)
+            rstd = torch.rsqrt(var + eps)
+            unbias = n_tot / (n_tot - 1).clamp(min=1)
+            rm, rv = lay.pad_vec(rmean), lay.pad_vec(rvar, 1.0)
+            for g in range(groups):
+                rm = (1 - momentum) * rm + momentum * mean[g]
+                rv = (1 - momentum) * rv + momentum * var[g] * unbias
+            rmean.copy_(lay.unpad_vec(rm))
+            rvar.copy_(lay.unpad_vec(rv))
+            mean, rstd = mean.contiguous(), rstd.contiguous()
+            gp, bp = lay.pad_vec(gamma), lay.pad_vec(beta)
+            if out is not None:
+                assert out.shape == (M, Cp) and out.dtype == dt and out.stride(1) == 1
+                y = out.view_as(out)
+            else:
+                y = torch.empty(M, Cp, dtype=dt, device=x.device)
+            hip.bn_apply(X, mean, rstd, gp, bp, y, resid=None, groups=groups, relu=relu, unit=unit)
+            outs.append(y)
+            keep_y = relu and _BN_KEEP_Y
+            saved += [X, y if keep_y else None, mean, rstd, gp, bp if relu else None]
+            meta.append((relu, groups, lay, dt, in_dtype, unit, float(n_loc) / n_tot))
+        ctx.meta, ctx.n = meta, n
+        ctx.save_for_backward(*saved)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        import torch.distributed as dist
+        n, sv = ctx.n, ctx.saved_tensors
+        work, sums = [], []
+        for i in range(n):
+            relu, groups, lay, dt, in_dtype, unit, sum_scale = ctx.meta[i]
+            X, y, mean, rstd, gp, bp = sv[6 * i:6 * i + 6]
+            g = rowmajor(dys[i], dt)
+            dx = torch.empty_like(X)
+            s1, s2 = hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, None, groups, relu, True, phase=1, beta=bp, unit=unit)
+            work.append((g, dx, s1.clone(), s2.clone()))
+            sums.append(torch.stack([s1, s2]).reshape(2, -1))
+        both = torch.cat(sums, dim=1).contiguous()
+        dist.all_reduce(both)
+        COLLECTIVES["syncbn_all_reduce"] = COLLECTIVES.get("syncbn_all_reduce", 0) + 1
+        grads, off = [], 0
+        for i in range(n):
+            relu, groups, lay, dt, in_dtype, unit, sum_scale = ctx.meta[i]
+            X, y, mean, rstd, gp, bp = sv[6 * i:6 * i + 6]
+            g, dx, loc1, loc2 = work[i]
+            Cp = X.shape[1]
+            blk = (both[:, off:off + groups * Cp] * sum_scale).reshape(2, groups, Cp)
+            off += groups * Cp
+            hip.bn_bwd(g, X, y if relu else None, mean, rstd, gp, dx, None, groups, relu, True, phase=2,
+                       sums=(blk[0].contiguous(), blk[1].contiguous()), rows_total=0, beta=bp, unit=unit)
+            s1, s2 = (loc1.sum(0, keepdim=True), loc2.sum(0, keepdim=True)) if groups > 1 else (loc1, loc2)
+            grads += [dx.to(in_dtype), lay.unpad_vec(s2[0]), lay.unpad_vec(s1[0]), None, None]
+        return (None,) + (None,) * n + tuple(grads)
+
+
+class syncbn_group:
+    """with syncbn_group() as g: y_i = g.conv_bn_relu(...) for several INDEPENDENT conv -> BatchNorm (-> ReLU) branches; g.results()
+    after the block returns their outputs in call order.  Where the BatchNorms are nn.SyncBatchNorm in a process group (the
+    contrastive stage), the convolutions run at once and the BatchNorms wait for the end of the block, where BNTokGroupFn normalises
+    them all behind ONE statistics all-gather (and one all-reduce in the backward).  Everywhere else every call runs immediately,
+    exactly as conv_bn_relu."""
+
+    def __init__(self):
+        self.items, self.out = [], []
+
+    def __enter__(self):
+        return self
+
+    def conv_bn_relu(self, x_tok, conv, bn, geom, lin=None, lout=None, relu=True, groups=1, out=None):
+        training = bn.training or bn.running_mean is None
+        if not (training and _sync_world(bn) > 1):
+            self.out.append(conv_bn_relu(x_tok, conv, bn, geom, lin=lin, lout=lout, relu=relu, groups=groups, out=out))
+            return len(self.out) - 1
+        frames, Hh, Ww = geom
+        lout = lout or Layout.dense(conv.out_channels)
+        y = conv_tokens(x_tok, conv, frames, Hh, Ww, lin, lout, stats=False)[0]
+        return self.bn(y, bn, relu=relu, groups=groups, lay=lout, out=out)
+
+    def bn(self, y, bn, relu=True, groups=1, il_frames=0, lay=None, stats=None, out=None):
+        """BatchNorm (+ ReLU) of an already computed tensor, arguments as batchnorm_tokens (no residual)."""
+        training = bn.training or bn.running_mean is None
+        if not (training and _sync_world(bn) > 1):
+            self.out.append(batchnorm_tokens(y, bn, relu=relu, groups=groups, lay=lay, il_frames=il_frames, stats=stats, out=out))
+            return len(self.out) - 1
+        self.out.append(None)
+        self.items.append((len(self.out) - 1, y, bn, relu, groups, il_frames, lay or Layout.dense(bn.num_features), out))
+        return len(self.out) - 1
+
+    def __exit__(self, et, ev, tb):
+        if et is not None or not self.items:
+            return False
+        cfgs, tens = [], []
+        for _, y, bn, relu, groups, il_frames, lay, out in self.items:
+            if _BN_VIEWS is not None:                  # view batching: as batchnorm_tokens
+                views, clips = _BN_VIEWS
+                if il_frames:
+                    groups = groups * views
+                else:
+                    assert groups == 1, "view batching: contiguous multi-group BatchNorm inside an encoder is not supported"
+                    groups, il_frames = views, clips
+            if bn.num_batches_tracked is not None:
+                if _NBT_PENDING is not None:
+                    _NBT_PENDING.append((bn.num_batches_tracked, groups))
+                else:
+                    bn.num_batches_tracked += groups
+            unit = (y.shape[0] // il_frames) if (il_frames and groups > 1) else 0
+            cfgs.append((relu, groups, lay, bn.eps, bn.momentum if bn.momentum is not None else 0.1, unit, out))
+            tens += [y, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        ys = BNTokGroupFn.apply(len(self.items), *cfgs, *tens)
+        for (slot, *_), y in zip(self.items, ys):
+            self.out[slot] = y
+        return False
+
+    def results(self):
+        return list(self.out)
+
+
 _NBT_PENDING = None
 _BN_VIEWS = None
 

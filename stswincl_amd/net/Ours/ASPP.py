@@ -40,12 +40,14 @@ class ASPP(nn.Module):
         # backward hands every branch a strided view of the concat's gradient instead of a split copy
         nb = self.conv_1x1_1.out_channels
         buf, (v1, v2, v3, v4, v5) = H.concat_buffer(x.shape[0], [nb] * 5, H.compute_dtype(x), x.device)
-        o1 = H.conv_bn_relu(x, self.conv_1x1_1, self.bn_conv_1x1_1, geom, out=v1)
-        o2 = H.conv_bn_relu(x, self.conv_3x3_1, self.bn_conv_3x3_1, geom, out=v2)
-        o3 = H.conv_bn_relu(x, self.conv_3x3_2, self.bn_conv_3x3_2, geom, out=v3)
-        o4 = H.conv_bn_relu(x, self.conv_3x3_3, self.bn_conv_3x3_3, geom, out=v4)
-        img = H.AvgPoolTokFn.apply(x, f)
-        img = H.conv_bn_relu(img, self.conv_1x1_2, self.bn_conv_1x1_2, (f, 1, 1))
+        # (the five branches are independent: under SyncBatchNorm their statistics travel in ONE all-gather - H.syncbn_group)
+        with H.syncbn_group() as g:
+            g.conv_bn_relu(x, self.conv_1x1_1, self.bn_conv_1x1_1, geom, out=v1)
+            g.conv_bn_relu(x, self.conv_3x3_1, self.bn_conv_3x3_1, geom, out=v2)
+            g.conv_bn_relu(x, self.conv_3x3_2, self.bn_conv_3x3_2, geom, out=v3)
+            g.conv_bn_relu(x, self.conv_3x3_3, self.bn_conv_3x3_3, geom, out=v4)
+            g.conv_bn_relu(H.AvgPoolTokFn.apply(x, f), self.conv_1x1_2, self.bn_conv_1x1_2, (f, 1, 1))
+        o1, o2, o3, o4, img = g.results()
         img = H.BroadcastTokFn.apply(img, h * w, v5)
         cat = H.ConcatColsFn.apply(buf, (nb,) * 5, o1, o2, o3, o4, img)
         out = H.conv_bn_relu(cat, self.conv_1x1_3, self.bn_conv_1x1_3, geom)

@@ -39,9 +39,11 @@ def decode_tokens(resnet, swin, aspp, proj1, proj2, proj3, x):
     # the four parts are written straight into their column slices of the 448-wide padded concat (base18.py:104): no cat kernel
     widths = (L48.width, L48.width, L48.width, a.shape[1])
     buf, (v1, v2, v3, v4) = H.concat_buffer(b * h * w, widths, a.dtype, a.device)
-    p1 = H.conv_bn_relu(res_last, proj1[0], proj1[1], (b, h, w), lout=L48, out=v1)
-    p2 = H.conv_bn_relu(t1, proj2[0], proj2[1], (b, h, w), lout=L48, out=v2)
-    p3 = H.conv_bn_relu(t2, proj3[0], proj3[1], (b, h2, w2), lout=L48)
+    with H.syncbn_group() as g:                  # three independent projections: one SyncBatchNorm exchange
+        g.conv_bn_relu(res_last, proj1[0], proj1[1], (b, h, w), lout=L48, out=v1)
+        g.conv_bn_relu(t1, proj2[0], proj2[1], (b, h, w), lout=L48, out=v2)
+        g.conv_bn_relu(t2, proj3[0], proj3[1], (b, h2, w2), lout=L48)
+    p1, p2, p3 = g.results()
     p3 = H.BilinearTokFn.apply(p3, (b, h2, w2, h, w), v3)
     a = H.BilinearTokFn.apply(a, (b, h2, w2, h, w), v4)
     return H.ConcatColsFn.apply(buf, widths, p1, p2, p3, a), (b, h, w)

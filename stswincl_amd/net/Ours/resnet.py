@@ -81,12 +81,18 @@ def _block_tokens(blk, x, frames, h, w, groups, il=False):
     link = H.GradLink(2 if has_ds else 1) if (H._RESID_GRAD_LINK and torch.is_grad_enabled() and x.requires_grad) else None
     y, ho, wo, tab = H.conv_tokens(x, blk.conv1, frames, h, w, stats=tr, link=link)
     ilf = frames if il else 0
+    if has_ds:
+        # conv1 and the shortcut's 1x1 convolution both read x: their two BatchNorms go through ONE exchange under SyncBatchNorm
+        # (H.syncbn_group; without a process group both calls run at once, exactly as before)
+        idn, _, _, tabd = H.conv_tokens(x, ds[0], frames, h, w, stats=tr, link=link)
+        with H.syncbn_group() as g:
+            g.bn(y, blk.bn1, relu=True, groups=groups, il_frames=ilf, stats=tab)
+            g.bn(idn, ds[1], relu=False, groups=groups, il_frames=ilf, stats=tabd)
+        y, idn = g.results()
+        y, _, _, tab2 = H.conv_tokens(y, blk.conv2, frames, ho, wo, stats=tr)
+        return H.batchnorm_tokens(y, blk.bn2, relu=True, resid=idn, groups=groups, il_frames=ilf, stats=tab2), ho, wo
     y = H.batchnorm_tokens(y, blk.bn1, relu=True, groups=groups, il_frames=ilf, stats=tab)
     y, _, _, tab2 = H.conv_tokens(y, blk.conv2, frames, ho, wo, stats=tr)
-    if has_ds:
-        idn, _, _, tabd = H.conv_tokens(x, ds[0], frames, h, w, stats=tr, link=link)
-        idn = H.batchnorm_tokens(idn, ds[1], relu=False, groups=groups, il_frames=ilf, stats=tabd)
-        return H.batchnorm_tokens(y, blk.bn2, relu=True, resid=idn, groups=groups, il_frames=ilf, stats=tab2), ho, wo
     return H.batchnorm_tokens(y, blk.bn2, relu=True, resid=x, groups=groups, il_frames=ilf, stats=tab2, resid_link=link), ho, wo
 
 

@@ -382,11 +382,22 @@ def test_bench_two_ranks_sharing_the_gpu_runs_the_data_parallel_path():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, STSWIN_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
-                          "--size", "256", "--no-cpu-baseline", "--no-secondary"], env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["dist"]["rccl_ranks"] == 2 and d["dist"]["shared_gpu_functional_test"] is True
-    assert d["dist"]["allreduce_bytes_per_step_per_rank"] > 4e8         # ~125 M fp32 gradients
-    assert d["config"]["parallelism"] == "dp2" and d["value"] > 0 and d["config"]["loss"] == d["config"]["loss"]
+    losses = {}
+    for comm, lo, hi in (("fp32", 4e8, 6e8), ("bf16", 2e8, 3e8)):
+        # --graph 1 is REQUESTED: over gloo that cannot be honoured, and the line must say so (an explicit reason, never a silent
+        # eager run); STSWIN_BENCH_STRICT_GRAPH=1 turns a failed capture over RCCL into an error instead of a fallback
+        env["STSWIN_BENCH_STRICT_GRAPH"] = "1"
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                              "--size", "256", "--no-cpu-baseline", "--no-secondary", "--no-profile", "--graph", "1", "--comm-dtype", comm],
+                             env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')][-1]
+        d = json.loads(line)
+        assert d["n_gpus"] == 2 and d["dist"]["rccl_ranks"] == 2 and d["dist"]["shared_gpu_functional_test"] is True
+        assert lo < d["dist"]["allreduce_bytes_per_step_per_rank"] < hi, d["dist"]       # ~125 M gradients, 4 or 2 bytes each on the wire
+        assert d["dist"]["comm_dtype"] == ("float32" if comm == "fp32" else "bfloat16")
+        assert d["config"]["parallelism"] == "dp2" and d["value"] > 0 and d["config"]["loss"] == d["config"]["loss"]
+        assert d["config"]["graph_requested"] is True
+        assert d["config"]["launch"].startswith("eager launches (hipGraph capture needs the RCCL backend"), d["config"]["launch"]
+        losses[comm] = d["config"]["loss"]
+    assert abs(losses["bf16"] - losses["fp32"]) < 2e-2 * abs(losses["fp32"]), losses      # bf16 on the wire: same training, rounded gradients
