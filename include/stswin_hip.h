@@ -200,6 +200,24 @@ int stswin_tn_combine(const float* workspace, float* C, long ldc, int Ni, int Nj
 #define STSWIN_VAR_TN_TAPMINOR 0x4000      /* the combine stored the result tap-minor (STSWIN_TN_OUT_TAPMINOR was honoured) */
 #define STSWIN_TN_OUT_TAPMINOR (1 << 25)   /* bit of `splits` (with bseg > 0): store C[i][c * S + s] for GEMM column j = s * bseg + c, S = Nj / bseg - the [cout][cin][k][k]
                                             * layout of a convolution weight gradient; only where split-K slabs are combined (check stswin_last_variant) */
+/* The QKV projection with an fp8 (OCP e4m3) result + one fp32 scale per (window problem, head of q / k / v): BASELINE.json configs[4]
+ * ("fp8 MFMA attention"), swin_512.py:115-121 with q | k | v stored in 8 bits.  out8 [M][ld8] bytes, scales [M / rows_per_problem][ld_scales]
+ * (column = n / head_dim: the heads of q, then of k, then of v); value = e4m3 byte * scale.  stswin_win_attn_fwd_f8 / _bwd_f8 read them. */
+int stswin_gemm_nt_qkv_fp8(const void* A, long lda, const int* a_rows, const void* B, long ldb, void* out8, long ld8, float* scales,
+                           long ld_scales, const float* bias, int M, int N, int Kseg, float scale, int scale_cols, int rows_per_problem,
+                           int head_dim, void* stream);
+/* Window attention on fp8-STORED q | k | v (stswin_gemm_nt_qkv_fp8's output): the core of swin_512.py:117-138 with both products on the fp8
+ * MFMA, fp32 softmax; out bf16 [rows][ldo].  Geometries: (T ws^2, head dim) = (128, 128) and (32, 256) - the two stages of the model;
+ * anything else returns -1201 (the caller keeps bf16 storage there). */
+int stswin_win_attn_fwd_f8(const void* qkv8, long ld8, const float* scales, long ld_scales, void* out, long ldo, const float* biasT,
+                           const float* maskT, int nB_, int nW, int T_frames, int ws, int heads, int C, int bias_windows,
+                           const int* bias_index, void* stream);
+/* ... and its backward: dqkv (bf16 [rows][lddq], the gradient of the dequantised q | k | v), dbiasT / dqkv_colsum as stswin_win_attn_bwd; scratch =
+ * stswin_win_attn_bwd_scratch(nB_, ws, heads, C) floats.  Geometries: 8x8 windows x 2 frames x head dim 128, 4x4 x 2 x 256. */
+int stswin_win_attn_bwd_f8(const void* qkv8, long ld8, const float* scales, long ld_scales, const void* dout, long lddo, void* dqkv, long lddq,
+                           const float* biasT, const float* maskT, float* dbiasT, float* dqkv_colsum, int nB_, int nW, int T_frames, int ws,
+                           int heads, int C, float scale, int bias_windows, const int* bias_index, float* scratch, long scratch_floats,
+                           void* stream);
 int stswin_last_variant(int family);
 /* 1: the library was built with -DSTSWIN_TUNING (STSWIN_TUNING=1 python __graft_entry__.py --force) and holds the A/B-only gemm_nt variants
  * (STSWIN_GF_MID / _HALF / _NOPIPE / duo / stream: each measured slower than the default dispatch); 0: the product build, which ignores

@@ -28,6 +28,7 @@ struct AttnArgs {
   float scale;                    // bwd: dq = scale * (dS k)
   int bias_windows;               // 1: biasT is [heads][N][N]; > 1: biasT is [bias_windows][heads][N][N] with the mask already added
   const int* bias_index;          // optional [nW]: table slot of each window (null: slot = window, bias_windows == nW)
+  const float* qscale; long ld_scale;   // fp8 q | k | v (the *_f8 kernels): qkv is e4m3 bytes (ld in BYTES), value = byte * qscale[problem][t * heads + head], t = 0 q, 1 k, 2 v
 };
 
 template <int CPR> DEVI int swz_cpr(int row) {
@@ -137,7 +138,7 @@ DEVI void load_row_frags(bf16x8 (&f)[HD / 16], const T* base, long ld, int row) 
 
 template <typename T, int NTOK, int HD, int NC>
 DEVI void scores_softmax(f32x16 (&p)[NTOK / 32], const AttnArgs& a, const char* Kt, const T* qbase, const T* kbase,
-                         int q0, int head, int widx, const bf16x8 (&qf)[HD / 16]) {
+                         int q0, int head, int widx, const bf16x8 (&qf)[HD / 16], float sscale = 1.0f) {
   using Cfg = AttnCfg<T, NTOK, HD>;
   const int l = threadIdx.x & 63, lr = l & 31, half = l >> 5;
 #pragma unroll
@@ -183,7 +184,7 @@ DEVI void scores_softmax(f32x16 (&p)[NTOK / 32], const AttnArgs& a, const char* 
   for (int kt = 0; kt < Cfg::KT; ++kt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float sc = p[kt][r] + tb[kt][r];
+      const float sc = p[kt][r] * sscale + tb[kt][r];     // (sscale: fp8-stored q | k | v, the product of their scales; x 1.0f is exact)
       p[kt][r] = sc;
       mx = fmaxf(mx, sc);
     }
@@ -303,6 +304,45 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) ob[(long)crow32(r, half) * a.ldo + dt * 32 + lr] = from_f32<T>(o[dt][r]);
 }
+
+// ---- fp8 (e4m3) tile -> bf16 tile, in registers: one 16-byte chunk (16 values) -> two bf16x8.  e4m3 values are exact in bf16, so the
+// expanded tile holds the stored bytes' values; the per-(window, head) scales are applied to accumulators, not to the tile.
+DEVI void f8_chunk_to_bf16(const int (&w4)[4], bf16x8& lo, bf16x8& hi) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(w4[d], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(w4[d], true);
+    bf16x8& t = d < 2 ? lo : hi;
+    const int o = (d & 1) * 4;
+    t[o] = (bf16)a[0]; t[o + 1] = (bf16)a[1]; t[o + 2] = (bf16)b[0]; t[o + 3] = (bf16)b[1];
+  }
+}
+// A [ROWS][HD-byte] fp8 tile image (tile_off<HD>, at `src`) -> the [ROWS][2 HD-byte] bf16 image (tile_off<2 HD>, at `dst`), by NTHR
+// threads (this one is number `t`).  load() then - after a barrier of those threads when dst overlaps src - store().
+template <int ROWS, int HD, int NTHR>
+struct F8Expand {
+  static constexpr int CPR = HD / 16, NCH = ROWS * CPR / NTHR;     // 16-byte fp8 chunks per row / per thread
+  static_assert(ROWS * CPR % NTHR == 0 && NCH >= 1, "F8Expand geometry");
+  int v[NCH][4];
+  DEVI void load(const char* src, int t) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int idx = t * NCH + c, row = idx / CPR, ch = idx % CPR;
+      const int4 q = *(const int4*)(src + tile_off<HD>(row, ch));
+      v[c][0] = q.x; v[c][1] = q.y; v[c][2] = q.z; v[c][3] = q.w;
+    }
+  }
+  DEVI void store(char* dst, int t) const {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int idx = t * NCH + c, row = idx / CPR, ch = idx % CPR;
+      bf16x8 lo, hi;
+      f8_chunk_to_bf16(v[c], lo, hi);
+      *(bf16x8*)(dst + tile_off<2 * HD>(row, 2 * ch)) = lo;
+      *(bf16x8*)(dst + tile_off<2 * HD>(row, 2 * ch + 1)) = hi;
+    }
+  }
+};
+DEVI float sloadf(const float* p, long idx) { return ((const __attribute__((address_space(4))) float*)p)[idx]; }
 
 // ====================================================================================================
 // QKV-fused forward for the stage-1 shape (bf16, 128 tokens per window pair, head dim 128): the window gather, the QKV
@@ -635,15 +675,137 @@ __global__ __launch_bounds__(256) void attn_fwd_fp8_kernel(AttnArgs a) {
 }
 
 // ====================================================================================================
+// fp8-STORAGE forward (round 4; BASELINE configs[4] as a training path): q | k | v arrive as e4m3 bytes with one fp32 scale per
+// (window problem, head, q / k / v) - written by stswin_gemm_nt_qkv_fp8 - so the kernel reads HALF the bytes of the bf16 forward
+// and feeds the fp8 MFMA without a conversion: K rows are 8-byte LDS reads, the Q row pieces 8-byte global loads.  V has to reach
+// the MFMA with the contraction (key) index contiguous, i.e. transposed; ds_read_b64_tr_b16 on the fp8 tile viewed as 16-bit
+// elements transposes BYTE PAIRS (columns 2c, 2c + 1), and two v_perm_b32 per dword pair split them into the operand of the even and
+// of the odd column - two MFMAs per transposed read instead of one, and the lane ends up with two NEIGHBOURING output columns
+// (one 4-byte store).  P is quantised as in attn_fwd_fp8_kernel (x 128, e4m3).  scores = sq sk (q^ . k^), out = sv / 128 (P^ v^).
+template <int NTOK, int HD, int NC>
+__global__ __launch_bounds__(256) void attn_fwd_f8_kernel(AttnArgs a) {
+  using Cfg = AttnCfg<bf16, NTOK, HD>;
+  constexpr int KV8 = NTOK * HD, CT = HD / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int l = threadIdx.x & 63, lr = l & 31, half = l >> 5, w = wave_id();
+  const int sp = w / Cfg::QW, qt = w % Cfg::QW;
+  const long prob = (long)blockIdx.x * Cfg::PPB + sp;
+  const int b_ = min((int)(prob / a.heads), a.nB_ - 1), head = prob % a.heads;
+  const bool live = prob / a.heads < a.nB_;
+  const long rowbase = (long)b_ * NTOK;
+  const char* qb = (const char*)a.qkv + rowbase * a.ld + head * HD;      // e4m3 bytes; k at + C, v at + 2C
+  char* Kt = smem + sp * 2 * KV8;
+  char* Vt = Kt + KV8;
+  const int q0 = qt * 32;
+  stage_tile<NTOK, HD>(Kt, qb + a.C, a.ld, qt, Cfg::QW);
+  stage_tile<NTOK, HD>(Vt, qb + 2 * a.C, a.ld, qt, Cfg::QW);
+  long q8[HD / 16];
+#pragma unroll
+  for (int ks = 0; ks < HD / 16; ++ks) q8[ks] = *(const long*)(qb + (long)(q0 + lr) * a.ld + 16 * ks + 8 * half);
+  const float* scp = a.qscale + (long)b_ * a.ld_scale;
+  const float sq = scp[head], sk = scp[a.heads + head], sv = scp[2 * a.heads + head];
+  wait_vm0();
+  __syncthreads();
+  f32x16 p[Cfg::KT];
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[kt][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks)
+      p[kt] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(*(const long*)(Kt + tile_off<HD>(kt * 32 + lr, ks) + 8 * half), q8[ks], p[kt], 0, 0, 0);
+  }
+  const int N = NC ? NC : a.N;
+  const int qn = (q0 + lr) % N, widx = b_ % a.nW;
+  const int slot = (a.bias_windows & 0xffffff) > 1 ? (a.bias_index ? a.bias_index[widx] : widx) : 0;
+  const float* bt = a.biasT + ((long)slot * a.heads + head) * N * N + qn;
+  const float* mt = a.maskT ? a.maskT + (long)widx * N * N + qn : nullptr;
+  float tb[Cfg::KT][16];
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tb[kt][r] = bt[((kt * 32 + crow32(r, half)) % N) * N];
+  if (mt) {
+#pragma unroll
+    for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tb[kt][r] += mt[((kt * 32 + crow32(r, half)) % N) * N];
+  }
+  const float ssc = sq * sk;
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sc = p[kt][r] * ssc + tb[kt][r];
+      p[kt][r] = sc;
+      mx = fmaxf(mx, sc);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __expf(p[kt][r] - mx);
+      p[kt][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32);
+  const float pscale = 128.0f / sum;               // P * 128 in e4m3 (softmax outputs below 2^-6 would fall into the subnormals)
+  f32x16 oe[CT], oo[CT];                           // even / odd output columns 64 ct + 2 lr (+ 1)
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oe[ct][r] = 0.f; oo[ct][r] = 0.f; }
+#pragma unroll
+  for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(p[kt][8 * m + 0] * pscale, p[kt][8 * m + 1] * pscale, lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(p[kt][8 * m + 2] * pscale, p[kt][8 * m + 3] * pscale, lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(p[kt][8 * m + 4] * pscale, p[kt][8 * m + 5] * pscale, hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(p[kt][8 * m + 6] * pscale, p[kt][8 * m + 7] * pscale, hi, true);
+      const long pa = (long)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        // eight (key) k-slots in accumulator order x one byte PAIR per slot: dword m2 holds slots 2 m2, 2 m2 + 1
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        const u4v wv = __builtin_bit_cast(u4v, frag_tr_perm<HD>(Vt, kt * 32 + 16 * m, ct));
+        const unsigned e0 = __builtin_amdgcn_perm(wv[1], wv[0], 0x06040200u), e1 = __builtin_amdgcn_perm(wv[3], wv[2], 0x06040200u);
+        const unsigned d0 = __builtin_amdgcn_perm(wv[1], wv[0], 0x07050301u), d1 = __builtin_amdgcn_perm(wv[3], wv[2], 0x07050301u);
+        oe[ct] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(pa, (long)(((unsigned long)e1 << 32) | e0), oe[ct], 0, 0, 0);
+        oo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(pa, (long)(((unsigned long)d1 << 32) | d0), oo[ct], 0, 0, 0);
+      }
+    }
+  if (!live) return;
+  const float osc = sv * (1.0f / 128.0f);
+  bf16* ob = (bf16*)a.out + (rowbase + q0) * a.ldo + head * HD;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bf16x2 o2 = {(bf16)(oe[ct][r] * osc), (bf16)(oo[ct][r] * osc)};
+      *(bf16x2*)(ob + (long)crow32(r, half) * a.ldo + ct * 64 + 2 * lr) = o2;
+    }
+}
+
+// ====================================================================================================
 // Backward: dq = scale * dS k ; dk = dS^T q_s ; dv = P^T dO ; dbias += fold(dS) ;  dS = P o (dP - rowsum(P o dP)).
 // Persistent over problems: a workgroup walks problem groups blockIdx.x, blockIdx.x + gridDim.x, ... and the launcher
 // makes gridDim.x * PPB a multiple of `heads`, so a lane meets the same (head, query n, key n) and the same dqkv columns
 // in every iteration.  The relative-position-bias gradient and the qkv-bias column sums are therefore summed in
 // registers across iterations and leave as ONE atomic per lane-entry per workgroup: issued per problem they were 33 M
 // (stage 1) / 2 M (stage 2) fp32 atomics onto 16 K / 1 K addresses and cost 25 % / 65 % of the kernel.
-template <typename T, int NTOK, int HD, int NC>
+// F8 (bf16 instantiations with one problem per wave, i.e. the stage-2 shape 32 x 256; BASELINE configs[4]): q | k | v arrive as e4m3
+// bytes + per-(window, head) scales.  Every fp8 tile is copied into the UPPER half of the bf16 tile's buffer and expanded in place by the
+// wave that owns the problem (F8Expand: all loads of the wave precede its stores); the Q row pieces are 8-byte global loads converted in
+// registers; the scales ride on the accumulators as in attn_bwd8_kernel<.., F8>.
+template <typename T, int NTOK, int HD, int NC, bool F8 = false>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   using Cfg = AttnCfg<T, NTOK, HD>;
+  static_assert(!F8 || (TT<T>::IS_BF16 && Cfg::QW == 1 && !Cfg::BWD_PF), "fp8 variant: bf16 kernels with one problem per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int l = threadIdx.x & 63, lr = l & 31, half = l >> 5, w = wave_id();
   const int sp = w / Cfg::QW, qt = w % Cfg::QW;
@@ -694,6 +856,39 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   const int q0 = qt * 32;
   stamp(0);
   bf16x8 qf[HD / 16], df[HD / 16];
+  const char* q8b = (const char*)a.qkv + rowbase * a.ld + head * HD;     // F8: e4m3 bytes (a.ld in bytes); k at + C, v at + 2C
+  float sq = 1.f, sk = 1.f, sv = 1.f;
+  if constexpr (F8) {
+    const float* scp = a.qscale + (long)b_ * a.ld_scale;
+    sq = scp[head]; sk = scp[a.heads + head]; sv = scp[2 * a.heads + head];
+    long q8[HD / 16];
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) q8[ks] = *(const long*)(q8b + (long)(q0 + lr) * a.ld + 16 * ks + 8 * half);
+    stage_tile<NTOK, HD>(Kt + Cfg::KV_BYTES / 2, q8b + a.C, a.ld, qt, Cfg::QW);
+    stage_tile<NTOK, HD>(Vt + Cfg::KV_BYTES / 2, q8b + 2 * a.C, a.ld, qt, Cfg::QW);
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {           // 8 e4m3 bytes -> this lane's bf16x8 row piece
+      const int lo = (int)(q8[ks] & 0xffffffffL), hi = (int)(q8[ks] >> 32);
+      const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+      const f32x2 b0 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), b1 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+      qf[ks] = (bf16x8){(bf16)a0[0], (bf16)a0[1], (bf16)a1[0], (bf16)a1[1], (bf16)b0[0], (bf16)b0[1], (bf16)b1[0], (bf16)b1[1]};
+    }
+    wait_vm0();
+    __syncthreads();
+    {                                               // the wave's own K and V: fp8 upper halves -> bf16 images (loads, then stores)
+      F8Expand<NTOK, HD, 64> ex;                    // (one tile at a time: 32 registers of bytes, not 64)
+      ex.load(Kt + Cfg::KV_BYTES / 2, l);
+      __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): every lane's bytes are in registers
+      __builtin_amdgcn_wave_barrier();
+      ex.store(Kt, l);
+      ex.load(Vt + Cfg::KV_BYTES / 2, l);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      ex.store(Vt, l);
+    }
+    load_row_frags<T, HD>(df, dobase, a.lddo, q0 + lr);   // (behind the expansion: 64 registers that would sit beside its 32 + the 64 of qf;
+    __syncthreads();                                       //  the scores + softmax below cover the loads)
+  } else {
   load_row_frags<T, HD>(qf, qbase, a.ld, q0 + lr);        // Q (and dO) row pieces: in flight during the tile wait
   if constexpr (!PF) load_row_frags<T, HD>(df, dobase, a.lddo, q0 + lr);   // (PF: dO pieces come from the LDS tile below)
   if constexpr (TT<T>::IS_BF16) {
@@ -705,9 +900,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     __syncthreads();
     if constexpr (PF) stage_tile<NTOK, Cfg::RB>(Xt, (const char*)dobase, a.lddo * sizeof(T), qt, Cfg::QW);
   }
+  }
   stamp(1);
   f32x16 p[Cfg::KT], dp[Cfg::KT];
-  scores_softmax<T, NTOK, HD, NC>(p, a, Kt, qbase, kbase, q0, head, b_ % a.nW, qf);
+  scores_softmax<T, NTOK, HD, NC>(p, a, Kt, qbase, kbase, q0, head, b_ % a.nW, qf, F8 ? sq * sk : 1.0f);
   stamp(2);
   if constexpr (PF) {                            // the dO tile requested before the scores has landed: row pieces from LDS
     wait_vm0();
@@ -737,6 +933,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   }
   stamp(3);
   float delta = 0.f;
+  if constexpr (F8) {
+#pragma unroll
+    for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[kt][r] *= sv;                              // dP = sv (v^ dO)
+  }
 #pragma unroll
   for (int kt = 0; kt < Cfg::KT; ++kt)
 #pragma unroll
@@ -786,12 +988,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   };
   // dV / dK need no column sums: sum_key dK = 0 (rows of dS sum to zero) and sum_key dV = column sums of dO (softmax
   // rows sum to one), which the caller takes from the GEMM that produced dO.
-  auto store_acc_plain = [&](T* base, int row0) {
+  auto store_acc_plain = [&](T* base, int row0, float mul = 1.0f) {
     if (!live) return;
 #pragma unroll
     for (int dt = 0; dt < Cfg::DT; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) base[(long)(row0 + crow32(r, half)) * a.ldo + dt * 32 + lr] = from_f32<T>(acc[dt][r]);
+      for (int r = 0; r < 16; ++r)
+        base[(long)(row0 + crow32(r, half)) * a.ldo + dt * 32 + lr] = from_f32<T>(F8 ? acc[dt][r] * mul : acc[dt][r]);
   };
 
   // ---- dV[key][d] = sum_q P[q][key] dO[q][d]
@@ -843,8 +1046,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   // ---- dK[key][d] = sum_q dS[q][key] q_s[q][d]
   if constexpr (TT<T>::IS_BF16 && !PF) {
     __syncthreads();                             // all waves finished reading the dO tile
-    stage_tile<NTOK, Cfg::RB>(Vt, (const char*)qbase, a.ld * sizeof(T), qt, Cfg::QW);
-    wait_vm0();
+    if constexpr (F8) {
+      stage_tile<NTOK, HD>(Vt + Cfg::KV_BYTES / 2, q8b, a.ld, qt, Cfg::QW);
+      wait_vm0();
+      __syncthreads();
+      F8Expand<NTOK, HD, 64> eq;
+      eq.load(Vt + Cfg::KV_BYTES / 2, l);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      eq.store(Vt, l);
+    } else {
+      stage_tile<NTOK, Cfg::RB>(Vt, (const char*)qbase, a.ld * sizeof(T), qt, Cfg::QW);
+      wait_vm0();
+    }
     __syncthreads();
   }
   zero_acc();
@@ -866,7 +1080,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, qbase[(long)qq * a.ld + dt * 32 + lr], acc[dt], 0, 0, 0);
     }
   }
-  store_acc_plain(dkb, k0);
+  store_acc_plain(dkb, k0, sq);                  // (F8: dK = sq (dS^T q^))
   stamp(8);
 
   // ---- dQ[q][d] = scale * sum_key dS[q][key] K[key][d]
@@ -889,7 +1103,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, kbase[(long)key * a.ld + dt * 32 + lr], acc[dt], 0, 0, 0);
     }
   }
-  store_acc(dqb, q0, a.scale);
+  store_acc(dqb, q0, F8 ? a.scale * sk : a.scale);
   stamp(9);
   __syncthreads();                               // the next problem's tiles overwrite K / dS
   stamp(10);
@@ -992,9 +1206,16 @@ DEVI bf16x8 lds_tr_pair(const char* tile, int off0, int off1, int imm) {
 //  * The copies are raw ISA and the lane-constant LDS offsets are formed at their use (see stage_tile, ld_row, tro): at the 256-register
 //    cap every spilled constant and every scratch-resident table came back through s_waitcnt vmcnt(0), i.e. behind the output stores
 //    and the prefetch in flight - that, not the arithmetic, was most of the "latency-bound" phases of the round-2/3 timelines.
-template <int NC, bool QPF = false>
+// F8 (with QPF; BASELINE configs[4]): q | k | v arrive as e4m3 bytes + per-(window, head) scales (stswin_gemm_nt_qkv_fp8).  The next
+// problem's K, Q and V are prefetched as fp8 tiles (16 KB each) into the UPPER halves of the three buffers they will live in; at the top
+// of a problem every thread takes its 2 x 16 bytes of each tile into registers, and after a barrier writes the bf16 image over the whole
+// buffer - from there on the kernel is the bf16 kernel.  e4m3 values are exact in bf16, so the scales ride on the accumulators:
+// S = sq sk (q^ k^), dP = sv (v^ dO), dQ = scale sk (dS k^), dK = sq (dS^T q^): the probabilities are those of the fp8 forward
+// up to its own e4m3 rounding of P.  The backward then reads 131 KB per problem instead of 229 KB.
+template <int NC, bool QPF = false, bool F8 = false>
 __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
   using T = bf16;
+  static_assert(!F8 || QPF, "the fp8 variant uses the round-4 schedule");
   constexpr int NTOK = 128, HD = 128, ROWB = 256;          // K / V / Q / dO tiles and the P / dS tiles all have 256-byte rows
   using Cfg = AttnCfg<T, NTOK, HD>;
   constexpr int KV = Cfg::KV_BYTES;
@@ -1050,10 +1271,17 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
   auto ld_tr = [&](const char* tile, int ks, int ct) -> bf16x8 { return lds_tr_pair(tile, tro(ct, 0), tro(ct, 1), ks * 16 * ROWB); };
   {
     const long rb0 = (long)(blockIdx.x / a.heads) * NTOK;
-    const T* q0b = (const T*)a.qkv + rb0 * a.ld + head * HD;
-    stage_tile<NTOK, ROWB, QPF>(smem, (const char*)(q0b + a.C), a.ld * sizeof(T), w, 8);
-    stage_tile<NTOK, ROWB, QPF>(smem + KV, (const char*)(QPF ? q0b : q0b + 2 * a.C), a.ld * sizeof(T), w, 8);
-    if constexpr (QPF) stage_tile<NTOK, ROWB, QPF>(smem + 2 * KV, (const char*)(q0b + 2 * a.C), a.ld * sizeof(T), w, 8);   // V (buffer xb)
+    if constexpr (F8) {                              // (a.ld counts bytes; fp8 tiles have 128-byte rows and sit in the upper buffer halves)
+      const char* q0b = (const char*)a.qkv + rb0 * a.ld + head * HD;
+      stage_tile<NTOK, HD, true>(smem + KV / 2, q0b + a.C, a.ld, w, 8);
+      stage_tile<NTOK, HD, true>(smem + KV + KV / 2, q0b, a.ld, w, 8);
+      stage_tile<NTOK, HD, true>(smem + 2 * KV + KV / 2, q0b + 2 * a.C, a.ld, w, 8);
+    } else {
+      const T* q0b = (const T*)a.qkv + rb0 * a.ld + head * HD;
+      stage_tile<NTOK, ROWB, QPF>(smem, (const char*)(q0b + a.C), a.ld * sizeof(T), w, 8);
+      stage_tile<NTOK, ROWB, QPF>(smem + KV, (const char*)(QPF ? q0b : q0b + 2 * a.C), a.ld * sizeof(T), w, 8);
+      if constexpr (QPF) stage_tile<NTOK, ROWB, QPF>(smem + 2 * KV, (const char*)(q0b + 2 * a.C), a.ld * sizeof(T), w, 8);   // V (buffer xb)
+    }
   }
   // bias (+ mask) values of a problem's 2 x 16 (key, query) entries per lane
   float tb[2][16];
@@ -1099,7 +1327,7 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
   for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int b_ = (int)(grp / a.heads);
     const long rowbase = (long)b_ * NTOK;
-    const T* qbase = (const T*)a.qkv + rowbase * a.ld + head * HD;
+    const T* qbase = (const T*)a.qkv + rowbase * a.ld + head * HD;        // (bf16 storage only)
     const T* dobase = (const T*)a.dout + rowbase * a.lddo + head * HD;
     char* Kt = smem + kb * KV;
     char* Vt = smem + (QPF ? xb : vb) * KV;        // V, later Q                  (QPF: V, later P, later the next problem's Q)
@@ -1110,6 +1338,12 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
     const T* nqbase = (const T*)a.qkv + (long)((grp + gridDim.x) / a.heads) * NTOK * a.ld + head * HD;
     stamp_on = has_next || ngroups <= (long)gridDim.x;
     stamp(0);
+    float sq = 1.f, sk = 1.f, sv = 1.f;            // F8: value = e4m3 byte * scale of (window, head, q | k | v)
+    if constexpr (F8) {
+      sq = sloadf(a.qscale, (long)b_ * a.ld_scale + head);
+      sk = sloadf(a.qscale, (long)b_ * a.ld_scale + a.heads + head);
+      sv = sloadf(a.qscale, (long)b_ * a.ld_scale + 2 * a.heads + head);
+    }
     bf16x8 qf[HD / 16];
     if constexpr (!QPF) {
       load_row_frags<T, HD>(qf, qbase, a.ld, q0 + lr);
@@ -1129,6 +1363,15 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
       int lv = l;                                  // (re-derive the copies' lane offsets here: see stage_tile)
       asm volatile("" : "+v"(lv));
       stage_tile<NTOK, ROWB, QPF>(Xt, (const char*)dobase, a.lddo * sizeof(T), w, 8, lv);   // (V was prefetched with K and Q)
+      if constexpr (F8) {                          // fp8 tiles (upper buffer halves) -> bf16 images over the whole buffers
+        int tv = threadIdx.x;
+        asm volatile("" : "+v"(tv));
+        F8Expand<NTOK, HD, 512> ek, eq, ev;
+        ek.load(Kt + KV / 2, tv); eq.load(Qt + KV / 2, tv); ev.load(Vt + KV / 2, tv);
+        __syncthreads();                           // every thread holds its bytes: the images may overwrite the fp8 halves
+        ek.store(Kt, tv); eq.store(Qt, tv); ev.store(Vt, tv);
+        __syncthreads();
+      }
     } else {
       stage_tile<NTOK, ROWB, QPF>(Xt, (const char*)dobase, a.lddo * sizeof(T), w, 8);
     }
@@ -1158,7 +1401,8 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        p[kk][r] += tb[kk][r];
+        if constexpr (F8) p[kk][r] = p[kk][r] * (sq * sk) + tb[kk][r];
+        else p[kk][r] += tb[kk][r];
         mx = fmaxf(mx, p[kk][r]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -1213,6 +1457,12 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
           dp[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Vt, (2 * hw + kk) * 32, ks), qf[ks], dp[kk], 0, 0, 0);
     }
     float delta = 0.f;
+    if constexpr (F8) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[kk][r] *= sv;                            // dP = sv (v^ dO)
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -1271,12 +1521,14 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
       buf_store_b16(a.out, __builtin_bit_cast(bf16, (unsigned short)sw[0]), out_voff, soff);
       buf_store_b16(a.out, __builtin_bit_cast(bf16, (unsigned short)sw[1]), out_voff, soff + 4 * (int)a.ldo * 2);
     };
-    auto store4 = [&](int sbase, int row0) {
+    auto store4 = [&](int sbase, int row0, float mul = 1.0f) {
 #pragma unroll
       for (int dt = 0; dt < 4; dt += 2)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          store_pair(acc[dt][r], acc[dt + 1][r], sbase + ((row0 + crow32(r, 0)) * (int)a.ldo + dt * 32) * 2);
+        for (int r = 0; r < 16; ++r) {
+          if constexpr (F8) store_pair(acc[dt][r] * mul, acc[dt + 1][r] * mul, sbase + ((row0 + crow32(r, 0)) * (int)a.ldo + dt * 32) * 2);
+          else store_pair(acc[dt][r], acc[dt + 1][r], sbase + ((row0 + crow32(r, 0)) * (int)a.ldo + dt * 32) * 2);
+        }
     };
     // acc[0..3] += A^T(tile at, column tile qt) x B(tile bt) over the 128 contraction rows: dV (P, dO) and dK (dS, Q).
     // (the operands of step ks + 1 are requested before the MFMAs of step ks; the scheduling barrier keeps hipcc from
@@ -1324,17 +1576,18 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
         sa = sa_n; kb[0] = kb_n[0]; kb[1] = kb_n[1];
       }
     };
+    const float qmul = F8 ? a.scale * sk : a.scale;   // dQ = scale (dS k) = scale sk (dS k^)
     auto dq_store = [&]() {
 #pragma unroll
       for (int dd = 0; dd < 2; ++dd) {
         float csum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) csum += (float)(bf16)(acc[dd][r] * a.scale);        // (sums of the ROUNDED values, own column)
+        for (int r = 0; r < 16; ++r) csum += (float)(bf16)(acc[dd][r] * qmul);        // (sums of the ROUNDED values, own column)
         csacc[dd] += csum;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        store_pair(acc[0][r] * a.scale, acc[1][r] * a.scale, so_q + ((q0 + crow32(r, 0)) * (int)a.ldo + 2 * hw * 32) * 2);
+        store_pair(acc[0][r] * qmul, acc[1][r] * qmul, so_q + ((q0 + crow32(r, 0)) * (int)a.ldo + 2 * hw * 32) * 2);
     };
     if constexpr (QPF) {
       // product 1: dV (waves 0-3: P, dO) and dK (waves 4-7: dS, Q) - four tile products each; after it P, dO AND Q are dead, so the
@@ -1346,13 +1599,20 @@ __global__ __launch_bounds__(512) void attn_bwd8_kernel(AttnArgs a) {
       stamp(7);
       __syncthreads();                             // every wave is done with dO, P and Q
       stamp(8);
-      store4(hw == 0 ? so_v : so_k, k0);
+      store4(hw == 0 ? so_v : so_k, k0, hw == 0 ? 1.0f : sq);        // (F8: dK = sq (dS^T q^))
       if (has_next) {
         int lv = l;
         asm volatile("" : "+v"(lv));
-        stage_tile<NTOK, ROWB, true>(Xt, (const char*)(nqbase + a.C), a.ld * sizeof(T), w, 8, lv);       // next K
-        stage_tile<NTOK, ROWB, true>(Pt, (const char*)nqbase, a.ld * sizeof(T), w, 8, lv);               // next Q
-        stage_tile<NTOK, ROWB, true>(Qt, (const char*)(nqbase + 2 * a.C), a.ld * sizeof(T), w, 8, lv);   // next V
+        if constexpr (F8) {                          // fp8 tiles into the upper halves of the buffers they will be expanded in
+          const char* nq8 = (const char*)a.qkv + (long)((grp + gridDim.x) / a.heads) * NTOK * a.ld + head * HD;
+          stage_tile<NTOK, HD, true>(Xt + KV / 2, nq8 + a.C, a.ld, w, 8, lv);
+          stage_tile<NTOK, HD, true>(Pt + KV / 2, nq8, a.ld, w, 8, lv);
+          stage_tile<NTOK, HD, true>(Qt + KV / 2, nq8 + 2 * a.C, a.ld, w, 8, lv);
+        } else {
+          stage_tile<NTOK, ROWB, true>(Xt, (const char*)(nqbase + a.C), a.ld * sizeof(T), w, 8, lv);       // next K
+          stage_tile<NTOK, ROWB, true>(Pt, (const char*)nqbase, a.ld * sizeof(T), w, 8, lv);               // next Q
+          stage_tile<NTOK, ROWB, true>(Qt, (const char*)(nqbase + 2 * a.C), a.ld * sizeof(T), w, 8, lv);   // next V
+        }
       }
       stamp(9);
       dq_half();
@@ -1624,5 +1884,84 @@ extern "C" int stswin_win_attn_fwd_fp8(const void* qkv, long ld, void* out, long
   if (ntok == 32 && hd == 256) return launch_attn_fp8<32, 256, 0>(a, st);
   if (ntok == 128 && hd == 32) return launch_attn_fp8<128, 32, 0>(a, st);
   if (ntok == 32 && hd == 64) return launch_attn_fp8<32, 64, 0>(a, st);
+  return -1201;
+}
+
+// ------------------------------------------------------------------------------------------------ fp8-storage attention (configs[4])
+template <int NTOK, int HD, int NC>
+static int launch_attn_f8_fwd(const AttnArgs& a, hipStream_t st) {
+  using Cfg = AttnCfg<bf16, NTOK, HD>;
+  const long probs = (long)a.nB_ * a.heads;
+  const int grid = (int)((probs + Cfg::PPB - 1) / Cfg::PPB);
+  constexpr int lds = Cfg::PPB * 2 * NTOK * HD;
+  static const int attr = (int)hipFuncSetAttribute((const void*)attn_fwd_f8_kernel<NTOK, HD, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (attr != 0) return -attr;
+  hipLaunchKernelGGL((attn_fwd_f8_kernel<NTOK, HD, NC>), dim3(grid), dim3(256), lds, st, a);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_win_attn_fwd_f8(const void* qkv8, long ld8, const float* scales, long ld_scales, void* out, long ldo, const float* biasT,
+                                      const float* maskT, int nB_, int nW, int T_frames, int ws, int heads, int C, int bias_windows,
+                                      const int* bias_index, void* stream) {
+  AttnArgs a{qkv8, ld8, out, ldo, nullptr, 0, biasT, maskT, nullptr, nullptr, nullptr, nB_, nW, heads, C, ws * ws, 1.0f, bias_windows, bias_index,
+             scales, ld_scales};
+  const int ntok = T_frames * ws * ws;
+  if (C % heads || nW <= 0 || nB_ % nW || !scales || ld_scales < 3 * heads) return -1202;
+  const int hd = C / heads;
+  hipStream_t st = (hipStream_t)stream;
+  if (ntok == 128 && hd == 128) return a.N == 64 ? launch_attn_f8_fwd<128, 128, 64>(a, st) : launch_attn_f8_fwd<128, 128, 0>(a, st);
+  if (ntok == 32 && hd == 256) return a.N == 16 ? launch_attn_f8_fwd<32, 256, 16>(a, st) : launch_attn_f8_fwd<32, 256, 0>(a, st);
+  return -1201;                                            // (other geometries keep the bf16 kernels)
+}
+
+// backward on fp8-stored q | k | v: stage 1 = attn_bwd8_kernel<64, true, true> (8x8 windows over a frame pair, head dim 128), stage 2 =
+// attn_bwd_kernel<bf16, 32, 256, NC, true>.  dqkv is bf16 (the gradient of the DEQUANTISED q | k | v: straight-through).
+extern "C" int stswin_win_attn_bwd_f8(const void* qkv8, long ld8, const float* scales, long ld_scales, const void* dout, long lddo, void* dqkv,
+                                      long lddq, const float* biasT, const float* maskT, float* dbiasT, float* dqkv_colsum, int nB_, int nW,
+                                      int T_frames, int ws, int heads, int C, float scale, int bias_windows, const int* bias_index,
+                                      float* scratch, long scratch_floats, void* stream) {
+  if (C % heads || nW <= 0 || nB_ % nW || !scales || ld_scales < 3 * heads) return -1202;
+  const int ntok = T_frames * ws * ws, hd = C / heads, N = ws * ws;
+  AttnArgs a{qkv8, ld8, dqkv, lddq, dout, lddo, biasT, maskT, dbiasT, dqkv_colsum, scratch, nB_, nW, heads, C, N, scale, bias_windows, bias_index,
+             scales, ld_scales};
+  a_scratch_floats = scratch_floats;
+  hipStream_t st = (hipStream_t)stream;
+  const long probs = (long)nB_ * heads;
+  if (ntok == 128 && hd == 128 && N == 64) {
+    using Cfg = AttnCfg<bf16, 128, 128>;
+    static const int attr8 = (int)hipFuncSetAttribute((const void*)attn_bwd8_kernel<64, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::BWD_LDS);
+    if (attr8 != 0) return -attr8;
+    if ((long)nB_ * 128 * lddq * 2 >= 0x7FFF0000L || probs % heads) return -1201;
+    int g = 256;
+    if (g > probs) g = (int)probs;
+    g = (g / heads) * heads;
+    if (g < heads) return -1201;
+    if (a.slabs && (long)g * (N * N + 128) > a_scratch_floats) return -1205;
+    hipLaunchKernelGGL((attn_bwd8_kernel<64, true, true>), dim3(g), dim3(512), Cfg::BWD_LDS, st, a);
+    const int rf = attn_bwd_fold(a, g, 128, st);
+    if (rf) return rf;
+    STSWIN_CHECK_LAUNCH();
+    return 0;
+  }
+  if (ntok == 32 && hd == 256 && N == 16) {
+    using Cfg = AttnCfg<bf16, 32, 256>;
+    static const int attr = (int)hipFuncSetAttribute((const void*)attn_bwd_kernel<bf16, 32, 256, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::BWD_LDS);
+    if (attr != 0) return -attr;
+    const int grid = (int)((probs + Cfg::PPB - 1) / Cfg::PPB);
+    const int per_cu = (160 * 1024) / Cfg::BWD_LDS > 0 ? (160 * 1024) / Cfg::BWD_LDS : 1;
+    int g = 256 * per_cu, step = heads;
+    for (int d = Cfg::PPB; d > 1; --d)
+      if (Cfg::PPB % d == 0 && heads % d == 0) { step = heads / d; break; }
+    if (g > grid) g = grid;
+    g = (g / step) * step;
+    if (g < step) g = step;
+    if (a.slabs && (long)g * Cfg::PPB * (N * N + 256) > a_scratch_floats) return -1205;
+    hipLaunchKernelGGL((attn_bwd_kernel<bf16, 32, 256, 16, true>), dim3(g), dim3(256), Cfg::BWD_LDS, st, a);
+    const int rf = attn_bwd_fold(a, g * Cfg::PPB, 256, st);
+    if (rf) return rf;
+    STSWIN_CHECK_LAUNCH();
+    return 0;
+  }
   return -1201;
 }

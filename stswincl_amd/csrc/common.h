@@ -213,6 +213,14 @@ DEVI float wave_sum(float v) {
   v += __shfl_xor(v, 16);
   return v + __shfl_xor(v, 32);
 }
+DEVI float wave_max_dpp(float v) {                 // (16-lane rows by DPP - no LDS crossbar round trips - then two exchanges)
+  v = fmaxf(v, dpp_f32<0xB1>(v));
+  v = fmaxf(v, dpp_f32<0x4E>(v));
+  v = fmaxf(v, dpp_f32<0x141>(v));
+  v = fmaxf(v, dpp_f32<0x140>(v));
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
 DEVI float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

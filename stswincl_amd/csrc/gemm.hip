@@ -61,6 +61,9 @@ struct GemmNT {
   int flags;
   float* colsum;                 // optional fp32 [N]: += column sums of the values written to C
   int qsplit;                    // ring kernels, split-K launches (stswin_gemm_nt_splitk): 32-deep stages per blockIdx.y slice, 0 = whole K
+  // fp8 (e4m3) q | k | v output (stswin_gemm_nt_qkv_fp8): C is uint8 [M][ldc], C2 the fp32 scale table [M / f8_rows][N / f8_cols];
+  // one scale per (f8_rows consecutive rows = one window problem, f8_cols consecutive columns = one head of q, k or v)
+  int f8_rows, f8_cols;
 };
 
 // Column sum `v` of output rows [128*blk, 128*blk + 128*nblk) of column gn.  Default: one fp32 atomic per (tile, column) -
@@ -848,7 +851,83 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     }
 #undef EPI_HAS
   };
+  // ---------------- fp8 epilogue (SWAP kernels, BASELINE configs[4]): the QKV projection leaves as e4m3 bytes + per-(window, head)
+  // scales, so that the attention forward AND backward read half the bytes (swin_512.py:115-121 with q | k | v stored in fp8).
+  // bias, q scaling on the accumulators; |v| maximum per (row group, column group): in-lane over the group's fragments, across the
+  // wave by DPP, across the 2 (head dim 128) or 4 (256) waves that share the head through 32 floats of LDS; scale = amax / 448;
+  // 4 values -> one dword of e4m3 (v_cvt_pk_fp8_f32), a [256][256 B] LDS image (16-byte chunk ^= row & 15), whole 16-byte row
+  // pieces out.  One lane per (wave, row group) writes the scale.
+  auto epilogue_fp8 = [&]() __attribute__((always_inline)) {
+    constexpr int NG = 4;                              // row groups per wave tile at 32 rows per problem (1 group at 128)
+    char* img = smem;
+    float* ex = (float*)(smem + BM * BN);              // [WM][WN][NG] wave maxima
+    const int rg = p.f8_rows, cgw = p.f8_cols / TN;    // rows per scale, waves per column group (2 or 4)
+    const int ngroups = TM / rg;                       // 1 (128 rows) or 4 (32 rows)
+    const int colb = n0 + wc * TN + 4 * fq;
+    f32x4 bj[FJ];
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) bj[j] = p.bias ? *(const f32x4*)(p.bias + colb + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool qcols = n0 + wc * TN < p.scale_cols;    // (scale_cols is a multiple of the head dim: a wave tile is all-q or not)
+    float gm[NG] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) {
+        f32x4 v = acc[i][j] + bj[j];
+        if (qcols) v *= p.scale;
+        acc[i][j] = v;
+        const float m4 = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        const int g = ngroups == 1 ? 0 : i / 2;        // 16-row fragments 2g, 2g + 1 = rows 32g .. 32g + 31
+        gm[g] = fmaxf(gm[g], m4);
+      }
+    // (|values| are non-negative: their maximum is order-free, so the wave reduction runs BEFORE the barrier that frees the ring)
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      if (g < ngroups) gm[g] = wave_max_dpp(gm[g]);
+    __syncthreads();                                   // every wave is done with the ring stages (ex / img live there)
+    if (l == 0) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) ex[(wr * WN + wc) * NG + g] = gm[g];
+    }
+    __syncthreads();
+    float inv[NG], sc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float m = 0.f;
+      const int w0 = (wc / cgw) * cgw;
+      for (int u = 0; u < cgw; ++u) m = fmaxf(m, ex[(wr * WN + w0 + u) * NG + g]);
+      sc[g] = m > 0.f ? m * (1.0f / 448.0f) : 1.0f;
+      inv[g] = 1.0f / sc[g];
+    }
+    // (the image [0, 64 KB) and the exchange area behind it do not overlap: no barrier between reading one and writing the other)
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) {
+        const float k = inv[ngroups == 1 ? 0 : i / 2];
+        int pk = 0;
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(acc[i][j][0] * k, acc[i][j][1] * k, pk, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(acc[i][j][2] * k, acc[i][j][3] * k, pk, true);
+        const int row = wr * TM + i * 16 + fr, chunk = wc * (TN / 16) + j;
+        *(int*)(img + row * BN + (((chunk ^ fr) & (BN / 16 - 1)) << 4) + 4 * fq) = pk;
+      }
+    if (l == 0 && (wc % cgw) == 0) {
+      float* st = (float*)p.C2 + (long)((m0 + wr * TM) / rg) * p.ldc2 + (n0 + wc * TN) / p.f8_cols;
+      for (int g = 0; g < ngroups; ++g) st[(long)g * p.ldc2] = sc[g];
+    }
+    __syncthreads();
+    constexpr int CPRW8 = BN / 16, RPP8 = NTHR / CPRW8;   // 16-byte pieces per image row, rows per pass
+    const int rb_row = tid / CPRW8, rb_chunk = tid % CPRW8;
+    typedef int v4i32e __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int ps = 0; ps < BM / RPP8; ++ps) {
+      const int row = ps * RPP8 + rb_row;
+      const v4i32e val = *(const v4i32e*)(img + row * BN + (((rb_chunk ^ (row & 15)) & (CPRW8 - 1)) << 4));
+      __builtin_nontemporal_store(val, (v4i32e*)((char*)p.C + (long)(m0 + row) * p.ldc + n0 + rb_chunk * 16));
+    }
+  };
   auto epilogue_reg = [&]() __attribute__((always_inline)) {
+    if (p.f8_rows > 0) { epilogue_fp8(); return; }
     if (p.flags & (1 << 21)) {        // DBG: no epilogue at all (keeps the accumulators alive)
       stamp(3); stamp(4); stamp(5);
       float t = 0.f;
@@ -2133,6 +2212,30 @@ extern "C" int stswin_gemm_nt_splitk(const void* A, long lda, const int* a_rows,
                      (bf16*)C, ldc, bias, relu);
   else hipLaunchKernelGGL(nt_splitk_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, splits, (long)M * N, M, N,
                      (bf16*)C, ldc, bias, relu);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+/* The QKV projection of a Swin block with an fp8 (OCP e4m3) result (BASELINE.json configs[4]; swin_512.py:115-121):
+ * out8[m][n] = e4m3((sum_k A[a_rows[m]][k] * B[n][k] + bias[n]) * (n < scale_cols ? scale : 1) / s), s = scales[m / rows_per_problem][n / head_dim]
+ * = (largest |value| of that rows_per_problem x head_dim block) / 448 (1 for an all-zero block).  bf16 operands; M % 256 == 0,
+ * N % 256 == 0, Kseg % 32 == 0, rows_per_problem in {32, 128}, head_dim in {128, 256}, scale_cols % head_dim == 0, ld8 % 16 == 0.
+ * 256x256 ring kernel (as stswin_gemm_nt picks for these shapes), register epilogue. */
+extern "C" int stswin_gemm_nt_qkv_fp8(const void* A, long lda, const int* a_rows, const void* B, long ldb, void* out8, long ld8,
+                                      float* scales, long ld_scales, const float* bias, int M, int N, int Kseg, float scale, int scale_cols,
+                                      int rows_per_problem, int head_dim, void* stream) {
+  if (M <= 0 || N <= 0 || M % 256 || N % 256 || Kseg <= 0 || Kseg % 32 || lda % 8 || ldb % 8) return -1001;
+  if ((rows_per_problem != 32 && rows_per_problem != 128) || (head_dim != 128 && head_dim != 256) || scale_cols % head_dim || N % head_dim)
+    return -1010;
+  if (ld8 % 16 || ((uintptr_t)out8 & 15) || !scales || ld_scales < N / head_dim || (bias && ((uintptr_t)bias & 15))) return -1011;
+  if ((!a_rows && (long)M * lda * 2 > 0xFFFF0000L) || (long)N * ldb * 2 > 0xFFFF0000L) return -1008;
+  GemmNT p{A, lda, a_rows, B, ldb, out8, ld8, nullptr, scales, ld_scales, bias, nullptr, 0, nullptr, M, N, Kseg, 1, scale, scale_cols, 0, nullptr, 0,
+           rows_per_problem, head_dim};
+  static const int attr = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  if (attr != 0) return -attr;
+  const long tiles = (long)(M / 256) * (N / 256);
+  g_last_variant[0] = STSWIN_VAR_NT_RING256_REGEPI;
+  hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>), dim3((unsigned)tiles), dim3(512), 131072, (hipStream_t)stream, p);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

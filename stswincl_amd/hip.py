@@ -551,6 +551,22 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
     return out
 
 
+def gemm_nt_qkv_fp8(A: torch.Tensor, Bw: torch.Tensor, *, M: int, a_rows=None, bias=None, scale: float = 1.0, scale_cols: int = 0,
+                    rows_per_problem: int, head_dim: int):
+    """QKV projection with an e4m3 result: returns (out8 uint8 [M][N], scales fp32 [M / rows_per_problem][N / head_dim]); see
+    include/stswin_hip.h.  Raises StswinHipError on shapes the kernel does not take (the caller keeps the bf16 path for those)."""
+    N, K = Bw.shape
+    assert A.dtype == torch.bfloat16 and Bw.dtype == torch.bfloat16 and A.shape[1] >= K
+    out8 = torch.empty(M, N, dtype=torch.uint8, device=A.device)
+    scales = torch.empty(M // rows_per_problem, N // head_dim, dtype=torch.float32, device=A.device)
+    with _Span("gemm_nt_bf16" + (f" M={M} N={N} K={K} S=1 a={int(a_rows is not None)} c=0 fl=fp8out" if _SHAPE_NAMES else ""), 2.0 * M * N * K):
+        rc = load().stswin_gemm_nt_qkv_fp8(_p(A), _c_long(_ld(A)), _p(a_rows), _p(Bw), _c_long(_ld(Bw)), _p(out8), _c_long(N), _p(scales),
+                                           _c_long(N // head_dim), _p(bias), M, N, K, _c_float(scale), scale_cols, rows_per_problem, head_dim,
+                                           _stream())
+    _check(rc, "gemm_nt_qkv_fp8")
+    return out8, scales
+
+
 _WARNED = {}
 _NT_SPLITK = os.environ.get("STSWIN_NO_NT_SPLITK") != "1"                 # (A/B switch)
 _CS_PARTIAL_MIN_M = int(os.environ.get("STSWIN_CS_PARTIAL_MIN_M", "1"))   # (the table + fold path is the deterministic one: always)
@@ -791,6 +807,35 @@ def win_attn_fwd(qkv, biasT, maskT, *, nB_, nW, T, ws, heads, C, bias_index=None
                                     _stream())
     _check(rc, "win_attn_fwd")
     return out
+
+
+def win_attn_fwd_f8(qkv8, scales, biasT, maskT, *, nB_, nW, T, ws, heads, C, bias_index=None):
+    """Attention forward on e4m3-stored q | k | v (gemm_nt_qkv_fp8): bf16 [rows][C]."""
+    assert qkv8.dtype == torch.uint8 and qkv8.is_contiguous() and scales.dtype == torch.float32 and scales.is_contiguous()
+    out = torch.empty(qkv8.shape[0], C, dtype=torch.bfloat16, device=qkv8.device)
+    with _Span("attn_fwd_f8", 4.0 * nB_ * heads * (T * ws * ws) ** 2 * (C // heads)):
+        rc = load().stswin_win_attn_fwd_f8(_p(qkv8), _c_long(qkv8.shape[1]), _p(scales), _c_long(scales.shape[1]), _p(out), _c_long(_ld(out)),
+                                           _p(biasT), _p(maskT), nB_, nW, T, ws, heads, C, _bias_windows(biasT, maskT, nW, bias_index),
+                                           _p(bias_index), _stream())
+    _check(rc, "win_attn_fwd_f8")
+    return out
+
+
+def win_attn_bwd_f8(qkv8, scales, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, scale, colsum_out=None, bias_index=None):
+    """Attention backward on e4m3-stored q | k | v: bf16 dqkv [rows][3C]."""
+    dqkv = torch.empty(qkv8.shape[0], 3 * C, dtype=torch.bfloat16, device=qkv8.device)
+    lib = load()
+    need = lib.stswin_win_attn_bwd_scratch(nB_, ws, heads, C)
+    if need < 0:
+        raise StswinHipError(f"win_attn_bwd_f8: bad geometry ({need})")
+    sc = scratch(qkv8.device, need)
+    with _Span("attn_bwd_f8", 10.0 * nB_ * heads * (T * ws * ws) ** 2 * (C // heads)):
+        rc = lib.stswin_win_attn_bwd_f8(_p(qkv8), _c_long(qkv8.shape[1]), _p(scales), _c_long(scales.shape[1]), _p(dout), _c_long(_ld(dout)),
+                                        _p(dqkv), _c_long(_ld(dqkv)), _p(biasT), _p(maskT), _p(dbiasT), _p(colsum_out), nB_, nW, T, ws, heads, C,
+                                        _c_float(scale), _bias_windows(biasT, maskT, nW, bias_index), _p(bias_index), _p(sc),
+                                        _c_long(sc.numel()), _stream())
+    _check(rc, "win_attn_bwd_f8")
+    return dqkv
 
 
 def win_attn_qkv_fwd(x, rmap, w, bqkv, biasT, *, nB_, nW, T, ws, heads, C, scale, bias_index=None, want_qkv=True, debug_ts=None):

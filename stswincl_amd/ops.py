@@ -365,6 +365,7 @@ class SwinBlockFn(torch.autograd.Function):
         rmap = window_rowmap(Bp, T, H, W, ws, shift, dev)
         rmap_in = rmap if src is None else src.compose(rmap)          # window row -> row of X2
         scale = d ** -0.5
+        qscale = None
         # one [nW][heads][N][N] table = bias + SW-MSA mask (swin_512.py:122-131): the kernels then read one value per
         # score instead of two (the separate mask read cost +60 % on the stage-1 forward kernel)
         maskT = None
@@ -380,13 +381,20 @@ class SwinBlockFn(torch.autograd.Function):
             # backward will read them (swin_512.py:115-141)
             o, qkv = hip.win_attn_qkv_fwd(X2, rmap_in, wcast(qkv_w, dt), _f32(qkv_b), biasT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads,
                                           C=C, scale=scale, bias_index=bidx, want_qkv=need_bwd)
+        elif fp8 and (T * N, d) in ((128, 128), (32, 256)) and N in (64, 16) and M % 256 == 0 and (3 * C) % 256 == 0:
+            # STSWIN_FP8_ATTN=1 (BASELINE configs[4], "fp8 MFMA attention") as a TRAINING path: the QKV GEMM's epilogue writes q | k | v as
+            # e4m3 bytes + one scale per (window, head), the forward core runs both products on the fp8 MFMA from those bytes, and the
+            # backward (below) reads the same bytes - half the q | k | v traffic in all three kernels
+            qkv, qscale = hip.gemm_nt_qkv_fp8(X2, wcast(qkv_w, dt), M=M, a_rows=rmap_in, bias=_f32(qkv_b), scale=scale, scale_cols=C,
+                                              rows_per_problem=T * N, head_dim=d)
+            o = hip.win_attn_fwd_f8(qkv, qscale, biasT, maskT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads, C=C, bias_index=bidx)
         else:
             qkv = torch.empty(M, 3 * C, dtype=dt, device=dev)
             hip.gemm_nt(X2, wcast(qkv_w, dt), qkv, M=M, a_rows=rmap_in, bias=_f32(qkv_b), scale=scale, scale_cols=C)
-            # STSWIN_FP8_ATTN=1 (BASELINE configs[4]): e4m3 q / k / v / P on the fp8 MFMA in the forward; the backward stays bf16
+            # (fp8 on a geometry the fp8-storage kernels do not take: e4m3 q / k / v / P in the forward core only, bf16 storage + backward)
             o = hip.win_attn_fwd(qkv, biasT, maskT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads, C=C, bias_index=bidx, fp8=fp8)
         if ATTN_TAP is not None:      # test instrumentation (tests/test_hip_configs.py): what the attention core read and wrote
-            ATTN_TAP.append({"qkv": qkv, "o": o, "table": table.detach(), "index": index, "mask": attn_mask, "geom": geom,
+            ATTN_TAP.append({"qkv": qkv, "qscale": qscale, "o": o, "table": table.detach(), "index": index, "mask": attn_mask, "geom": geom,
                              "Bp": Bp, "C": C, "fp8": fp8})
         x1 = torch.empty(M, C, dtype=dt, device=dev)
         # (window row m lands on token row rmap[m] of x1; its shortcut is row rmap_in[m] of X2)
@@ -415,14 +423,14 @@ class SwinBlockFn(torch.autograd.Function):
         ctx.bidx = bidx
         ctx.gelu_bwd = gelu_bwd
         ctx.save_for_backward(X2, rmap, qkv, biasT, maskT, o, x1, mean2, rstd2, n2, h_pre, h, y2, mean1, rstd1,
-                              qkv_w, proj_w, n1_w, n2_w, fc1_w, fc2_w, index)
+                              qkv_w, proj_w, n1_w, n2_w, fc1_w, fc2_w, index, qscale)
         return out.view(Bp, T, L, C)
 
     @staticmethod
     @hip.tn_deferred_backward
     def backward(ctx, dout):
         (X2, rmap, qkv, biasT, maskT, o, x1, mean2, rstd2, n2, h_pre, h, y2, mean1, rstd1,
-         qkv_w, proj_w, n1_w, n2_w, fc1_w, fc2_w, index) = ctx.saved_tensors
+         qkv_w, proj_w, n1_w, n2_w, fc1_w, fc2_w, index, qscale) = ctx.saved_tensors
         H, W, ws, shift, heads = ctx.geom
         dt = ctx.dt
         M, C = rmap.numel(), X2.shape[1]          # (X2 may be a larger source matrix: ctx.src)
@@ -463,8 +471,12 @@ class SwinBlockFn(torch.autograd.Function):
             # (dv third of the qkv bias gradient = column sums of dO: softmax rows sum to one; the dk third is exactly zero)
             hip.gemm_nt(dx1, wcast(proj_w, dt, True), do, M=M, a_rows=rmap, colsum_out=dqkv_b[2 * C:])
             # attention core (also yields the dq third of the qkv bias gradient)
-            dqkv = hip.win_attn_bwd(qkv, do, biasT, maskT, dbiasT, nB_=(M // (2 * N)), nW=nW, T=2, ws=ws, heads=heads,
-                                    C=C, scale=d ** -0.5, colsum_out=dqkv_b, bias_index=ctx.bidx)
+            if qscale is not None:                     # fp8-stored q | k | v (STSWIN_FP8_ATTN=1): the backward reads the same bytes
+                dqkv = hip.win_attn_bwd_f8(qkv, qscale, do, biasT, maskT, dbiasT, nB_=(M // (2 * N)), nW=nW, T=2, ws=ws, heads=heads,
+                                           C=C, scale=d ** -0.5, colsum_out=dqkv_b, bias_index=ctx.bidx)
+            else:
+                dqkv = hip.win_attn_bwd(qkv, do, biasT, maskT, dbiasT, nB_=(M // (2 * N)), nW=nW, T=2, ws=ws, heads=heads,
+                                        C=C, scale=d ** -0.5, colsum_out=dqkv_b, bias_index=ctx.bidx)
         except BaseException:
             folds.abort()
             raise

@@ -265,8 +265,13 @@ def test_config4_full_size_fp8_finetune_step_vs_the_oracle(tmp_path):
 
 
 def _tap_qkv_f32(t):
-    """q (pre-scaled) | k | v rows as fp32, as the attention kernel read them."""
-    return t["qkv"].float()
+    """q (pre-scaled) | k | v rows as fp32, as the attention kernel read them: bf16 rows, or e4m3 bytes x their (window, head) scales."""
+    if t.get("qscale") is None:
+        return t["qkv"].float()
+    H, W, ws, shift, heads = t["geom"]
+    rows, d = 2 * ws * ws, t["C"] // heads
+    v = t["qkv"].view(torch.float8_e4m3fn).float()
+    return v * t["qscale"].repeat_interleave(rows, 0).repeat_interleave(d, 1)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, BF])

@@ -44,6 +44,20 @@ def main():
         t = timeit(lambda: hip.win_attn_bwd(qkv, do, tab4, None, dbiasT, nB_=nB_, nW=nW, T=T, ws=ws, heads=heads, C=C,
                                             scale=hd ** -0.5, colsum_out=cs, bias_index=bidx))
         print(f"{name} bwd table+index {t:8.1f} us {f_bwd / t / 1e6:7.1f} TF/s   (the shifted blocks of the training step)", flush=True)
+        # BASELINE configs[4]: q | k | v stored as e4m3 + per-(window, head) scales (written by the QKV GEMM epilogue)
+        x = torch.randn(rows, C, device=dev).to(dt)
+        wq = (torch.randn(3 * C, C, device=dev) / C ** 0.5).to(dt)
+        bq = torch.randn(3 * C, device=dev) * 0.1
+        q8, sc = hip.gemm_nt_qkv_fp8(x, wq, M=rows, bias=bq, scale=hd ** -0.5, scale_cols=C, rows_per_problem=ntok, head_dim=hd)
+        qkv16 = torch.empty(rows, 3 * C, device=dev, dtype=dt)
+        t = timeit(lambda: hip.gemm_nt(x, wq, qkv16, M=rows, bias=bq, scale=hd ** -0.5, scale_cols=C))
+        t8 = timeit(lambda: hip.gemm_nt_qkv_fp8(x, wq, M=rows, bias=bq, scale=hd ** -0.5, scale_cols=C, rows_per_problem=ntok, head_dim=hd))
+        print(f"{name} qkv GEMM  bf16 out {t:8.1f} us   e4m3 out + scales {t8:8.1f} us")
+        t = timeit(lambda: hip.win_attn_fwd_f8(q8, sc, tab4, None, nB_=nB_, nW=nW, T=T, ws=ws, heads=heads, C=C, bias_index=bidx))
+        print(f"{name} fwd fp8-stored q|k|v (table+index) {t:8.1f} us {f_fwd / t / 1e6:7.1f} TF/s")
+        t = timeit(lambda: hip.win_attn_bwd_f8(q8, sc, do, tab4, None, dbiasT, nB_=nB_, nW=nW, T=T, ws=ws, heads=heads, C=C,
+                                               scale=hd ** -0.5, colsum_out=cs, bias_index=bidx))
+        print(f"{name} bwd fp8-stored q|k|v (table+index) {t:8.1f} us {f_bwd / t / 1e6:7.1f} TF/s", flush=True)
         for mname, m in (("mask", maskT), ("nomask", None)):
             t = timeit(lambda: hip.win_attn_fwd(qkv, biasT, m, nB_=nB_, nW=nW, T=T, ws=ws, heads=heads, C=C))
             print(f"{name} fwd {mname:7s} {t:8.1f} us {f_fwd / t / 1e6:7.1f} TF/s")
