@@ -1010,10 +1010,17 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     auto read_frags = [&](int q) {
       const char* Ab = smem + (q % NST) * STAGE;
       const char* Bb = Ab + A_BYTES;
+#ifdef STSWIN_DEBUG_HALF_READS                         // diagnosis build (tools/probes/half_reads.sh): HALF the fragment reads, the other fragments
+#pragma unroll                                         // are copies (wrong results, same MFMA stream on data) - what do the LDS reads cost in clock?
+      for (int j = 0; j < FJ; j += 2) { b[j] = *(const bf16x8*)(Bb + (wc * TN + j * 16) * ROWB + rd_off); b[j + 1] = b[j]; }
+#pragma unroll
+      for (int i = 0; i < FI; i += 2) { a[i] = *(const bf16x8*)(Ab + (wr * TM + i * 16) * ROWB + rd_off); a[i + 1] = a[i]; }
+#else
 #pragma unroll
       for (int j = 0; j < FJ; ++j) b[j] = *(const bf16x8*)(Bb + (wc * TN + j * 16) * ROWB + rd_off);
 #pragma unroll
       for (int i = 0; i < FI; ++i) a[i] = *(const bf16x8*)(Ab + (wr * TM + i * 16) * ROWB + rd_off);
+#endif
     };
     auto mma_all = [&]() {
       __builtin_amdgcn_s_setprio(1);
