@@ -78,14 +78,14 @@ class LARS:
         if closure is not None:                    # (torch.optim re-enables grad for the closure: it runs forward + backward)
             with torch.enable_grad():
                 loss = closure()
-        for gi, group in enumerate(self.optim.param_groups):
+        for group in self.optim.param_groups:
             if group.get("dampening", 0) != 0 or group.get("nesterov", False) or group.get("maximize", False):
                 raise hip.StswinHipError("fused LARS wraps plain SGD-momentum (dampening 0, nesterov off)")
             momentum = float(group.get("momentum", 0.0))
             wd = float(group["weight_decay"])
             ignore = group.get("ignore", None)              # set by add_weight_decay
             adaptive = ignore is not None and not ignore     # lars.py:129: groups without the key are never scaled
-            first, later, touched = ([], [], [], []), ([], [], [], []), []
+            first, later, touched = ([], [], []), ([], [], []), []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -99,12 +99,10 @@ class LARS:
                 tgt[0].append(p.data)
                 tgt[1].append(g)
                 tgt[2].append(st["momentum_buffer"])
-                tgt[3].append(id(p))
                 touched.append(p)
-            for (ps, gs, ms, ids), is_first in ((first, True), (later, False)):
+            for (ps, gs, ms), is_first in ((first, True), (later, False)):
                 if ps:
                     hip.multi_tensor_lars(ps, gs, ms, None, lr=float(group["lr"]), momentum=momentum,
-                                          wd=wd, trust_coef=self.trust_coef, eps=self.eps, first=is_first, adaptive=adaptive,
-                                          key=(id(self), gi, is_first, hash(tuple(ids))))
+                                          wd=wd, trust_coef=self.trust_coef, eps=self.eps, first=is_first, adaptive=adaptive)
             _mark_updated(touched)
         return loss

@@ -1080,74 +1080,40 @@ def upsample_argmax(logits, H, W, gt=None):
     return labels, counts
 
 
-_MT_CACHE = {}        # (key, lo) -> prepared pointer arrays of the STATIC tensor lists of a multi-tensor launch (see _mt_chunk)
-
-
-def _mt_chunk(key, lo, hi, static_lists, what):
-    """ctypes pointer arrays (and the element counts of the first list) of tensors [lo, hi) of every list in static_lists - parameters and
-    optimizer state, whose storage does not move from step to step.  With a key (the optimizer passes (id(self), group, tag)) the arrays
-    are built once and reused while the chunk still starts and ends at the same addresses in every list (a reallocated parameter or a
-    reloaded state rebuilds them); the tensors of a cached chunk are validated once.  Per step this replaces ~150 us of Python per 48-tensor
-    chunk (attribute checks + data_ptr() calls) by a dozen data_ptr() calls - the optimizer step of the contrastive workload was
-    host-bound (profiles/r04_contrast_steady_state_kernels.txt: 163 us of device idle in front of every multi_tensor launch)."""
-    k = hi - lo
-    sig = tuple((ts[lo].data_ptr(), ts[hi - 1].data_ptr()) if ts is not None else None for ts in static_lists)
-    ent = _MT_CACHE.get((key, lo)) if key is not None else None
-    if ent is not None and ent[0] == k and ent[1] == sig:
-        return ent[2], ent[3]
-    for ts in static_lists:
-        if ts is not None:
-            for t in ts[lo:hi]:
-                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
-                    raise StswinHipError(f"{what} needs contiguous fp32 GPU tensors")
-    arrs = [(_c_void_p * k)(*[t.data_ptr() for t in ts[lo:hi]]) if ts is not None else None for ts in static_lists]
-    ns = [t.numel() for t in static_lists[0][lo:hi]]
-    if key is not None:
-        if len(_MT_CACHE) > 512:
-            _MT_CACHE.clear()
-        _MT_CACHE[(key, lo)] = (k, sig, arrs, ns)
-    return arrs, ns
-
-
-def _mt_grads(gs, lo, hi, what):
-    out = []
-    for t in gs[lo:hi]:
-        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
-            raise StswinHipError(f"{what} needs contiguous fp32 GPU tensors")
-        out.append(t.data_ptr())
-    return (_c_void_p * (hi - lo))(*out)
-
-
-def multi_tensor(mode, ps, gs, ms=None, vs=None, lr=0.0, b1=0.0, b2=0.0, eps=0.0, wd=0.0, c1=1.0, c2=1.0, key=None, gs_static=False):
-    """mode 0 Adam / 1 SGD-momentum / 2 EMA over lists of fp32 tensors (chunks of 48 tensors per launch).  key: see _mt_chunk;
-    gs_static: the second list is long-lived too (EMA: the query parameters)."""
+def multi_tensor(mode, ps, gs, ms=None, vs=None, lr=0.0, b1=0.0, b2=0.0, eps=0.0, wd=0.0, c1=1.0, c2=1.0):
+    """mode 0 Adam / 1 SGD-momentum / 2 EMA over lists of fp32 tensors (chunks of 48 tensors per launch)."""
     lib = load()
     st = _stream()
+    for t in ps:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise StswinHipError("multi_tensor needs contiguous fp32 GPU tensors")
     for lo in range(0, len(ps), 48):
         hi = min(len(ps), lo + 48)
         k = hi - lo
-        (ap, am, av, ag), ns = _mt_chunk(key, lo, hi, (ps, ms, vs, gs if gs_static else None), "multi_tensor")
-        if not gs_static:
-            ag = _mt_grads(gs, lo, hi, "multi_tensor")
-        _check(lib.stswin_multi_tensor(mode, k, ap, ag, am, av, (_c_int * k)(*ns), _c_float(lr), _c_float(b1),
+        arr = lambda ts: (_c_void_p * k)(*[t.data_ptr() for t in ts[lo:hi]]) if ts is not None else None  # noqa: E731
+        ns = (_c_int * k)(*[t.numel() for t in ps[lo:hi]])
+        _check(lib.stswin_multi_tensor(mode, k, arr(ps), arr(gs), arr(ms), arr(vs), ns, _c_float(lr), _c_float(b1),
                                        _c_float(b2), _c_float(eps), _c_float(wd), _c_float(c1), _c_float(c2), st),
                "multi_tensor")
 
 
-def multi_tensor_lars(ps, gs, ms, norms, *, lr, momentum, wd, trust_coef, eps, first, adaptive, key=None):
+def multi_tensor_lars(ps, gs, ms, norms, *, lr, momentum, wd, trust_coef, eps, first, adaptive):
     """LARS-scaled SGD-momentum step of one parameter group (lists of contiguous fp32 GPU tensors; chunks of 48 tensors,
-    two launches each: norms, update).  norms: fp32 scratch of >= 96 floats, or None (the shared scratch).  key: see _mt_chunk."""
+    two launches each: norms, update).  norms: fp32 scratch of >= 96 floats."""
     lib = load()
     st = _stream()
+    for t in list(ps) + list(gs) + list(ms):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise StswinHipError("multi_tensor_lars needs contiguous fp32 GPU tensors")
     for lo in range(0, len(ps), 48):
         hi = min(len(ps), lo + 48)
         k = hi - lo
-        (ap, am), ns = _mt_chunk(key, lo, hi, (ps, ms), "multi_tensor_lars")
-        ag = _mt_grads(gs, lo, hi, "multi_tensor_lars")
-        need = 2 * k + 2 * sum((n + 8191) // 8192 for n in ns)
+        arr = lambda ts: (_c_void_p * k)(*[t.data_ptr() for t in ts[lo:hi]])  # noqa: E731
+        ns = (_c_int * k)(*[t.numel() for t in ps[lo:hi]])
+        need = 2 * k + 2 * sum((t.numel() + 8191) // 8192 for t in ps[lo:hi])
         if norms is None or norms.numel() < need:
             norms = scratch(ps[lo].device, need)
-        _check(lib.stswin_multi_tensor_lars(k, ap, ag, am, (_c_int * k)(*ns), _p(norms), _c_long(norms.numel()), _c_float(lr), _c_float(momentum),
+        _check(lib.stswin_multi_tensor_lars(k, arr(ps), arr(gs), arr(ms), ns, _p(norms), _c_long(norms.numel()), _c_float(lr), _c_float(momentum),
                                             _c_float(wd), _c_float(trust_coef), _c_float(eps), 1 if first else 0,
                                             1 if adaptive else 0, st), "multi_tensor_lars")
 

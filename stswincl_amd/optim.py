@@ -46,7 +46,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:                    # (torch.optim re-enables grad for the closure: it runs forward + backward)
             with torch.enable_grad():
                 loss = closure()
-        for gi, group in enumerate(self.param_groups):
+        for group in self.param_groups:
             b1, b2 = group["betas"]
             by_step = {}          # torch.optim.Adam keeps the step count PER PARAMETER (bias corrections differ when a branch
             touched = []          # had no gradient on some steps, or a parameter was unfrozen later): one launch per count
@@ -61,17 +61,15 @@ class FusedAdam(torch.optim.Optimizer):
                 if not isinstance(st["step"], int):          # a state loaded from torch.optim.Adam holds tensor steps: one host
                     st["step"] = int(st["step"])             # read, here, before any capture (see load_state_dict)
                 st["step"] += 1
-                ps, gs, ms, vs, ids = by_step.setdefault(st["step"], ([], [], [], [], []))
+                ps, gs, ms, vs = by_step.setdefault(st["step"], ([], [], [], []))
                 ps.append(p.data)
-                ids.append(id(p))
                 touched.append(p)
                 gs.append(p.grad.contiguous() if not p.grad.is_contiguous() else p.grad)
                 ms.append(st["exp_avg"])
                 vs.append(st["exp_avg_sq"])
-            for step, (ps, gs, ms, vs, ids) in by_step.items():
-                # (key: WHICH parameters are in the list - a parameter that gets a gradient only on some steps changes it)
+            for step, (ps, gs, ms, vs) in by_step.items():
                 hip.multi_tensor(0, ps, gs, ms, vs, lr=group["lr"], b1=b1, b2=b2, eps=group["eps"], wd=group["weight_decay"],
-                                 c1=1.0 - b1 ** step, c2=math.sqrt(1.0 - b2 ** step), key=(id(self), gi, "adam", hash(tuple(ids))))
+                                 c1=1.0 - b1 ** step, c2=math.sqrt(1.0 - b2 ** step))
             _mark_updated(touched)
         return loss
 
@@ -96,8 +94,8 @@ class FusedSGD(torch.optim.Optimizer):
         if closure is not None:                    # (torch.optim re-enables grad for the closure: it runs forward + backward)
             with torch.enable_grad():
                 loss = closure()
-        for gi, group in enumerate(self.param_groups):
-            first, later, touched = ([], [], [], []), ([], [], [], []), []
+        for group in self.param_groups:
+            first, later, touched = ([], [], []), ([], [], []), []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -112,11 +110,9 @@ class FusedSGD(torch.optim.Optimizer):
                 touched.append(p)
                 tgt[1].append(g)
                 tgt[2].append(st["momentum_buffer"])
-                tgt[3].append(id(p))
-            for (ps, gs, ms, ids), c1 in ((first, 1.0), (later, 0.0)):
+            for (ps, gs, ms), c1 in ((first, 1.0), (later, 0.0)):
                 if ps:
-                    hip.multi_tensor(1, ps, gs, ms, None, lr=group["lr"], b1=group["momentum"], wd=group["weight_decay"], c1=c1,
-                                     key=(id(self), gi, "sgd", hash(tuple(ids))))
+                    hip.multi_tensor(1, ps, gs, ms, None, lr=group["lr"], b1=group["momentum"], wd=group["weight_decay"], c1=c1)
             _mark_updated(touched)
         return loss
 
@@ -125,8 +121,7 @@ class FusedSGD(torch.optim.Optimizer):
 def ema_update(keys: Sequence[torch.Tensor], queries: Sequence[torch.Tensor], momentum: float) -> None:
     """key <- key * momentum + query * (1 - momentum) for every pair.  Pass the key PARAMETERS (not their .data aliases):
     their version counters are bumped so that caches keyed on them see the update."""
-    hip.multi_tensor(2, [k.data for k in keys], [q.data for q in queries], b1=momentum,
-                     key=("ema", hash(tuple(map(id, keys))), hash(tuple(map(id, queries)))), gs_static=True)
+    hip.multi_tensor(2, [k.data for k in keys], [q.data for q in queries], b1=momentum)
     _mark_updated(list(keys))
 
 
