@@ -177,6 +177,7 @@ int stswin_tn_combine(const float* workspace, float* C, long ldc, int Ni, int Nj
 #define STSWIN_VAR_NT_RING256_REGEPI 1     /* 256x256 ping-pong ring, operand-swapped MFMA + register epilogue (production) */
 #define STSWIN_VAR_NT_RING256_LDSEPI 2     /* 256x256 ping-pong ring, fp32 LDS epilogue (fp32 outputs, unaligned operands) */
 #define STSWIN_VAR_NT_RING256_NOPIPE 3
+#define STSWIN_VAR_NT_RING256_W4 14        /* 256x256 ring, 4 waves of 128x128, register-pipelined main loop (GF_W4R / STSWIN_NT_W4=1) */
 #define STSWIN_VAR_NT_STREAM 4
 #define STSWIN_VAR_NT_DUO 5
 #define STSWIN_VAR_NT_RING256x128_PP 6

@@ -44,6 +44,7 @@ enum {
                             // SQUARES of the same values - the BatchNorm statistics of a convolution output without a pass over it
   GF_NOSTREAM = 1 << 23,  // tuning: 256x256 ring without the persistent streaming variant
   GF_NOREGEPI = 1 << 22,  // tuning: 256x256 ring with the LDS-staged fp32 epilogue instead of the register epilogue
+  GF_W4R = 1 << 30,       // tuning: 256x256 ring with the 4-wave register-pipelined main loop (one wave per SIMD, 128x128 wave tiles)
   GF_WAVES4 = 64,    // tuning: 4 waves of 64x64 per tile instead of the default 8 waves of 64x32 (4 waves/SIMD)
   GF_NODEEP = 1 << 27,    // tuning: the 128x64 few-tiles kernel with its double buffer instead of the 4-stage ring
   GF_DEEP = 1 << 28,      // tuning: 3-stage rings for the 128x128 / 256x64 kernels too (one workgroup per CU)
@@ -442,13 +443,18 @@ DEVI int swz64(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 // BM x BN x 32 tile, 8 waves as WM x WN, NST-stage ring (prefetch distance NST-1), epilogue in EH row slabs.
 //   <256,256,2,4,4>: 128 KB LDS, 1 workgroup / CU (128 FLOP per L2 byte)
 //   <256,128,4,2,3>:  72 KB LDS, 2 workgroups / CU (87 FLOP per L2 byte; the neighbour's main loop hides the epilogue)
-template <int BM, int BN, int WM, int WN, int NST, int MINW, bool PIPE, bool SWAP = false>
+template <int BM, int BN, int WM, int WN, int NST, int MINW, int PIPE, bool SWAP = false>   // PIPE: 0 plain, 1 ping-pong (8 waves), 2 register-pipelined (4 waves)
 __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT p) {
   using T = bf16;
   constexpr int BK = 32, ROWB = 64;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
   constexpr int TM = BM / WM, TN = BN / WN;          // wave tile
-  constexpr int FI = TM / 16, FJ = TN / 16;          // fragments per wave
+  // Fragment geometry.  16x16x32 MFMA (PIPE 0 / 1): fragment (i, j) = rows i*16 + fr, 4 columns j*16 + 4*fq + e per lane (fr = l & 15,
+  // fq = l >> 4).  32x32x16 MFMA (PIPE 2): a 32x32 accumulator tile is FOUR such sub-fragments - rows i*32 + fr, columns j*8 + 4*fq + e
+  // with fr = l & 31, fq = l >> 5 and j = 4 * tile + r / 4 - so the register epilogue below is written once on (FRH, FCW).
+  constexpr bool M32 = PIPE == 2;
+  constexpr int FRH = M32 ? 32 : 16, FCW = M32 ? 8 : 16;   // rows of a fragment, column step between fragments
+  constexpr int FI = TM / FRH, FJ = TN / FCW;         // fragments per wave
   constexpr int NWV = WM * WN, NTHR = NWV * 64;     // waves / threads per workgroup (8 / 512, or 4 / 256)
   constexpr int NIA = BM / 16 / NWV, NIB = BN / 16 / NWV; // LDS-DMA instructions per wave per stage (16 rows each)
   constexpr int PER_STAGE = NIA + NIB;
@@ -517,10 +523,26 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     for (int i = 0; i < NIB; ++i) glds16_buf(p.B, boff[i], Q * (BK * (int)sizeof(T)), Bb + (w * NIB + i) * 1024);
   };
 
-  f32x4 acc[FI][FJ];                                 // zeroed AFTER the prologue copies are requested (below)
+  f32x4 acc[M32 ? 1 : FI][M32 ? 1 : FJ];             // zeroed AFTER the prologue copies are requested (below)
+  f32x16 acc32[M32 ? FI : 1][M32 ? FJ / 4 : 1];      // (PIPE 2: 32x32 tiles)
+  auto accg = [&](int i, int j) __attribute__((always_inline)) -> f32x4 {
+    if constexpr (M32) {
+      const int o = (j & 3) * 4;
+      return (f32x4){acc32[i][j >> 2][o], acc32[i][j >> 2][o + 1], acc32[i][j >> 2][o + 2], acc32[i][j >> 2][o + 3]};
+    } else return acc[i][j];
+  };
+  auto accs = [&](int i, int j, f32x4 v) __attribute__((always_inline)) {
+    if constexpr (M32) {
+      const int o = (j & 3) * 4;
+      acc32[i][j >> 2][o] = v[0]; acc32[i][j >> 2][o + 1] = v[1]; acc32[i][j >> 2][o + 2] = v[2]; acc32[i][j >> 2][o + 3] = v[3];
+    } else acc[i][j] = v;
+  };
 
-  const int fr = l & 15, fq = l >> 4;
+  const int fr = M32 ? (l & 31) : (l & 15), fq = M32 ? (l >> 5) : (l >> 4), fr15 = fr & 15;
+  // LDS fragment reads.  16x16x32: lane (fr, fq) reads 16-byte chunk fq of row fr.  32x32x16: chunk 2*kh + fq of row fr for the k half
+  // kh; with the chunk ^ swz64(row) layout the second half's address is the first one's ^ 32 (rd_off1).
   const int rd_off = fr * ROWB + ((fq ^ swz64(fr)) << 4);
+  const int rd_off1 = rd_off ^ 32;
   const bool dbg_ts = (p.flags & (1 << 19)) != 0;     // DBG: p.colsum is a u64 [blocks][8] timestamp buffer (100 MHz clock)
   auto stamp = [&](int slot) {
     if (dbg_ts && tid == 0) ((unsigned long long*)p.colsum)[(long)blockIdx.x * 8 + slot] = wall_clock64();
@@ -550,7 +572,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
 #pragma unroll
       for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < FJ; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        for (int j = 0; j < FJ; ++j) { const f32x4 q = accg(i, j); t += q[0] + q[1] + q[2] + q[3]; }
       if (t == 123.456f) ((T*)p.C)[tid] = from_f32<T>(t);
       return;
     }
@@ -584,7 +606,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
 #pragma unroll
           for (int j = 0; j < FJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ct[(rbase + i * 16 + 4 * fq + r) * BN + wc * TN + j * 16 + fr] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r) { if constexpr (!M32) ct[(rbase + i * 16 + 4 * fq + r) * BN + wc * TN + j * 16 + fr] = acc[i][j][r]; }
       }
       __syncthreads();
 #pragma unroll
@@ -642,28 +664,28 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     f32x4 bj[FJ];
     if (has_bias) {
 #pragma unroll
-      for (int j = 0; j < FJ; ++j) bj[j] = *(const f32x4*)(p.bias + min(colb + j * 16, p.N - 4));   // columns >= N are never stored
+      for (int j = 0; j < FJ; ++j) bj[j] = *(const f32x4*)(p.bias + min(colb + j * FCW, p.N - 4));   // columns >= N are never stored
     }
     auto pre_act = [&](int i, int j) -> f32x4 {
-      f32x4 v = acc[i][j];
+      f32x4 v = accg(i, j);
       if (has_bias) v += bj[j];
       if (has_scale) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (colb + j * 16 + e < p.scale_cols) v[e] *= p.scale;
+          if (colb + j * FCW + e < p.scale_cols) v[e] *= p.scale;
       }
       return v;
     };
     auto put = [&](int i, int j, f32x4 v) {
-      const int row = wr * TM + i * 16 + fr;
-      const int chunk = (wc * TN + j * 16 + 4 * fq) >> 3;
+      const int row = wr * TM + i * FRH + fr;
+      const int chunk = (wc * TN + j * FCW + 4 * fq) >> 3;
       bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-      *(bf16x4*)(img + row * PITCH + (((chunk ^ fr) & (CPRW - 1)) << 4) + (fq & 1) * 8) = o;
+      *(bf16x4*)(img + row * PITCH + (((chunk ^ fr15) & (CPRW - 1)) << 4) + (fq & 1) * 8) = o;
     };
     auto put_pk = [&](int i, int j, bf16x4 o) {
-      const int row = wr * TM + i * 16 + fr;
-      const int chunk = (wc * TN + j * 16 + 4 * fq) >> 3;
-      *(bf16x4*)(img + row * PITCH + (((chunk ^ fr) & (CPRW - 1)) << 4) + (fq & 1) * 8) = o;
+      const int row = wr * TM + i * FRH + fr;
+      const int chunk = (wc * TN + j * FCW + 4 * fq) >> 3;
+      *(bf16x4*)(img + row * PITCH + (((chunk ^ fr15) & (CPRW - 1)) << 4) + (fq & 1) * 8) = o;
     };
     // fc1 forward (GELU to C, GELU' to C2): one pass computes both from one polynomial, the GELU' tile waits as packed
     // bf16 in the registers the accumulators vacate and goes through the image after C has left
@@ -766,7 +788,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     }
     // one fragment: activation / R operand / ReLU on the accumulators, the result into the bf16 image; its column sums into csj / cs2j
     auto fragment = [&](int i, int j, f32x4& csj, f32x4& cs2j) __attribute__((always_inline)) {
-      const bool row_ok = m0 + wr * TM + i * 16 + fr < p.M;
+      const bool row_ok = m0 + wr * TM + i * FRH + fr < p.M;
       f32x4 v = pre_act(i, j);
       if constexpr (FUSED_C2D) {
         // the two volatile asms pin this fragment between its neighbours: without them the polynomials of all 32
@@ -784,8 +806,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
         v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
       }
       if (has_r) {
-        const bf16x4 rb = *(const bf16x4*)(img + (wr * TM + i * 16 + fr) * PITCH +
-                                           (((((wc * TN + j * 16 + 4 * fq) >> 3) ^ fr) & (CPRW - 1)) << 4) + (fq & 1) * 8);
+        const bf16x4 rb = *(const bf16x4*)(img + (wr * TM + i * FRH + fr) * PITCH +
+                                           (((((wc * TN + j * FCW + 4 * fq) >> 3) ^ fr15) & (CPRW - 1)) << 4) + (fq & 1) * 8);
         const f32x4 r = {(float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]};
         if (do_resid) v += r;
         else if (do_mulr) v *= r;
@@ -815,14 +837,16 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
         if (do_cs) {                                   // fold the 16 rows (fr) of each lane group, then one value per column
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float t = sum16(csj[e]);
-            const int gn = colb + j * 16 + e;
+            float t = sum16(csj[e]);
+            if constexpr (M32) t += __shfl_xor(t, 16);   // 32 rows per fragment: the two 16-lane rows of this column group
+            const int gn = colb + j * FCW + e;
             if (fr == 0 && gn < p.N) {                 // (register epilogue = SWAP kernels only: TM is 128 there)
               if (TM % 128 == 0) cs_emit(p, (m0 + wr * TM) / 128, TM / 128, gn, t);
               else atomicAdd(p.colsum + gn, t);
             }
             if (do_sq) {
-              const float t2 = sum16(cs2j[e]);
+              float t2 = sum16(cs2j[e]);
+              if constexpr (M32) t2 += __shfl_xor(t2, 16);
               if (fr == 0 && gn < p.N && TM % 128 == 0) cs_emit_sq(p, (m0 + wr * TM) / 128, TM / 128, gn, t2);
             }
           }
@@ -866,18 +890,18 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     const int colb = n0 + wc * TN + 4 * fq;
     f32x4 bj[FJ];
 #pragma unroll
-    for (int j = 0; j < FJ; ++j) bj[j] = p.bias ? *(const f32x4*)(p.bias + colb + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FJ; ++j) bj[j] = p.bias ? *(const f32x4*)(p.bias + colb + j * FCW) : (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool qcols = n0 + wc * TN < p.scale_cols;    // (scale_cols is a multiple of the head dim: a wave tile is all-q or not)
     float gm[NG] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < FI; ++i)
 #pragma unroll
       for (int j = 0; j < FJ; ++j) {
-        f32x4 v = acc[i][j] + bj[j];
+        f32x4 v = accg(i, j) + bj[j];
         if (qcols) v *= p.scale;
-        acc[i][j] = v;
+        accs(i, j, v);
         const float m4 = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-        const int g = ngroups == 1 ? 0 : i / 2;        // 16-row fragments 2g, 2g + 1 = rows 32g .. 32g + 31
+        const int g = ngroups == 1 ? 0 : i * FRH / 32; // the fragments of rows 32g .. 32g + 31
         gm[g] = fmaxf(gm[g], m4);
       }
     // (|values| are non-negative: their maximum is order-free, so the wave reduction runs BEFORE the barrier that frees the ring)
@@ -904,12 +928,14 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     for (int i = 0; i < FI; ++i)
 #pragma unroll
       for (int j = 0; j < FJ; ++j) {
-        const float k = inv[ngroups == 1 ? 0 : i / 2];
+        const float k = inv[ngroups == 1 ? 0 : i * FRH / 32];
+        const f32x4 q = accg(i, j);
         int pk = 0;
-        pk = __builtin_amdgcn_cvt_pk_fp8_f32(acc[i][j][0] * k, acc[i][j][1] * k, pk, false);
-        pk = __builtin_amdgcn_cvt_pk_fp8_f32(acc[i][j][2] * k, acc[i][j][3] * k, pk, true);
-        const int row = wr * TM + i * 16 + fr, chunk = wc * (TN / 16) + j;
-        *(int*)(img + row * BN + (((chunk ^ fr) & (BN / 16 - 1)) << 4) + 4 * fq) = pk;
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(q[0] * k, q[1] * k, pk, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(q[2] * k, q[3] * k, pk, true);
+        const int cl = wc * TN + j * FCW + 4 * fq;         // tile column of this lane's 4 values: 16-byte chunk cl >> 4, byte cl & 15
+        const int row = wr * TM + i * FRH + fr, chunk = cl >> 4;
+        *(int*)(img + row * BN + (((chunk ^ fr15) & (BN / 16 - 1)) << 4) + (cl & 15)) = pk;
       }
     if (l == 0 && (wc % cgw) == 0) {
       float* st = (float*)p.C2 + (long)((m0 + wr * TM) / rg) * p.ldc2 + (n0 + wc * TN) / p.f8_cols;
@@ -934,7 +960,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
 #pragma unroll
       for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < FJ; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        for (int j = 0; j < FJ; ++j) { const f32x4 q = accg(i, j); t += q[0] + q[1] + q[2] + q[3]; }
       if (t == 123.456f) ((T*)p.C)[tid] = from_f32<T>(t);
       stamp(6);
       return;
@@ -966,11 +992,20 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   };
   for (int q = 0; q < NST - 1 && q < nt; ++q) issue(q);
   __builtin_amdgcn_sched_barrier(0);                 // first get the copies going, then spend 128 v_mov on the accumulators
+  if constexpr (M32) {
 #pragma unroll
-  for (int i = 0; i < FI; ++i)
+    for (int i = 0; i < FI; ++i)
 #pragma unroll
-    for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if constexpr (!PIPE) {
+      for (int j = 0; j < FJ / 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  if constexpr (PIPE == 0) {
     for (int kt = 0; kt < nt; ++kt) {
       const int newer = min(NST - 2, nt - 1 - kt);     // later tiles that may stay in flight
       if (newer >= 2) wait_vmcnt<2 * PER_STAGE>();
@@ -997,6 +1032,124 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     }
     if constexpr (SWAP) epilogue_reg();
     else epilogue();
+  } else if constexpr (PIPE == 2) {
+    // Register-pipelined main loop, ONE wave per SIMD (4 waves of 128x128: 8x8 fragments, 256 accumulator registers): nothing else
+    // runs on the SIMD, so the wave overlaps its own work - while the 64 MFMAs of stage kt run on fragment set kt & 1, the 16
+    // ds_read_b128 of stage kt+1 fill the other set and the 8 LDS-DMA copies of stage kt+3 are requested, one read per four MFMAs
+    // and one copy per eight (sched_barrier keeps the groups apart).  16 fragment reads per 64 MFMAs (the 8-wave ping-pong
+    // kernel: 12 per 32 - its LDS read traffic is what tools/probes/half_reads.sh priced at 5-8 % of the loop), one barrier per
+    // stage and no second wave row to hand the matrix pipe to.
+    // Ring safety: slot (kt+3) % 4 held stage kt-1, whose fragments every wave read during step kt-2 and consumed in step kt-1,
+    // i.e. before it arrived at the barrier on top of step kt.  Stage kt+1 (read in step kt) was requested in step kt-2: each wave
+    // waits for its own copies of it (one newer stage may stay in flight) before that barrier.
+    static_assert(NST == 4 && SWAP && NWV == 4 && FI == 4 && FJ == 16 && PER_STAGE == 8, "4-wave register-pipelined variant");
+    constexpr int NT = FJ / 4;                         // 32-column accumulator tiles per wave (4)
+    bf16x8 fa[2][2 * FI], fb[2][2 * NT];               // [set][tile * 2 + k half]
+    int is_koff = 0, is_qoff = 0;
+    auto issue_prep = [&](int q) {
+      const int Q = q + qbase;
+      int sg = 0, kt = Q;
+      if (p.S > 1) { sg = Q / kps; kt = Q - sg * kps; }
+      if (sg != seg) { seg = sg; load_a_bases(sg); }
+      is_koff = kt * (BK * (int)sizeof(T));
+      is_qoff = Q * (BK * (int)sizeof(T));
+    };
+    auto issue_one = [&](int slot, int part) __attribute__((always_inline)) {
+      char* Ab = smem + slot * STAGE;
+      if (part < NIA) glds16_buf(p.A, aoff[part], is_koff, Ab + (w * NIA + part) * 1024);
+      else glds16_buf(p.B, boff[part - NIA], is_qoff, Ab + A_BYTES + (w * NIB + part - NIA) * 1024);
+    };
+    auto read_frag = [&](int set, int slot, int g) __attribute__((always_inline)) {   // g: 0..7 weight tiles x k halves, 8..15 activation tiles
+      const char* Ab = smem + slot * STAGE;
+      const int t = (g & 7) >> 1, off = (g & 1) ? rd_off1 : rd_off;
+      if (g < 2 * NT) fb[set][g] = *(const bf16x8*)(Ab + A_BYTES + (wc * TN + t * 32) * ROWB + off);
+      else fa[set][g - 2 * NT] = *(const bf16x8*)(Ab + (wr * TM + t * 32) * ROWB + off);
+    };
+    auto step = [&](auto setc, auto slotc, int kt, bool do_issue, bool do_read) __attribute__((always_inline)) {
+      constexpr int SET = decltype(setc)::value, SLOT = decltype(slotc)::value;
+      if (do_issue) issue_prep(kt + 3);
+#ifndef STSWIN_W4X_SCHED
+#define STSWIN_W4X_SCHED 0
+#endif
+#if STSWIN_W4X_SCHED == 0
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+#ifndef STSWIN_W4X_NO_READ                             // (diagnosis builds, tools/probes/w4_variants.sh: what does each stream cost?)
+        if (do_read) read_frag(SET ^ 1, (SLOT + 1) % NST, g);
+#endif
+#ifndef STSWIN_W4X_NO_DMA
+        if (do_issue && (g & 1) == 0) issue_one((SLOT + 3) % NST, g >> 1);
+#endif
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                    // k half 0 of all 16 tiles, then k half 1: 16 MFMAs between two uses of a tile
+          const int idx = g * 2 + u, kh = idx / 16, tt = idx % 16, i = tt / NT, j = tt % NT;
+          acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[SET][j * 2 + kh], fa[SET][i * 2 + kh], acc32[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
+      // the two streams apart: SCHED 1 / 2 = fragment reads behind MFMAs 0..15, copies behind MFMAs 16, 18, .. 30 (2: after an explicit
+      // lgkmcnt(0)); SCHED 3 = copies first (MFMAs 0, 2, .. 14), reads behind MFMAs 16..31
+#pragma unroll
+      for (int idx = 0; idx < 32; ++idx) {
+        constexpr bool RF = STSWIN_W4X_SCHED != 3;       // reads in the first half
+        const bool rd_slot = RF ? idx < 16 : idx >= 16, cp_slot = (RF ? idx >= 16 : idx < 16) && (idx & 1) == 0;
+        if (do_read && rd_slot) read_frag(SET ^ 1, (SLOT + 1) % NST, idx & 15);
+#if STSWIN_W4X_SCHED == 2
+        if (idx == 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        if (do_issue && cp_slot) issue_one((SLOT + 3) % NST, (idx & 15) >> 1);
+        const int kh = idx / 16, tt = idx % 16, i = tt / NT, j = tt % NT;
+        acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[SET][j * 2 + kh], fa[SET][i * 2 + kh], acc32[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
+    };
+    using std::integral_constant;
+    stamp(1);
+    // stage 0 landed (the prologue requested min(3, nt) stages): its fragments into set 0
+    if (nt >= 3) wait_vmcnt<2 * PER_STAGE>();
+    else if (nt == 2) wait_vmcnt<PER_STAGE>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    stamp(2);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) read_frag(0, 0, g);
+    auto stage_sync = [&]() __attribute__((always_inline)) {   // this wave's copies of the next stage have landed; so have everybody's behind the barrier
+#ifndef STSWIN_W4X_NO_WAIT
+      wait_vmcnt<PER_STAGE>();
+#endif
+#ifndef STSWIN_W4X_NO_BARRIER
+      __builtin_amdgcn_s_barrier();
+#endif
+    };
+    int kt = 0;
+    for (; kt + 6 < nt; kt += 4) {                       // steady state: every step requests a stage and reads one
+      stage_sync();
+      step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt, true, true);
+      stage_sync();
+      step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1, true, true);
+      stage_sync();
+      step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2, true, true);
+      stage_sync();
+      step(integral_constant<int, 1>{}, integral_constant<int, 3>{}, kt + 3, true, true);
+    }
+    auto tail_step = [&](auto setc, auto slotc, int k) __attribute__((always_inline)) {
+      if (k >= nt) return;
+      if (k + 2 < nt) wait_vmcnt<PER_STAGE>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      step(setc, slotc, k, k + 3 < nt, k + 1 < nt);
+    };
+    // the last 1..6 steps (kt is a multiple of 4 here): runtime tests of what is left to request / read
+    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt);
+    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1);
+    tail_step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2);
+    tail_step(integral_constant<int, 1>{}, integral_constant<int, 3>{}, kt + 3);
+    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt + 4);
+    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 5);
+    if (arow_bad) __builtin_trap();
+    epilogue_reg();
   } else {
     // Ping-pong: waves w and w+4 share a SIMD (wave rows wr = 0 / 1).  With ONE barrier per stage both read their
     // fragments at the same time (matrix pipe idle) and then serialise their MFMAs.  Here every stage has two barriers
@@ -2255,7 +2408,7 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
 #ifndef STSWIN_TUNING
   // the stream / duo / mid / half / nopipe kernels (measured slower everywhere, kept for A/B runs) exist in STSWIN_TUNING builds
   // only: the product library ignores their flags (stswin_tuning_build() tells a caller which library it has)
-  flags &= ~(GF_MID | GF_HALF | GF_DUO | GF_STREAM | GF_NOPIPE);
+  flags &= ~(GF_MID | GF_HALF | GF_DUO | GF_STREAM | GF_NOPIPE | GF_W4R);
 #endif
   const int bk = dtype == 0 ? 64 : 32;
   if (Kseg <= 0 || Kseg % bk || S <= 0) return -1001;
@@ -2355,6 +2508,21 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
       (void)once_np;
       g_last_variant[0] = STSWIN_VAR_NT_RING256_NOPIPE;
       hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, false>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
+      STSWIN_CHECK_LAUNCH();
+      return 0;
+    }
+#endif
+#ifdef STSWIN_TUNING
+    // 4 waves of 128x128 (one per SIMD, 32x32x16 MFMA, 256 accumulator registers), register-pipelined: 16 fragment reads per stage
+    // instead of the 8-wave kernel's 24 - and measured SLOWER (profiles/r04_gemm_w4_experiment.txt): with nobody else on the SIMD
+    // every LDS-DMA piece costs the wave ~57 cycles of issue (8 per stage = 0.26 us of a 0.87 us stage, whatever their placement),
+    // which the ping-pong partner otherwise hides; and half the threads run the same epilogue.
+    static const int env_w4 = getenv("STSWIN_NT_W4") ? atoi(getenv("STSWIN_NT_W4")) : 0;
+    if (regepi && ((flags & GF_W4R) || env_w4)) {
+      static int once_w4 = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 2, 4, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)once_w4;
+      g_last_variant[0] = STSWIN_VAR_NT_RING256_W4;
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 2, 4, 1, 2, true>), dim3((unsigned)big_tiles), dim3(256), 131072, (hipStream_t)stream, p);
       STSWIN_CHECK_LAUNCH();
       return 0;
     }
