@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""4-wave register-pipelined 256x256 ring (GF_W4R) against the 8-wave ping-pong ring: results per epilogue mode, then times."""
+"""4-wave register-pipelined 256x256 ring (GF_W4R) against the 8-wave ping-pong ring: results per epilogue mode, then times.
+Needs a tuning build of the library (STSWIN_TUNING=1 python __graft_entry__.py): the product build ignores the flag (both columns then
+run the 8-wave kernel; the `var` column shows which kernel ran: 1 = 8-wave, 14 = 4-wave)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -17,11 +17,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "contrast":          # the contrastive p
     S, B = 256, 8
     args = types.SimpleNamespace(pixpro_p=1.0, pixpro_momentum=0.99, pixpro_clamp_value=0.0, pixpro_transform_layer=1,
                                  pixpro_ins_loss_weight=0.0, pixpro_pos_ratio=0.7, data="endo18", tag="1", pretrainpth=None,
-                                 num_instances=2235, batch_size=B, epochs=150, start_epoch=1)
+                                 num_instances=2235, batch_size=B, epochs=150, start_epoch=1, pixpro_bank="sample")
     torch.manual_seed(0)
     model = ConsistencyLoss(args, input_resolution=(S // 8, S // 8)).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.SGD(params, 0.05, momentum=0.9, weight_decay=1e-5)
+    from stswincl_amd.optim import make_contrast_optimizer
+    opt, _ = make_contrast_optimizer(params, batch_size=B)      # LARS over SGD-momentum, as bench.py's secondary workload
     ims = [torch.randn(B, 4, 3, S, S, device=dev) for _ in range(6)]
     masks = [torch.randint(0, 12, (B, 1, S, S), device=dev).float() for _ in range(6)]
 
