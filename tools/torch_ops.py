@@ -65,17 +65,13 @@ for ev in prof.events():
     dt = getattr(ev, "self_device_time_total", 0) or getattr(ev, "self_cuda_time_total", 0)
     if dt <= 0:
         continue
-    frame = "?"
-    for fr in (ev.stack or []):
-        if "stswincl_amd/" in fr and "hip.py" not in fr:
-            frame = fr.split("stswincl_amd/")[-1][:70]
-            break
-    if frame == "?" and ev.stack:
-        frame = ev.stack[0][-70:]
+    # innermost-first stack: the first two repo frames (a custom autograd Function's forward / backward + its caller)
+    fr2 = [fr.split("stswincl_amd/")[-1][:60] for fr in (ev.stack or []) if "stswincl_amd/" in fr and "hip.py" not in fr][:2]
+    frame = " <- ".join(fr2) if fr2 else (ev.stack[0][-70:] if ev.stack else "?")
     k = (ev.name, frame)
     agg[k][0] += 1
     agg[k][1] += dt
 tot = sum(v[1] for v in agg.values())
 print(f"aten device time: {tot / NSTEP / 1e3:.3f} ms/step")
-for (name, frame), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
-    print(f"{t / NSTEP / 1e3:8.3f} ms/step {c // NSTEP:4d}x  {name:28s} {frame}")
+for (name, frame), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
+    print(f"{t / NSTEP / 1e3:8.3f} ms/step {c // NSTEP:4d}x  {name:24s} {frame}")
