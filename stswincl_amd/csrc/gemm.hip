@@ -44,6 +44,7 @@ enum {
                             // SQUARES of the same values - the BatchNorm statistics of a convolution output without a pass over it
   GF_NOSTREAM = 1 << 23,  // tuning: 256x256 ring without the persistent streaming variant
   GF_NOREGEPI = 1 << 22,  // tuning: 256x256 ring with the LDS-staged fp32 epilogue instead of the register epilogue
+  GF_M32PP = (int)(1u << 31),   // tuning: the 8-wave ping-pong 256x256 ring on 32x32x16 MFMA tiles
   GF_W4R = 1 << 30,       // tuning: 256x256 ring with the 4-wave register-pipelined main loop (one wave per SIMD, 128x128 wave tiles)
   GF_WAVES4 = 64,    // tuning: 4 waves of 64x64 per tile instead of the default 8 waves of 64x32 (4 waves/SIMD)
   GF_NODEEP = 1 << 27,    // tuning: the 128x64 few-tiles kernel with its double buffer instead of the 4-stage ring
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   // Fragment geometry.  16x16x32 MFMA (PIPE 0 / 1): fragment (i, j) = rows i*16 + fr, 4 columns j*16 + 4*fq + e per lane (fr = l & 15,
   // fq = l >> 4).  32x32x16 MFMA (PIPE 2): a 32x32 accumulator tile is FOUR such sub-fragments - rows i*32 + fr, columns j*8 + 4*fq + e
   // with fr = l & 31, fq = l >> 5 and j = 4 * tile + r / 4 - so the register epilogue below is written once on (FRH, FCW).
-  constexpr bool M32 = PIPE == 2;
+  constexpr bool M32 = PIPE >= 2;                     // PIPE 3: the 8-wave ping-pong schedule on 32x32x16 tiles (tuning)
   constexpr int FRH = M32 ? 32 : 16, FCW = M32 ? 8 : 16;   // rows of a fragment, column step between fragments
   constexpr int FI = TM / FRH, FJ = TN / FCW;         // fragments per wave
   constexpr int NWV = WM * WN, NTHR = NWV * 64;     // waves / threads per workgroup (8 / 512, or 4 / 256)
@@ -1159,10 +1160,17 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     // rows may request tile kt+3 into that slot.
     static_assert(NST >= 4 && WM == 2, "ping-pong variant: 4-stage ring, two wave rows");
     const bool lag = (wr == 1);                        // wave-uniform
-    bf16x8 a[FI], b[FJ];
+    constexpr int NA = M32 ? 2 * FI : FI, NB = M32 ? FJ / 2 : FJ;   // fragment registers (32x32x16: [tile * 2 + k half])
+    bf16x8 a[NA], b[NB];
     auto read_frags = [&](int q) {
       const char* Ab = smem + (q % NST) * STAGE;
       const char* Bb = Ab + A_BYTES;
+      if constexpr (M32) {
+#pragma unroll
+        for (int g = 0; g < NB; ++g) b[g] = *(const bf16x8*)(Bb + (wc * TN + (g >> 1) * 32) * ROWB + ((g & 1) ? rd_off1 : rd_off));
+#pragma unroll
+        for (int g = 0; g < NA; ++g) a[g] = *(const bf16x8*)(Ab + (wr * TM + (g >> 1) * 32) * ROWB + ((g & 1) ? rd_off1 : rd_off));
+      } else {
 #ifdef STSWIN_DEBUG_HALF_READS                         // diagnosis build (tools/probes/half_reads.sh): HALF the fragment reads, the other fragments
 #pragma unroll                                         // are copies (wrong results, same MFMA stream on data) - what do the LDS reads cost in clock?
       for (int j = 0; j < FJ; j += 2) { b[j] = *(const bf16x8*)(Bb + (wc * TN + j * 16) * ROWB + rd_off); b[j + 1] = b[j]; }
@@ -1174,9 +1182,20 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
 #pragma unroll
       for (int i = 0; i < FI; ++i) a[i] = *(const bf16x8*)(Ab + (wr * TM + i * 16) * ROWB + rd_off);
 #endif
+      }
     };
     auto mma_all = [&]() {
       __builtin_amdgcn_s_setprio(1);
+      if constexpr (M32) {
+        static_assert(!M32 || SWAP, "32x32x16 tiles: register epilogue only");
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+          for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ / 4; ++j)
+              acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j * 2 + kh], a[i * 2 + kh], acc32[i][j], 0, 0, 0);
+      } else {
 #pragma unroll
       for (int i = 0; i < FI; ++i)
 #pragma unroll
@@ -1186,6 +1205,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
           if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
           else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+      }
       __builtin_amdgcn_s_setprio(0);
     };
     // Both rows run the SAME loop body {barrier; request + read tile kt; barrier; MFMAs of tile kt}; the lag row enters
@@ -2408,7 +2428,7 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
 #ifndef STSWIN_TUNING
   // the stream / duo / mid / half / nopipe kernels (measured slower everywhere, kept for A/B runs) exist in STSWIN_TUNING builds
   // only: the product library ignores their flags (stswin_tuning_build() tells a caller which library it has)
-  flags &= ~(GF_MID | GF_HALF | GF_DUO | GF_STREAM | GF_NOPIPE | GF_W4R);
+  flags &= ~(GF_MID | GF_HALF | GF_DUO | GF_STREAM | GF_NOPIPE | GF_W4R | GF_M32PP);
 #endif
   const int bk = dtype == 0 ? 64 : 32;
   if (Kseg <= 0 || Kseg % bk || S <= 0) return -1001;
@@ -2518,6 +2538,14 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     // every LDS-DMA piece costs the wave ~57 cycles of issue (8 per stage = 0.26 us of a 0.87 us stage, whatever their placement),
     // which the ping-pong partner otherwise hides; and half the threads run the same epilogue.
     static const int env_w4 = getenv("STSWIN_NT_W4") ? atoi(getenv("STSWIN_NT_W4")) : 0;
+    if (regepi && (env_w4 == 2 || (flags & GF_M32PP))) {   // the 8-wave ping-pong schedule on 32x32x16 MFMA tiles (same wave tile, same LDS traffic)
+      static int once_m32 = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)once_m32;
+      g_last_variant[0] = STSWIN_VAR_NT_RING256_W4 + 1;
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, 3, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
+      STSWIN_CHECK_LAUNCH();
+      return 0;
+    }
     if (regepi && ((flags & GF_W4R) || env_w4)) {
       static int once_w4 = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 2, 4, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       (void)once_w4;

@@ -26,6 +26,7 @@ GF_DUO = 1 << 24
 GF_STREAM = 1 << 25
 GF_NONARROW = 1 << 26
 GF_TAPSKIP = 1 << 29
+GF_M32PP = -(1 << 31)        # tuning builds: the 8-wave ping-pong ring on 32x32x16 MFMA tiles (bit 31 of the int flags word)
 GF_W4R = 1 << 30            # 256x256 ring: 4 waves of 128x128, register-pipelined main loop (32x32x16 MFMA)
 GF_NODEEP, GF_DEEP = 1 << 27, 1 << 28        # tuning: prefetch depth of the 128x64 / 128x128 / 256x64 kernels
 TN_OVERWRITE = 1 << 27
