@@ -428,3 +428,49 @@ def test_split_k_gemm_nt_unaligned_out_slice_falls_back_or_runs_correctly(col0, 
             @ b.double()[:, s_ * Kseg:(s_ + 1) * Kseg].t()
     assert float((out.double() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) * 1.01 + 1e-6
     assert bool((buf[:, :col0] == 7.0).all()) and bool((buf[:, col0 + N:] == 7.0).all())
+
+
+@pytest.mark.parametrize("mk,ni,nj,mode,ow", [(65536, 512, 2048, "plain", True), (16384, 1024, 1024, "plain", False), (65536, 520, 1000, "plain", True),
+                                              (65536, 512, 512, "at_rows", True), (65536, 1536, 512, "bt_rows", True),
+                                              (65536, 256, 2304, "taps", True), (65536, 512, 4608, "taps_tapminor", True)])
+def test_gemm_tn_fused_split_k_combine_equals_the_separate_reduce(mk, ni, nj, mode, ow, monkeypatch):
+    """The split-K combine inside the weight-gradient GEMM launch (gemm_tn_ring_kernel<MODE, true>: arrival / departure counters, partials handed
+    over through write-through stores) gives bit for bit what the separate tn_reduce pass gives (STSWIN_TN_FUSED=0, read per call): plain,
+    gathered A rows, gathered B rows, per-tap maps (convolution weight gradients, also with the tap-minor output order), ragged tile edges,
+    overwrite and accumulate - and again on the second launch (the counters re-arm themselves) with another shape in between."""
+    torch.manual_seed(mk + ni)
+    dev = "cuda"
+    rows = mk
+    at = torch.randn(rows, ni, device=dev).bfloat16()
+    kw = {}
+    if mode in ("taps", "taps_tapminor"):
+        S, bseg = 9, nj // 9
+        bt = (torch.randn(rows, bseg, device=dev) / 8).bfloat16()
+        kw = {"bt_rows": torch.randint(-1, rows, (S, mk), device=dev, dtype=torch.int32), "bseg": bseg, "tapminor": mode == "taps_tapminor"}
+    else:
+        bt = (torch.randn(rows, nj, device=dev) / 8).bfloat16()
+        if mode == "at_rows":
+            kw = {"at_rows": torch.randperm(rows, device=dev).to(torch.int32)}
+        elif mode == "bt_rows":
+            kw = {"bt_rows": torch.randperm(rows, device=dev).to(torch.int32)}
+
+    def run(fused):
+        monkeypatch.setenv("STSWIN_TN_FUSED", "1" if fused else "0")
+        out = torch.empty(ni, nj, device=dev) if ow else torch.full((ni, nj), 0.5, device=dev)
+        hip.gemm_tn(at, bt, out, Mk=mk, overwrite=ow, **kw)
+        v = hip.load().stswin_last_variant(1)
+        return out, bool(v & hip.VAR_TN_FUSED), hip.last_tn_tapminor() if mode == "taps_tapminor" else None
+
+    a, fa, ta = run(True)
+    b, fb, tb = run(False)
+    assert fa and not fb, "the fused combine did not run where the training step relies on it"
+    assert ta == tb
+    assert torch.equal(a, b)
+    other = torch.empty(512, 512, device=dev)          # another tile geometry between two launches of this one
+    hip.gemm_tn(at[:, :512].contiguous() if ni >= 512 else at, at[:, :512].contiguous() if ni >= 512 else at, other[:min(ni, 512), :min(ni, 512)].contiguous(), Mk=mk,
+                overwrite=True)
+    a2, fa2, _ = run(True)
+    assert fa2 and torch.equal(a2, a)
+    if mode == "plain":
+        ref = at.float().t() @ bt.float() + (0.0 if ow else 0.5)
+        assert float((a - ref).abs().max()) < 1e-2 * float(ref.abs().max())
