@@ -152,7 +152,8 @@ int stswin_cs_reduce(const float* partials, int M, int N, float* out, void* stre
  * uninitialised; saves the caller's zero fill); bits 28-30 are tuning overrides (forbid / force the 256x256 ring kernel,
  * 4-wave 128x128 variant) used by tools/tn_sweep.py; the low bits are the split count, 0 = automatic. */
 #define STSWIN_TN_OVERWRITE (1 << 27)
-#define STSWIN_TN_NO_COMBINE (1 << 26)   /* gemm_nt for few output tiles and a long K (ASPP.py:13-20,37-40: dilated 3x3 convolutions on 32x32 maps; M = 4096, N = 512,
+#define STSWIN_TN_NO_COMBINE (1 << 26)   /* with a workspace: leave the partials there; the caller runs stswin_tn_combine */
+/* gemm_nt for few output tiles and a long K (ASPP.py:13-20,37-40: dilated 3x3 convolutions on 32x32 maps; M = 4096, N = 512,
  * K = 9 x 1024): the 256x256 ring kernel over tiles x K-splits with fp32 partial slabs in `workspace`, then a fixed-order combine
  * (+ bias, ReLU) into C (bf16, pitch ldc).  bf16 only, plain epilogue only.  stswin_gemm_nt_splitk_scratch returns the floats of
  * workspace needed, or 0 when the shape is not a candidate (<= 32 tiles of 256x256, >= 64 stages of 32: call stswin_gemm_nt).
@@ -160,7 +161,13 @@ int stswin_cs_reduce(const float* partials, int M, int N, float* out, void* stre
 long stswin_gemm_nt_splitk_scratch(int M, int N, int Kseg, int S);
 int stswin_gemm_nt_splitk(const void* A, long lda, const int* a_rows, const void* B, long ldb, void* C, long ldc, const float* bias, int M, int N,
                           int Kseg, int S, int relu, float* workspace, long workspace_floats, void* stream);
-/* with a workspace: leave the partials there; the caller runs stswin_tn_combine */
+/* Fused split-K combine (the default where it applies; stswin_last_variant(1) then carries STSWIN_VAR_TN_FUSED): with bf16 operands, a
+ * workspace, the 256x256 ring kernel and a grid of at most one workgroup per compute unit, the partial tiles are combined INSIDE the
+ * launch - every workgroup of a tile signals an arrival counter, waits for the tile's other splits and adds its share of the rows in
+ * split order (bit for bit the separate pass's result; tests/test_hip_gemm.py).  The wait relies on the whole grid being resident, which
+ * holds for launches of ONE stream (kernels of a stream run one after the other); weight-gradient GEMMs issued concurrently from
+ * several streams of one device should set STSWIN_TN_FUSED=0 (environment, read per call: the separate tn_reduce pass).  The poll is
+ * bounded: a workgroup that never sees its tile complete traps (the launch fails) instead of hanging the device. */
 int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, const void* Bt, long ldb, const int* bt_rows,
                    float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg,
                    float* workspace /* optional caller-owned scratch: split-K partials are stored there and combined by a
