@@ -188,6 +188,8 @@ class Ctx:
                 "rccl_ranks": self.ranks_seen,
                 "comm_dtype": (str(reducer.comm_dtype).replace("torch.", "") if (reducer is not None and reducer.comm_dtype is not None) else "float32"),
                 "allreduce_bytes_per_step_per_rank": reducer.bytes_per_step() if reducer is not None else 0,
+                # (an overlapped reducer switches the weight-gradient GEMMs to the separate split-K combine pass: stswincl_amd/dp.py)
+                "tn_split_k_combine": "separate pass" if os.environ.get("STSWIN_TN_FUSED") == "0" else "fused into the GEMM launch",
                 "shared_gpu_functional_test": self.share}
 
 

@@ -11,6 +11,7 @@ they overlap the rest of backward.
 from __future__ import annotations
 
 import contextlib
+import os
 import weakref
 from typing import Iterable, List, Optional
 
@@ -92,6 +93,14 @@ class GradBucketReducer:
         if cur:
             self.buckets.append(cur)
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        # While an all-reduce runs on the comm stream its RCCL kernel holds compute units, so a 256-workgroup GEMM launched on the
+        # main stream is not resident all at once.  The weight-gradient GEMM with the fused split-K combine (stswin_gemm_tn, a
+        # workgroup waits for the other splits of its tile) would then sit out the collective; with the separate combine pass the
+        # late workgroups just run a second round.  Overlapped reducer => separate pass, unless the caller chose explicitly.
+        self._set_tn_env = False
+        if self.world > 1 and overlap and "STSWIN_TN_FUSED" not in os.environ:
+            os.environ["STSWIN_TN_FUSED"] = "0"
+            self._set_tn_env = True
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         # persistent flat buffers (parameter dtype) + per-parameter views; 64-byte aligned slices so that vector kernels can
@@ -137,6 +146,9 @@ class GradBucketReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self._set_tn_env:
+            os.environ.pop("STSWIN_TN_FUSED", None)
+            self._set_tn_env = False
         for p in self.params:
             ent = getattr(p, "_stswin_grad_dest", None)
             if ent is not None and ent[0]() in (self, None):

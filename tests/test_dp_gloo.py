@@ -32,6 +32,8 @@ def _worker(rank, world, port, overlap, q):
         params = list(model.parameters()) + list(frozen.parameters())
         red = GradBucketReducer(params, bucket_mb=0.0005, overlap=overlap)  # tiny buckets -> several of them
         assert len(red.buckets) >= 3, len(red.buckets)
+        # an overlapped reducer of a world > 1 switches the weight-gradient GEMMs to the separate split-K combine pass (dp.py)
+        assert (os.environ.get("STSWIN_TN_FUSED") == "0") == overlap
         data = torch.arange(8 * 16, dtype=torch.float32).reshape(8, 16) / 100.0
         mine = shard_indices(8, rank, world)
         for step in range(2):                      # two steps: hooks / bucket state must reset
@@ -48,6 +50,8 @@ def _worker(rank, world, port, overlap, q):
         tot.backward()
         gr = torch.cat([p.grad.reshape(-1) for p in ref_model.parameters()])
         emb = all_gather_embeddings(torch.full((3, 2), float(rank)))
+        red.close()
+        assert "STSWIN_TN_FUSED" not in os.environ           # (restored: the reducer had set it, not the caller)
         q.put((rank, float((g - gr).abs().max()), emb.shape, emb[:, 0].tolist(), mine))
     finally:
         dist.destroy_process_group()
