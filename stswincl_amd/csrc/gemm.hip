@@ -545,8 +545,15 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   const int rd_off = fr * ROWB + ((fq ^ swz64(fr)) << 4);
   const int rd_off1 = rd_off ^ 32;
   const bool dbg_ts = (p.flags & (1 << 19)) != 0;     // DBG: p.colsum is a u64 [blocks][8] timestamp buffer (100 MHz clock)
+  // (slot 7: shader-clock cycles between stamps 2 and 3 = the main loop; with the 100 MHz stamps that is the clock the CU really
+  //  ran the loop at - tools/probes/gemm_clock.py)
+  unsigned long long dbg_c0 = 0;
   auto stamp = [&](int slot) {
-    if (dbg_ts && tid == 0) ((unsigned long long*)p.colsum)[(long)blockIdx.x * 8 + slot] = wall_clock64();
+    if (dbg_ts && tid == 0) {
+      ((unsigned long long*)p.colsum)[(long)blockIdx.x * 8 + slot] = wall_clock64();
+      if (slot == 2) dbg_c0 = clock64();
+      if (slot == 3) ((unsigned long long*)p.colsum)[(long)blockIdx.x * 8 + 7] = clock64() - dbg_c0;
+    }
   };
   // R tile by LDS-DMA, one 64-row block (= one ring stage buffer of the image layout) at a time; see the main loop's tail
   constexpr bool R_EARLY_OK = SWAP && BM == 256 && BN == 256 && NST == 4 && PER_STAGE == 4 && NTHR == 512;
@@ -991,7 +998,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
 #endif
     }
   };
-  for (int q = 0; q < NST - 1 && q < nt; ++q) issue(q);
+  if constexpr (PIPE != 4) {                          // (PIPE 4 stages through registers: its own prologue)
+    for (int q = 0; q < NST - 1 && q < nt; ++q) issue(q);
+  }
   __builtin_amdgcn_sched_barrier(0);                 // first get the copies going, then spend 128 v_mov on the accumulators
   if constexpr (M32) {
 #pragma unroll
@@ -1143,6 +1152,103 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
       step(setc, slotc, k, k + 3 < nt, k + 1 < nt);
     };
     // the last 1..6 steps (kt is a multiple of 4 here): runtime tests of what is left to request / read
+    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt);
+    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1);
+    tail_step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2);
+    tail_step(integral_constant<int, 1>{}, integral_constant<int, 3>{}, kt + 3);
+    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt + 4);
+    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 5);
+    if (arow_bad) __builtin_trap();
+    epilogue_reg();
+  } else if constexpr (PIPE == 4) {
+    // The 4-wave kernel once more, register-STAGED: a stage travels global -> VGPR (buffer_load_dwordx4, requested in step kt for
+    // stage kt+3) -> LDS (ds_write_b128 in step kt+1, the same linear piece layout the LDS-DMA copies produce) -> fragments (read in
+    // step kt+2) -> MFMAs (step kt+3).  No LDS-DMA piece (each holds a lone wave ~57 cycles, profiles/r04_gemm_w4_experiment.txt);
+    // two register sets of 8 x 16 bytes per lane carry the stages in flight.  hipcc tracks the loads itself (no counted vmcnt waits).
+    static_assert(NST == 4 && SWAP && NWV == 4 && FI == 4 && FJ == 16 && PER_STAGE == 8, "4-wave register-staged variant");
+    constexpr int NT = FJ / 4;
+    typedef int v4i32r __attribute__((ext_vector_type(4)));
+    bf16x8 fa[2][2 * FI], fb[2][2 * NT];
+    v4i32r rs[2][PER_STAGE];
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, (short)0, (int)0xFFFFFFFE, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, (short)0, (int)0xFFFFFFFE, 0x00020000);
+    int is_koff = 0, is_qoff = 0;
+    auto issue_prep = [&](int q) {
+      const int Q = q + qbase;
+      int sg = 0, kt = Q;
+      if (p.S > 1) { sg = Q / kps; kt = Q - sg * kps; }
+      if (sg != seg) { seg = sg; load_a_bases(sg); }
+      is_koff = kt * (BK * (int)sizeof(T));
+      is_qoff = Q * (BK * (int)sizeof(T));
+    };
+    auto load_one = [&](int set, int part) __attribute__((always_inline)) {
+      if (part < NIA) rs[set][part] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)aoff[part], is_koff, 0);
+      else rs[set][part] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)boff[part - NIA], is_qoff, 0);
+    };
+    auto write_one = [&](int set, int slot, int part) __attribute__((always_inline)) {
+      char* Ab = smem + slot * STAGE;
+      char* dst = (part < NIA ? Ab + (w * NIA + part) * 1024 : Ab + A_BYTES + (w * NIB + part - NIA) * 1024) + l * 16;
+      *(v4i32r*)dst = rs[set][part];
+    };
+    auto read_frag = [&](int set, int slot, int g) __attribute__((always_inline)) {
+      const char* Ab = smem + slot * STAGE;
+      const int t = (g & 7) >> 1, off = (g & 1) ? rd_off1 : rd_off;
+      if (g < 2 * NT) fb[set][g] = *(const bf16x8*)(Ab + A_BYTES + (wc * TN + t * 32) * ROWB + off);
+      else fa[set][g - 2 * NT] = *(const bf16x8*)(Ab + (wr * TM + t * 32) * ROWB + off);
+    };
+    auto step = [&](auto setc, auto slotc, int kt, bool do_load, bool do_write, bool do_read) __attribute__((always_inline)) {
+      constexpr int SET = decltype(setc)::value, SLOT = decltype(slotc)::value;
+      if (do_load) issue_prep(kt + 3);
+#pragma unroll
+      for (int idx = 0; idx < 32; ++idx) {
+        if (do_read && idx < 16) read_frag(SET ^ 1, (SLOT + 1) % NST, idx);                       // stage kt+1 -> the other fragment set
+        if (do_load && idx >= 16 && (idx & 1) == 0) load_one(SET, (idx - 16) >> 1);              // stage kt+3 -> this step's register set
+        if (do_write && idx >= 16 && (idx & 1) == 1) write_one(SET ^ 1, (SLOT + 2) % NST, (idx - 16) >> 1);   // stage kt+2 (requested a step ago)
+        const int kh = idx / 16, tt = idx % 16, i = tt / NT, j = tt % NT;
+        acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[SET][j * 2 + kh], fa[SET][i * 2 + kh], acc32[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    using std::integral_constant;
+    auto stage_sync = [&]() __attribute__((always_inline)) {   // this wave's LDS writes (and reads) are done; behind the barrier so are everybody's
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    stamp(1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (q < nt) {
+        issue_prep(q);
+#pragma unroll
+        for (int part = 0; part < PER_STAGE; ++part) load_one(0, part);
+#pragma unroll
+        for (int part = 0; part < PER_STAGE; ++part) write_one(0, q, part);
+      }
+    if (2 < nt) {
+      issue_prep(2);
+#pragma unroll
+      for (int part = 0; part < PER_STAGE; ++part) load_one(1, part);
+    }
+    stage_sync();
+    stamp(2);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) read_frag(0, 0, g);
+    int kt = 0;
+    for (; kt + 6 < nt; kt += 4) {
+      stage_sync();
+      step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt, true, true, true);
+      stage_sync();
+      step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1, true, true, true);
+      stage_sync();
+      step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2, true, true, true);
+      stage_sync();
+      step(integral_constant<int, 1>{}, integral_constant<int, 3>{}, kt + 3, true, true, true);
+    }
+    auto tail_step = [&](auto setc, auto slotc, int k) __attribute__((always_inline)) {
+      if (k >= nt) return;
+      stage_sync();
+      step(setc, slotc, k, k + 3 < nt, k + 2 < nt, k + 1 < nt);
+    };
     tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt);
     tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1);
     tail_step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2);
@@ -2538,6 +2644,14 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     // every LDS-DMA piece costs the wave ~57 cycles of issue (8 per stage = 0.26 us of a 0.87 us stage, whatever their placement),
     // which the ping-pong partner otherwise hides; and half the threads run the same epilogue.
     static const int env_w4 = getenv("STSWIN_NT_W4") ? atoi(getenv("STSWIN_NT_W4")) : 0;
+    if (regepi && (env_w4 == 3 || ((flags & GF_M32PP) && (flags & GF_W4R)))) {   // 4 waves, register-staged (no LDS-DMA)
+      static int once_rs = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 2, 4, 1, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)once_rs;
+      g_last_variant[0] = STSWIN_VAR_NT_RING256_W4 + 2;
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 2, 4, 1, 4, true>), dim3((unsigned)big_tiles), dim3(256), 131072, (hipStream_t)stream, p);
+      STSWIN_CHECK_LAUNCH();
+      return 0;
+    }
     if (regepi && (env_w4 == 2 || (flags & GF_M32PP))) {   // the 8-wave ping-pong schedule on 32x32x16 MFMA tiles (same wave tile, same LDS traffic)
       static int once_m32 = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       (void)once_m32;

@@ -80,7 +80,8 @@ def run(M, N, K, mode, fl, S=1):
 
 
 def main():
-    fl = hip.GF_M32PP if os.environ.get("W4_CHECK") == "m32" else hip.GF_W4R
+    mode_ = os.environ.get("W4_CHECK")
+    fl = hip.GF_M32PP if mode_ == "m32" else (hip.GF_M32PP | hip.GF_W4R) if mode_ == "rs" else hip.GF_W4R
     for mode in ("plain", "bias", "bias_scale", "gelu_c2", "gelu", "bias_resid", "resid", "gelu_c2d", "mulr_cs", "dgelu_cs", "cs", "stats",
                  "bias_stats", "relu"):
         run(4096, 512, 512, mode, fl)
