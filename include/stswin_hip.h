@@ -48,7 +48,7 @@ extern "C" {
 #define STSWIN_GF_HALF 2048     /* tuning: force the 256x128 ping-pong ring kernel */
 #define STSWIN_GF_W4R (1 << 30) /* tuning (STSWIN_TUNING builds only): 256x256 ring with 4 waves of 128x128, one per SIMD, register-pipelined
                                  * 32x32x16 main loop - the vendor kernel's structure; same results, measured slower (profiles/r04_gemm_w4_experiment.txt) */
-#define STSWIN_GF_NOHALF 4096   /* tuning: forbid it */
+#define STSWIN_GF_ROT 4096      /* tuning (STSWIN_TUNING builds): 256x256 ring with the rotated ping-pong loop, one barrier per stage */
 #define STSWIN_GF_NOBIG 256     /* tuning: forbid it (default: chosen when >= 256 big tiles fill the chip) */
 #define STSWIN_GF_WAVES4 64     /* tuning: 4 waves of 64x64 per 128x128 tile instead of the default 8 waves of 64x32 */
 

@@ -34,7 +34,7 @@ enum {
   GF_MID = 512,      // tuning: 256x128x32 tile, 3-stage ring, 2 workgroups per CU
   GF_NOPIPE = 1024,  // tuning: 256x256 ring without the ping-pong schedule
   GF_HALF = 2048,    // tuning: force the 256x128 ping-pong ring
-  GF_NOHALF = 4096,  // tuning: forbid it
+  GF_ROT = 4096,     // tuning: the rotated ping-pong loop of the 256x256 ring (one barrier per stage)   [was GF_NOHALF, never tested anywhere]
   GF_NONARROW = 1 << 26,  // tuning: forbid the 256x64 tile for N <= 64
   GF_STREAM = 1 << 25,    // tuning: persistent streaming 256x256 variant (measured no faster: both wave rows idle through each other's epilogue)
   GF_DUO = 1 << 24,       // tuning: 128x256 tiles, 4 waves, two workgroups per CU
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   // Fragment geometry.  16x16x32 MFMA (PIPE 0 / 1): fragment (i, j) = rows i*16 + fr, 4 columns j*16 + 4*fq + e per lane (fr = l & 15,
   // fq = l >> 4).  32x32x16 MFMA (PIPE 2): a 32x32 accumulator tile is FOUR such sub-fragments - rows i*32 + fr, columns j*8 + 4*fq + e
   // with fr = l & 31, fq = l >> 5 and j = 4 * tile + r / 4 - so the register epilogue below is written once on (FRH, FCW).
-  constexpr bool M32 = PIPE >= 2;                     // PIPE 3: the 8-wave ping-pong schedule on 32x32x16 tiles (tuning)
+  constexpr bool M32 = PIPE >= 2 && PIPE <= 4;         // PIPE 3: the 8-wave ping-pong schedule on 32x32x16 tiles (tuning)
   constexpr int FRH = M32 ? 32 : 16, FCW = M32 ? 8 : 16;   // rows of a fragment, column step between fragments
   constexpr int FI = TM / FRH, FJ = TN / FCW;         // fragments per wave
   constexpr int NWV = WM * WN, NTHR = NWV * 64;     // waves / threads per workgroup (8 / 512, or 4 / 256)
@@ -1255,6 +1255,97 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     tail_step(integral_constant<int, 1>{}, integral_constant<int, 3>{}, kt + 3);
     tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt + 4);
     tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 5);
+    if (arow_bad) __builtin_trap();
+    epilogue_reg();
+  } else if constexpr (PIPE == 5) {
+    // Rotated ping-pong, ONE barrier per stage.  The two waves of a SIMD (wave rows 0 / 1) no longer hand the matrix pipe over at a
+    // second barrier in mid-stage (each hand-over leaves it idle for the barrier's release latency: the loop above spends ~1224
+    // cycles per stage against the pipe's 1024, tools/probes/gemm_clock.py): the lag row runs its stage ROTATED - after barrier kt
+    // it first issues the MFMAs of fragment rows [R, FI) of stage kt-1 (operands still in its registers), then requests stage kt+3,
+    // reads the fragments of stage kt and issues rows [0, R) of it - while the lead row requests / reads and then issues all FI rows.
+    // The lag row's first burst covers the lead row's copy requests and reads, the lead row's MFMAs cover the lag row's; which
+    // wave gets the pipe inside an interval is the hardware's choice.  Every accumulator still adds the stages in order: same bits.
+    // Ring safety and data arrival as in the two-barrier loop: stage kt-1 was read by both rows before barrier kt (the request of
+    // stage kt+3 into its slot comes after it), and every wave has waited for its own pieces of stage kt before barrier kt.
+    static_assert(NST >= 4 && WM == 2 && !M32 && SWAP, "rotated ping-pong variant");
+    constexpr int R = 2;
+    const bool lag = (wr == 1);
+    bf16x8 a[FI], b[FJ];
+    auto read_frags = [&](int q) __attribute__((always_inline)) {
+      const char* Ab = smem + (q % NST) * STAGE;
+      const char* Bb = Ab + A_BYTES;
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) b[j] = *(const bf16x8*)(Bb + (wc * TN + j * 16) * ROWB + rd_off);
+#pragma unroll
+      for (int i = 0; i < FI; ++i) a[i] = *(const bf16x8*)(Ab + (wr * TM + i * 16) * ROWB + rd_off);
+    };
+    auto mma_rows = [&](auto i0c, auto i1c) __attribute__((always_inline)) {
+      constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = I0; i < I1; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto wait_tile = [&](int kt) {
+      const int newer = min(NST - 2, nt - 1 - kt);
+      if (newer >= 2) wait_vmcnt<2 * PER_STAGE>();
+      else if (newer == 1) wait_vmcnt<PER_STAGE>();
+      else wait_vmcnt<0>();
+    };
+    using IC0 = std::integral_constant<int, 0>;
+    using ICR = std::integral_constant<int, R>;
+    using ICF = std::integral_constant<int, FI>;
+    stamp(1);
+    wait_tile(0);
+    stamp(2);
+    if (!lag) {
+      int kt = 0;
+      if (p.S == 1)
+        for (; kt + NST - 1 < nt; ++kt) {                // steady state: constant wait, no data-dependent branch
+          __builtin_amdgcn_s_barrier();
+          issue(kt + NST - 1);
+          read_frags(kt);
+          wait_vmcnt<2 * PER_STAGE>();
+          mma_rows(IC0{}, ICF{});
+        }
+      for (; kt < nt; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        if (kt + NST - 1 < nt) issue(kt + NST - 1);
+        read_frags(kt);
+        if (kt + 1 < nt) wait_tile(kt + 1);
+        mma_rows(IC0{}, ICF{});
+      }
+    } else {
+      int kt = 0;
+      if (nt > 0) {                                      // stage 0: nothing of a previous stage to finish
+        __builtin_amdgcn_s_barrier();
+        if (NST - 1 < nt) issue(NST - 1);
+        read_frags(0);
+        if (1 < nt) wait_tile(1);
+        mma_rows(IC0{}, ICR{});
+        kt = 1;
+      }
+      if (p.S == 1)
+        for (; kt + NST - 1 < nt; ++kt) {
+          __builtin_amdgcn_s_barrier();
+          mma_rows(ICR{}, ICF{});
+          issue(kt + NST - 1);
+          read_frags(kt);
+          wait_vmcnt<2 * PER_STAGE>();
+          mma_rows(IC0{}, ICR{});
+        }
+      for (; kt < nt; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        mma_rows(ICR{}, ICF{});
+        if (kt + NST - 1 < nt) issue(kt + NST - 1);
+        read_frags(kt);
+        if (kt + 1 < nt) wait_tile(kt + 1);
+        mma_rows(IC0{}, ICR{});
+      }
+      if (nt > 0) mma_rows(ICR{}, ICF{});
+    }
     if (arow_bad) __builtin_trap();
     epilogue_reg();
   } else {
@@ -2534,7 +2625,7 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
 #ifndef STSWIN_TUNING
   // the stream / duo / mid / half / nopipe kernels (measured slower everywhere, kept for A/B runs) exist in STSWIN_TUNING builds
   // only: the product library ignores their flags (stswin_tuning_build() tells a caller which library it has)
-  flags &= ~(GF_MID | GF_HALF | GF_DUO | GF_STREAM | GF_NOPIPE | GF_W4R | GF_M32PP);
+  flags &= ~(GF_MID | GF_HALF | GF_DUO | GF_STREAM | GF_NOPIPE | GF_W4R | GF_M32PP | GF_ROT);
 #endif
   const int bk = dtype == 0 ? 64 : 32;
   if (Kseg <= 0 || Kseg % bk || S <= 0) return -1001;
@@ -2644,6 +2735,14 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     // every LDS-DMA piece costs the wave ~57 cycles of issue (8 per stage = 0.26 us of a 0.87 us stage, whatever their placement),
     // which the ping-pong partner otherwise hides; and half the threads run the same epilogue.
     static const int env_w4 = getenv("STSWIN_NT_W4") ? atoi(getenv("STSWIN_NT_W4")) : 0;
+    if (regepi && (env_w4 == 5 || (flags & GF_ROT))) {     // rotated ping-pong: one barrier per stage
+      static int once_rot = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)once_rot;
+      g_last_variant[0] = STSWIN_VAR_NT_RING256_W4 + 3;
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, 5, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
+      STSWIN_CHECK_LAUNCH();
+      return 0;
+    }
     if (regepi && (env_w4 == 3 || ((flags & GF_M32PP) && (flags & GF_W4R)))) {   // 4 waves, register-staged (no LDS-DMA)
       static int once_rs = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 2, 4, 1, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       (void)once_rs;

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("STSWIN_HIP_LIB") or os.path.join(_ROOT, "stswincl_amd
 HEADER_PATH = os.path.join(_ROOT, "include", "stswin_hip.h")
 _lib: Optional[ctypes.CDLL] = None
 
-GF_GELU, GF_RESID, GF_MUL_DGELU, GF_OUT_F32, GF_ACCUM, GF_RELU, GF_WAVES4, GF_BIG, GF_NOBIG, GF_MID, GF_NOPIPE, GF_HALF, GF_NOHALF = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
+GF_GELU, GF_RESID, GF_MUL_DGELU, GF_OUT_F32, GF_ACCUM, GF_RELU, GF_WAVES4, GF_BIG, GF_NOBIG, GF_MID, GF_NOPIPE, GF_HALF, GF_ROT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
 GF_MUL_R, GF_C2_DGELU, GF_CS_PARTIAL = 8192, 16384, 32768
 GF_CS_SQ = 1 << 16
 GF_NOREGEPI = 1 << 22
