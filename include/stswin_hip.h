@@ -46,6 +46,8 @@ extern "C" {
 #define STSWIN_GF_MID 512       /* tuning: 256x128x32 tile, 3-stage ring, 2 workgroups per CU (bf16) */
 #define STSWIN_GF_NOPIPE 1024   /* tuning: 256x256 ring kernel without software-pipelined LDS fragment reads */
 #define STSWIN_GF_HALF 2048     /* tuning: force the 256x128 ping-pong ring kernel */
+#define STSWIN_GF_M32PP (1u << 31) /* tuning (STSWIN_TUNING builds): the 8-wave ping-pong ring on 32x32x16 MFMA tiles; with STSWIN_GF_W4R: the 4-wave
+                                  * register-staged variant (global_load + ds_write_b128 instead of LDS-DMA).  All measured slower: profiles/r04_gemm_w4_experiment.txt */
 #define STSWIN_GF_W4R (1 << 30) /* tuning (STSWIN_TUNING builds only): 256x256 ring with 4 waves of 128x128, one per SIMD, register-pipelined
                                  * 32x32x16 main loop - the vendor kernel's structure; same results, measured slower (profiles/r04_gemm_w4_experiment.txt) */
 #define STSWIN_GF_ROT 4096      /* tuning (STSWIN_TUNING builds): 256x256 ring with the rotated ping-pong loop, one barrier per stage */
