@@ -406,6 +406,10 @@ def seg_run(a, ctx):
                                                     f"separate rocprofv3 --pmc passes over this command; a committed number, "
                                                     f"not collected during this run (measured on commit {traffic_commit})" if traffic_src else None,
                            "algorithmic_flops_per_launch": q["work"] / q["sampled"],
+                           # (context for `frac`, measured once, not during this run: under MFMA load on random operands the shader clock
+                           #  of this kernel's main loop is 1.66-1.78 GHz, not 2.4 - profiles/r04_gemm_clock_under_load.txt)
+                           "peak_note": "data-sheet dense bf16 peak at 2.4 GHz; the chip is power-limited under MFMA load (1.66-1.78 GHz "
+                                        "measured inside this kernel's main loop on random operands: 1.73-1.85 PFLOP/s at that clock)",
                            "launches_per_step": q["launches"] / a.steps,
                            "launches_timed": q["sampled"],
                            "timing": f"HIP events on the launch stream around one launch in {profile_stride} inside the timed region; "
