@@ -1257,6 +1257,92 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 5);
     if (arow_bad) __builtin_trap();
     epilogue_reg();
+  } else if constexpr (PIPE == 6) {
+    // 8 waves WITHOUT phases: every wave software-pipelines its own 128x64 tile - fragment sets kt & 1, the 12 ds_read_b128 of stage kt+1
+    // and its 4 LDS-DMA pieces of stage kt+3 spread between the 32 MFMAs of stage kt, ONE barrier per stage - and which of the two waves of
+    // a SIMD issues next is left to the hardware.  The ping-pong loop makes one wave read while the other multiplies and hands over at a
+    // barrier twice per stage; its bare structure costs 1220 cycles per stage, this one 1153 (tools/probes/pp_rows_probe.hip: bursts
+    // of reads or of pieces, or MFMAs under s_setprio, are all worse than the even spread).  48 more fragment registers per lane.
+    // Ring safety / data arrival as in the 4-wave loop above: slot (kt+3) % 4 held stage kt-1, read by every wave during step kt-2;
+    // each wave waits for its own pieces of stage kt+1 (one newer stage may be in flight) before the barrier on top of step kt.
+    static_assert(NST == 4 && SWAP && !M32 && NWV == 8 && PER_STAGE == 4, "8-wave software-pipelined variant");
+    constexpr int NG = FI + FJ;                        // fragment reads per stage (12)
+    bf16x8 fa[2][FI], fb[2][FJ];
+    int is_koff = 0, is_qoff = 0;
+    auto issue_prep = [&](int q) {
+      const int Q = q + qbase;
+      int sg = 0, kt = Q;
+      if (p.S > 1) { sg = Q / kps; kt = Q - sg * kps; }
+      if (sg != seg) { seg = sg; load_a_bases(sg); }
+      is_koff = kt * (BK * (int)sizeof(T));
+      is_qoff = Q * (BK * (int)sizeof(T));
+    };
+    auto issue_one = [&](int slot, int part) __attribute__((always_inline)) {
+      char* Ab = smem + slot * STAGE;
+      if (part < NIA) glds16_buf(p.A, aoff[part], is_koff, Ab + (w * NIA + part) * 1024);
+      else glds16_buf(p.B, boff[part - NIA], is_qoff, Ab + A_BYTES + (w * NIB + part - NIA) * 1024);
+    };
+    auto read_frag = [&](int set, int slot, int g) __attribute__((always_inline)) {
+      const char* Ab = smem + slot * STAGE;
+      if (g < FI) fa[set][g] = *(const bf16x8*)(Ab + (wr * TM + g * 16) * ROWB + rd_off);
+      else fb[set][g - FI] = *(const bf16x8*)(Ab + A_BYTES + (wc * TN + (g - FI) * 16) * ROWB + rd_off);
+    };
+    auto step = [&](auto setc, auto slotc, int kt, bool do_issue, bool do_read) __attribute__((always_inline)) {
+      constexpr int SET = decltype(setc)::value, SLOT = decltype(slotc)::value;
+      if (do_issue) issue_prep(kt + 3);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (do_read) read_frag(SET ^ 1, (SLOT + 1) % NST, g);
+        if (do_issue && g % (NG / PER_STAGE) == 0) issue_one((SLOT + 3) % NST, g / (NG / PER_STAGE));
+#pragma unroll
+        for (int m = g * (FI * FJ) / NG; m < (g + 1) * (FI * FJ) / NG; ++m) {
+          const int i = m / FJ, j = m % FJ;
+          // (as inline assembly with the destination TIED to the accumulator: left to hipcc, with 224 of 256 registers live it picks the
+          //  untied form of the instruction, rotates the accumulators through fresh registers and spills ~100 of them)
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fb[SET][j]), "v"(fa[SET][i]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    using std::integral_constant;
+    auto stage_sync = [&]() __attribute__((always_inline)) {
+      wait_vmcnt<PER_STAGE>();
+      __builtin_amdgcn_s_barrier();
+    };
+    stamp(1);
+    if (nt >= 3) wait_vmcnt<2 * PER_STAGE>();
+    else if (nt == 2) wait_vmcnt<PER_STAGE>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    stamp(2);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) read_frag(0, 0, g);
+    int kt = 0;
+    for (; kt + 6 < nt; kt += 4) {
+      stage_sync();
+      step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt, true, true);
+      stage_sync();
+      step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1, true, true);
+      stage_sync();
+      step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2, true, true);
+      stage_sync();
+      step(integral_constant<int, 1>{}, integral_constant<int, 3>{}, kt + 3, true, true);
+    }
+    auto tail_step = [&](auto setc, auto slotc, int k) __attribute__((always_inline)) {
+      if (k >= nt) return;
+      if (k + 2 < nt) wait_vmcnt<PER_STAGE>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      step(setc, slotc, k, k + 3 < nt, k + 1 < nt);
+    };
+    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt);
+    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1);
+    tail_step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2);
+    tail_step(integral_constant<int, 1>{}, integral_constant<int, 3>{}, kt + 3);
+    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt + 4);
+    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 5);
+    if (arow_bad) __builtin_trap();
+    epilogue_reg();
   } else if constexpr (PIPE == 5) {
     // Rotated ping-pong, ONE barrier per stage.  The two waves of a SIMD (wave rows 0 / 1) no longer hand the matrix pipe over at a
     // second barrier in mid-stage (each hand-over leaves it idle for the barrier's release latency: the loop above spends ~1224
@@ -2735,6 +2821,14 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     // every LDS-DMA piece costs the wave ~57 cycles of issue (8 per stage = 0.26 us of a 0.87 us stage, whatever their placement),
     // which the ping-pong partner otherwise hides; and half the threads run the same epilogue.
     static const int env_w4 = getenv("STSWIN_NT_W4") ? atoi(getenv("STSWIN_NT_W4")) : 0;
+    if (regepi && (env_w4 == 6 || ((flags & GF_ROT) && (flags & GF_W4R)))) {   // 8 waves, software-pipelined, no phases
+      static int once_swp = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)once_swp;
+      g_last_variant[0] = STSWIN_VAR_NT_RING256_W4 + 4;
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, 6, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
+      STSWIN_CHECK_LAUNCH();
+      return 0;
+    }
     if (regepi && (env_w4 == 5 || (flags & GF_ROT))) {     // rotated ping-pong: one barrier per stage
       static int once_rot = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       (void)once_rot;

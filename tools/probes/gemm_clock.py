@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from stswincl_amd import hip
 mode = os.environ.get("W4_CHECK", "")
-extra = {"w4": hip.GF_W4R, "rs": hip.GF_W4R | hip.GF_M32PP, "m32": hip.GF_M32PP, "rot": hip.GF_ROT}.get(mode, 0)
+extra = {"w4": hip.GF_W4R, "rs": hip.GF_W4R | hip.GF_M32PP, "m32": hip.GF_M32PP, "rot": hip.GF_ROT, "swp": hip.GF_ROT | hip.GF_W4R}.get(mode, 0)
 for M, N, K in ((4096, 4096, 4096), (65536, 512, 2048), (65536, 2048, 512)):
     for zero in (False, True):
         A = torch.randn(M, K, device="cuda").bfloat16()

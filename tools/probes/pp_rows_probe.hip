@@ -62,6 +62,94 @@ __global__ __launch_bounds__(512, 2) void probe(const char* src, unsigned long l
   if (tid == 0) { out[blockIdx.x * 2] = t1 - t0; out[blockIdx.x * 2 + 1] = w1 - w0; }
   if (s == 123.456f) out[0] = 0;
 }
+// The same 8 waves WITHOUT phases: every wave software-pipelines its own stage (fragment sets kt & 1: the 12 reads of stage kt+1 and the 4 pieces of
+// stage kt+3 go between the 32 MFMAs of stage kt, one barrier per stage); which of the two waves of a SIMD issues is left to the hardware.
+// V 0: a read in front of every 2-3 MFMAs, a piece every third group.  1: the 12 reads as one burst in front of the MFMAs, pieces spread.
+// 2: as 0 with the pieces as one burst behind the barrier.  3: as 0, MFMAs under s_setprio 1.
+template <int V>
+__global__ __launch_bounds__(512, 2) void probe_swp(const char* src, unsigned long long* out, int nt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 32768, NST = 4, PIECES = 4;
+  const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)(blockIdx.x & 7) * 4194304), (short)0, (int)0x7FFFFFFE, 0x00020000);
+  const unsigned voff = (unsigned)((w * 64 + (l >> 2)) * 8192 + (l & 3) * 16);
+  f32x4 acc[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = (f32x4){0, 0, 0, 0};
+  bf16x8 fr[2][12];
+  auto piece = [&](int q, int i) {
+    char* st = smem + (q % NST) * STAGE + w * (PIECES * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS3 void*)(st + i * 1024), 16, voff + i * 16u * 8192u, (q * 64) & 8191, 0, 0);
+  };
+  for (int q = 0; q < NST - 1; ++q)
+    for (int i = 0; i < PIECES; ++i) piece(q, i);
+  wait_vmcnt<0>();
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 12; ++i) fr[0][i] = *(const bf16x8*)(smem + (l & 15) * 64 + ((l >> 4) << 4) + i * 2048);
+  const unsigned long long t0 = clock64(), w0 = wall_clock64();
+  auto step = [&](auto setc, int kt) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value;
+    wait_vmcnt<PIECES>();
+    __builtin_amdgcn_s_barrier();
+    const char* st = smem + ((kt + 1) % NST) * STAGE + (l & 15) * 64 + ((l >> 4) << 4);
+    if (V == 4) {      // ONE set of A fragments, refreshed in place row by row behind the row's last MFMA; only the 4 B fragments are double-buffered
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[SET][8 + j], fr[0][i], acc[i * 4 + j], 0, 0, 0);
+        fr[0][i] = *(const bf16x8*)(st + i * 2048);
+        if (i < 4) fr[SET ^ 1][8 + i] = *(const bf16x8*)(st + (8 + i) * 2048);
+        if (i % 2 == 0) piece(kt + 3, i / 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
+    if (V == 1) {
+#pragma unroll
+      for (int g = 0; g < 12; ++g) fr[SET ^ 1][g] = *(const bf16x8*)(st + g * 2048);
+    }
+    if (V == 2) {
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) piece(kt + 3, i);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      if (V != 1) fr[SET ^ 1][g] = *(const bf16x8*)(st + g * 2048);
+      if (V != 2 && g % 3 == 0) piece(kt + 3, g / 3);
+      // 32 MFMAs over 12 groups: 3, 3, 2 repeating
+      const int m0 = g * 32 / 12, m1 = (g + 1) * 32 / 12;
+      if (V == 3) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int m = m0; m < m1; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[SET][8 + (m & 3)], fr[SET][m >> 2], acc[m], 0, 0, 0);
+      if (V == 3) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  for (int kt = 0; kt < nt; kt += 2) {
+    step(std::integral_constant<int, 0>{}, kt);
+    step(std::integral_constant<int, 1>{}, kt + 1);
+  }
+  const unsigned long long t1 = clock64(), w1 = wall_clock64();
+  wait_vmcnt<0>();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) s += acc[i][0];
+  if (tid == 0) { out[blockIdx.x * 2] = t1 - t0; out[blockIdx.x * 2 + 1] = w1 - w0; }
+  if (s == 123.456f) out[0] = 0;
+}
+template <int V> static void run_swp(const char* src, unsigned long long* out, const char* name) {
+  hipFuncSetAttribute((const void*)probe_swp<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  const int nt = 256;
+  for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(probe_swp<V>, dim3(256), dim3(512), 131072, 0, src, out, nt);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h(512);
+  hipMemcpy(h.data(), out, 512 * 8, hipMemcpyDeviceToHost);
+  double c = 0, wl = 0;
+  for (int i = 0; i < 256; ++i) { c += (double)h[2 * i]; wl += (double)h[2 * i + 1]; }
+  printf("%-58s %7.1f cycles, %6.1f ns per 32-deep stage (%.0f MHz)\n", name, c / 256 / 256.0, wl / 256 / 256.0 * 10.0, c / wl * 100.0);
+}
 template <int PAT> static void run(const char* src, unsigned long long* out, const char* name) {
   hipFuncSetAttribute((const void*)probe<PAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   const int nt = PAT == 2 ? 128 : 256;
@@ -82,5 +170,11 @@ int main() {
   run<1>(src, out, "stage 32 deep, pieces of 16 rows x 64 B (the kernel's)");
   run<2>(src, out, "stage 64 deep, pieces of 8 rows x 128 B, two-stage ring");
   run<1>(src, out, "stage 32 deep, pieces of 16 rows x 64 B (again)");
+  run_swp<0>(src, out, "no phases: every wave software-pipelined, one barrier");
+  run_swp<1>(src, out, "no phases, the 12 reads as one burst");
+  run_swp<2>(src, out, "no phases, the 4 pieces as one burst");
+  run_swp<3>(src, out, "no phases, MFMAs under s_setprio 1");
+  run_swp<4>(src, out, "no phases, A fragments refreshed in place (one A set)");
+  run_swp<0>(src, out, "no phases (again)");
   return 0;
 }

@@ -81,7 +81,7 @@ def run(M, N, K, mode, fl, S=1):
 
 def main():
     mode_ = os.environ.get("W4_CHECK")
-    fl = {"m32": hip.GF_M32PP, "rs": hip.GF_M32PP | hip.GF_W4R, "rot": hip.GF_ROT}.get(mode_, hip.GF_W4R)
+    fl = {"m32": hip.GF_M32PP, "rs": hip.GF_M32PP | hip.GF_W4R, "rot": hip.GF_ROT, "swp": hip.GF_ROT | hip.GF_W4R}.get(mode_, hip.GF_W4R)
     for mode in ("plain", "bias", "bias_scale", "gelu_c2", "gelu", "bias_resid", "resid", "gelu_c2d", "mulr_cs", "dgelu_cs", "cs", "stats",
                  "bias_stats", "relu"):
         run(4096, 512, 512, mode, fl)
