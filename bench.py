@@ -184,12 +184,15 @@ class Ctx:
         return float(tt.item())
 
     def dist_info(self, reducer):
+        from stswincl_amd import hip as _hip
         return {"backend": ("rccl (torch.distributed 'nccl')" if self.backend == "nccl" else self.backend),
                 "rccl_ranks": self.ranks_seen,
                 "comm_dtype": (str(reducer.comm_dtype).replace("torch.", "") if (reducer is not None and reducer.comm_dtype is not None) else "float32"),
                 "allreduce_bytes_per_step_per_rank": reducer.bytes_per_step() if reducer is not None else 0,
                 # (an overlapped reducer switches the weight-gradient GEMMs to the separate split-K combine pass: stswincl_amd/dp.py)
-                "tn_split_k_combine": "separate pass" if os.environ.get("STSWIN_TN_FUSED") == "0" else "fused into the GEMM launch",
+                "tn_split_k_combine": ("separate pass" if (os.environ.get("STSWIN_TN_FUSED") == "0" or
+                                                           (os.environ.get("STSWIN_TN_FUSED") is None and _hip.tn_fused_holds() > 0))
+                                       else "fused into the GEMM launch"),
                 "shared_gpu_functional_test": self.share}
 
 

@@ -165,11 +165,15 @@ int stswin_gemm_nt_splitk(const void* A, long lda, const int* a_rows, const void
                           int Kseg, int S, int relu, float* workspace, long workspace_floats, void* stream);
 /* Fused split-K combine (the default where it applies; stswin_last_variant(1) then carries STSWIN_VAR_TN_FUSED): with bf16 operands, a
  * workspace, the 256x256 ring kernel and a grid of at most one workgroup per compute unit, the partial tiles are combined INSIDE the
- * launch - every workgroup of a tile signals an arrival counter, waits for the tile's other splits and adds its share of the rows in
- * split order (bit for bit the separate pass's result; tests/test_hip_gemm.py).  The wait relies on the whole grid being resident, which
- * holds for launches of ONE stream (kernels of a stream run one after the other); weight-gradient GEMMs issued concurrently from
- * several streams of one device should set STSWIN_TN_FUSED=0 (environment, read per call: the separate tn_reduce pass).  The poll is
- * bounded: a workgroup that never sees its tile complete traps (the launch fails) instead of hanging the device. */
+ * launch - every workgroup of a tile signals an arrival counter; once the tile's partials are complete its row slices are handed out by
+ * ticket to the workgroups of the tile that are present and added in split order (bit for bit the separate pass's result;
+ * tests/test_hip_gemm.py).  No workgroup depends on another one being resident: an early workgroup polls for a bounded time
+ * (200 us) and then leaves, the last arriver takes whatever slices are left - a second stream, a second process or an RCCL kernel
+ * holding compute units costs time, never correctness, and nothing traps.  Counter regions are per (device, stream).
+ * stswin_tn_fused_hold(+1 / -1 / 0) adds / releases / reads a process-wide hold: while any hold is outstanding the separate
+ * tn_reduce pass is used (GradBucketReducer holds one while its collectives overlap backward); environment STSWIN_TN_FUSED=0 / 1
+ * overrides the holds (read per call). */
+int stswin_tn_fused_hold(int delta);
 int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, const void* Bt, long ldb, const int* bt_rows,
                    float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg,
                    float* workspace /* optional caller-owned scratch: split-K partials are stored there and combined by a

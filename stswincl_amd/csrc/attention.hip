@@ -122,6 +122,35 @@ struct AttnCfg {
   static_assert(NTOK % 32 == 0 && HD % 32 == 0 && (QW == 1 || QW == 2 || QW == 4), "shape");
 };
 
+// ---- buffer-addressed stores / loads: a wave-uniform base (descriptor in SGPRs), ONE per-lane 32-bit byte offset and a scalar byte
+// offset per instruction.  The row-strided output stores of the attention kernels (16 rows per lane and tile) otherwise cost a 64-bit
+// VGPR address pair per row, which hipcc hoists out of the persistent loops and - at the register cap - spills to scratch.
+DEVI const void* uniform_ptr(const void* p) {        // the same pointer, provably wave-uniform (two v_readfirstlane)
+  const unsigned long a = (unsigned long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32));
+  return (const void*)(((unsigned long)hi << 32) | lo);
+}
+DEVI void buf_store_b16(void* base, bf16 v, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)0xFFFFFFFE, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, v), rs, voff, soff, 0);
+}
+typedef int v4i32_t __attribute__((ext_vector_type(4)));
+DEVI void buf_store_b128(void* base, bf16x8 v, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)0xFFFFFFFE, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32_t, v), rs, voff, soff, 0);
+}
+DEVI float buf_load_f32(const void* base, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)0xFFFFFFFE, 0x00020000);
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+DEVI void buf_store_b32(void* base, float v, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)0xFFFFFFFE, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff, soff, 0);
+}
+template <typename T> DEVI void buf_store_elem(void* base, float v, int voff, int soff) {
+  if constexpr (TT<T>::IS_BF16) buf_store_b16(base, (bf16)v, voff, soff);
+  else buf_store_b32(base, v, voff, soff);
+}
 // ---- S^T (+bias, +mask) and softmax for this wave's 32 queries: returns normalised P^T in p[KT] -------------
 // NC: ws*ws when known at compile time (0 = read a.N): with it the compiler sees which table addresses repeat over the
 // T frames of a window (kn = key mod N) and loads each bias value once instead of T times.
@@ -163,12 +192,32 @@ DEVI void scores_softmax(f32x16 (&p)[NTOK / 32], const AttnArgs& a, const char* 
   // + bias + mask (transposed tables: [key n][query n], lanes contiguous in query)
   const int N = NC ? NC : a.N;
   const int qn = (q0 + lr) % N;
-  const int slot = (a.bias_windows & 0xffffff) > 1 ? (a.bias_index ? a.bias_index[widx] : widx) : 0;
+  // (scalar load: the slot index is wave-uniform - it becomes part of a scalar offset below, and a vector load of it would be followed by
+  //  s_waitcnt vmcnt(0))
+  const int slot = (a.bias_windows & 0xffffff) > 1 ? (a.bias_index ? sload(a.bias_index, widx) : widx) : 0;
   const float* bt = a.biasT + ((long)slot * a.heads + head) * N * N + qn;
   const float* mt = a.maskT ? a.maskT + (long)widx * N * N + qn : nullptr;
   // All table values are requested first and consumed afterwards.  (With the optional mask tested per element the loop
   // was load - branch - wait - add, 32 dependent L2 round trips: 11.7 of the backward kernel's 24 us per problem.)
   float tb[Cfg::KT][16];
+  if constexpr (NC != 0 && NC % 8 == 0) {
+    // window size known: key n = (32 kt + crow32(r, 0)) % NC + 4 half (no wrap: NC % 8 == 0), so a table value sits at
+    // lane part (4 half NC + qn) + scalar part (slot base + key row) - buffer loads with ONE lane offset instead of a 64-bit lane
+    // pointer per table (round 5: those pointer pairs were spilled by the kernels at their register cap)
+    const int tvoff = (4 * half * NC + qn) * 4;
+    const int tsoff = (slot * a.heads + head) * NC * NC * 4;
+#pragma unroll
+    for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tb[kt][r] = buf_load_f32(a.biasT, tvoff, tsoff + ((kt * 32 + crow32(r, 0)) % NC) * NC * 4);
+    if (a.maskT) {
+      const int msoff = widx * NC * NC * 4;
+#pragma unroll
+      for (int kt = 0; kt < Cfg::KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tb[kt][r] += buf_load_f32(a.maskT, tvoff, msoff + ((kt * 32 + crow32(r, 0)) % NC) * NC * 4);
+    }
+  } else {
 #pragma unroll
   for (int kt = 0; kt < Cfg::KT; ++kt)
 #pragma unroll
@@ -178,6 +227,7 @@ DEVI void scores_softmax(f32x16 (&p)[NTOK / 32], const AttnArgs& a, const char* 
     for (int kt = 0; kt < Cfg::KT; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) tb[kt][r] += mt[((kt * 32 + crow32(r, half)) % N) * N];
+  }
   }
   float mx = -3.0e38f;
 #pragma unroll
@@ -402,6 +452,9 @@ __global__ __launch_bounds__(512) void attn_qkv_fwd_kernel(AttnQkvArgs q) {
     return q.rmap ? q.rmap[rb + arow] : (int)(rb + arow);
   };
   int srow_next = blockIdx.x < nprob ? map_row(blockIdx.x) : -1;
+  const buf_rsrc_t rsX = make_buf_rsrc(q.X), rsW = make_buf_rsrc(q.W);
+  const int xrow_lim = (int)(0xFFFF0000u / (unsigned)(q.ldx * 2)) - 1;       // token rows a 32-bit byte offset reaches
+  bool xrow_bad = false;                                                     // a gathered row beyond that: trap at the end (fail loudly)
   for (long prob = blockIdx.x; prob < nprob; prob += gridDim.x, ++pcount) {
     const int b_ = (int)(prob / a.heads), head = (int)(prob - (long)b_ * a.heads);
     const long rowbase = (long)b_ * NTOK;
@@ -409,13 +462,17 @@ __global__ __launch_bounds__(512) void attn_qkv_fwd_kernel(AttnQkvArgs q) {
     const int srow = srow_next;
     // (the next problem's map entry is requested now: at its start the first copies no longer wait for a dependent load)
     if (prob + gridDim.x < nprob) srow_next = map_row(prob + gridDim.x);
-    const T* asrc = srow >= 0 ? q.X + (long)srow * q.ldx + apiece * 8 : (const T*)g_stswin_zero;
-    const int astep = srow >= 0 ? 32 : 0;                                  // (padding rows keep reading the zero block)
-    const T* wsrc[3];                                                      // weight copy: pieces tid, tid + 512, tid + 1024 of the chunk
+    // Copies are buffer-addressed (round 5): ONE 32-bit byte offset per lane and copy (token piece + three weight pieces) against two
+    // descriptors in SGPRs, the chunk position as the instruction's scalar offset - four 64-bit pointer pairs less per lane in a kernel
+    // that sits at its 256-register cap (they were part of what it spilled).  Padding rows (map entry -1) get an out-of-range offset:
+    // the copy delivers zeros.
+    const unsigned aoff = (srow >= 0 && srow <= xrow_lim) ? (unsigned)srow * (unsigned)(q.ldx * 2) + apiece * 16 : 0xFFFFFFFFu;
+    xrow_bad |= srow > xrow_lim;
+    unsigned woffs[3];                                                     // weight copy: pieces tid, tid + 512, tid + 1024 of the chunk
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int pc = tid + 512 * j, n = pc >> 2, part = n >> 7, within = n & 127;
-      wsrc[j] = q.W + ((long)part * C + head * HD + within) * q.ldw + (((pc & 3) ^ ((n >> 2) & 3)) << 3);
+      woffs[j] = (unsigned)(part * C + head * HD + within) * (unsigned)(q.ldw * 2) + (((pc & 3) ^ ((n >> 2) & 3)) << 4);
     }
     f32x4 acc[8][3];
 #pragma unroll
@@ -427,9 +484,9 @@ __global__ __launch_bounds__(512) void attn_qkv_fwd_kernel(AttnQkvArgs q) {
     // (1 token piece + 3 weight pieces), chunks are requested 3 ahead, so chunk ks has landed when <= 8 copies are outstanding.
     auto request = [&](int ks) {
       char* st = ring + (ks % NSTG) * STAGE;
-      glds16_raw(asrc + (long)ks * astep, st + w * 1024);
+      glds16_buf_raw(rsX, aoff, (unsigned)(ks * 64), st + w * 1024);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) glds16_raw(wsrc[j] + ks * 32, st + XB + j * 8192 + w * 1024);
+      for (int j = 0; j < 3; ++j) glds16_buf_raw(rsW, woffs[j], (unsigned)(ks * 64), st + XB + j * 8192 + w * 1024);
     };
     // Software pipeline: while the MFMAs of chunk ks run, the fragments of chunk ks + 1 are read from LDS into the other register
     // set (22 KB of fragment reads per wave and chunk take as long as its 24 MFMAs: back to back they halved the rate), and chunk
@@ -516,11 +573,13 @@ __global__ __launch_bounds__(512) void attn_qkv_fwd_kernel(AttnQkvArgs q) {
           for (int dt = 0; dt < Cfg::DT; ++dt)
             o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr_perm<ROWB>(Vt, kt * 32 + 16 * m, dt), o[dt], 0, 0, 0);
         }
-      T* ob = (T*)a.out + (rowbase + q0) * a.ldo + head * HD;
+      // (buffer stores: wave-uniform base = this wave's first output row, per lane (4 half ldo + lr) elements, scalar row offsets)
+      void* ob = (void*)uniform_ptr((T*)a.out + (rowbase + q0) * a.ldo + head * HD);
+      const int ldo_b = (int)a.ldo * 2, vo = (4 * half) * ldo_b + lr * 2;
 #pragma unroll
       for (int dt = 0; dt < Cfg::DT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ob[(long)crow32(r, half) * a.ldo + dt * 32 + lr] = (bf16)o[dt][r];
+        for (int r = 0; r < 16; ++r) buf_store_b16(ob, (bf16)o[dt][r], vo + dt * 64, crow32(r, 0) * ldo_b);
     } else if (q.qkv_out) {
       // the rows the backward will read: 3 tiles x 128 rows x 16 pieces of 16 bytes, 24 per thread of waves 4-7
       const int t4 = tid - 256;
@@ -536,6 +595,7 @@ __global__ __launch_bounds__(512) void attn_qkv_fwd_kernel(AttnQkvArgs q) {
     __syncthreads();                                   // tiles and ring are reused by the next problem
     stamp(6);
   }
+  if (xrow_bad) __builtin_trap();
 }
 
 // ====================================================================================================
@@ -959,9 +1019,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   store_qk_tile<T, NTOK>(St, dp, q0);
   stamp(4);
   __syncthreads();                               // P, dS complete; every wave is done with V
-  T* dqb = (T*)a.out + rowbase * a.ldo + head * HD;
-  T* dkb = dqb + a.C;
-  T* dvb = dqb + 2 * a.C;
+  // dqkv rows of this problem through a buffer descriptor on (dqkv + the problem's first element): wave-uniform base, per lane
+  // (4 half ldo + lr) elements, per store a scalar (row, column tile) offset - no 64-bit address pair per output row (round 5: the 16
+  // hoisted row addresses were what this kernel spilled at its 512-register cap; a problem spans < 2 MB, so 32-bit offsets always reach)
+  void* dqb = (void*)uniform_ptr((T*)a.out + rowbase * a.ldo + head * HD);
+  const int esz = (int)sizeof(T);
+  const int so_k = a.C * esz, so_v = 2 * a.C * esz;
+  const int ldo_b = (int)a.ldo * esz;
   const int k0 = qt * 32;                        // this wave's KEY tile for dV / dK
 
   f32x16 acc[Cfg::DT];
@@ -971,16 +1035,26 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
   };
+  auto out_voff = [&]() -> int {                 // (formed at its use: two lane constants, not kept live across the problem loop)
+    int lv = l;
+    asm volatile("" : "+v"(lv));
+    return (4 * (lv >> 5)) * ldo_b + (lv & 31) * esz;
+  };
   // dQ keeps the untransposed product (registers = query rows): its column sums - the q third of the qkv bias gradient -
   // are then in-lane.  `csacc` carries them across this workgroup's problems.
-  auto store_acc = [&](T* base, int row0, float mul) {
+  // (the scalar row offsets are formed from an opaque copy of the pitch at every store group: as loop invariants of the persistent
+  //  problem loop hipcc kept all 16 x 3 of them in SGPRs, ran out, and spilled SGPRs into VGPR lanes at the VGPR cap)
+  auto store_acc = [&](int sbase, int row0, float mul) {
+    const int vo = out_voff();
+    int ld_s = ldo_b;
+    asm volatile("" : "+s"(ld_s));
 #pragma unroll
     for (int dt = 0; dt < Cfg::DT; ++dt) {
       float csum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const T o = from_f32<T>(acc[dt][r] * mul);
-        if (live) base[(long)(row0 + crow32(r, half)) * a.ldo + dt * 32 + lr] = o;
+        if (live) buf_store_elem<T>(dqb, to_f32<T>(o), vo + dt * 32 * esz, sbase + (row0 + crow32(r, 0)) * ld_s);
         csum += to_f32<T>(o);
       }
       if (live) csacc[dt] += csum;
@@ -988,13 +1062,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   };
   // dV / dK need no column sums: sum_key dK = 0 (rows of dS sum to zero) and sum_key dV = column sums of dO (softmax
   // rows sum to one), which the caller takes from the GEMM that produced dO.
-  auto store_acc_plain = [&](T* base, int row0, float mul = 1.0f) {
+  auto store_acc_plain = [&](int sbase, int row0, float mul = 1.0f) {
     if (!live) return;
+    const int vo = out_voff();
+    int ld_s = ldo_b;
+    asm volatile("" : "+s"(ld_s));
 #pragma unroll
     for (int dt = 0; dt < Cfg::DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        base[(long)(row0 + crow32(r, half)) * a.ldo + dt * 32 + lr] = from_f32<T>(F8 ? acc[dt][r] * mul : acc[dt][r]);
+        buf_store_elem<T>(dqb, F8 ? acc[dt][r] * mul : acc[dt][r], vo + dt * 32 * esz, sbase + (row0 + crow32(r, 0)) * ld_s);
   };
 
   // ---- dV[key][d] = sum_q P[q][key] dO[q][d]
@@ -1033,13 +1110,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   if constexpr (PF) {
     wait_vm0();                                  // Q has landed (waited for BEFORE the dV stores are issued)
     __syncthreads();                             // ... and every wave is done with the dO tile
-    store_acc_plain(dvb, k0);
+    store_acc_plain(so_v, k0);
     if (grp + gridDim.x < ngroups) {             // the next problem's K into the buffer dO just left
       const T* nq = (const T*)a.qkv + problem_rowbase(grp + gridDim.x) * a.ld + head * HD;
       stage_tile<NTOK, Cfg::RB>(Xt, (const char*)(nq + a.C), a.ld * sizeof(T), qt, Cfg::QW);
     }
   } else {
-    store_acc_plain(dvb, k0);
+    store_acc_plain(so_v, k0);
   }
 
   stamp(7);
@@ -1080,7 +1157,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, qbase[(long)qq * a.ld + dt * 32 + lr], acc[dt], 0, 0, 0);
     }
   }
-  store_acc_plain(dkb, k0, sq);                  // (F8: dK = sq (dS^T q^))
+  store_acc_plain(so_k, k0, sq);                 // (F8: dK = sq (dS^T q^))
   stamp(8);
 
   // ---- dQ[q][d] = scale * sum_key dS[q][key] K[key][d]
@@ -1103,7 +1180,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, kbase[(long)key * a.ld + dt * 32 + lr], acc[dt], 0, 0, 0);
     }
   }
-  store_acc(dqb, q0, F8 ? a.scale * sk : a.scale);
+  store_acc(0, q0, F8 ? a.scale * sk : a.scale);
   stamp(9);
   __syncthreads();                               // the next problem's tiles overwrite K / dS
   stamp(10);
@@ -1174,19 +1251,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
 // through a private 4 KB of the dead P tile as whole 16-byte row pieces (4 store instructions of 1 KB instead of 32 of 128 B)
 // measured only 3 % faster (145.7 -> 141.1 us) - the kernel is bound by exposed load latency, not by its stores - and the P
 // tile's buffer is better spent on the next problem's V (below).
-DEVI void buf_store_b16(void* base, bf16 v, int voff, int soff) {
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)0xFFFFFFFE, 0x00020000);
-  __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, v), rs, voff, soff, 0);
-}
-typedef int v4i32_t __attribute__((ext_vector_type(4)));
-DEVI void buf_store_b128(void* base, bf16x8 v, int voff, int soff) {
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)0xFFFFFFFE, 0x00020000);
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32_t, v), rs, voff, soff, 0);
-}
-DEVI float buf_load_f32(const void* base, int voff, int soff) {
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)0xFFFFFFFE, 0x00020000);
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
-}
 DEVI bf16x8 lds_tr_pair(const char* tile, int off0, int off1, int imm) {
   const short4v t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(tile + off0 + imm));
   const short4v t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(tile + off1 + imm));

@@ -51,6 +51,16 @@ enum {
   GF_DEEP = 1 << 28,      // tuning: 3-stage rings for the 128x128 / 256x64 kernels too (one workgroup per CU)
 };
 
+// Diagnosis switches of the ring kernels (flag bits 17 stagger, 18 late R, 19 timestamps through p.colsum, 20 no stores, 21 no epilogue;
+// tools/gemm_timeline.py, tools/epi_decomp.py, tools/probes/*): compiled into STSWIN_TUNING builds only - the product library neither
+// tests them nor lets them through the launcher (a stray bit 19 would turn the column-sum table into a stamp buffer).
+#ifdef STSWIN_TUNING
+#define STSWIN_DBG(flags, bit) (((flags) & (1 << (bit))) != 0)
+#else
+#define STSWIN_DBG(flags, bit) false
+#endif
+enum { GF_DEBUG_BITS = (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) };
+
 struct GemmNT {
   const void* A; long lda; const int* a_rows;
   const void* B; long ldb;
@@ -180,7 +190,7 @@ DEVI void epi_piece(const GemmNT& p, float (&v)[8], const float (&bv)[8], float 
     }
   } else {
     T* dst = (T*)p.C + orow * p.ldc + gn0;
-    if (p.flags & (1 << 20)) { if (v[0] == 123.456f) dst[0] = from_f32<T>(v[1]); }   // DBG: no stores
+    if (STSWIN_DBG(p.flags, 20)) { if (v[0] == 123.456f) dst[0] = from_f32<T>(v[1]); }   // DBG: no stores
     else if (vec_ok && (p.ldc % PACK) == 0) {
 #pragma unroll
       for (int h = 0; h < 8 / PACK; ++h) {
@@ -544,17 +554,23 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   // kh; with the chunk ^ swz64(row) layout the second half's address is the first one's ^ 32 (rd_off1).
   const int rd_off = fr * ROWB + ((fq ^ swz64(fr)) << 4);
   const int rd_off1 = rd_off ^ 32;
-  const bool dbg_ts = (p.flags & (1 << 19)) != 0;     // DBG: p.colsum is a u64 [blocks][8] timestamp buffer (100 MHz clock)
-  // (slot 7: shader-clock cycles between stamps 2 and 3 = the main loop; with the 100 MHz stamps that is the clock the CU really
-  //  ran the loop at - tools/probes/gemm_clock.py)
+  // DBG (STSWIN_TUNING builds): p.colsum is a u64 [blocks][16] timestamp buffer (100 MHz clock).  Slots: 0 start, 1 prologue requested,
+  // 2 first stage landed, 3 main loop done, 4 ring free (barrier), 5 C image written (activation math), 6 C stores issued, 7 shader-clock
+  // cycles between stamps 2 and 3 (with the 100 MHz stamps: the clock the CU really ran the loop at - tools/probes/gemm_clock.py),
+  // 8 second-output image written, 9 its stores issued, 10 R tile landed.
+  const bool dbg_ts = STSWIN_DBG(p.flags, 19);
+#ifdef STSWIN_TUNING
   unsigned long long dbg_c0 = 0;
   auto stamp = [&](int slot) {
     if (dbg_ts && tid == 0) {
-      ((unsigned long long*)p.colsum)[(long)blockIdx.x * 8 + slot] = wall_clock64();
+      ((unsigned long long*)p.colsum)[(long)blockIdx.x * 16 + slot] = wall_clock64();
       if (slot == 2) dbg_c0 = clock64();
-      if (slot == 3) ((unsigned long long*)p.colsum)[(long)blockIdx.x * 8 + 7] = clock64() - dbg_c0;
+      if (slot == 3) ((unsigned long long*)p.colsum)[(long)blockIdx.x * 16 + 7] = clock64() - dbg_c0;
     }
   };
+#else
+  auto stamp = [&](int) {};
+#endif
   // R tile by LDS-DMA, one 64-row block (= one ring stage buffer of the image layout) at a time; see the main loop's tail
   constexpr bool R_EARLY_OK = SWAP && BM == 256 && BN == 256 && NST == 4 && PER_STAGE == 4 && NTHR == 512;
   bool r_early = false;
@@ -569,13 +585,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   // Stagger (flag bit 17): the first round's workgroups start up to 7/8 of a tile time apart (8 phases among the CUs of an
   // XCD).  All 256 CUs otherwise run in lock-step and their C stores (128 KB each: 32 MB per round, more than the L2s hold)
   // leave as one burst; the next tile's first loads queue behind the CU's own share of that HBM write drain.
-  if ((p.flags & (1 << 17)) && blockIdx.x < 256) {
+  if (STSWIN_DBG(p.flags, 17) && blockIdx.x < 256) {
     const unsigned long long t_go = wall_clock64() + (unsigned long long)(((blockIdx.x >> 3) & 7) * (nt + 4) * 100 / 8);
     while (wall_clock64() < t_go) __builtin_amdgcn_s_sleep(8);
   }
   stamp(0);
   auto epilogue = [&]() {
-    if (p.flags & (1 << 21)) {        // DBG: no epilogue at all (keeps the accumulators alive)
+    if (STSWIN_DBG(p.flags, 21)) {    // DBG: no epilogue at all (keeps the accumulators alive)
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < FI; ++i)
@@ -728,7 +744,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
       } else {
         __syncthreads();
 #ifdef STSWIN_DEBUG_LOOP_STAMPS                        // diagnosis build: bit 20 really drops the stores of this path
-        if (p.flags & (1 << 20)) return;
+        if (STSWIN_DBG(p.flags, 20)) return;
 #endif
         T* cbase = (T*)Cout + (long)(m0 + rb_row) * ldo + n0 + rb_chunk * 8;
 #pragma unroll
@@ -757,7 +773,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
           put(i, j, v);
           __builtin_amdgcn_sched_barrier(0);
         }
+      stamp(8);
       readback(p.C2, p.ldc2);
+      stamp(9);
       __syncthreads();
       // launder the bias registers: otherwise hipcc keeps all 128 bias-added values of the pass above for the pass
       // below (common subexpression) and spills them
@@ -775,6 +793,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
       issue_r_block((nt - 1) % NST);
       wait_vmcnt<0>();
       __syncthreads();
+      stamp(10);
     } else if (has_r) {
       constexpr int RPW = 64 / CPRW;                   // image rows per wave request (a row = CPRW 16-byte chunks)
       constexpr int RROWS = NTHR / 64 * RPW, RPASS = BM / RROWS;
@@ -793,6 +812,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
       }
       wait_vmcnt<0>();
       __syncthreads();
+      stamp(10);
     }
     // one fragment: activation / R operand / ReLU on the accumulators, the result into the bf16 image; its column sums into csj / cs2j
     auto fragment = [&](int i, int j, f32x4& csj, f32x4& cs2j) __attribute__((always_inline)) {
@@ -879,7 +899,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
       for (int i = 0; i < FI; ++i)
 #pragma unroll
         for (int j = 0; j < FJ; ++j) put_pk(i, j, dpk[i][j]);
+      stamp(8);
       readback(p.C2, p.ldc2);
+      stamp(9);
     }
 #undef EPI_HAS
   };
@@ -962,7 +984,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   };
   auto epilogue_reg = [&]() __attribute__((always_inline)) {
     if (p.f8_rows > 0) { epilogue_fp8(); return; }
-    if (p.flags & (1 << 21)) {        // DBG: no epilogue at all (keeps the accumulators alive)
+    if (STSWIN_DBG(p.flags, 21)) {    // DBG: no epilogue at all (keeps the accumulators alive)
       stamp(3); stamp(4); stamp(5);
       float t = 0.f;
 #pragma unroll
@@ -975,8 +997,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     }
     const int mode = (p.bias ? E_BIAS : 0) | (p.scale_cols > 0 ? E_SCALE : 0) | ((p.flags & GF_GELU) ? E_GELU : 0) |
                      (p.C2 ? E_C2 : 0) | ((p.flags & GF_RESID) ? E_RESID : 0) | ((p.flags & GF_MUL_DGELU) ? E_DGELU : 0) |
-                     (p.colsum ? E_COLSUM : 0) | ((p.flags & GF_RELU) ? E_RELU : 0) | ((p.flags & GF_MUL_R) ? E_MULR : 0) |
-                     ((p.flags & GF_C2_DGELU) ? E_C2D : 0) | ((p.colsum && (p.flags & GF_CS_SQ)) ? E_COLSQ : 0);
+                     ((p.colsum && !dbg_ts) ? E_COLSUM : 0) | ((p.flags & GF_RELU) ? E_RELU : 0) | ((p.flags & GF_MUL_R) ? E_MULR : 0) |
+                     ((p.flags & GF_C2_DGELU) ? E_C2D : 0) | ((p.colsum && !dbg_ts && (p.flags & GF_CS_SQ)) ? E_COLSQ : 0);
     switch (mode) {                                   // the combinations the Swin / conv paths issue; anything else: generic
       case 0: epilogue_body(std::integral_constant<int, 0>{}); break;
 #ifndef STSWIN_DEBUG_ONLY_PLAIN_EPI                   // diagnosis build: a kernel with ONE epilogue body (code size experiment)
@@ -999,7 +1021,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     }
   };
   if constexpr (PIPE != 4) {                          // (PIPE 4 stages through registers: its own prologue)
-    for (int q = 0; q < NST - 1 && q < nt; ++q) issue(q);
+    // (PIPE 7 keeps a stage's fragments in registers one step ahead, so all NST slots can be in flight: prefetch distance NST)
+    for (int q = 0; q < (PIPE == 7 ? NST : NST - 1) && q < nt; ++q) issue(q);
   }
   __builtin_amdgcn_sched_barrier(0);                 // first get the copies going, then spend 128 v_mov on the accumulators
   if constexpr (M32) {
@@ -1343,6 +1366,107 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 5);
     if (arow_bad) __builtin_trap();
     epilogue_reg();
+  } else if constexpr (PIPE == 7) {
+    // "Duo" (round 5): 128x256 tile, FOUR waves (one per SIMD) of 128x64, three 24 KB ring slots = 72 KB, so TWO independent workgroups
+    // share a CU (2 x 72 KB LDS, 2 x 4 waves of <= 256 registers) - while one of them is in its epilogue (activation polynomials on
+    // the VALU, LDS image, stores), waits for its first stages or is being replaced by its successor, the other one owns the matrix
+    // pipe.  The 8-wave 256x256 kernel cannot do that: its two wave rows share every barrier, so the whole CU goes through the
+    // epilogue together with the matrix pipe idle (fc1 + GELU + GELU': 12.7 us of main loop in a 27 us tile,
+    // profiles/r05_gemm_tile_timeline.txt).  Round 2's duo kernel (PIPE 0: read 12 fragments, then 32 MFMAs, per stage) lost in the
+    // main loop what it gained in the epilogue, because a lone wave that reads and then multiplies leaves its SIMD idle half the
+    // time and two un-coordinated workgroups do not interleave reliably.  Here every wave software-pipelines ITSELF (the structure
+    // of PIPE 6): fragment sets kt & 1, the 12 ds_read_b128 of stage kt+1 and its 6 LDS-DMA pieces of stage kt+3 spread between the
+    // 32 MFMAs of stage kt, one barrier per stage - a wave alone on its SIMD keeps the pipe busy, two of them (the other
+    // workgroup's) share it.
+    // Ring safety with THREE slots: stage kt's fragments were read during step kt-1; every wave drains its LDS reads (lgkmcnt(0))
+    // before the barrier on top of step kt, after which slot kt % 3 takes stage kt+3.  Data arrival: before that barrier each wave
+    // waits for its own pieces of stage kt+1 (stage kt+2's may stay in flight).
+    static_assert(NST == 3 && SWAP && !M32 && NWV == 4 && WM == 1, "4-wave self-pipelined variant");
+    constexpr int NG = FI + FJ;                        // fragment reads per stage (8 + 4)
+    static_assert(NG % PER_STAGE == 0, "copy pieces spread evenly over the read groups");
+    bf16x8 fa[2][FI], fb[2][FJ];
+    int is_koff = 0, is_qoff = 0;
+    auto issue_prep = [&](int q) {
+      const int Q = q + qbase;
+      int sg = 0, kt = Q;
+      if (p.S > 1) { sg = Q / kps; kt = Q - sg * kps; }
+      if (sg != seg) { seg = sg; load_a_bases(sg); }
+      is_koff = kt * (BK * (int)sizeof(T));
+      is_qoff = Q * (BK * (int)sizeof(T));
+    };
+    auto issue_one = [&](int slot, int part) __attribute__((always_inline)) {
+      char* Ab = smem + slot * STAGE;
+      if (part < NIA) glds16_buf(p.A, aoff[part], is_koff, Ab + (w * NIA + part) * 1024);
+      else glds16_buf(p.B, boff[part - NIA], is_qoff, Ab + A_BYTES + (w * NIB + part - NIA) * 1024);
+    };
+    auto read_frag = [&](int set, int slot, int g) __attribute__((always_inline)) {
+      const char* Ab = smem + slot * STAGE;
+      if (g < FJ) fb[set][g] = *(const bf16x8*)(Ab + A_BYTES + (wc * TN + g * 16) * ROWB + rd_off);
+      else fa[set][g - FJ] = *(const bf16x8*)(Ab + (wr * TM + (g - FJ) * 16) * ROWB + rd_off);
+    };
+    auto step = [&](auto setc, auto slotc, int kt, bool do_issue, bool do_read) __attribute__((always_inline)) {
+      constexpr int SET = decltype(setc)::value, SLOT = decltype(slotc)::value;
+      if (do_issue) issue_prep(kt + NST);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (do_read) read_frag(SET ^ 1, (SLOT + 1) % NST, g);
+        if (do_issue && g % (NG / PER_STAGE) == 0) issue_one(SLOT, g / (NG / PER_STAGE));
+#pragma unroll
+        for (int m = g * (FI * FJ) / NG; m < (g + 1) * (FI * FJ) / NG; ++m) {
+          // row-major over the fragment rows: row i needs fa[i] (read group FJ + i of the PREVIOUS step) and all four fb
+          const int i = m / FJ, j = m % FJ;
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fb[SET][j]), "v"(fa[SET][i]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    using std::integral_constant;
+    auto stage_sync = [&]() __attribute__((always_inline)) {
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      static_assert(PER_STAGE == 6, "literal wait count");
+      __builtin_amdgcn_s_barrier();
+    };
+    stamp(1);
+    if (nt >= 3) wait_vmcnt<2 * PER_STAGE>();
+    else if (nt == 2) wait_vmcnt<PER_STAGE>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    stamp(2);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) read_frag(0, 0, g);
+    int kt = 0;
+    for (; kt + 8 < nt; kt += 6) {                       // steady state (period 6 = fragment sets x ring slots): every step requests a stage and reads one
+      stage_sync();
+      step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt, true, true);
+      stage_sync();
+      step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1, true, true);
+      stage_sync();
+      step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2, true, true);
+      stage_sync();
+      step(integral_constant<int, 1>{}, integral_constant<int, 0>{}, kt + 3, true, true);
+      stage_sync();
+      step(integral_constant<int, 0>{}, integral_constant<int, 1>{}, kt + 4, true, true);
+      stage_sync();
+      step(integral_constant<int, 1>{}, integral_constant<int, 2>{}, kt + 5, true, true);
+    }
+    auto tail_step = [&](auto setc, auto slotc, int k) __attribute__((always_inline)) {
+      if (k >= nt) return;
+      if (k + 2 < nt) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      step(setc, slotc, k, k + NST < nt, k + 1 < nt);
+    };
+    // the last 1..8 steps (kt is a multiple of 6 here): runtime tests of what is left to request / read
+    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt);
+    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1);
+    tail_step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2);
+    tail_step(integral_constant<int, 1>{}, integral_constant<int, 0>{}, kt + 3);
+    tail_step(integral_constant<int, 0>{}, integral_constant<int, 1>{}, kt + 4);
+    tail_step(integral_constant<int, 1>{}, integral_constant<int, 2>{}, kt + 5);
+    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt + 6);
+    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 7);
+    if (arow_bad) __builtin_trap();
+    epilogue_reg();
   } else if constexpr (PIPE == 5) {
     // Rotated ping-pong, ONE barrier per stage.  The two waves of a SIMD (wave rows 0 / 1) no longer hand the matrix pipe over at a
     // second barrier in mid-stage (each hand-over leaves it idle for the barrier's release latency: the loop above spends ~1224
@@ -1532,7 +1656,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
       // wave.  So the loop keeps its steady-state form (same wait constant, no branches) and requests R block (kt-1) % NST
       // into the buffer that stage kt-1 just vacated: three quarters of R are under way 1-3 stages before the epilogue.
       if constexpr (R_EARLY_OK) {
-        if ((p.flags & (GF_RESID | GF_MUL_R | GF_MUL_DGELU)) && !p.r_rows && kt + NST - 1 == nt && !(p.flags & (1 << 18))) {
+        if ((p.flags & (GF_RESID | GF_MUL_R | GF_MUL_DGELU)) && !p.r_rows && kt + NST - 1 == nt && !STSWIN_DBG(p.flags, 18)) {
           r_early = true;
           for (; kt < nt; ++kt) {
             __builtin_amdgcn_s_barrier();
@@ -2103,13 +2227,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(GemmTN p) {
 // tests it was 18 scalar branches and ~150 SALU instructions per stage, longer than the partner row's MFMA phase.
 // FUSE (round 4): the split-K combine runs INSIDE this launch.  The MFMA operands are swapped (a lane then holds 4 consecutive output
 // COLUMNS of one row), the bf16 partial tile goes through one [256][256] LDS image and leaves as whole 16-byte row pieces - written
-// THROUGH the caches (sc1) - every wave drains its stores, one lane adds 1 to the tile's arrival counter (agent scope) and polls it
-// until all `splits` workgroups of the tile have arrived; then each of them adds rows [split * 256 / splits, ...) of the tile's
-// `splits` partial tiles in split order (sc1 loads: no acquire fence needed, MI355X_MICROARCH.md "Valid forms", row 1) and stores the
-// fp32 result.  Same values bit for bit as tn_reduce_kernel (same fp32 additions in the same order).  It replaces a 9.6 us
+// THROUGH the caches (sc1) - every wave drains its stores, one lane adds 1 to the tile's arrival counter (agent scope); once all
+// `splits` partial tiles of the output tile are complete the workgroups of the tile that are present add its row slices
+// [slice * 256 / splits, ...) in split order (sc1 loads: no acquire fence needed, MI355X_MICROARCH.md "Valid forms", row 1) and store
+// the fp32 result.  Same values bit for bit as tn_reduce_kernel (same fp32 additions in the same order).  It replaces a 9.6 us
 // all-chip pass and a kernel boundary per weight gradient (69 of them per training step), and the 128 two-byte stores per lane
-// of the unfused epilogue.  Progress: the launcher only fuses when the whole grid is resident at once (<= one workgroup per CU),
-// so no arrival can wait for a workgroup that has not started; the poll is bounded and traps instead of hanging.
+// of the unfused epilogue.  Progress (round 5): slices are handed out by ticket and an early workgroup waits a bounded time, then
+// leaves (see the hand-over below) - no workgroup needs another one to be resident, so a busy second stream, a second process or an
+// RCCL kernel holding compute units costs time, never correctness; the launcher still fuses only grids of <= one workgroup per CU,
+// because that is where the distributed combine is faster than the separate pass.
 template <int MODE, bool FUSE = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
   constexpr bool MAPS = MODE != 0, MAP_A = MODE == 1, MAP_B = MODE >= 2, TAPS = MODE == 3;
@@ -2346,70 +2472,95 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores ...
-    __syncthreads();                                   // ... before the one lane that signals for all of them
+    __syncthreads();                                   // ... before the one lane that signals for all of them (the image is dead now)
     typedef __attribute__((address_space(1))) unsigned gu32;
+    const int ntiles = gridDim.x / p.splits;
     gu32* arrive = (gu32*)p.tile_cnt + tile_id;
-    gu32* depart = (gu32*)p.tile_cnt + gridDim.x / p.splits + tile_id;
+    gu32* depart = (gu32*)p.tile_cnt + ntiles + tile_id;
+    gu32* ticket = (gu32*)p.tile_cnt + 2 * ntiles + tile_id;
+    // Round 5: NO workgroup depends on another one being resident.  The combine of a tile is cut into `splits` row slices that are
+    // handed out by TICKET to whichever workgroups of the tile are present once all `splits` partial tiles are complete: the workgroup
+    // whose arrival was the last one (it never waits) and every earlier one that is still polling.  An early workgroup polls for at most
+    // TN_WAIT_TICKS and then simply leaves - its CU goes to workgroups that have not started yet (a grid larger than the free CUs: another
+    // stream or process, an RCCL kernel of the communication stream) - and the slices it would have taken fall to those who stay; in the
+    // worst case the last arriver adds the whole tile.  Every slice is summed in split order by exactly one workgroup, so the result is
+    // bit for bit that of tn_reduce_kernel whoever does it.  (Round 4 made every workgroup wait for its tile's other splits: correct only
+    // with the whole grid resident, and a trap after 2^26 polls otherwise.)
+    constexpr unsigned long long TN_WAIT_TICKS = 20000ull;   // 200 us of the 100 MHz clock: arrival skew of a resident tile is < 20 us
+    int* bc = (int*)smem;                              // [0] combine? [1] slice ticket - broadcast words
     if (tid == 0) {
-      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned spins = 0;
-      while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.splits) {
-        __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1u << 26)) __builtin_trap();    // (~10 s: a workgroup of this tile never arrived - fail loudly, do not hang)
+      const unsigned n = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      int ok = 1;
+      if (n < (unsigned)p.splits) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.splits) {
+          __builtin_amdgcn_s_sleep(8);
+          if (wall_clock64() - t0 > TN_WAIT_TICKS) { ok = 0; break; }
+        }
       }
+      bc[0] = ok;
     }
     __syncthreads();                                   // the other waves load behind the barrier the polling wave joins
     stamp(4);
-    const int per = (256 + p.splits - 1) / p.splits;   // rows of the tile this workgroup combines
-    const int r_end = min(256, (split_id + 1) * per);
-    if (gj < p.Nj) {
-      for (int row = split_id * per + rb_row; row < r_end; row += 16) {
-        const int gi = i0 + row;
-        if (gi >= p.Ni) break;
-        const int off0 = (int)(((long)gi * p.Nj + gj) * 2);
-        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int sp = 0;
-        for (; sp + 8 <= p.splits; sp += 8) {          // eight partial rows in flight, added in split order
-          v4i32 v[8];
+    const bool go = bc[0] != 0;
+    const int per = (256 + p.splits - 1) / p.splits;   // rows of a slice
+    while (go) {
+      __syncthreads();                                 // (everybody has read the previous ticket)
+      if (tid == 0) bc[1] = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int slice = bc[1];
+      if (slice >= p.splits) break;
+      const int r_end = min(256, (slice + 1) * per);
+      if (gj < p.Nj) {
+        for (int row = slice * per + rb_row; row < r_end; row += 16) {
+          const int gi = i0 + row;
+          if (gi >= p.Ni) break;
+          const int off0 = (int)(((long)gi * p.Nj + gj) * 2);
+          float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          int sp = 0;
+          for (; sp + 8 <= p.splits; sp += 8) {          // eight partial rows in flight, added in split order
+            v4i32 v[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsS, off0, (int)((long)(sp + u) * plane * 2), 16);   // sc1
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsS, off0, (int)((long)(sp + u) * plane * 2), 16);   // sc1
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const bf16x8 h = __builtin_bit_cast(bf16x8, v[u]);
+            for (int u = 0; u < 8; ++u) {
+              const bf16x8 h = __builtin_bit_cast(bf16x8, v[u]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) s8[e] += (float)h[e];
+            }
+          }
+          for (; sp < p.splits; ++sp) {
+            const bf16x8 h = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsS, off0, (int)((long)sp * plane * 2), 16));
 #pragma unroll
             for (int e = 0; e < 8; ++e) s8[e] += (float)h[e];
           }
-        }
-        for (; sp < p.splits; ++sp) {
-          const bf16x8 h = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsS, off0, (int)((long)sp * plane * 2), 16));
+          if (p.perm > 0) {                              // tap-minor output (see tn_reduce_kernel)
+            const int S = p.Nj / p.perm, sg = gj / p.perm, c = gj - sg * p.perm;
+            float* d = p.C + (long)gi * p.ldc + (long)c * S + sg;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) s8[e] += (float)h[e];
-        }
-        if (p.perm > 0) {                              // tap-minor output (see tn_reduce_kernel)
-          const int S = p.Nj / p.perm, sg = gj / p.perm, c = gj - sg * p.perm;
-          float* d = p.C + (long)gi * p.ldc + (long)c * S + sg;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) d[(long)e * S] = p.overwrite ? s8[e] : d[(long)e * S] + s8[e];
-        } else {
-          float* dst = p.C + (long)gi * p.ldc + gj;
-          if ((p.ldc & 3) == 0) {
-            f32x4 lo = {s8[0], s8[1], s8[2], s8[3]}, hi = {s8[4], s8[5], s8[6], s8[7]};
-            if (!p.overwrite) { lo += *(const f32x4*)dst; hi += *(const f32x4*)(dst + 4); }
-            *(f32x4*)dst = lo;
-            *(f32x4*)(dst + 4) = hi;
+            for (int e = 0; e < 8; ++e) d[(long)e * S] = p.overwrite ? s8[e] : d[(long)e * S] + s8[e];
           } else {
-            for (int e = 0; e < 8; ++e) dst[e] = p.overwrite ? s8[e] : dst[e] + s8[e];
+            float* dst = p.C + (long)gi * p.ldc + gj;
+            if ((p.ldc & 3) == 0) {
+              f32x4 lo = {s8[0], s8[1], s8[2], s8[3]}, hi = {s8[4], s8[5], s8[6], s8[7]};
+              if (!p.overwrite) { lo += *(const f32x4*)dst; hi += *(const f32x4*)(dst + 4); }
+              *(f32x4*)dst = lo;
+              *(f32x4*)(dst + 4) = hi;
+            } else {
+              for (int e = 0; e < 8; ++e) dst[e] = p.overwrite ? s8[e] : dst[e] + s8[e];
+            }
           }
         }
       }
     }
-    // departure: the last workgroup of the tile to finish its share zeroes both counters for the next launch (every load of the
-    // tile's partials has returned by then: the sums above consumed them)
+    // departure: the last workgroup of the tile to leave (its own slices done, every other one gone) zeroes the three counters for the
+    // next launch on this stream
     __syncthreads();
     if (tid == 0) {
       const unsigned d = __hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (d == (unsigned)p.splits - 1) {
         __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -2711,12 +2862,12 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
 #ifndef STSWIN_TUNING
   // the stream / duo / mid / half / nopipe kernels (measured slower everywhere, kept for A/B runs) exist in STSWIN_TUNING builds
   // only: the product library ignores their flags (stswin_tuning_build() tells a caller which library it has)
-  flags &= ~(GF_MID | GF_HALF | GF_DUO | GF_STREAM | GF_NOPIPE | GF_W4R | GF_M32PP | GF_ROT);
+  flags &= ~(GF_MID | GF_HALF | GF_STREAM | GF_NOPIPE | GF_W4R | GF_M32PP | GF_ROT | GF_DEBUG_BITS);
 #endif
   const int bk = dtype == 0 ? 64 : 32;
   if (Kseg <= 0 || Kseg % bk || S <= 0) return -1001;
   if ((flags & GF_ACCUM) && !(flags & GF_OUT_F32)) return -1002;
-  if ((flags & GF_CS_SQ) && (!(flags & GF_CS_PARTIAL) || !colsum || (flags & (GF_MID | GF_HALF | GF_DUO | GF_STREAM | GF_NOREGEPI))))
+  if ((flags & GF_CS_SQ) && (!(flags & GF_CS_PARTIAL) || !colsum || (flags & (GF_MID | GF_HALF | GF_STREAM | GF_NOREGEPI))))
     return -1006;                                            // squares need the per-block table and a kernel that writes them
   if ((flags & GF_CS_PARTIAL) && colsum && ((M + 127) / 128) % 2) { // 128-row tiles never touch the last row of the [2*ceil(M/256)][N] table
     (void)hipMemsetAsync(colsum + (long)(2 * ((M + 255) / 256) - 1) * N, 0, sizeof(float) * N, (hipStream_t)stream);
@@ -2783,6 +2934,22 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     static int once_swap = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)once_swap;
     if ((flags & GF_CS_SQ) && (!regepi || (flags & GF_NOPIPE))) return -1006;   // (only the register epilogue sums squares)
+    // "duo" (round 5, gemm_nt_ring_kernel<128, 256, 1, 4, 3, 2, 7, true>): 128x256 tiles, 4 self-pipelined waves, 72 KB of LDS - two
+    // independent workgroups per CU, one multiplying while the other runs its epilogue.  Chosen (GF_DUO from the caller, or by the rule
+    // below) for the epilogue-heavy short-K launches of the Swin MLP; see the kernel's PIPE 7 branch.
+    if (regepi && (flags & GF_DUO)
+#ifdef STSWIN_TUNING
+        && !(flags & GF_NOPIPE)
+#endif
+    ) {
+      static int once_duo7 = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<128, 256, 1, 4, 3, 2, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+      (void)once_duo7;
+      const long duo_tiles = (long)((M + 127) / 128) * ((N + 255) / 256);
+      g_last_variant[0] = STSWIN_VAR_NT_DUO;
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<128, 256, 1, 4, 3, 2, 7, true>), dim3((unsigned)duo_tiles), dim3(256), 73728, (hipStream_t)stream, p);
+      STSWIN_CHECK_LAUNCH();
+      return 0;
+    }
 #ifdef STSWIN_TUNING
     // persistent streaming variant: plain Linear GEMMs (S = 1, no A gather) with the register epilogue
     const bool streamk = regepi && S == 1 && !a_rows && (flags & GF_STREAM) && !(flags & (GF_NOPIPE | GF_NOSTREAM));
@@ -2795,9 +2962,8 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
       STSWIN_CHECK_LAUNCH();
       return 0;
     }
-    // "duo": 128x256 tiles, 4 waves of 128x64 (the same wave tile), 3-stage ring of 24 KB, TWO independent workgroups per
-    // CU: while one is in its epilogue / store drain / prologue the other one multiplies
-    if (regepi && (flags & GF_DUO)) {
+    // round-2 "duo" (PIPE 0 main loop; GF_DUO | GF_NOPIPE): kept for A/B against the self-pipelined one below
+    if (regepi && (flags & GF_DUO) && (flags & GF_NOPIPE)) {
       static int once_duo = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<128, 256, 1, 4, 3, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
       (void)once_duo;
       const long duo_tiles = (long)((M + 127) / 128) * ((N + 255) / 256);
@@ -2960,23 +3126,52 @@ static long tn_resident_workgroups() {
   }
   return cus;
 }
-// Arrival / departure counters of the fused split-K combine: [2][tiles] unsigned per launch, zero when a launch starts and zeroed
-// again by its last workgroups.  16 regions per device, handed out round-robin (a captured hipGraph node keeps the region it was
-// captured with; launches that share a region are ordered by their stream).  Allocated and cleared once per device, outside
-// any stream capture (the first fused launch of a process is a warm-up launch; if it is not, the unfused path is taken).
-static unsigned* tn_tile_counters(int tiles) {
-  constexpr int REGIONS = 16, PER = 2 * 1024;
+// Arrival / ticket / departure counters of the fused split-K combine: [3][tiles] unsigned per launch, zero when a launch starts and
+// zeroed again by the last workgroup of each tile to leave.  One region per (device, stream): launches that share a region are
+// ordered by their stream, two host threads or two streams never share one (round-4 advisor: the round-robin hand-out could give two
+// concurrent launches the same counters).  Up to 16 streams per device; a 17th takes the unfused path.  Allocated and cleared once
+// per device, outside any stream capture (the first fused launch of a process is a warm-up launch; if it is not, the unfused path
+// is taken).  A captured hipGraph node keeps the region of the stream it was captured on: replay it on that stream.
+#include <atomic>
+#include <mutex>
+static std::mutex g_tn_mutex;
+static std::atomic<int> g_tn_fused_holds{0};
+static unsigned* tn_tile_counters(int tiles, hipStream_t stream) {
+  constexpr int REGIONS = 16, PER = 3 * 1024;
   static unsigned* bufs[64] = {nullptr};
-  static unsigned next[64] = {0};
+  static hipStream_t owners[64][REGIONS];
+  static int nown[64] = {0};
   int dev = 0;
   if (tiles > 1024 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(g_tn_mutex);
   if (!bufs[dev]) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
     unsigned* b = nullptr;
     if (hipMalloc((void**)&b, sizeof(unsigned) * REGIONS * PER) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (hipMemset(b, 0, sizeof(unsigned) * REGIONS * PER) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(b); return nullptr; }
     bufs[dev] = b;
   }
-  return bufs[dev] + (size_t)(next[dev]++ % REGIONS) * PER;
+  int r = -1;
+  for (int i = 0; i < nown[dev]; ++i)
+    if (owners[dev][i] == stream) { r = i; break; }
+  if (r < 0) {
+    if (nown[dev] >= REGIONS) return nullptr;
+    r = nown[dev]++;
+    owners[dev][r] = stream;
+  }
+  return bufs[dev] + (size_t)r * PER;
+}
+// Process-wide switch of the fused combine: every hold (+1) turns it off until released (-1).  GradBucketReducer holds it while its
+// collectives overlap backward (stswincl_amd/dp.py).  STSWIN_TN_FUSED=0 / 1 in the environment overrides the holds (read per call).
+extern "C" int stswin_tn_fused_hold(int delta) {
+  if (delta > 0) return g_tn_fused_holds.fetch_add(1) + 1;
+  if (delta < 0) {
+    int cur = g_tn_fused_holds.load();
+    while (cur > 0 && !g_tn_fused_holds.compare_exchange_weak(cur, cur - 1)) {}
+    return cur > 0 ? cur - 1 : 0;
+  }
+  return g_tn_fused_holds.load();
 }
 
 extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, const void* Bt, long ldb,
@@ -3047,13 +3242,14 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
     if (ring) {
       const bool slabs = workspace && rs > 1 && (long)rs * Ni * Nj <= workspace_floats;
       if (overwrite && !slabs) (void)hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)Nj * sizeof(float), (size_t)Ni, (hipStream_t)stream);
-      // Fused split-K combine (gemm_tn_ring_kernel<MODE, true>): bf16 partials, the whole grid resident at once (one workgroup per
-      // CU: a workgroup polls for the other splits of its tile), byte offsets of the partials within 31 bits.
-      // STSWIN_TN_FUSED=0: the separate tn_reduce pass (A/B switch, read per call).
+      // Fused split-K combine (gemm_tn_ring_kernel<MODE, true>): bf16 partials, a grid of at most one workgroup per CU (where the
+      // distributed combine beats the separate pass; residency is NOT needed for correctness any more), byte offsets of the partials
+      // within 31 bits.  Off while stswin_tn_fused_hold() holds are outstanding; STSWIN_TN_FUSED=0 / 1 overrides (read per call).
       unsigned* tile_cnt = nullptr;
       if (slabs && slab_bf16 && !no_combine && ldc >= 0 && (long)t256 * rs <= tn_resident_workgroups() && (long)rs * Ni * Nj * 2 < 0x7FFFFFF0L) {
         const char* ef = getenv("STSWIN_TN_FUSED");
-        if (!(ef && atoi(ef) == 0)) tile_cnt = tn_tile_counters(t256);
+        const bool on = ef ? atoi(ef) != 0 : g_tn_fused_holds.load() == 0;
+        if (on) tile_cnt = tn_tile_counters(t256, (hipStream_t)stream);
       }
       GemmTN q{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, rs, bseg, slabs ? workspace : nullptr, slab_bf16, tile_cnt, overwrite, perm};
       static int once_r = (int)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |

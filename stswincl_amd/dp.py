@@ -97,10 +97,12 @@ class GradBucketReducer:
         # main stream is not resident all at once.  The weight-gradient GEMM with the fused split-K combine (stswin_gemm_tn, a
         # workgroup waits for the other splits of its tile) would then sit out the collective; with the separate combine pass the
         # late workgroups just run a second round.  Overlapped reducer => separate pass, unless the caller chose explicitly.
-        self._set_tn_env = False
-        if self.world > 1 and overlap and "STSWIN_TN_FUSED" not in os.environ:
-            os.environ["STSWIN_TN_FUSED"] = "0"
-            self._set_tn_env = True
+        # (Round 5: the fused combine no longer NEEDS residency - it degrades instead of trapping - so this is a speed choice; a
+        #  refcounted library switch, not a process-global environment write; STSWIN_TN_FUSED=0 / 1 in the environment overrides it.)
+        self._tn_hold = None
+        if self.world > 1 and overlap:
+            from . import hip
+            self._tn_hold = hip.TnFusedHold()
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         # persistent flat buffers (parameter dtype) + per-parameter views; 64-byte aligned slices so that vector kernels can
@@ -146,9 +148,9 @@ class GradBucketReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
-        if self._set_tn_env:
-            os.environ.pop("STSWIN_TN_FUSED", None)
-            self._set_tn_env = False
+        if self._tn_hold is not None:
+            self._tn_hold.release()
+            self._tn_hold = None
         for p in self.params:
             ent = getattr(p, "_stswin_grad_dest", None)
             if ent is not None and ent[0]() in (self, None):

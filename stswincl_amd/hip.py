@@ -71,6 +71,31 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+def tuning_build() -> bool:
+    """True when the loaded library was built with STSWIN_TUNING=1 (A/B-only kernel variants and the in-kernel diagnosis switches)."""
+    return bool(load().stswin_tuning_build())
+
+
+def tn_fused_holds() -> int:
+    """Outstanding holds on the fused split-K combine of stswin_gemm_tn (0 = fused where it applies)."""
+    return int(load().stswin_tn_fused_hold(0))
+
+
+class TnFusedHold:
+    """While alive (until release()), weight-gradient GEMMs use the separate split-K combine pass instead of the one fused into the
+    launch.  Refcounted inside the library (include/stswin_hip.h, stswin_tn_fused_hold): several holders, any order of release, and a
+    holder dropped without release() gives its hold back when it is collected."""
+
+    def __init__(self):
+        import weakref
+        lib = load()
+        lib.stswin_tn_fused_hold(1)
+        self._fin = weakref.finalize(self, lib.stswin_tn_fused_hold, -1)
+
+    def release(self):
+        self._fin()            # (idempotent: a finalizer runs once)
+
+
 def _check(rc: int, what: str) -> None:
     if rc != 0:
         raise StswinHipError(f"{what} failed with code {rc}")

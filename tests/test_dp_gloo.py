@@ -32,8 +32,12 @@ def _worker(rank, world, port, overlap, q):
         params = list(model.parameters()) + list(frozen.parameters())
         red = GradBucketReducer(params, bucket_mb=0.0005, overlap=overlap)  # tiny buckets -> several of them
         assert len(red.buckets) >= 3, len(red.buckets)
-        # an overlapped reducer of a world > 1 switches the weight-gradient GEMMs to the separate split-K combine pass (dp.py)
-        assert (os.environ.get("STSWIN_TN_FUSED") == "0") == overlap
+        # an overlapped reducer of a world > 1 holds the library's refcounted switch: weight-gradient GEMMs use the separate split-K
+        # combine pass while it lives (dp.py); a second holder and any order of release must work, and the environment is not touched
+        from stswincl_amd import hip
+        assert hip.tn_fused_holds() == (1 if overlap else 0) and "STSWIN_TN_FUSED" not in os.environ
+        extra = hip.TnFusedHold()
+        assert hip.tn_fused_holds() == (2 if overlap else 1)
         data = torch.arange(8 * 16, dtype=torch.float32).reshape(8, 16) / 100.0
         mine = shard_indices(8, rank, world)
         for step in range(2):                      # two steps: hooks / bucket state must reset
@@ -51,7 +55,13 @@ def _worker(rank, world, port, overlap, q):
         gr = torch.cat([p.grad.reshape(-1) for p in ref_model.parameters()])
         emb = all_gather_embeddings(torch.full((3, 2), float(rank)))
         red.close()
-        assert "STSWIN_TN_FUSED" not in os.environ           # (restored: the reducer had set it, not the caller)
+        assert hip.tn_fused_holds() == 1                     # (the reducer's hold is back, the second holder's is not)
+        red.close()                                          # idempotent
+        assert hip.tn_fused_holds() == 1
+        del extra                                            # a holder dropped without release() gives its hold back
+        import gc
+        gc.collect()
+        assert hip.tn_fused_holds() == 0
         q.put((rank, float((g - gr).abs().max()), emb.shape, emb[:, 0].tolist(), mine))
     finally:
         dist.destroy_process_group()

@@ -17,10 +17,10 @@ for M, N, K in ((4096, 4096, 4096), (65536, 512, 2048), (65536, 2048, 512)):
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         nblk = (M // 256) * (N // 256)
         for _ in range(3):
-            ts = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
+            ts = torch.zeros(nblk * 16, dtype=torch.int64, device="cuda")
             hip.gemm_nt(A, W, out, M=M, flags=hip.GF_BIG | extra | (1 << 19), colsum_out=ts.view(torch.float32))
         torch.cuda.synchronize()
-        t = ts.view(nblk, 8).cpu().double()
+        t = ts.view(nblk, 16).cpu().double()
         wall_us = (t[:, 3] - t[:, 2]) / 100.0
         cyc = t[:, 7]
         ok = (wall_us > 0) & (cyc > 0)
