@@ -174,6 +174,10 @@ int stswin_gemm_nt_splitk(const void* A, long lda, const int* a_rows, const void
  * tn_reduce pass is used (GradBucketReducer holds one while its collectives overlap backward); environment STSWIN_TN_FUSED=0 / 1
  * overrides the holds (read per call). */
 int stswin_tn_fused_hold(int delta);
+/* Compute units the one-workgroup-per-CU launches plan for (split-K factor of the gemm_tn ring kernel, persistent grids of the attention
+ * backward): the whole device (256) by default; lower it while a communication kernel is known to hold k units (256 - k), 0 restores
+ * the default.  Returns the previous setting.  A planning hint only: any value gives correct results. */
+int stswin_set_cu_budget(int cus);
 int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, const void* Bt, long ldb, const int* bt_rows,
                    float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg,
                    float* workspace /* optional caller-owned scratch: split-K partials are stored there and combined by a
@@ -465,6 +469,10 @@ int stswin_multi_tensor_lars(int count, void* const* p, const void* const* g, vo
 /* ---- device self-test of the MFMA / LDS primitives the kernels are built on; writes a report into `out`
  * (fp32, >= 64 KiB) and returns the number of failed checks (0 = all good). Used by tests only. */
 int stswin_selftest(float* out, int which, void* stream);
+/* Measurement stand-in for an RCCL all-reduce of one gradient bucket as the main stream sees it (tools/overlap_proxy.py): `workgroups`
+ * workgroups of 256 threads copy src -> dst (`bytes`, 16-byte pieces) `passes` times, i.e. hold that many compute units for that long.
+ * No peer traffic; never on the product path. */
+int stswin_proxy_collective(const void* src, void* dst, long bytes, int workgroups, int passes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1796,7 +1796,7 @@ static int launch_attn(const AttnArgs& a, bool bwd, hipStream_t st) {
       if (attr8 != 0) return -attr8;
       const char* eq = getenv("STSWIN_ATTN_BWD_QPF");                        // A/B switch (read per call): 0 = the round-3 schedule
       const bool qpf = !(eq && atoi(eq) == 0);
-      int g = 256;
+      int g = stswin_cu_budget();
       if (g > grid) g = grid;
       g = (g / a.heads) * a.heads;
       if (g < a.heads) g = a.heads;
@@ -1814,7 +1814,7 @@ static int launch_attn(const AttnArgs& a, bool bwd, hipStream_t st) {
   if (bwd) {
     // persistent: as many workgroups as fit the chip at once (LDS bound), rounded so that grid * PPB is a multiple of heads
     const int per_cu = (160 * 1024) / Cfg::BWD_LDS > 0 ? (160 * 1024) / Cfg::BWD_LDS : 1;
-    int g = 256 * per_cu;
+    int g = stswin_cu_budget() * per_cu;
     int step = a.heads;                          // smallest g granularity with (g * PPB) % heads == 0
     for (int d = Cfg::PPB; d > 1; --d)
       if (Cfg::PPB % d == 0 && a.heads % d == 0) { step = a.heads / d; break; }
@@ -1997,7 +1997,7 @@ extern "C" int stswin_win_attn_bwd_f8(const void* qkv8, long ld8, const float* s
     static const int attr8 = (int)hipFuncSetAttribute((const void*)attn_bwd8_kernel<64, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::BWD_LDS);
     if (attr8 != 0) return -attr8;
     if ((long)nB_ * 128 * lddq * 2 >= 0x7FFF0000L || probs % heads) return -1201;
-    int g = 256;
+    int g = stswin_cu_budget();
     if (g > probs) g = (int)probs;
     g = (g / heads) * heads;
     if (g < heads) return -1201;
@@ -2014,7 +2014,7 @@ extern "C" int stswin_win_attn_bwd_f8(const void* qkv8, long ld8, const float* s
     if (attr != 0) return -attr;
     const int grid = (int)((probs + Cfg::PPB - 1) / Cfg::PPB);
     const int per_cu = (160 * 1024) / Cfg::BWD_LDS > 0 ? (160 * 1024) / Cfg::BWD_LDS : 1;
-    int g = 256 * per_cu, step = heads;
+    int g = stswin_cu_budget() * per_cu, step = heads;
     for (int d = Cfg::PPB; d > 1; --d)
       if (Cfg::PPB % d == 0 && heads % d == 0) { step = heads / d; break; }
     if (g > grid) g = grid;

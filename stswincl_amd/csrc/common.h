@@ -30,6 +30,9 @@ int stswin_fold_launch(const float* ws, long slab_stride, long ws_batch_stride, 
 int stswin_fold3_launch(const float* ws, long slab_stride, long ws_batch_stride, int nslabs, const int* len /* [3] */, float* const* out /* [3] */,
                         const long* obs /* [3] batch strides of the outputs */, int batch, int accumulate, hipStream_t st);
 
+// gemm.hip: compute units the persistent / one-workgroup-per-CU launches plan for (stswin_set_cu_budget; 256 by default)
+int stswin_cu_budget();
+
 // 256 B of zeros in device memory: the source of every padded / out-of-range 16-byte chunk.
 static __device__ uint4 g_stswin_zero[16];  // per-TU copy (no -fgpu-rdc); zero-initialised
 

@@ -2862,12 +2862,12 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
 #ifndef STSWIN_TUNING
   // the stream / duo / mid / half / nopipe kernels (measured slower everywhere, kept for A/B runs) exist in STSWIN_TUNING builds
   // only: the product library ignores their flags (stswin_tuning_build() tells a caller which library it has)
-  flags &= ~(GF_MID | GF_HALF | GF_STREAM | GF_NOPIPE | GF_W4R | GF_M32PP | GF_ROT | GF_DEBUG_BITS);
+  flags &= ~(GF_MID | GF_HALF | GF_DUO | GF_STREAM | GF_NOPIPE | GF_W4R | GF_M32PP | GF_ROT | GF_DEBUG_BITS);
 #endif
   const int bk = dtype == 0 ? 64 : 32;
   if (Kseg <= 0 || Kseg % bk || S <= 0) return -1001;
   if ((flags & GF_ACCUM) && !(flags & GF_OUT_F32)) return -1002;
-  if ((flags & GF_CS_SQ) && (!(flags & GF_CS_PARTIAL) || !colsum || (flags & (GF_MID | GF_HALF | GF_STREAM | GF_NOREGEPI))))
+  if ((flags & GF_CS_SQ) && (!(flags & GF_CS_PARTIAL) || !colsum || (flags & (GF_MID | GF_HALF | GF_DUO | GF_STREAM | GF_NOREGEPI))))
     return -1006;                                            // squares need the per-block table and a kernel that writes them
   if ((flags & GF_CS_PARTIAL) && colsum && ((M + 127) / 128) % 2) { // 128-row tiles never touch the last row of the [2*ceil(M/256)][N] table
     (void)hipMemsetAsync(colsum + (long)(2 * ((M + 255) / 256) - 1) * N, 0, sizeof(float) * N, (hipStream_t)stream);
@@ -2934,14 +2934,13 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
     static int once_swap = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)once_swap;
     if ((flags & GF_CS_SQ) && (!regepi || (flags & GF_NOPIPE))) return -1006;   // (only the register epilogue sums squares)
-    // "duo" (round 5, gemm_nt_ring_kernel<128, 256, 1, 4, 3, 2, 7, true>): 128x256 tiles, 4 self-pipelined waves, 72 KB of LDS - two
-    // independent workgroups per CU, one multiplying while the other runs its epilogue.  Chosen (GF_DUO from the caller, or by the rule
-    // below) for the epilogue-heavy short-K launches of the Swin MLP; see the kernel's PIPE 7 branch.
-    if (regepi && (flags & GF_DUO)
 #ifdef STSWIN_TUNING
-        && !(flags & GF_NOPIPE)
-#endif
-    ) {
+    // "duo" (round 5, gemm_nt_ring_kernel<128, 256, 1, 4, 3, 2, 7, true>): 128x256 tiles, 4 self-pipelined waves, 72 KB of LDS - two
+    // independent workgroups per CU, one multiplying while the other runs its epilogue; see the kernel's PIPE 7 branch.  Measured
+    // (profiles/r05_epi_sweep_duo.txt, r05_duo_in_step_ab.txt): 5 % faster than the 256x256 ring on the fc1 + GELU + GELU' launch in a
+    // back-to-back loop, 7-13 % slower with an R operand or a plain epilogue (two 128x256 tiles stream 1.5x the operand bytes per flop
+    // through L2: ~20 TB/s at full MFMA rate), and 0.3-1.3 % SLOWER inside the training step - a tuning build variant, not a product path.
+    if (regepi && (flags & GF_DUO) && !(flags & GF_NOPIPE)) {
       static int once_duo7 = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<128, 256, 1, 4, 3, 2, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
       (void)once_duo7;
       const long duo_tiles = (long)((M + 127) / 128) * ((N + 255) / 256);
@@ -2950,6 +2949,7 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
       STSWIN_CHECK_LAUNCH();
       return 0;
     }
+#endif
 #ifdef STSWIN_TUNING
     // persistent streaming variant: plain Linear GEMMs (S = 1, no A gather) with the register epilogue
     const bool streamk = regepi && S == 1 && !a_rows && (flags & GF_STREAM) && !(flags & (GF_NOPIPE | GF_NOSTREAM));
@@ -3162,6 +3162,20 @@ static unsigned* tn_tile_counters(int tiles, hipStream_t stream) {
   }
   return bufs[dev] + (size_t)r * PER;
 }
+// Compute units the persistent / one-workgroup-per-CU launches plan for (gemm_tn ring: tiles x splits; attention backward: persistent
+// workgroups): all of the device by default; stswin_set_cu_budget(n) lowers it to n while a communication kernel is known to hold the
+// rest (a grid of 256 on 256 - k free units runs as one round + a tail round of k workgroups).  0 restores the default.
+static std::atomic<int> g_cu_budget{0};
+extern "C" int stswin_set_cu_budget(int cus) {
+  const int old = g_cu_budget.load();
+  g_cu_budget.store(cus > 0 ? cus : 0);
+  return old;
+}
+int stswin_cu_budget() {
+  const int b = g_cu_budget.load();
+  return b > 0 ? b : 256;
+}
+
 // Process-wide switch of the fused combine: every hold (+1) turns it off until released (-1).  GradBucketReducer holds it while its
 // collectives overlap backward (stswincl_amd/dp.py).  STSWIN_TN_FUSED=0 / 1 in the environment overrides the holds (read per call).
 extern "C" int stswin_tn_fused_hold(int delta) {
@@ -3228,14 +3242,15 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   if (ring) {
     const int t256 = ((Ni + 255) / 256) * ((Nj + 255) / 256);
     const int nst = (Mk + 31) / 32;
-    int rs = splits > 0 ? splits : 256 / t256;
+    const int cus = stswin_cu_budget();               // 256 unless the caller lowered it (stswin_set_cu_budget)
+    int rs = splits > 0 ? splits : cus / t256;
     if (splits <= 0) {
       const int max_by_k = nst / 16 > 0 ? nst / 16 : 1;
       if (rs > max_by_k) rs = max_by_k;
       if (rs < 1) rs = 1;
       while (rs > 1 && workspace && (long)rs * Ni * Nj > workspace_floats) --rs;
       const long blocks = (long)t256 * rs;
-      if (blocks < 176 || (blocks > 256 && blocks % 256 != 0 && blocks % 256 < 200)) ring = false;
+      if (blocks < cus * 11 / 16 || (blocks > cus && blocks % cus != 0 && blocks % cus < cus * 25 / 32)) ring = false;
     }
     if (rs > nst) rs = nst;
     { const int per = (nst + rs - 1) / rs; rs = (nst + per - 1) / per; }   // no empty split (its slab would never be written)

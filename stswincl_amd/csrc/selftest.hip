@@ -59,6 +59,24 @@ __global__ void st_glds(float* out, const float* src) {
   for (int i = threadIdx.x; i < 512; i += 128) out[i] = buf[i];
 }
 
+// ---- a stand-in for an RCCL ring all-reduce of one gradient bucket, as the MAIN stream sees it (tools/overlap_proxy.py; round-4 verdict
+// item 5): `workgroups` workgroups of 256 threads hold their compute units for the duration of `passes` sweeps over the bucket (a plain
+// 16-byte-per-lane copy, src -> dst).  No peer traffic - what is measured is the compute-side cost of a communication kernel that sits
+// on k CUs beside the backward pass: a ring-kernel workgroup needs a whole CU (128 KB LDS, 8 waves x 256 registers), so it cannot
+// co-reside with even one such workgroup.  Measurement infrastructure only - never on the product path.
+__global__ __launch_bounds__(256) void proxy_collective_kernel(const uint4* src, uint4* dst, long n16, int passes) {
+  const long stride = (long)gridDim.x * 256;
+  for (int p = 0; p < passes; ++p)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+extern "C" int stswin_proxy_collective(const void* src, void* dst, long bytes, int workgroups, int passes, void* stream) {
+  if (!src || !dst || bytes < 16 || workgroups < 1 || passes < 1) return -1302;
+  hipLaunchKernelGGL(proxy_collective_kernel, dim3((unsigned)workgroups), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst,
+                     bytes / 16, passes);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int stswin_abi_version(void) { return 1; }
 
 extern "C" int stswin_selftest(float* out, int which, void* stream) {

@@ -61,6 +61,11 @@ def grad_dest(p: torch.Tensor, shape=None, dtype=torch.float32):
     return out
 
 
+class _Done:
+    def wait(self):
+        return None
+
+
 class GradBucketReducer:
     """Bucketed, overlapped all-reduce(mean) of parameter gradients.
 
@@ -76,10 +81,14 @@ class GradBucketReducer:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0, comm_dtype: Optional[torch.dtype] = None,
-                 group=None, overlap: bool = True):
+                 group=None, overlap: bool = True, simulate=None):
+        """simulate = (world, collective): measurement hook (tools/overlap_proxy.py) - behave like rank 0 of `world` ranks without a
+        process group; collective(msg) is enqueued on the communication stream in place of dist.all_reduce (a stand-in kernel that
+        holds compute units the way an RCCL kernel does) and returns None or an object with wait()."""
         self.params = [p for p in params if p.requires_grad]
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._simulate = simulate
+        self.world = simulate[0] if simulate is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.comm_dtype = comm_dtype
         self.overlap = overlap
         self.buckets: List[List[torch.nn.Parameter]] = []
@@ -136,7 +145,7 @@ class GradBucketReducer:
         self._accumulate_only = 0
         self.collectives = 0                      # all-reduce launches so far (tests count them)
         self.copied_bytes = 0                     # gradient bytes that had to be copied into their slices so far
-        backend = dist.get_backend(group) if dist.is_initialized() else ""
+        backend = dist.get_backend(group) if (dist.is_initialized() and simulate is None) else ""
         self._avg_op = dist.ReduceOp.AVG if backend == "nccl" else None
         if self.world > 1 and overlap:
             for p in self.params:
@@ -220,6 +229,11 @@ class GradBucketReducer:
             ctx = contextlib.nullcontext()
         with ctx:
             msg = flat if self.comm_dtype in (None, flat.dtype) else flat.to(self.comm_dtype)
+            if self._simulate is not None:                 # measurement stand-in for the collective (no peers, values unchanged)
+                self._comm[i] = msg
+                self._work[i] = self._simulate[1](msg) or _Done()
+                self.collectives += 1
+                return
             if self._avg_op is not None:                   # RCCL: the division rides in the collective (one pass less)
                 op = self._avg_op
             else:

@@ -1145,6 +1145,19 @@ def multi_tensor_lars(ps, gs, ms, norms, *, lr, momentum, wd, trust_coef, eps, f
                                             1 if adaptive else 0, st), "multi_tensor_lars")
 
 
+def proxy_collective(src: torch.Tensor, dst: torch.Tensor, workgroups: int, passes: int) -> None:
+    """Measurement stand-in for an RCCL all-reduce of a bucket (include/stswin_hip.h; tools/overlap_proxy.py): `workgroups` workgroups hold
+    their compute units while they copy src -> dst `passes` times, on the current stream."""
+    assert src.numel() * src.element_size() == dst.numel() * dst.element_size() and src.is_contiguous() and dst.is_contiguous()
+    _check(load().stswin_proxy_collective(_p(src), _p(dst), _c_long(src.numel() * src.element_size()), workgroups, passes, _stream()),
+           "proxy_collective")
+
+
+def set_cu_budget(cus: int) -> int:
+    """Compute units the one-workgroup-per-CU launches plan for (0 = the whole device); returns the previous setting."""
+    return int(load().stswin_set_cu_budget(int(cus)))
+
+
 def selftest(which: int) -> torch.Tensor:
     out = torch.zeros(16384, dtype=torch.float32, device="cuda")
     if which == 5:

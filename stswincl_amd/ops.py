@@ -192,6 +192,14 @@ def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 _UNIQ_MASKS: Dict[int, tuple] = {}
 
 
+def _duo(site: str, M: int, N: int, K: int) -> int:
+    """GF_DUO (the two-workgroups-per-CU gemm_nt of STSWIN_TUNING builds) for the named call sites: STSWIN_DUO=fc1,fc2d,...  (read per
+    call: the in-step A/B of profiles/r05_duo_in_step_ab.txt - it measured 0.3-1.3 % slower than the 256x256 ring kernel inside the
+    training step, so nothing selects it by default and the product library ignores the flag)."""
+    env = os.environ.get("STSWIN_DUO")
+    return hip.GF_DUO if (env and site in env.split(",")) else 0
+
+
 def _fused_qkv(need_bwd: bool) -> bool:
     """Whether a stage-1 Swin block runs the QKV-fused attention forward (hip.win_attn_qkv_fwd) instead of the qkv GEMM + attention
     kernel pair.  Default: in no-grad passes (momentum-key encoders, evaluation), where q | k | v then never reach memory and the
@@ -403,14 +411,15 @@ class SwinBlockFn(torch.autograd.Function):
         # no gradient wanted (the momentum-key passes of the contrastive step, evaluation): nothing is kept for a backward, and the
         # fc1 epilogue skips its second output (the GELU' tile: 268 MB and a third of the epilogue's polynomial work at stage 1)
         n2, mean2, rstd2 = hip.layernorm_fwd(x1, _f32(n2_w), _f32(n2_b), M=M, save_stats=need_bwd)
-        h = torch.empty(M, fc1_w.shape[0], dtype=dt, device=dev)
+        hid_ = fc1_w.shape[0]
+        h = torch.empty(M, hid_, dtype=dt, device=dev)
         h_pre = torch.empty_like(h) if need_bwd else None
         # out2 = gelu'(fc1 pre-activation): the backward epilogue is then a plain multiply (Phi is shared with the GELU here)
         # (STSWIN_GELU_BWD=1, A/B switch for the round-2 verdict's question: store the pre-activation instead and evaluate gelu' in
         #  the backward epilogue - one polynomial on each side instead of both here; measured slower, profiles/r03_gelu_split_ab.txt)
         gelu_bwd = os.environ.get("STSWIN_GELU_BWD") == "1"
         hip.gemm_nt(n2, wcast(fc1_w, dt), h, M=M, bias=_f32(fc1_b), out2=h_pre,
-                    flags=(hip.GF_GELU | (0 if gelu_bwd else hip.GF_C2_DGELU)) if need_bwd else hip.GF_GELU)
+                    flags=((hip.GF_GELU | (0 if gelu_bwd else hip.GF_C2_DGELU)) if need_bwd else hip.GF_GELU) | _duo("fc1" if need_bwd else "fc1ng", M, hid_, C))
         y2 = torch.empty(M, C, dtype=dt, device=dev)
         hip.gemm_nt(h, wcast(fc2_w, dt), y2, M=M, bias=_f32(fc2_b), resid=x1, flags=hip.GF_RESID)
         out, mean1, rstd1 = hip.layernorm_fwd(y2, _f32(n1_w), _f32(n1_b), M=M, save_stats=need_bwd, out=out)
@@ -455,8 +464,8 @@ class SwinBlockFn(torch.autograd.Function):
             # fc2 (+ GELU', + fc1's bias gradient from the epilogue)
             hip.gemm_tn(dy2, h, dfc2_w, Mk=M, overwrite=True)
             dh_pre = torch.empty(M, hid, dtype=dt, device=dev)
-            hip.gemm_nt(dy2, wcast(fc2_w, dt, True), dh_pre, M=M, resid=h_pre, flags=hip.GF_MUL_DGELU if ctx.gelu_bwd else hip.GF_MUL_R,
-                        colsum_out=dfc1_b)
+            hip.gemm_nt(dy2, wcast(fc2_w, dt, True), dh_pre, M=M, resid=h_pre,
+                        flags=(hip.GF_MUL_DGELU if ctx.gelu_bwd else hip.GF_MUL_R) | _duo("fc2d", M, hid, C), colsum_out=dfc1_b)
             # fc1
             hip.gemm_tn(dh_pre, n2, dfc1_w, Mk=M, overwrite=True)
             dn2 = torch.empty(M, C, dtype=dt, device=dev)
