@@ -280,6 +280,9 @@ long stswin_layernorm_bwd_scratch(int M, int C);
 /* out[i] = map[i] >= 0 ? v[map[i]] : fill, i < n: padding of per-channel parameter vectors (BatchNorm weight / bias / running
  * statistics) to the 64-aligned channel layout of the token matrices and the gather back (base18.py:60-77 concat layout). */
 int stswin_vec_gather(const float* v, const int* map, float* out, int n, float fill, void* stream);
+/* the same for `count` (<= 4) vectors that share the map, in one launch: out[k][i] = map[i] >= 0 ? v[k][map[i]] : fill[k]
+ * (v, out, fill: host arrays).  out[k] may be a parameter / buffer itself (the un-padded running statistics are written in place). */
+int stswin_vec_gather_multi(int count, const float* const* v, const int* map, float* const* out, int n, const float* fill, void* stream);
 
 /* ---- relative position bias (swin_512.py:122-131).  expand: out[w][h][j][i] = table[index[i*N + j]][h] (+ mask[w][i][j]),
  * the [key][query] layout of stswin_win_attn_fwd's biasT (nW = 1, mask = NULL: plain [heads][N][N]; with the SW-MSA mask the
@@ -444,6 +447,33 @@ long stswin_contrast_class_sums_scratch(int maps, int seg, int bank_block, int C
 int stswin_contrast_bank_dq(const float* dpos, const float* dneg, const float* cnt, const int* lq, const float* ksum, float* dq,
                             long lddq, int M, int C, int q_sets, int q_block, int seg, int bank_block, int ncls, int groups, const int* gmap,
                             void* stream);
+
+/* ---- the glue of the contrastive step (round 5; pixcontrast_18/contrast/models/PixPro_swin_v5.py): what the reference does in ~125
+ * elementwise torch launches per step.
+ * stswin_rownorm_scatter: Y[(view, sample, pixel)] = X[row] / max(||X[row]||_2, 1e-12), fp32 arithmetic, compute-dtype result
+ *   (F.normalize(proj.float(), dim=1) of PixPro._embed, :369-557) with the batched views de-interleaved: X rows are clip-major
+ *   ((sample * views + view) * HW + pixel), Y is the view-major [views][samples * HW][C] matrix the pair loss reads (its key bank /
+ *   query matrix: no NCHW permute, slice, stack or cat in between).  inv (optional) keeps 1 / norm per row for the backward:
+ *   dX = inv (dY - y (y . dY)).  C % 64 == 0, C <= 1024, R == views * samples * HW.
+ * stswin_labels_resize: `maps` (<= 8) float label maps [N][1][Hs][Ws] -> int32 lb[maps][N * h * w], nearest neighbour with ATen's index
+ *   rule (F.interpolate(mode='nearest') + .to(int32), ConsistencyLoss.forward :590-593).
+ * stswin_label_counts: cnt[m][g] = number of rows of bank block blk(m) of map gmap[set(m)][g] whose label equals lq[m] (labels clamped
+ *   to [0, ncls - 1]): the row sums of posMask (:48-57, :116-118) from per-block class histograms (hist: int scratch
+ *   [maps][seg / bank_block][ncls]).
+ * stswin_pair_loss / _bwd: loss = sum over the query sets of mean(-log(e^P / (e^P + e^N) + 1e-6)), P = sum_g pos_g / (sum_g cnt_g + 1e-6),
+ *   N = sum_g (all_g - pos_g) / (visible - cnt_g + 1e-6) (:119-129); one workgroup, fixed-order sums (deterministic); the backward gives
+ *   d loss / d pos and d loss / d (all - pos). */
+int stswin_rownorm_scatter(int dtype, const void* X, long ldx, void* Y, long ldy, float* inv, int R, int C, int views, int HW, int samples,
+                           void* stream);
+int stswin_rownorm_scatter_bwd(int dtype, const void* X, long ldx, const float* inv, const float* dY, long lddy, void* dX, long lddx, int R,
+                               int C, int views, int HW, int samples, void* stream);
+int stswin_labels_resize(const float* const* masks, int maps, int N, int Hs, int Ws, int h, int w, int* lb, void* stream);
+int stswin_label_counts(const int* lq, const int* lb, int M, int maps, int seg, int q_sets, int q_block, int bank_block, int ncls, int groups,
+                        const int* gmap, int* hist, float* cnt, void* stream);
+int stswin_pair_loss(const float* pos, const float* all, const float* cnt, int M, int groups, int q_sets, int visible, float* loss,
+                     void* stream);
+int stswin_pair_loss_bwd(const float* pos, const float* all, const float* cnt, const float* dloss, int M, int groups, int q_sets, int visible,
+                         float* dpos, float* dneg, void* stream);
 
 /* ---- f4: inference post-processing (seg18/test.py:153-158 + utils/EndoMetric.py): labels[f][y][x] = argmax_c of the
  * bilinear (align_corners = True) resize of NCHW logits [F][nc][h][w] to (H, W); with gt (int64 [F][H][W]) also

@@ -206,6 +206,59 @@ def consistency_pair_loss(pred_1, pred_2, k1, k2, a1, a2, a3, n3, m, class_num, 
     return bank_contrast_loss(q_tok, lq, bank, lb, gmap, q_block, bank_block, class_num, inv_tau, want_lse)
 
 
+class PairLossFn(torch.autograd.Function):
+    """Round 5: the whole tail of ConsistencyLoss.forward behind the projector as ONE autograd node of HIP launches -
+    F.normalize of the query embeddings, both regression_loss calls (PixPro_swin_v5.py:594-595) and every reduction between them:
+    proj_q [2 b HW][C] (clip-major token rows of the batched query pass, pre-normalisation) -> loss.  Forward: rownorm_scatter
+    (normalise + de-interleave the two views), label counts, the bank similarity kernel, the loss kernel; backward: loss derivative,
+    per-class key sums, query gradient, normalisation backward.  The reference formulation ran as ~60 torch elementwise / reduce /
+    copy launches forward and as many backward."""
+
+    @staticmethod
+    def forward(ctx, proj_q, bank, lb, cfg):
+        b, HW, q_block, bank_block, class_num, inv_tau, want_lse = cfg
+        gmap = ((1, 2, 3, 4, 5), (0, 2, 3, 4, 5))
+        X = proj_q.detach()
+        if X.stride(1) != 1:
+            X = X.contiguous()
+        q_tok = torch.empty(2 * b * HW, X.shape[1], dtype=X.dtype, device=X.device)
+        inv = hip.rownorm_scatter(X, q_tok, 2, HW, b, want_inv=True)
+        lq = lb[:2].reshape(-1)                         # (the first two maps' labels are the two query views': a view, no copy)
+        cnt = hip.label_counts(lq, lb, q_sets=2, q_block=q_block, bank_block=bank_block, ncls=class_num, gmap=gmap)
+        pos, tot, rmax, lse = hip.contrast_bank_fwd(q_tok, lq, bank, lb, q_sets=2, q_block=q_block, bank_block=bank_block, gmap=gmap,
+                                                    inv_tau=inv_tau, want_lse=want_lse)
+        loss = hip.pair_loss(pos, tot, cnt, 2, bank_block)
+        ctx.cfg = (b, HW, q_block, bank_block, class_num, gmap)
+        ctx.save_for_backward(X, inv, lq, bank, lb, cnt, pos, tot)
+        if not want_lse:
+            rmax = lse = pos.new_zeros(())
+        ctx.mark_non_differentiable(rmax, lse)
+        return loss.view(()), rmax, lse
+
+    @staticmethod
+    def backward(ctx, dloss, _dm, _dl):
+        X, inv, lq, bank, lb, cnt, pos, tot = ctx.saved_tensors
+        b, HW, q_block, bank_block, class_num, gmap = ctx.cfg
+        dpos, dneg = hip.pair_loss_bwd(pos, tot, cnt, dloss.detach().float().contiguous(), 2, bank_block)
+        ksum = hip.contrast_class_sums(bank, lb, bank_block, class_num)
+        dq = hip.contrast_bank_dq(dpos, dneg, cnt, lq, ksum, q_sets=2, q_block=q_block, seg=bank.shape[1], bank_block=bank_block, gmap=gmap)
+        return hip.rownorm_scatter_bwd(X, inv, dq, 2, HW, b), None, None, None
+
+
+def pair_loss_tokens(proj_q, bank, lb, b, HW, class_num, bank_mode="sample", inv_tau=1.0, want_lse=False):
+    """consistency_pair_loss on the token operands the batched encoder passes leave behind: proj_q = projector output of the batched
+    query pass (clip-major rows, before F.normalize), bank [6][b HW][C] = normalised key embeddings (view-major), lb int32 [6][b HW]."""
+    if bank_mode == "sample":
+        q_block = bank_block = HW
+    else:
+        if bank_mode == "world":
+            bank, lb = gather_bank(bank, lb)
+        elif bank_mode != "batch":
+            raise ValueError(f"bank_mode {bank_mode!r}")
+        q_block, bank_block = b * HW, bank.shape[1]
+    return PairLossFn.apply(proj_q, bank, lb, (b, HW, q_block, bank_block, class_num, float(inv_tau), bool(want_lse)))
+
+
 def Proj_Head(in_dim=400, inner_dim=512, out_dim=256):
     return MLP2d(in_dim, inner_dim, out_dim)
 
@@ -295,15 +348,39 @@ class PixPro(nn.Module):
         from ...optim import ema_update
         ema_update(ks, qs, m)
 
-    def _embed(self, seq, key: bool):
+    def _embed(self, seq, key: bool, tokens: bool = False):
         e1, e2, e3, p1, p2, p3, head = ((self.encoder_k_1, self.encoder_k_2, self.encoder_k_3, self.proj_k_1, self.proj_k_2,
                                          self.proj_k_3, self.projector_k) if key else
                                         (self.encoder_1, self.encoder_2, self.encoder_3, self.proj1, self.proj2, self.proj3,
                                          self.projector))
         cat, (b, h, w) = decode_tokens(e1, e2, e3, p1, p2, p3, seq)
         proj = head.forward_tokens(cat, (b, h, w), LCAT)
+        if tokens:
+            return proj, (b, h, w)
         pred = F.normalize(proj.float(), dim=1)
         return H.from_tokens(pred, b, h, w)
+
+    def forward_tokens(self, seqs):
+        """The eight encoder passes for ConsistencyLoss (round 5): -> (proj_q, bank, (b, h, w)).  proj_q [2 b h w][C]: the projector
+        output of the batched query pass (clip-major rows: clip = sample * 2 + view; carries the gradient; NOT yet normalised - the pair
+        loss normalises it in its first kernel).  bank [6][b h w][C]: the six key views' normalised embeddings, view-major - written
+        in place by one normalise-and-scatter kernel instead of normalize -> NCHW -> six strided slices -> tokens -> stack."""
+        H.refuse_replica(self)
+        hip.arena_reset(seqs[0].device)
+        b = seqs[0].shape[0]
+        with H.deferred_bn_counters():
+            xq = torch.stack(seqs[:2], 1).reshape(2 * b, *seqs[0].shape[1:])
+            with H.bn_views(2, 2 * b):
+                proj_q, (_, h, w) = self._embed(xq, False, tokens=True)
+            with torch.no_grad():
+                self._momentum_update_key_encoder()
+                xk = torch.stack(seqs, 1).reshape(6 * b, *seqs[0].shape[1:])
+                with H.bn_views(6, 6 * b):
+                    proj_k, _ = self._embed(xk, True, tokens=True)
+                C = proj_k.shape[1]
+                bank = torch.empty(6, b * h * w, C, dtype=proj_k.dtype, device=proj_k.device)
+                hip.rownorm_scatter(proj_k if proj_k.stride(1) == 1 else proj_k.contiguous(), bank.view(6 * b * h * w, C), 6, h * w, b)
+        return proj_q, bank, (b, h, w)
 
     def forward(self, seq_1, seq_2, seq_3, seq_4, seq_5, seq_6):
         # (the num_batches_tracked increments of the 8 encoder passes - 240 one-element add kernels - are applied by one
@@ -355,6 +432,14 @@ class ConsistencyLoss(nn.Module):
         self.last_rowmax = self.last_lse = None
 
     def forward(self, im_1, im_2, im_3, im_4, im_5, im_6, mask_1, mask_2, mask_3, mask_4, mask_5, mask_6):
+        if _batched_views_ok(self.pixpro) and os.environ.get("STSWIN_CONTRAST_TORCH_GLUE") != "1":
+            # token path (round 5): the embeddings never leave their token matrices and the glue between the encoders and the loss is
+            # six HIP launches (STSWIN_CONTRAST_TORCH_GLUE=1: the torch formulation below, for A/B runs and the parity test)
+            proj_q, bank, (b, hh, ww) = self.pixpro.forward_tokens((im_1, im_2, im_3, im_4, im_5, im_6))
+            lb = hip.labels_resize((mask_1, mask_2, mask_3, mask_4, mask_5, mask_6), hh, ww)
+            loss, self.last_rowmax, self.last_lse = pair_loss_tokens(proj_q, bank, lb, b, hh * ww, self.class_num, self.bank_mode,
+                                                                     self.bank_inv_tau, self.bank_stats)
+            return loss
         pred_1, pred_2, k1, k2, a1, a2, a3, n3 = self.pixpro(im_1, im_2, im_3, im_4, im_5, im_6)
         hh, ww = pred_1.shape[2:]
         m = [F.interpolate(x, size=[hh, ww], mode='nearest') for x in (mask_1, mask_2, mask_3, mask_4, mask_5, mask_6)]

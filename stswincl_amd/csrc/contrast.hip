@@ -645,3 +645,219 @@ extern "C" int stswin_contrast_bank_dq(const float* dpos, const float* dneg, con
   STSWIN_CHECK_LAUNCH();
   return 0;
 }
+
+// =====================================================================================================================
+// Round 5: the glue of the contrastive step as kernels (it was ~125 torch elementwise launches per step: F.normalize, the
+// NCHW <-> token permutes around it, view slices, stack / cat of the loss operands, six F.interpolate + casts, one_hot + sum of the
+// label counts, exp / log / mean of the loss and their autograd adds - profiles/r04_contrast_steady_state_kernels.txt).
+//   rownorm_scatter  : y = x / max(||x||_2, 1e-12) per token row in fp32 (F.normalize(proj.float(), dim=1), PixPro_swin_v5.py:_embed),
+//                      stored in the compute dtype at row (view, sample, pixel) of a view-major matrix: the [maps][N*HW][C] key bank
+//                      and the [2][N*HW][C] query matrix of the pair loss are written in place by the encoder passes' last kernel;
+//   labels_resize    : the six label maps -> int32 [maps][N*h*w], nearest neighbour (F.interpolate(mode='nearest') + .int());
+//   label_hist       : per (map, bank block) class histogram;  count_gather: cnt[m][g] = |{visible rows of group g with label lq[m]}|
+//                      (the row sums of posMask, PixPro_swin_v5.py:116-118);
+//   pair_loss fwd/bwd: P, N, -log(e^P / (e^P + e^N) + 1e-6), the per-set means and their derivatives (PixPro_swin_v5.py:119-129).
+// =====================================================================================================================
+struct RowNormArgs {
+  const void* X; long ldx;        // [R][C] token rows, clip-major: row = (sample * V + view) * HW + pixel
+  void* Y; long ldy;              // [V][b * HW][C] view-major result (compute dtype)
+  float* inv;                     // [R] 1 / max(norm, 1e-12), kept for the backward (optional)
+  const float* dY; long lddy;     // backward: fp32 gradient of Y (view-major rows)
+  void* dX; long lddx;            // backward: gradient of X (X's dtype and row order)
+  int R, C, V, HW, b;
+};
+DEVI long rn_out_row(const RowNormArgs& p, int r) {
+  const int c = r / p.HW, px = r - c * p.HW, v = c % p.V, i = c / p.V;
+  return (long)v * p.b * p.HW + (long)i * p.HW + px;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void rownorm_scatter_fwd_kernel(RowNormArgs p) {
+  const int l = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= p.R) return;
+  const T* x = (const T*)p.X + (long)r * p.ldx;
+  T* y = (T*)p.Y + rn_out_row(p, r) * p.ldy;
+  float ss = 0.f;
+  const int per = p.C >> 6;                         // elements per lane (C % 64 == 0, C <= 1024); the row is re-read in the second sweep
+  for (int e = 0; e < per; ++e) { const float v = to_f32<T>(x[l * per + e]); ss += v * v; }   // (from L1: no per-lane array, no scratch)
+  ss = wave_sum(ss);
+  const float den = fmaxf(sqrtf(ss), 1e-12f);          // x / max(||x||, eps): a division like ATen's, so the bf16 roundings agree
+  if (p.inv && l == 0) p.inv[r] = 1.0f / den;
+  for (int e = 0; e < per; ++e) y[l * per + e] = from_f32<T>(to_f32<T>(x[l * per + e]) / den);
+}
+// dx = inv * (dy - y (y . dy)),  y = x * inv in fp32 (autograd of F.normalize for norm > eps)
+template <typename T>
+__global__ __launch_bounds__(256) void rownorm_scatter_bwd_kernel(RowNormArgs p) {
+  const int l = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= p.R) return;
+  const T* x = (const T*)p.X + (long)r * p.ldx;
+  const float* dy = p.dY + rn_out_row(p, r) * p.lddy;
+  T* dx = (T*)p.dX + (long)r * p.lddx;
+  const float inv = p.inv[r];
+  const int per = p.C >> 6;
+  float dot = 0.f;
+  for (int e = 0; e < per; ++e) dot += to_f32<T>(x[l * per + e]) * inv * dy[l * per + e];
+  dot = wave_sum(dot);
+  for (int e = 0; e < per; ++e) dx[l * per + e] = from_f32<T>(inv * (dy[l * per + e] - to_f32<T>(x[l * per + e]) * inv * dot));
+}
+extern "C" int stswin_rownorm_scatter(int dtype, const void* X, long ldx, void* Y, long ldy, float* inv, int R, int C, int views, int HW,
+                                      int samples, void* stream) {
+  if (R <= 0) return 0;
+  if (C % 64 || C > 1024 || views < 1 || HW < 1 || samples < 1 || R != views * samples * HW) return -1541;
+  RowNormArgs a{X, ldx, Y, ldy, inv, nullptr, 0, nullptr, 0, R, C, views, HW, samples};
+  const dim3 grid((unsigned)((R + 3) / 4));
+  if (dtype == 0) hipLaunchKernelGGL(rownorm_scatter_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(rownorm_scatter_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int stswin_rownorm_scatter_bwd(int dtype, const void* X, long ldx, const float* inv, const float* dY, long lddy, void* dX,
+                                          long lddx, int R, int C, int views, int HW, int samples, void* stream) {
+  if (R <= 0) return 0;
+  if (C % 64 || C > 1024 || views < 1 || HW < 1 || samples < 1 || R != views * samples * HW || !inv) return -1541;
+  RowNormArgs a{X, ldx, nullptr, 0, const_cast<float*>(inv), dY, lddy, dX, lddx, R, C, views, HW, samples};
+  const dim3 grid((unsigned)((R + 3) / 4));
+  if (dtype == 0) hipLaunchKernelGGL(rownorm_scatter_bwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(rownorm_scatter_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- labels: up to 8 float label maps [N][1][S][S'] -> int32 [maps][N * h * w], nearest neighbour as F.interpolate(mode='nearest')
+// (source index = min(floor(dst * in / out), in - 1), fp32 scale like ATen), then truncation toward zero like .to(torch.int32)
+struct LabelArgs { const float* m[8]; int maps, N, Hs, Ws, h, w; int* lb; };
+__global__ __launch_bounds__(256) void labels_resize_kernel(LabelArgs p) {
+  const long per = (long)p.N * p.h * p.w;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= per * p.maps) return;
+  const int mp = (int)(idx / per);
+  const long r = idx - mp * per;
+  const int n = (int)(r / (p.h * p.w)), y = (int)((r / p.w) % p.h), x = (int)(r % p.w);
+  const float sy = (float)p.Hs / (float)p.h, sx = (float)p.Ws / (float)p.w;
+  const int ys = min((int)floorf((float)y * sy), p.Hs - 1), xs = min((int)floorf((float)x * sx), p.Ws - 1);
+  p.lb[idx] = (int)p.m[mp][((long)n * p.Hs + ys) * p.Ws + xs];
+}
+extern "C" int stswin_labels_resize(const float* const* masks /* host array of `maps` device pointers */, int maps, int N, int Hs, int Ws,
+                                    int h, int w, int* lb, void* stream) {
+  if (maps < 1 || maps > 8 || N < 1 || Hs < 1 || Ws < 1 || h < 1 || w < 1) return -1542;
+  LabelArgs a;
+  for (int i = 0; i < 8; ++i) a.m[i] = i < maps ? masks[i] : nullptr;
+  a.maps = maps; a.N = N; a.Hs = Hs; a.Ws = Ws; a.h = h; a.w = w; a.lb = lb;
+  const long n = (long)maps * N * h * w;
+  hipLaunchKernelGGL(labels_resize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+// hist[map][block][cls] = rows of the block whose label (clamped to [0, ncls - 1] like the reference's one_hot operand) is cls: integer
+// LDS atomics - exact, order-free
+__global__ __launch_bounds__(256) void label_hist_kernel(const int* lb, int seg, int bank_block, int ncls, int* hist) {
+  __shared__ int hs[64];
+  const int blk = blockIdx.x, mp = blockIdx.y, nb = seg / bank_block;
+  if (threadIdx.x < 64) hs[threadIdx.x] = 0;
+  __syncthreads();
+  const int* src = lb + (long)mp * seg + (long)blk * bank_block;
+  for (int i = threadIdx.x; i < bank_block; i += 256) atomicAdd(&hs[min(max(src[i], 0), ncls - 1)], 1);
+  __syncthreads();
+  if (threadIdx.x < ncls) hist[((long)mp * nb + blk) * ncls + threadIdx.x] = hs[threadIdx.x];
+}
+struct CountArgs { const int* lq; const int* hist; float* cnt; int M, q_sets, q_block, nb, ncls, groups; int gmap[2][CB_MAX_GROUPS]; };
+__global__ __launch_bounds__(256) void count_gather_kernel(CountArgs p) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= p.M) return;
+  const int per_set = p.M / p.q_sets, qs = m / per_set;
+  const int blk = p.nb > 1 ? (m - qs * per_set) / p.q_block : 0;
+  const int lab = min(max(p.lq[m], 0), p.ncls - 1);
+  for (int g = 0; g < p.groups; ++g) p.cnt[(long)m * p.groups + g] = (float)p.hist[((long)p.gmap[qs][g] * p.nb + blk) * p.ncls + lab];
+}
+extern "C" int stswin_label_counts(const int* lq, const int* lb, int M, int maps, int seg, int q_sets, int q_block, int bank_block, int ncls,
+                                   int groups, const int* gmap /* host [q_sets][groups] */, int* hist /* [maps][seg / bank_block][ncls] */,
+                                   float* cnt /* [M][groups] */, void* stream) {
+  if (M <= 0) return 0;
+  if (ncls < 1 || ncls > 64 || groups < 1 || groups > CB_MAX_GROUPS || q_sets < 1 || q_sets > 2 || bank_block < 1 || seg % bank_block ||
+      M % q_sets)
+    return -1543;
+  const int nb = seg / bank_block;
+  hipLaunchKernelGGL(label_hist_kernel, dim3((unsigned)nb, (unsigned)maps), dim3(256), 0, (hipStream_t)stream, lb, seg, bank_block, ncls, hist);
+  CountArgs a;
+  a.lq = lq; a.hist = hist; a.cnt = cnt; a.M = M; a.q_sets = q_sets; a.q_block = q_block; a.nb = nb; a.ncls = ncls; a.groups = groups;
+  for (int s = 0; s < 2; ++s)
+    for (int g = 0; g < CB_MAX_GROUPS; ++g) {
+      a.gmap[s][g] = (s < q_sets && g < groups) ? gmap[s * groups + g] : 0;
+      if (a.gmap[s][g] < 0 || a.gmap[s][g] >= maps) return -1543;
+    }
+  hipLaunchKernelGGL(count_gather_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- the loss of PixPro_swin_v5.py:119-129 on the masked sums: per query row
+//      P = sum_g pos_g / (sum_g cnt_g + 1e-6),  N = sum_g (all_g - pos_g) / (visible - cnt_g + 1e-6),  term = -log(e^P / (e^P + e^N) + 1e-6);
+//      loss = sum over the query sets of mean(term).  ONE workgroup: every thread adds its strided rows, the 1024 partial sums are added in
+//      a fixed tree - deterministic.  The backward writes dpos / dneg (neg = all - pos is formed here, so "dneg" multiplies (all - pos)).
+struct PairLossArgs { const float* pos; const float* all; const float* cnt; float* loss; const float* dloss; float* dpos; float* dneg; int M, groups, q_sets; float visible; };
+DEVI void pair_terms(const PairLossArgs& p, int m, float& P, float& Nn, float& csum) {
+  float ps = 0.f;
+  csum = 0.f; Nn = 0.f;
+  for (int g = 0; g < p.groups; ++g) {
+    const float c = p.cnt[(long)m * p.groups + g], po = p.pos[(long)m * p.groups + g];
+    ps += po; csum += c;
+    Nn += (p.all[(long)m * p.groups + g] - po) / ((p.visible - c) + 1e-6f);
+  }
+  P = ps / (csum + 1e-6f);
+}
+__global__ __launch_bounds__(1024) void pair_loss_fwd_kernel(PairLossArgs p) {
+  __shared__ float red[1024];
+  const int per_set = p.M / p.q_sets;
+  float total = 0.f;
+  for (int s = 0; s < p.q_sets; ++s) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < per_set; i += 1024) {
+      float P, Nn, cs;
+      pair_terms(p, s * per_set + i, P, Nn, cs);
+      const float pe = expf(P), ne = expf(Nn);
+      acc += -logf(pe / (pe + ne) + 1e-6f);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    total += red[0] / (float)per_set;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) p.loss[0] = total;
+}
+__global__ __launch_bounds__(256) void pair_loss_bwd_kernel(PairLossArgs p) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= p.M) return;
+  const int per_set = p.M / p.q_sets;
+  float P, Nn, cs;
+  pair_terms(p, m, P, Nn, cs);
+  const float pe = expf(P), ne = expf(Nn), s = pe / (pe + ne);
+  // term = -log(s + 1e-6), s = pe / (pe + ne): ds/dP = s (1 - s), ds/dN = -s (1 - s)
+  const float dterm = p.dloss[0] / (float)per_set;
+  const float ds = -dterm / (s + 1e-6f), k = s * (1.0f - s);
+  const float dP = ds * k, dN = -ds * k;
+  for (int g = 0; g < p.groups; ++g) {
+    const float c = p.cnt[(long)m * p.groups + g];
+    p.dpos[(long)m * p.groups + g] = dP / (cs + 1e-6f);
+    p.dneg[(long)m * p.groups + g] = dN / ((p.visible - c) + 1e-6f);
+  }
+}
+extern "C" int stswin_pair_loss(const float* pos, const float* all, const float* cnt, int M, int groups, int q_sets, int visible, float* loss,
+                                void* stream) {
+  if (M <= 0 || groups < 1 || q_sets < 1 || M % q_sets) return -1544;
+  PairLossArgs a{pos, all, cnt, loss, nullptr, nullptr, nullptr, M, groups, q_sets, (float)visible};
+  hipLaunchKernelGGL(pair_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int stswin_pair_loss_bwd(const float* pos, const float* all, const float* cnt, const float* dloss, int M, int groups, int q_sets,
+                                    int visible, float* dpos, float* dneg, void* stream) {
+  if (M <= 0 || groups < 1 || q_sets < 1 || M % q_sets) return -1544;
+  PairLossArgs a{pos, all, cnt, nullptr, dloss, dpos, dneg, M, groups, q_sets, (float)visible};
+  hipLaunchKernelGGL(pair_loss_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}

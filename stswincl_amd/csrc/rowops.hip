@@ -682,6 +682,14 @@ __global__ __launch_bounds__(256) void vec_gather_kernel(const float* v, const i
   if (i < n) { const int j = map[i]; out[i] = j >= 0 ? v[j] : fill; }
 }
 
+// the same for up to four vectors that share the map (a BatchNorm's weight | bias | running mean | running variance, or its two
+// parameter gradients): one launch instead of four, blockIdx.y = vector
+struct VecGatherMulti { const float* v[4]; float* out[4]; float fill[4]; const int* map; int n; };
+__global__ __launch_bounds__(256) void vec_gather_multi_kernel(VecGatherMulti p) {
+  const int i = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+  if (i < p.n) { const int j = p.map[i]; p.out[k][i] = j >= 0 ? p.v[k][j] : p.fill[k]; }
+}
+
 // ---- relative position bias (swin_512.py:122-131): table[index] -> the attention kernels' [key][query] layout, with the
 // SW-MSA mask folded in per window, and the transposed scatter of its gradient.  One launch each instead of the
 // index / permute / contiguous / add chain (6 tiny kernels per block forward, index_add_ + permute per backward).
@@ -956,6 +964,18 @@ extern "C" int stswin_bias_scatter(const float* dbiasT, const int* order, const 
 extern "C" int stswin_vec_gather(const float* v, const int* map, float* out, int n, float fill, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(vec_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, map, out, n, fill);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_vec_gather_multi(int count, const float* const* v, const int* map, float* const* out, int n, const float* fill,
+                                       void* stream) {
+  if (n <= 0 || count <= 0) return 0;
+  if (count > 4) return -1114;
+  VecGatherMulti a;
+  for (int k = 0; k < 4; ++k) { a.v[k] = k < count ? v[k] : nullptr; a.out[k] = k < count ? out[k] : nullptr; a.fill[k] = k < count ? fill[k] : 0.f; }
+  a.map = map; a.n = n;
+  hipLaunchKernelGGL(vec_gather_multi_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)count), dim3(256), 0, (hipStream_t)stream, a);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

@@ -59,6 +59,28 @@ class Layout:
             out[b:b + n] = v.detach()[a:a + n]
         return out
 
+    def pad_vecs(self, vs, fills):
+        """pad_vec of several vectors (a BatchNorm's weight | bias | running statistics) in ONE launch."""
+        vs = [v.detach() for v in vs]
+        if (self.is_identity or _TORCH_PADVEC or not all(v.is_cuda and v.dim() == 1 and v.dtype == torch.float32 and v.is_contiguous() for v in vs)
+                or len(vs) > 4):
+            return [self.pad_vec(v, f) for v, f in zip(vs, fills)]
+        return hip.vec_gather_multi(vs, self.index_map(vs[0].device), fills)
+
+    def unpad_vecs(self, vs, into=None):
+        """unpad_vec of several vectors in ONE launch; into: tensors that receive the results in place (running statistics)."""
+        ok = (not self.is_identity and not _TORCH_PADVEC and len(vs) <= 4
+              and all(v.is_cuda and v.dim() == 1 and v.dtype == torch.float32 and v.is_contiguous() for v in vs)
+              and (into is None or all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == self.logical for t in into)))
+        if not ok:
+            outs = [self.unpad_vec(v) for v in vs]
+            if into is not None:
+                for t, o in zip(into, outs):
+                    t.copy_(o)
+                return list(into)
+            return outs
+        return hip.vec_gather_multi(vs, self.position_map(vs[0].device), None, outs=into)
+
     def unpad_vec(self, v: torch.Tensor) -> torch.Tensor:
         if self.is_identity:
             return v
@@ -506,7 +528,11 @@ class BNTokFn(torch.autograd.Function):
         X = x.detach().to(dt)
         M, Cp = X.shape
         assert Cp == lay.width
-        gp, bp = lay.pad_vec(gamma), lay.pad_vec(beta)
+        fused_pad = training and world == 1 and not lay.is_identity      # weight | bias | running statistics padded in ONE launch
+        if fused_pad:
+            gp, bp, rm_p, rv_p = lay.pad_vecs([gamma, beta, running_mean, running_var], [0.0, 0.0, 0.0, 1.0])
+        else:
+            gp, bp = lay.pad_vec(gamma), lay.pad_vec(beta)
         rows_total = 0
         if training and world > 1:
             # nn.SyncBatchNorm (PixPro_swin_v5.py:215-228): batch statistics over ALL ranks.  ONE all-gather of the per-group
@@ -554,10 +580,8 @@ class BNTokFn(torch.autograd.Function):
             if lay.is_identity:
                 mean, rstd = finalize(running_mean, running_var)
             else:
-                rm, rv = lay.pad_vec(running_mean), lay.pad_vec(running_var, 1.0)
-                mean, rstd = finalize(rm, rv)
-                running_mean.copy_(lay.unpad_vec(rm))
-                running_var.copy_(lay.unpad_vec(rv))
+                mean, rstd = finalize(rm_p, rv_p)
+                lay.unpad_vecs([rm_p, rv_p], into=[running_mean, running_var])      # (one launch, straight into the buffers)
         else:
             mean = lay.pad_vec(running_mean).view(1, Cp).expand(groups, Cp).contiguous()
             rstd = torch.rsqrt(lay.pad_vec(running_var, 1.0) + eps).view(1, Cp).expand(groups, Cp).contiguous()
@@ -607,8 +631,10 @@ class BNTokFn(torch.autograd.Function):
                 s1, s2 = both[0:1], both[1:2]
             else:
                 s1, s2 = s1.sum(0, keepdim=True), s2.sum(0, keepdim=True)
-        dgamma = lay.unpad_vec(s2[0])
-        dbeta = lay.unpad_vec(s1[0])
+        if lay.is_identity:
+            dgamma, dbeta = s2[0], s1[0]
+        else:
+            dgamma, dbeta = lay.unpad_vecs([s2[0].contiguous(), s1[0].contiguous()])
         dres = dres.to(in_dtype) if has_res else None
         if dres is not None and ctx.link is not None:    # the shortcut's gradient travels to conv1's input-gradient GEMM
             ctx.link.put(dres)

@@ -743,6 +743,22 @@ def vec_gather(v: torch.Tensor, imap: torch.Tensor, fill: float = 0.0) -> torch.
     return out
 
 
+def vec_gather_multi(vs, imap: torch.Tensor, fills=None, outs=None):
+    """[out_k[i] = vs[k][imap[i]] (fills[k] where imap[i] < 0)] for up to 4 fp32 contiguous vectors sharing the map, ONE launch.
+    outs: write into these tensors (e.g. the running-statistic buffers themselves) instead of fresh ones."""
+    k, n = len(vs), imap.numel()
+    assert 1 <= k <= 4 and all(v.dtype == torch.float32 and v.is_contiguous() for v in vs)
+    if outs is None:
+        flat = torch.empty(k, (n + 15) // 16 * 16, dtype=torch.float32, device=imap.device)
+        outs = [flat[i, :n] for i in range(k)]
+    else:
+        assert len(outs) == k and all(o.dtype == torch.float32 and o.is_contiguous() and o.numel() == n for o in outs)
+    fills = list(fills) if fills is not None else [0.0] * k
+    _check(load().stswin_vec_gather_multi(k, (_c_void_p * k)(*[v.data_ptr() for v in vs]), _p(imap), (_c_void_p * k)(*[o.data_ptr() for o in outs]),
+                                          n, (_c_float * k)(*[float(f) for f in fills]), _stream()), "vec_gather_multi")
+    return outs
+
+
 def colsum(y: torch.Tensor, out_f32: torch.Tensor, M: Optional[int] = None):
     M = y.shape[0] if M is None else M
     lib = load()
@@ -1094,6 +1110,62 @@ def contrast_bank_dq(dpos, dneg, cnt, lq, ksum, *, q_sets, q_block, seg, bank_bl
     _check(load().stswin_contrast_bank_dq(_p(dpos.contiguous()), _p(dneg.contiguous()), _p(cnt.contiguous()), _p(lq), _p(ksum), _p(dq), _c_long(C), M, C,
                                           q_sets, q_block, seg, bank_block, ncls, groups, gm, _stream()), "contrast_bank_dq")
     return dq
+
+
+def rownorm_scatter(X: torch.Tensor, Y: torch.Tensor, views: int, HW: int, samples: int, want_inv: bool = False):
+    """Y[view][sample * HW + px] = normalize(X[(sample * views + view) * HW + px]) (fp32 arithmetic, Y's dtype = X's); -> inv or None."""
+    R, C = X.shape
+    assert Y.dtype == X.dtype and Y.shape == (R, C) and X.stride(1) == 1 and Y.stride(1) == 1
+    inv = torch.empty(R, dtype=torch.float32, device=X.device) if want_inv else None
+    _check(load().stswin_rownorm_scatter(_dt(X), _p(X), _c_long(X.stride(0)), _p(Y), _c_long(Y.stride(0)), _p(inv), R, C, views, HW, samples,
+                                         _stream()), "rownorm_scatter")
+    return inv
+
+
+def rownorm_scatter_bwd(X: torch.Tensor, inv: torch.Tensor, dY: torch.Tensor, views: int, HW: int, samples: int) -> torch.Tensor:
+    R, C = X.shape
+    assert dY.dtype == torch.float32 and dY.shape == (R, C) and dY.stride(1) == 1
+    dX = torch.empty(R, C, dtype=X.dtype, device=X.device)
+    _check(load().stswin_rownorm_scatter_bwd(_dt(X), _p(X), _c_long(X.stride(0)), _p(inv), _p(dY), _c_long(dY.stride(0)), _p(dX), _c_long(C), R, C,
+                                             views, HW, samples, _stream()), "rownorm_scatter_bwd")
+    return dX
+
+
+def labels_resize(masks, h: int, w: int) -> torch.Tensor:
+    """len(masks) float label maps (N, 1, Hs, Ws) -> int32 [maps][N * h * w] (nearest neighbour + truncation)."""
+    N, _, Hs, Ws = masks[0].shape
+    ms = [m.contiguous() if (m.dtype == torch.float32 and m.is_contiguous()) else m.float().contiguous() for m in masks]
+    assert all(m.shape == (N, 1, Hs, Ws) and m.is_cuda for m in ms)
+    lb = torch.empty(len(ms), N * h * w, dtype=torch.int32, device=ms[0].device)
+    arr = (_c_void_p * len(ms))(*[m.data_ptr() for m in ms])
+    _check(load().stswin_labels_resize(arr, len(ms), N, Hs, Ws, h, w, _p(lb), _stream()), "labels_resize")
+    return lb
+
+
+def label_counts(lq: torch.Tensor, lb: torch.Tensor, *, q_sets, q_block, bank_block, ncls, gmap) -> torch.Tensor:
+    """cnt fp32 [M][groups]: visible bank rows of each group whose label equals the query's."""
+    M, (maps, seg), groups = lq.numel(), lb.shape, len(gmap[0])
+    hist = torch.empty(maps, seg // bank_block, ncls, dtype=torch.int32, device=lq.device)
+    cnt = torch.empty(M, groups, dtype=torch.float32, device=lq.device)
+    gm = (_c_int * (q_sets * groups))(*[int(v) for row in gmap for v in row])
+    _check(load().stswin_label_counts(_p(lq), _p(lb), M, maps, seg, q_sets, q_block, bank_block, ncls, groups, gm, _p(hist), _p(cnt), _stream()),
+           "label_counts")
+    return cnt
+
+
+def pair_loss(pos, tot, cnt, q_sets: int, visible: int) -> torch.Tensor:
+    M, groups = pos.shape
+    loss = torch.empty(1, dtype=torch.float32, device=pos.device)
+    _check(load().stswin_pair_loss(_p(pos), _p(tot), _p(cnt), M, groups, q_sets, visible, _p(loss), _stream()), "pair_loss")
+    return loss
+
+
+def pair_loss_bwd(pos, tot, cnt, dloss, q_sets: int, visible: int):
+    M, groups = pos.shape
+    dpos, dneg = torch.empty_like(pos), torch.empty_like(pos)
+    _check(load().stswin_pair_loss_bwd(_p(pos), _p(tot), _p(cnt), _p(dloss), M, groups, q_sets, visible, _p(dpos), _p(dneg), _stream()),
+           "pair_loss_bwd")
+    return dpos, dneg
 
 
 def upsample_argmax(logits, H, W, gt=None):

@@ -3,9 +3,11 @@ import types
 
 import pytest
 import torch
+import torch.nn.functional as F
 
 import golden_util as gu
 from oracle import stswin_oracle as O
+from stswincl_amd import hip
 from stswincl_amd.contrast.models import PixPro_swin_v5 as P
 
 pytestmark = pytest.mark.gpu
@@ -155,3 +157,94 @@ def test_consistency_loss_non_square_256x448():
     loss.backward()
     gs = [p.grad for p in net.pixpro.parameters() if p.requires_grad and p.grad is not None]
     assert len(gs) > 100 and all(torch.isfinite(g).all() for g in gs)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 5: the glue between the encoders and the similarity kernel as HIP launches (rownorm_scatter, labels_resize, label_counts,
+# pair_loss) - each against the torch formulation it replaces, then the whole token path against the torch-glue path.
+@pytest.mark.parametrize("dtype,views,b,hw,c", [(torch.float32, 2, 3, 40, 256), (torch.bfloat16, 6, 2, 64, 256), (torch.bfloat16, 1, 5, 17, 128)])
+def test_rownorm_scatter_is_normalize_plus_view_deinterleave(dtype, views, b, hw, c):
+    torch.manual_seed(views + b)
+    R = views * b * hw
+    x = (torch.randn(R, c, device="cuda") * 3).to(dtype)
+    x[5] = 0                                                 # a zero row: x / max(0, 1e-12) = 0, no NaN
+    y = torch.empty(R, c, dtype=dtype, device="cuda")
+    inv = hip.rownorm_scatter(x, y, views, hw, b, want_inv=True)
+    xr = x.float().requires_grad_(True)
+    ref = F.normalize(xr, dim=1)                             # [clip = sample * views + view][px]
+    ref_v = ref.view(b, views, hw, c).permute(1, 0, 2, 3).reshape(R, c)
+    assert torch.equal(y, ref_v.to(dtype)), float((y.float() - ref_v).abs().max())
+    dy = torch.randn(R, c, device="cuda")
+    ref_v.backward(dy)
+    dx = hip.rownorm_scatter_bwd(x, inv, dy, views, hw, b)
+    assert dx.dtype == dtype
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert float((dx.float() - xr.grad).abs().max()) <= tol * float(xr.grad.abs().max())
+    assert float(dx[5].abs().max()) < 1e30 and bool(torch.isfinite(dx).all())
+
+
+def test_labels_resize_and_counts_match_the_torch_formulation():
+    torch.manual_seed(3)
+    N, S, h = 3, 64, 8
+    masks = [torch.randint(0, 12, (N, 1, S, S + 16), device="cuda").float() for _ in range(6)]
+    masks[2][0, 0, :8] = 13.0                                # a label beyond class_num - 1: clamped in the counts like one_hot's operand
+    lb = hip.labels_resize(masks, h, h + 2)
+    ref = torch.stack([F.interpolate(m, size=[h, h + 2], mode="nearest").reshape(-1).to(torch.int32) for m in masks], 0)
+    assert torch.equal(lb, ref)
+    HW = h * (h + 2)
+    gmap = [[1, 2, 3, 4, 5], [0, 2, 3, 4, 5]]
+    lq = torch.cat([lb[0], lb[1]], 0).contiguous()
+    for q_block, bank_block in ((HW, HW), (N * HW, N * HW)):
+        cnt = hip.label_counts(lq, lb, q_sets=2, q_block=q_block, bank_block=bank_block, ncls=12, gmap=gmap)
+        ref_cnt = P._label_counts(lq, lb, gmap, 2, q_block, bank_block, 12)
+        assert torch.equal(cnt, ref_cnt)
+
+
+@pytest.mark.parametrize("M,groups,visible", [(2 * 512, 5, 300), (2 * 4096, 5, 1024), (2 * 7, 3, 9)])
+def test_pair_loss_kernel_forward_and_backward(M, groups, visible):
+    torch.manual_seed(M)
+    cnt = torch.randint(0, visible + 1, (M, groups), device="cuda").float()
+    cnt[0] = 0.0                                             # empty positive sets
+    cnt[1] = float(visible)                                  # empty negative sets
+    pos = (torch.randn(M, groups, device="cuda") * cnt * 0.3).requires_grad_(True)
+    neg = (torch.randn(M, groups, device="cuda") * (visible - cnt) * 0.3).requires_grad_(True)
+    Pp = pos.sum(-1) / (cnt.sum(-1) + 1e-6)
+    Nn = (neg / ((visible - cnt) + 1e-6)).sum(-1)
+    pe, ne = torch.exp(Pp), torch.exp(Nn)
+    ref = (-torch.log(pe / (pe + ne) + 1e-6)).view(2, -1).mean(1).sum()
+    ref.backward()
+    tot = (pos + neg).detach()
+    loss = hip.pair_loss(pos.detach(), tot, cnt, 2, visible)
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref)) + 1e-7
+    assert torch.equal(loss, hip.pair_loss(pos.detach(), tot, cnt, 2, visible))          # fixed-order sums
+    dpos, dneg = hip.pair_loss_bwd(pos.detach(), tot, cnt, torch.ones(1, device="cuda"), 2, visible)
+    assert float((dpos - pos.grad).abs().max()) <= 1e-5 * float(pos.grad.abs().max()) + 1e-12
+    assert float((dneg - neg.grad).abs().max()) <= 1e-5 * float(neg.grad.abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize("bank", ["sample", "batch"])
+def test_token_path_of_the_consistency_loss_equals_the_torch_glue_path(bank, monkeypatch):
+    """ConsistencyLoss.forward through the token path (one normalise-and-scatter launch per encoder pass, labels / counts / loss
+    kernels: PairLossFn) against the same module with the torch formulation of the glue (STSWIN_CONTRAST_TORCH_GLUE=1): same loss to
+    fp32 rounding, same gradients to bf16 rounding of the projector output's gradient, and far fewer torch launches."""
+    a = _args()
+    a.pixpro_bank = bank
+    a.pixpro_bank_stats = True
+    g = gu.load("consistency.npz")
+    hh, ww = [int(v) for v in g["hw"]]
+    ims = [gu.det_tensor(f"consistency/im{i}", (2, 4, 3, hh, ww)).cuda() for i in range(6)]
+    masks = [torch.floor(gu.det_tensor(f"consistency/mask{i}", (2, 1, hh // 8, ww // 8), "uniform", 12.0))
+             .clamp(0, 11).repeat_interleave(8, 2).repeat_interleave(8, 3).cuda() for i in range(6)]
+    res = {}
+    for glue in ("1", "0"):
+        monkeypatch.setenv("STSWIN_CONTRAST_TORCH_GLUE", glue)
+        torch.manual_seed(0)
+        net = P.ConsistencyLoss(a, input_resolution=(hh // 8, ww // 8)).cuda().train()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = net(*ims, *masks)
+        loss.backward()
+        res[glue] = (float(loss), net.pixpro.projector.linear2.weight.grad.clone(), None, net.last_lse.clone(), net.last_rowmax.clone())
+    assert abs(res["0"][0] - res["1"][0]) <= 2e-6 * abs(res["1"][0]), (res["0"][0], res["1"][0])
+    assert rel(res["0"][1], res["1"][1]) < 2e-3
+    # the (query, map) rows of the monitoring outputs are ordered the same way in both paths
+    assert torch.allclose(res["0"][3], res["1"][3], rtol=1e-5, atol=1e-5) and torch.allclose(res["0"][4], res["1"][4], rtol=1e-5, atol=1e-5)
