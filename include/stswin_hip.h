@@ -290,6 +290,10 @@ int stswin_vec_gather_multi(int count, const float* const* v, const int* map, fl
  * table / dtable fp32 [(2ws-1)^2][heads], index int64 [N*N] (the module's relative_position_index buffer). */
 int stswin_bias_expand(const float* table, const long* index, const float* mask, float* out, int N, int heads, int nW,
                        void* stream);
+/* the same for `count` (<= 16) tables in one launch (host arrays of device pointers / sizes; mask[e] may be NULL): every Swin block's
+ * table right after an optimizer step instead of one launch per block forward */
+int stswin_bias_expand_multi(int count, const float* const* table, const long* const* index, const float* const* mask, float* const* out,
+                             const int* N, const int* heads, const int* nW, void* stream);
 /* scatter in gather form (no atomics: thread (table row e, head h) adds the pairs of row e in a fixed order).  order int32 [N*N] =
  * the pairs i*N + j sorted by index[i*N + j] (stable), offs int32 [table_rows + 1] = start of every table row's range in it
  * (table_rows = (2ws-1)^2); both are functions of the index buffer alone (stswincl_amd/hip.py caches them per buffer).

@@ -704,6 +704,22 @@ __global__ __launch_bounds__(256) void bias_expand_kernel(const float* table, co
     out[t] = v;
   }
 }
+// the same for up to 16 tables at once (every Swin block's table after an optimizer step: ops.repack), blockIdx.y = table
+#define BEM_MAX 16
+struct BiasExpandMulti { const float* table[BEM_MAX]; const long* index[BEM_MAX]; const float* mask[BEM_MAX]; float* out[BEM_MAX];
+                         int N[BEM_MAX], heads[BEM_MAX], nW[BEM_MAX]; };
+__global__ __launch_bounds__(256) void bias_expand_multi_kernel(BiasExpandMulti p) {
+  const int e = blockIdx.y, N = p.N[e], heads = p.heads[e];
+  const float* table = p.table[e]; const long* index = p.index[e]; const float* mask = p.mask[e]; float* out = p.out[e];
+  const long n = (long)p.nW[e] * heads * N * N;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
+    const int i = (int)(t % N), j = (int)((t / N) % N);
+    const int h = (int)((t / ((long)N * N)) % heads), w = (int)(t / ((long)N * N * heads));
+    float v = table[index[(long)i * N + j] * heads + h];
+    if (mask) v += mask[((long)w * N + i) * N + j];
+    out[t] = v;
+  }
+}
 // Gradient of the gather, in gather form (deterministic: no atomics).  `order` lists the (query i, key j) pairs (as i * N + j) sorted
 // by their table row, `offs[e] .. offs[e + 1]` is row e's range (both built once per relative_position_index buffer by the
 // caller): thread (e, h) adds its <= N pairs in list order.  nslabs > 1: dbiasT is [nslabs][heads][N][N] and the slabs are added on
@@ -948,6 +964,24 @@ extern "C" int stswin_bias_expand(const float* table, const long* index, const f
   const long n = (long)nW * heads * N * N;
   hipLaunchKernelGGL(bias_expand_kernel, dim3((unsigned)min(2048L, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table,
                      index, mask, out, N, heads, nW);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int stswin_bias_expand_multi(int count, const float* const* table, const long* const* index, const float* const* mask,
+                                        float* const* out, const int* N, const int* heads, const int* nW, void* stream) {
+  if (count <= 0) return 0;
+  if (count > BEM_MAX) return -1108;
+  BiasExpandMulti a;
+  long most = 0;
+  for (int e = 0; e < BEM_MAX; ++e) {
+    const int s = e < count ? e : 0;
+    if (N[s] <= 0 || heads[s] <= 0 || nW[s] <= 0) return -1108;
+    a.table[e] = table[s]; a.index[e] = index[s]; a.mask[e] = mask[s]; a.out[e] = out[s]; a.N[e] = N[s]; a.heads[e] = heads[s]; a.nW[e] = nW[s];
+    const long n = (long)nW[s] * heads[s] * N[s] * N[s];
+    if (n > most) most = n;
+  }
+  hipLaunchKernelGGL(bias_expand_multi_kernel, dim3((unsigned)min(256L, (most + 255) / 256), (unsigned)count), dim3(256), 0, (hipStream_t)stream, a);
   STSWIN_CHECK_LAUNCH();
   return 0;
 }

@@ -808,6 +808,17 @@ def bias_expand(table, index, mask, N, heads):
     return out
 
 
+def bias_expand_multi(entries) -> None:
+    """entries: [(table, index, mask or None, out, N, heads)] - bias_expand of every entry into its existing `out`, 16 per launch."""
+    lib, st = load(), _stream()
+    for lo in range(0, len(entries), 16):
+        ch = entries[lo:lo + 16]
+        k = len(ch)
+        arr = lambda i: (_c_void_p * k)(*[(e[i].data_ptr() if e[i] is not None else 0) for e in ch])   # noqa: E731
+        _check(lib.stswin_bias_expand_multi(k, arr(0), arr(1), arr(2), arr(3), (_c_int * k)(*[e[4] for e in ch]), (_c_int * k)(*[e[5] for e in ch]),
+                                            (_c_int * k)(*[(e[2].shape[0] if e[2] is not None else 1) for e in ch]), st), "bias_expand_multi")
+
+
 def scatter_lists(index: torch.Tensor, table_rows: int):
     """(order, offs) of stswin_bias_scatter for an index buffer: the pairs i * N + j sorted (stably) by their table row and the start of
     every row's range.  Three small torch kernels, no host sync; callers that scatter through the same index every step keep the

@@ -128,6 +128,17 @@ def repack(params) -> int:
         conv.setdefault(key[1], []).append((p.detach(), fwd, dg, omap, imap))
         headops._CW[key] = (ref, (p._version, p.data_ptr(), tuple(p.shape)), fwd, dg, omap, imap)
     n = 0
+    bias = []
+    for key, hit in _BIAS_TABLES.items():
+        p = ids.get(key)
+        if p is None or hit[0]() is not p:
+            continue
+        _, stamp, out, idx, umask = hit
+        bias.append((p.detach(), idx, umask, out, stamp[4], stamp[5]))
+        hit[1] = (p._version,) + tuple(stamp[1:])
+    if bias:
+        hip.bias_expand_multi(bias)
+        n += len(bias)
     for dt, entries in lin.items():
         hip.linear_pack_multi(entries, dt)
         n += len(entries)
@@ -144,6 +155,7 @@ def clear_caches() -> None:
     _SCATTER.clear()
     _WCACHE.clear()
     _UNIQ_MASKS.clear()
+    _BIAS_TABLES.clear()
     from . import headops
     headops._CW.clear()
 
@@ -155,10 +167,13 @@ def invalidate_weights(module: Optional[torch.nn.Module] = None) -> None:
     write that happens once the model has run.  stswincl_amd's own optimizers / EMA / checkpoint loaders do it themselves."""
     if module is None:
         _WCACHE.clear()
+        _BIAS_TABLES.clear()
     else:
         ids = {id(p) for p in module.parameters()}
         for k in [k for k in _WCACHE if k[0] in ids]:
             del _WCACHE[k]
+        for k in [k for k in _BIAS_TABLES if k in ids]:
+            del _BIAS_TABLES[k]
     from . import headops
     headops._CW.clear()
 
@@ -226,6 +241,30 @@ def unique_windows(attn_mask: torch.Tensor):
         hit = (weakref.ref(attn_mask), stamp, u.reshape(-1, *attn_mask.shape[1:]).contiguous(), inv.to(torch.int32).contiguous())
         _UNIQ_MASKS[id(attn_mask)] = hit
     return hit[2], hit[3]
+
+
+_BIAS_TABLES: Dict[int, list] = {}
+_BIAS_CACHE = os.environ.get("STSWIN_NO_BIAS_CACHE") != "1"        # (A/B switch: one bias_expand launch per block forward)
+
+
+def bias_table(table: torch.Tensor, index: torch.Tensor, umask, N: int, heads: int) -> torch.Tensor:
+    """hip.bias_expand(table[index] (+ mask)) of a Swin block, cached per table PARAMETER until it changes (version counter, like
+    wcast) - and re-made for every cached table at once by repack() right after an optimizer step / EMA update (one launch for the
+    12 blocks of the model instead of one per block forward)."""
+    t32 = _f32(table)
+    idx = index.reshape(-1).contiguous()
+    if not (_BIAS_CACHE and isinstance(table, torch.nn.Parameter) and table.is_cuda and table.dtype == torch.float32 and table.is_contiguous()):
+        return hip.bias_expand(t32, idx, umask, N, heads)
+    stamp = (table._version, table.data_ptr(), umask.data_ptr() if umask is not None else 0, idx.data_ptr(), N, heads)
+    hit = _BIAS_TABLES.get(id(table))
+    if hit is None or hit[0]() is not table or hit[1] != stamp:
+        out = hip.bias_expand(t32, idx, umask, N, heads)
+        if len(_BIAS_TABLES) > 1024:
+            for k_ in [k_ for k_, v in _BIAS_TABLES.items() if v[0]() is None]:
+                del _BIAS_TABLES[k_]
+        hit = [weakref.ref(table), stamp, out, idx, umask]
+        _BIAS_TABLES[id(table)] = hit
+    return hit[2]
 
 
 def expand_bias_T(table: torch.Tensor, index: torch.Tensor, N: int, heads: int) -> torch.Tensor:
@@ -380,7 +419,7 @@ class SwinBlockFn(torch.autograd.Function):
         # ... and the SW-MSA mask has only four distinct window patterns (interior / last column / last row / corner), so the
         # table holds one slot per pattern (4 MB instead of 64 MB at stage 1: L2 resident) and a window -> slot index
         umask, bidx = unique_windows(attn_mask) if shift > 0 and attn_mask is not None else (None, None)
-        biasT = hip.bias_expand(_f32(table), index.reshape(-1).contiguous(), umask, N, heads)
+        biasT = bias_table(table, index, umask, N, heads)
         need_bwd = any(ctx.needs_input_grad)
         fp8 = dt == torch.bfloat16 and os.environ.get("STSWIN_FP8_ATTN") == "1"
         if (_fused_qkv(need_bwd) and dt == torch.bfloat16 and not fp8 and T * N == 128 and d == 128 and C in (256, 512, 1024)
