@@ -60,6 +60,13 @@ enum {
 #define STSWIN_DBG(flags, bit) false
 #endif
 enum { GF_DEBUG_BITS = (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) };
+#ifdef STSWIN_TUNING
+static __device__ int g_dbg_stagger[2] = {8, 0};     // stagger experiment (flag bit 17): phases, 100 MHz ticks per phase (0: (nt + 4) / 8 us)
+extern "C" int stswin_debug_set_stagger(int phases, int ticks) {
+  const int v[2] = {phases, ticks};
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stagger), v, sizeof(v));
+}
+#endif
 
 struct GemmNT {
   const void* A; long lda; const int* a_rows;
@@ -585,10 +592,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   // Stagger (flag bit 17): the first round's workgroups start up to 7/8 of a tile time apart (8 phases among the CUs of an
   // XCD).  All 256 CUs otherwise run in lock-step and their C stores (128 KB each: 32 MB per round, more than the L2s hold)
   // leave as one burst; the next tile's first loads queue behind the CU's own share of that HBM write drain.
-  if (STSWIN_DBG(p.flags, 17) && blockIdx.x < 256) {
-    const unsigned long long t_go = wall_clock64() + (unsigned long long)(((blockIdx.x >> 3) & 7) * (nt + 4) * 100 / 8);
+#ifdef STSWIN_TUNING
+  if (STSWIN_DBG(p.flags, 17) && blockIdx.x < 256) {   // (phases / ticks per phase: stswin_debug_set_stagger, tools/stagger_ab2.py)
+    const int ph = g_dbg_stagger[0] > 0 ? g_dbg_stagger[0] : 8, tk = g_dbg_stagger[1] > 0 ? g_dbg_stagger[1] : (nt + 4) * 100 / 8;
+    const unsigned long long t_go = wall_clock64() + (unsigned long long)(((blockIdx.x >> 3) % ph) * tk);
     while (wall_clock64() < t_go) __builtin_amdgcn_s_sleep(8);
   }
+#endif
   stamp(0);
   auto epilogue = [&]() {
     if (STSWIN_DBG(p.flags, 21)) {    // DBG: no epilogue at all (keeps the accumulators alive)

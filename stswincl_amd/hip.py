@@ -182,6 +182,13 @@ def zeros(*shape, device) -> torch.Tensor:
 _SCRATCH = {}
 _SCRATCH_RETIRED = []        # superseded (smaller) scratch blocks: see scratch()
 _DEFER = [False, 0]          # [folds are being queued (deferred_folds), bump offset into the scratch buffer]
+_CAPTURED = [False]          # a hipGraph capture has happened in this process (note_capture)
+
+
+def note_capture() -> None:
+    """Tell the scratch allocator that a hipGraph has been (or is being) captured: from now on superseded scratch blocks are retired,
+    not freed (a captured kernel node keeps the address it was captured with).  scratch() also sets it when it sees a capture."""
+    _CAPTURED[0] = True
 
 
 def scratch(device, floats: int) -> torch.Tensor:
@@ -191,6 +198,8 @@ def scratch(device, floats: int) -> torch.Tensor:
     floats = (int(floats) + 63) // 64 * 64
     t = _SCRATCH.get(device)
     off = _DEFER[1] if _DEFER[0] else 0
+    if not _CAPTURED[0] and device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        _CAPTURED[0] = True
     if t is None or t.numel() < off + floats:
         if _DEFER[0] and off > 0:            # queued folds still read the regions handed out so far: run them, then start over
             _check(load().stswin_fold_flush(_stream()), "fold_flush")
@@ -198,11 +207,14 @@ def scratch(device, floats: int) -> torch.Tensor:
         if t is None or t.numel() < floats:
             if t is not None and torch.cuda.is_current_stream_capturing():
                 raise StswinHipError("scratch buffer would have to grow during a hipGraph capture: run the step once before capturing")
-            if t is not None:
+            if t is not None and _CAPTURED[0]:
                 # A hipGraph captured earlier may still write and read the old block on every replay (its address is baked into the
-                # graph's kernel arguments): superseded blocks are kept alive, never handed back to the caching allocator
+                # graph's kernel arguments): superseded blocks are kept alive, never handed back to the caching allocator - but only
+                # once a capture has happened in this process (note_capture(), called by whoever captures: bench.py, the tests);
+                # before that nothing can refer to the old block and it is simply freed (round-4 advisor)
                 _SCRATCH_RETIRED.append(t)
-            t = torch.empty(max(floats, 1 << 23), dtype=torch.float32, device=device)
+            # geometric growth: a run of increasing requests re-allocates O(log) times and retains at most ~2x the final size
+            t = torch.empty(max(floats, 2 * (t.numel() if t is not None else 0), 1 << 23), dtype=torch.float32, device=device)
             _SCRATCH[device] = t
     if _DEFER[0]:
         _DEFER[1] = off + floats

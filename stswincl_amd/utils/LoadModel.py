@@ -39,13 +39,25 @@ def _torch_load(path, map_location, trusted=None):
     import pickle
     if trusted is None:
         trusted = os.environ.get("STSWIN_TRUST_CHECKPOINTS") == "1"
-    # what the safe unpickler raises: UnpicklingError for a refused global; RuntimeError / AttributeError / ModuleNotFoundError / EOFError
-    # for legacy (non-zip, tar) files and classes that are not importable here
-    refused = (pickle.UnpicklingError, RuntimeError, AttributeError, ModuleNotFoundError, EOFError)
+    # Only a REFUSAL of the safe unpickler takes the fallback / gets the "refused" message: UnpicklingError (a global that is not on the
+    # allow-list), or one of the errors it raises for legacy formats and classes that cannot be imported here - recognised by their
+    # message.  Anything else (a truncated or corrupt file, a map_location / device error, an I/O error) is re-raised unchanged: retrying
+    # it with the unrestricted unpickler would run the file's code for nothing, and calling it "refused" would send the user to
+    # STSWIN_TRUST_CHECKPOINTS=1 for a problem that flag cannot fix (round-4 advisor).
+    def is_refusal(e: BaseException) -> bool:
+        if isinstance(e, pickle.UnpicklingError):
+            return True
+        msg = str(e)
+        hints = ("weights_only", "Weights only", "Unsupported global", "unsupported global", "legacy", "torch.serialization.add_safe_globals",
+                 "safe_globals", "was not an allowed global", "Can't get attribute", "No module named")
+        return isinstance(e, (RuntimeError, AttributeError, ModuleNotFoundError)) and any(h in msg for h in hints)
+
     try:
         with torch.serialization.safe_globals([argparse.Namespace]):
             return torch.load(path, map_location=map_location, weights_only=True)
-    except refused as e:
+    except (pickle.UnpicklingError, RuntimeError, AttributeError, ModuleNotFoundError) as e:
+        if not is_refusal(e):
+            raise
         if trusted:
             return torch.load(path, map_location=map_location, weights_only=False)
         raise pickle.UnpicklingError(

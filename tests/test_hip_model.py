@@ -193,9 +193,15 @@ def test_fused_adam_steps_reach_the_gemm_weight_cache():
         assert next(m.swin.parameters())._version > v0
         losses[name] = ls
     assert losses["fused"][1] != losses["fused"][0], "the second step must see the updated weights"
-    # (Adam divides by sqrt(v): with atomically summed gradients the two runs drift apart by ~1e-3 per step - loose bound)
-    for a, b in zip(losses["fused"], losses["torch"]):
-        assert abs(a - b) < 3e-2 * abs(b), (losses["fused"], losses["torch"])
+    # Both runs are bitwise reproducible (no atomics anywhere since round 3) and see the same first-step gradients, so the first loss
+    # is EQUAL; afterwards the two optimizers round differently (the fused kernel multiplies by precomputed 1 / bias-correction
+    # factors, torch.optim.Adam divides: last-bit differences of the updates), which the untrained 50-layer network with train-mode
+    # BatchNorm amplifies per step - measured 2e-6 / 4e-5 after one / two updates; 1e-3 leaves the amplification room and still
+    # catches a stale weight cache (the loss then does not move at all) or a wrong bias correction (1e-1).
+    print("losses fused", losses["fused"], "torch", losses["torch"])
+    assert losses["fused"][0] == losses["torch"][0], (losses["fused"], losses["torch"])
+    for a, b in zip(losses["fused"][1:], losses["torch"][1:]):
+        assert abs(a - b) < 1e-3 * abs(b), (losses["fused"], losses["torch"])
 
 
 @pytest.mark.parametrize("opt_name", ["torch", "fused"])
