@@ -484,6 +484,20 @@ def main():
                 sec = contrast_run(a, ctx, a.secondary_steps, 3, 0, eager=True)
                 res["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype")}
                 res["secondary"]["config"] = sec["config"]
+                # BASELINE configs[3]'s own mode - the inter-video key bank (every sample of the rank: 8192 entries per key map at
+                # 8 clips; `world`: all-gathered over the ranks) - on the driver's line too: a short eager run, the similarity kernel
+                # timed live (every launch of it: hip._PROFILE_ALWAYS)
+                del sec
+                gc.collect()
+                torch.cuda.empty_cache()
+                hip.arena_reset()
+                bank_mode = "world" if ctx.world > 1 else "batch"
+                secb = contrast_run(a, ctx, 8, 2, 9, bank=bank_mode, eager=True)
+                res["secondary"]["bank"] = {"mode": bank_mode, "value": secb["value"], "unit": secb["unit"], "steps": secb["steps"],
+                                            "ms_per_step": secb["ms_per_step"],
+                                            "bank_entries_per_key_map": secb["config"]["bank_entries_per_key_map"],
+                                            "roofline": {k: secb["roofline"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}
+                                            if "roofline" in secb else None}
             except Exception as e:     # noqa: BLE001
                 res["secondary"] = {"error": f"{type(e).__name__}: {e}"[:400]}
         if ctx.world == 1 and not a.no_cpu_baseline and ctx.rank == 0:

@@ -439,6 +439,13 @@ int stswin_contrast_bank_fwd(int dtype, const void* Q, long ldq, const int* lq, 
                              const void* bank, long ldb, const int* lb, int maps, int seg, int bank_block, int groups,
                              const int* gmap /* host memory, [q_sets][groups] */, float inv_tau, float* pos, float* all,
                              float* rowmax, float* lse, float* workspace, long workspace_floats, void* stream);
+/* The same for L2-NORMALISED query and bank rows (the embeddings ConsistencyLoss feeds it: F.normalize, PixPro_swin_v5.py:369-557):
+ * |S| <= 1, so rowmax / lse are formed with inv_tau as a FIXED reference point of the sum of exponentials - one fma + one exponential
+ * per score instead of a running maximum with rescaling (same values to fp32 rounding; the caller guarantees the norms). */
+int stswin_contrast_bank_fwd_unit(int dtype, const void* Q, long ldq, const int* lq, int M, int C, int q_sets, int q_block,
+                             const void* bank, long ldb, const int* lb, int maps, int seg, int bank_block, int groups,
+                             const int* gmap /* host memory, [q_sets][groups] */, float inv_tau, float* pos, float* all,
+                             float* rowmax, float* lse, float* workspace, long workspace_floats, void* stream);
 /* Backward to the queries (keys are no-grad, PixPro_swin_v5.py:366): the masked sums are linear in the scores, so
  * dq[m] = sum_g dpos[m][g] Kcls[map(g)][blk][lq[m]] + dneg[m][g] (Ktot[map(g)][blk] - Kcls[..][lq[m]]), where dpos / dneg are the
  * gradients of pos and of neg = all - pos.  class_sums writes ksum [maps][seg / bank_block][ncls + 1][C] fp32 (slot ncls = all

@@ -225,8 +225,9 @@ class PairLossFn(torch.autograd.Function):
         inv = hip.rownorm_scatter(X, q_tok, 2, HW, b, want_inv=True)
         lq = lb[:2].reshape(-1)                         # (the first two maps' labels are the two query views': a view, no copy)
         cnt = hip.label_counts(lq, lb, q_sets=2, q_block=q_block, bank_block=bank_block, ncls=class_num, gmap=gmap)
+        # (unit_rows: both operands were normalised by rownorm_scatter - the log-sum-exp takes the fixed-reference form)
         pos, tot, rmax, lse = hip.contrast_bank_fwd(q_tok, lq, bank, lb, q_sets=2, q_block=q_block, bank_block=bank_block, gmap=gmap,
-                                                    inv_tau=inv_tau, want_lse=want_lse)
+                                                    inv_tau=inv_tau, want_lse=want_lse, unit_rows=True)
         loss = hip.pair_loss(pos, tot, cnt, 2, bank_block)
         ctx.cfg = (b, HW, q_block, bank_block, class_num, gmap)
         ctx.save_for_backward(X, inv, lq, bank, lb, cnt, pos, tot)

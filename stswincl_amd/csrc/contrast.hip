@@ -369,7 +369,19 @@ __global__ __launch_bounds__(512, 2) void contrast_bank_kernel(BankArgs p) {
             pall[e] += (v0 + v1) + (v2 + v3);
             ppos[e] += ((lrow[e] == lcol[0] ? v0 : 0.f) + (lrow[e] == lcol[1] ? v1 : 0.f)) +
                        ((lrow[e] == lcol[2] ? v2 : 0.f) + (lrow[e] == lcol[3] ? v3 : 0.f));
-            if (p.want_lse) {
+            if (p.want_lse == 2) {
+              // unit-norm rows (stswin_contrast_bank_fwd_unit): |score| <= 1, so inv_tau is an upper bound of every scaled score and
+              // serves as the FIXED reference point of the sum of exponentials - no running maximum inside the sum, no rescaling
+              // of the partial sum per tile: one fma + one v_exp_f32 per score (the online form: 35 VALU per 4 scores, after the
+              // MFMAs of the tile and as long as them - 795 -> 609 TFLOP/s; profiles/r04_contrast_kernels.txt).  The row maximum
+              // (an output of its own) is two v_max3.
+              const float c2 = p.inv_tau * 1.4426950408889634f;
+              const float e0 = cok[0] ? __builtin_amdgcn_exp2f(__builtin_fmaf(v0, c2, -c2)) : 0.f, e1 = cok[1] ? __builtin_amdgcn_exp2f(__builtin_fmaf(v1, c2, -c2)) : 0.f;
+              const float e2 = cok[2] ? __builtin_amdgcn_exp2f(__builtin_fmaf(v2, c2, -c2)) : 0.f, e3 = cok[3] ? __builtin_amdgcn_exp2f(__builtin_fmaf(v3, c2, -c2)) : 0.f;
+              pse[e] += (e0 + e1) + (e2 + e3);
+              v0 = cok[0] ? v0 : -3.0e38f; v1 = cok[1] ? v1 : -3.0e38f; v2 = cok[2] ? v2 : -3.0e38f; v3 = cok[3] ? v3 : -3.0e38f;
+              pmax[e] = fmaxf(fmaxf(pmax[e], fmaxf(v0, v1)), fmaxf(v2, v3));        // (unscaled: x inv_tau at the end)
+            } else if (p.want_lse) {
               v0 = cok[0] ? v0 * p.inv_tau : -3.0e38f; v1 = cok[1] ? v1 * p.inv_tau : -3.0e38f;
               v2 = cok[2] ? v2 * p.inv_tau : -3.0e38f; v3 = cok[3] ? v3 * p.inv_tau : -3.0e38f;
               const float mx = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), pmax[e]);
@@ -390,7 +402,12 @@ __global__ __launch_bounds__(512, 2) void contrast_bank_kernel(BankArgs p) {
   for (int e = 0; e < FI * 4; ++e) {
     ppos[e] = sum16(ppos[e]);
     pall[e] = sum16(pall[e]);
-    if (p.want_lse) {                               // merge (max, sumexp) pairs over the 16 lanes: butterflies inside the row group
+    if (p.want_lse == 2) {                          // fixed reference point: plain sums and maxima over the 16 lanes
+      pse[e] = sum16(pse[e]);
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) pmax[e] = fmaxf(pmax[e], __shfl_xor(pmax[e], o));
+      pmax[e] = pmax[e] > -1.0e38f ? pmax[e] * p.inv_tau : pmax[e];
+    } else if (p.want_lse) {                        // merge (max, sumexp) pairs over the 16 lanes: butterflies inside the row group
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) {
         const float om = __shfl_xor(pmax[e], o), os = __shfl_xor(pse[e], o);
@@ -418,7 +435,10 @@ __global__ __launch_bounds__(512, 2) void contrast_bank_kernel(BankArgs p) {
     const long o = (long)(row_lo + tid) * gs + blockIdx.y, plane = (long)p.M * gs;
     p.part[o] = red[tid] + red[TM + tid];
     p.part[plane + o] = red[2 * TM + tid] + red[3 * TM + tid];
-    if (p.want_lse) {
+    if (p.want_lse == 2) {
+      p.part[2 * plane + o] = fmaxf(red[4 * TM + tid], red[5 * TM + tid]);
+      p.part[3 * plane + o] = red[6 * TM + tid] + red[7 * TM + tid];           // (both relative to inv_tau)
+    } else if (p.want_lse) {
       const float m0 = red[4 * TM + tid], m1 = red[5 * TM + tid], mx = fmaxf(m0, m1);
       p.part[2 * plane + o] = mx;
       p.part[3 * plane + o] = red[6 * TM + tid] * __expf(m0 - mx) + red[7 * TM + tid] * __expf(m1 - mx);
@@ -428,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void contrast_bank_kernel(BankArgs p) {
 
 // pos / all [M][groups] = sum over splits (fixed order); rowmax / lse [M] over all groups and splits.
 __global__ __launch_bounds__(256) void contrast_bank_combine_kernel(const float* part, int M, int groups, int splits, float* pos,
-                                                                    float* all, float* rowmax, float* lse) {
+                                                                    float* all, float* rowmax, float* lse, float lse_ref, int fixed_ref) {
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
   const int gs = groups * splits;
@@ -444,16 +464,17 @@ __global__ __launch_bounds__(256) void contrast_bank_combine_kernel(const float*
     float mx = -3.0e38f;
     for (int k = 0; k < gs; ++k) mx = fmaxf(mx, pp[2 * plane + k]);
     float se = 0.f;
-    for (int k = 0; k < gs; ++k) se += pp[3 * plane + k] * __expf(pp[2 * plane + k] - mx);
+    if (fixed_ref) { for (int k = 0; k < gs; ++k) se += pp[3 * plane + k]; }          // every partial is relative to lse_ref
+    else { for (int k = 0; k < gs; ++k) se += pp[3 * plane + k] * __expf(pp[2 * plane + k] - mx); }
     if (rowmax) rowmax[m] = mx;
-    if (lse) lse[m] = mx + __logf(se);
+    if (lse) lse[m] = (fixed_ref ? lse_ref : mx) + __logf(se);
   }
 }
 
-extern "C" int stswin_contrast_bank_fwd(int dtype, const void* Q, long ldq, const int* lq, int M, int C, int q_sets, int q_block,
-                                        const void* bank, long ldb, const int* lb, int maps, int seg, int bank_block, int groups,
-                                        const int* gmap /* host, [q_sets][groups] */, float inv_tau, float* pos, float* all,
-                                        float* rowmax, float* lse, float* workspace, long workspace_floats, void* stream) {
+static int contrast_bank_fwd_impl(int dtype, const void* Q, long ldq, const int* lq, int M, int C, int q_sets, int q_block,
+                                  const void* bank, long ldb, const int* lb, int maps, int seg, int bank_block, int groups,
+                                  const int* gmap /* host, [q_sets][groups] */, float inv_tau, float* pos, float* all,
+                                  float* rowmax, float* lse, float* workspace, long workspace_floats, void* stream, int unit_rows) {
   const int bk = dtype == 0 ? 64 : 32;
   if (M <= 0 || groups <= 0 || seg <= 0) return 0;
   if (C % bk || C > 256 || groups > CB_MAX_GROUPS || q_sets < 1 || q_sets > 2 || q_block <= 0 || bank_block <= 0) return -1511;
@@ -468,7 +489,7 @@ extern "C" int stswin_contrast_bank_fwd(int dtype, const void* Q, long ldq, cons
   for (int s = 0; s < 2; ++s)
     for (int g = 0; g < CB_MAX_GROUPS; ++g) a.gmap[s][g] = (s < q_sets && g < groups) ? gmap[s * groups + g] : 0;
   a.inv_tau = inv_tau;
-  a.want_lse = (rowmax || lse) ? 1 : 0;
+  a.want_lse = (rowmax || lse) ? (unit_rows && inv_tau > 0.f ? 2 : 1) : 0;
   const int TM = 128;
   const long row_tiles = (long)q_sets * nblk * ((q_block + TM - 1) / TM);
   // bank splits (one 8-wave workgroup per CU): the split count that minimises rounds x (bank tiles per workgroup + ~2 tiles of
@@ -505,9 +526,25 @@ extern "C" int stswin_contrast_bank_fwd(int dtype, const void* Q, long ldq, cons
   }
 #undef CB_LAUNCH
   hipLaunchKernelGGL(contrast_bank_combine_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace, M, groups, splits, pos, all, rowmax, lse);
+                     (const float*)workspace, M, groups, splits, pos, all, rowmax, lse, inv_tau, a.want_lse == 2 ? 1 : 0);
   STSWIN_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int stswin_contrast_bank_fwd(int dtype, const void* Q, long ldq, const int* lq, int M, int C, int q_sets, int q_block,
+                                        const void* bank, long ldb, const int* lb, int maps, int seg, int bank_block, int groups,
+                                        const int* gmap /* host, [q_sets][groups] */, float inv_tau, float* pos, float* all,
+                                        float* rowmax, float* lse, float* workspace, long workspace_floats, void* stream) {
+  return contrast_bank_fwd_impl(dtype, Q, ldq, lq, M, C, q_sets, q_block, bank, ldb, lb, maps, seg, bank_block, groups, gmap, inv_tau, pos, all,
+                                rowmax, lse, workspace, workspace_floats, stream, 0);
+}
+/* the same for L2-NORMALISED query and bank rows (what ConsistencyLoss feeds it: F.normalize'd embeddings, PixPro_swin_v5.py:_embed):
+ * |score| <= 1, so the log-sum-exp uses the fixed reference point inv_tau instead of a running maximum */
+extern "C" int stswin_contrast_bank_fwd_unit(int dtype, const void* Q, long ldq, const int* lq, int M, int C, int q_sets, int q_block,
+                                             const void* bank, long ldb, const int* lb, int maps, int seg, int bank_block, int groups,
+                                             const int* gmap, float inv_tau, float* pos, float* all, float* rowmax, float* lse,
+                                             float* workspace, long workspace_floats, void* stream) {
+  return contrast_bank_fwd_impl(dtype, Q, ldq, lq, M, C, q_sets, q_block, bank, ldb, lb, maps, seg, bank_block, groups, gmap, inv_tau, pos, all,
+                                rowmax, lse, workspace, workspace_floats, stream, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -83,6 +83,8 @@ struct GemmNT {
   // fp8 (e4m3) q | k | v output (stswin_gemm_nt_qkv_fp8): C is uint8 [M][ldc], C2 the fp32 scale table [M / f8_rows][N / f8_cols];
   // one scale per (f8_rows consecutive rows = one window problem, f8_cols consecutive columns = one head of q, k or v)
   int f8_rows, f8_cols;
+  // ring kernels: start-time stagger of the first round of workgroups (see stagger_wait): 100 MHz ticks per phase, 0 = off
+  int stagger_ticks;
 };
 
 // Column sum `v` of output rows [128*blk, 128*blk + 128*nblk) of column gn.  Default: one fp32 atomic per (tile, column) -
@@ -1033,6 +1035,19 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   if constexpr (PIPE != 4) {                          // (PIPE 4 stages through registers: its own prologue)
     // (PIPE 7 keeps a stage's fragments in registers one step ahead, so all NST slots can be in flight: prefetch distance NST)
     for (int q = 0; q < (PIPE == 7 ? NST : NST - 1) && q < nt; ++q) issue(q);
+  }
+  // Start-time stagger (round 5, product): without it the 256 CUs run their tiles in LOCK-STEP - every CU multiplies while HBM idles,
+  // then every CU stores its 128-256 KB at once: 32-64 MB per round arrive as one burst, the store instructions back up behind the
+  // memory side (C readback + stores 2.1 us on a plain tile, 4.1 + 2.7 us with the second output of fc1: profiles/r05_gemm_tile_timeline.txt)
+  // and the matrix pipes wait.  The first-round workgroups of the launch therefore start in 8 phases, `stagger_ticks` apart (4 CUs of
+  // every XCD per phase; the launcher spreads them over ~0.7 tile times): the phase pattern persists through the launch (a CU's
+  // next workgroup starts when its predecessor ends), the chip's store stream becomes smooth, and the start delay - paid once - is
+  // smaller than what every tile gains: -11 .. -17 % on the K = 512 launches with 6-8 tiles per CU behind an HBM-bound predecessor
+  // kernel (profiles/r05_stagger_behind_spacer.txt), nothing or a loss at K >= 1024 / <= 4 tiles per CU (the launcher leaves those
+  // alone).  The copies of the first stages are already in flight while a workgroup sleeps.
+  if (p.stagger_ticks > 0 && blockIdx.x < 256 && gridDim.y == 1) {
+    const unsigned long long t_go = wall_clock64() + (unsigned long long)(((blockIdx.x >> 3) & 7) * p.stagger_ticks);
+    while (wall_clock64() < t_go) __builtin_amdgcn_s_sleep(8);
   }
   __builtin_amdgcn_sched_barrier(0);                 // first get the copies going, then spend 128 v_mov on the accumulators
   if constexpr (M32) {
@@ -3038,6 +3053,21 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
       return 0;
     }
 #endif
+    // start-time stagger of the first round (see the kernel): launches of >= 6 tiles per CU whose tiles are short (<= 24 stages of 32)
+    // and end in a register epilogue; spread = 0.7 x the estimated tile time over 8 phases.  STSWIN_NT_STAGGER=0 switches it off,
+    // = N > 1 forces N ticks (of 10 ns) per phase whatever the shape (A/B runs, tools/stagger_sweep.py); read per call.
+    if (regepi) {
+      const int nt_ = S * (Kseg / 32);
+      const char* es = getenv("STSWIN_NT_STAGGER");
+      const int ev = es ? atoi(es) : 1;
+      static const int min_rounds = getenv("STSWIN_NT_STAGGER_MIN_ROUNDS") ? atoi(getenv("STSWIN_NT_STAGGER_MIN_ROUNDS")) : 6;
+      static const int max_nt = getenv("STSWIN_NT_STAGGER_MAX_NT") ? atoi(getenv("STSWIN_NT_STAGGER_MAX_NT")) : 24;
+      if (ev > 1) p.stagger_ticks = ev;
+      else if (ev == 1 && big_tiles >= (long)min_rounds * 256 && nt_ <= max_nt) {
+        const float epi_us = C2 ? 12.f : ((flags & (GF_GELU | GF_RESID | GF_MUL_R | GF_MUL_DGELU)) ? 6.f : 3.f);
+        p.stagger_ticks = (int)(0.7f * (0.75f * nt_ + epi_us) * 100.f / 8.f);
+      }
+    }
     g_last_variant[0] = regepi ? STSWIN_VAR_NT_RING256_REGEPI : STSWIN_VAR_NT_RING256_LDSEPI;
     if (regepi) hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);

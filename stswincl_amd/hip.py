@@ -1089,7 +1089,7 @@ def _bank_workspace(device, floats):
     return ws
 
 
-def contrast_bank_fwd(Q, lq, bank, lb, *, q_sets, q_block, bank_block, gmap, inv_tau=1.0, want_lse=False):
+def contrast_bank_fwd(Q, lq, bank, lb, *, q_sets, q_block, bank_block, gmap, inv_tau=1.0, want_lse=False, unit_rows=False):
     """Q [M][C], lq int32 [M]; bank [maps][seg][C], lb int32 [maps][seg]; gmap: q_sets lists of map indices (one per group).
     -> pos, all fp32 [M][groups] (+ rowmax, lse fp32 [M] or None, None); see include/stswin_hip.h."""
     M, C = Q.shape
@@ -1104,8 +1104,9 @@ def contrast_bank_fwd(Q, lq, bank, lb, *, q_sets, q_block, bank_block, gmap, inv
     ws = _bank_workspace(Q.device, 4 * M * groups * 8)
     gm = (_c_int * (q_sets * groups))(*[int(v) for row in gmap for v in row])
     name = "contrast_bank_fwd_bf16" if Q.dtype == torch.bfloat16 else "contrast_bank_fwd_f32"
+    fn = load().stswin_contrast_bank_fwd_unit if unit_rows else load().stswin_contrast_bank_fwd     # unit_rows: L2-normalised Q / bank rows
     with _Span(name, 2.0 * M * groups * bank_block * C):
-        rc = load().stswin_contrast_bank_fwd(_dt(Q), _p(Q), _c_long(_ld(Q)), _p(lq), M, C, q_sets, q_block, _p(bank),
+        rc = fn(_dt(Q), _p(Q), _c_long(_ld(Q)), _p(lq), M, C, q_sets, q_block, _p(bank),
                                              _c_long(bank.stride(1)), _p(lb), maps, seg, bank_block, groups, gm, _c_float(inv_tau),
                                              _p(pos), _p(tot), _p(rowmax), _p(lse), _p(ws), _c_long(ws.numel()), _stream())
     _check(rc, "contrast_bank_fwd")

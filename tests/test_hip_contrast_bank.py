@@ -136,3 +136,9 @@ def test_production_size_bank_of_65k_entries():
         assert float((tot[r].cpu() - ra).abs().max()) < 2e-2 * float(logits.abs().sum(1).max()) ** 0.5 + 0.05, r
         assert abs(float(rmax[r]) - 10.0 * float(logits.max())) < 2e-2
         assert abs(float(lse[r]) - float(torch.logsumexp(10.0 * logits.reshape(-1), 0))) < 2e-2
+    # the fixed-reference form for unit-norm rows (what the model's token path calls): same outputs to fp32 rounding
+    pos_u, tot_u, rmax_u, lse_u = hip.contrast_bank_fwd(qd.cuda(), lq.cuda(), bd.cuda(), lb.cuda(), q_sets=2, q_block=8192, bank_block=seg,
+                                                        gmap=gmap, inv_tau=10.0, want_lse=True, unit_rows=True)
+    assert torch.equal(pos_u, pos) and torch.equal(tot_u, tot)
+    assert float((rmax_u - rmax).abs().max()) <= 1e-5 * float(rmax.abs().max()) + 1e-6
+    assert float((lse_u - lse).abs().max()) <= 1e-4

@@ -51,11 +51,11 @@ def main():
     bank = F.normalize(torch.randn(6, seg, c, device=dev), dim=2).to(dt)
     lb = torch.randint(0, 12, (6, seg), dtype=torch.int32, device=dev)
     fl = 2.0 * 2 * n * hw * 5 * seg * c
-    for lse in (False, True):
+    for lse, unit in ((False, False), (True, False), (True, True)):
         t = timeit(lambda: hip.contrast_bank_fwd(q, lq, bank, lb, q_sets=2, q_block=n * hw, bank_block=seg, gmap=gmap, inv_tau=10.0,
-                                                 want_lse=lse), iters=5)
-        print(f"bank kernel, 65536-entry bank x 5 maps, lse={int(lse)}:   {t:8.1f} us  {fl / t / 1e6:7.1f} TFLOP/s  "
-              f"({fl / 2 / c / t / 1e-6:.3e} pairs/s)")
+                                                 want_lse=lse, unit_rows=unit), iters=5)
+        print(f"bank kernel, 65536-entry bank x 5 maps, lse={int(lse)}{' (unit rows: fixed reference point)' if unit else ''}:   {t:8.1f} us  "
+              f"{fl / t / 1e6:7.1f} TFLOP/s = {fl / t / 1e6 / 2500:.3f} of the bf16 MFMA peak  ({fl / 2 / c / t / 1e-6:.3e} pairs/s)")
 
 
 if __name__ == "__main__":
