@@ -1042,9 +1042,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   // and the matrix pipes wait.  The first-round workgroups of the launch therefore start in 8 phases, `stagger_ticks` apart (4 CUs of
   // every XCD per phase; the launcher spreads them over ~0.7 tile times): the phase pattern persists through the launch (a CU's
   // next workgroup starts when its predecessor ends), the chip's store stream becomes smooth, and the start delay - paid once - is
-  // smaller than what every tile gains: -11 .. -17 % on the K = 512 launches with 6-8 tiles per CU behind an HBM-bound predecessor
-  // kernel (profiles/r05_stagger_behind_spacer.txt), nothing or a loss at K >= 1024 / <= 4 tiles per CU (the launcher leaves those
-  // alone).  The copies of the first stages are already in flight while a workgroup sleeps.
+  // smaller than what every tile gains BEHIND AN HBM-BOUND SPACER KERNEL: -11 .. -19 % on the K = 512 launches with 6-8 tiles per CU
+  // (profiles/r05_stagger_behind_spacer.txt, r05_stagger_sweep.txt), nothing or a loss at K >= 1024 / <= 4 tiles per CU.  Inside the
+  // training step the same launches gain 0.2-0.7 % and the step nothing (profiles/r05_stagger_in_step_ab.txt,
+  // r05_gemm_shapes_in_step_stagger{0,1}.txt): the launcher therefore leaves stagger_ticks at 0 unless STSWIN_NT_STAGGER asks for it.
+  // The copies of the first stages are already in flight while a workgroup sleeps.
   if (p.stagger_ticks > 0 && blockIdx.x < 256 && gridDim.y == 1) {
     const unsigned long long t_go = wall_clock64() + (unsigned long long)(((blockIdx.x >> 3) & 7) * p.stagger_ticks);
     while (wall_clock64() < t_go) __builtin_amdgcn_s_sleep(8);
@@ -3053,13 +3055,16 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
       return 0;
     }
 #endif
-    // start-time stagger of the first round (see the kernel): launches of >= 6 tiles per CU whose tiles are short (<= 24 stages of 32)
-    // and end in a register epilogue; spread = 0.7 x the estimated tile time over 8 phases.  STSWIN_NT_STAGGER=0 switches it off,
-    // = N > 1 forces N ticks (of 10 ns) per phase whatever the shape (A/B runs, tools/stagger_sweep.py); read per call.
+    // start-time stagger of the first round (see the kernel), OPT-IN (STSWIN_NT_STAGGER=1; = N > 1 forces N ticks of 10 ns per phase
+    // whatever the shape; read per call): launches of >= 6 tiles per CU whose tiles are short (<= 24 stages of 32) and end in a register
+    // epilogue, spread = 0.7 x the estimated tile time over 8 phases.  Measured (profiles/r05_stagger_*.txt): behind an HBM-bound
+    // spacer kernel -11 .. -19 % on the fc1 / fc2-gradient launches of stage 1; INSIDE the training step 216.0 -> 214.5 us and
+    // 180.8 -> 180.4 us per launch, 604.9 -> 604.5 frames/s over three alternating runs - the start delay it pays is what it
+    // gains.  Off by default.
     if (regepi) {
       const int nt_ = S * (Kseg / 32);
       const char* es = getenv("STSWIN_NT_STAGGER");
-      const int ev = es ? atoi(es) : 1;
+      const int ev = es ? atoi(es) : 0;
       static const int min_rounds = getenv("STSWIN_NT_STAGGER_MIN_ROUNDS") ? atoi(getenv("STSWIN_NT_STAGGER_MIN_ROUNDS")) : 6;
       static const int max_nt = getenv("STSWIN_NT_STAGGER_MAX_NT") ? atoi(getenv("STSWIN_NT_STAGGER_MAX_NT")) : 24;
       if (ev > 1) p.stagger_ticks = ev;

@@ -81,7 +81,7 @@ class GradBucketReducer:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0, comm_dtype: Optional[torch.dtype] = None,
-                 group=None, overlap: bool = True, simulate=None):
+                 group=None, overlap: bool = True, simulate=None, hold_tn_fused: bool = False):
         """simulate = (world, collective): measurement hook (tools/overlap_proxy.py) - behave like rank 0 of `world` ranks without a
         process group; collective(msg) is enqueued on the communication stream in place of dist.all_reduce (a stand-in kernel that
         holds compute units the way an RCCL kernel does) and returns None or an object with wait()."""
@@ -102,14 +102,14 @@ class GradBucketReducer:
         if cur:
             self.buckets.append(cur)
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
-        # While an all-reduce runs on the comm stream its RCCL kernel holds compute units, so a 256-workgroup GEMM launched on the
-        # main stream is not resident all at once.  The weight-gradient GEMM with the fused split-K combine (stswin_gemm_tn, a
-        # workgroup waits for the other splits of its tile) would then sit out the collective; with the separate combine pass the
-        # late workgroups just run a second round.  Overlapped reducer => separate pass, unless the caller chose explicitly.
-        # (Round 5: the fused combine no longer NEEDS residency - it degrades instead of trapping - so this is a speed choice; a
-        #  refcounted library switch, not a process-global environment write; STSWIN_TN_FUSED=0 / 1 in the environment overrides it.)
+        # While an all-reduce runs on the comm stream its RCCL kernel holds compute units, so a 256-workgroup GEMM launched on the main
+        # stream is not resident all at once.  Since round 5 the fused split-K combine of the weight-gradient GEMMs does not need that
+        # (ticketed row slices, bounded wait: include/stswin_hip.h), and with a stand-in collective holding 8 / 16 / 32 CUs the step
+        # measures 29.02 / 29.68 / 29.40 ms with the fused combine against 29.14 / 29.75 / 29.35 ms with the separate pass
+        # (profiles/r05_overlap_proxy.txt): no reason to switch it off.  hold_tn_fused=True takes the library's refcounted hold for
+        # the reducer's lifetime anyway (separate pass; STSWIN_TN_FUSED=0 / 1 in the environment overrides either way).
         self._tn_hold = None
-        if self.world > 1 and overlap:
+        if self.world > 1 and overlap and hold_tn_fused:
             from . import hip
             self._tn_hold = hip.TnFusedHold()
         dev = self.params[0].device if self.params else torch.device("cpu")

@@ -30,10 +30,11 @@ def _worker(rank, world, port, overlap, q):
         for p in frozen.parameters():
             p.requires_grad = False
         params = list(model.parameters()) + list(frozen.parameters())
-        red = GradBucketReducer(params, bucket_mb=0.0005, overlap=overlap)  # tiny buckets -> several of them
+        red = GradBucketReducer(params, bucket_mb=0.0005, overlap=overlap, hold_tn_fused=True)  # tiny buckets -> several of them
         assert len(red.buckets) >= 3, len(red.buckets)
-        # an overlapped reducer of a world > 1 holds the library's refcounted switch: weight-gradient GEMMs use the separate split-K
-        # combine pass while it lives (dp.py); a second holder and any order of release must work, and the environment is not touched
+        # hold_tn_fused=True: an overlapped reducer of a world > 1 holds the library's refcounted switch - weight-gradient GEMMs use the
+        # separate split-K combine pass while it lives (dp.py; the default leaves the fused combine on: it no longer needs the whole grid
+        # resident); a second holder and any order of release must work, and the environment is not touched
         from stswincl_amd import hip
         assert hip.tn_fused_holds() == (1 if overlap else 0) and "STSWIN_TN_FUSED" not in os.environ
         extra = hip.TnFusedHold()
