@@ -2273,7 +2273,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
   const int tid = threadIdx.x, l = tid & 63, w = wave_id();
   const int wr = w >> 2, wc = w & 3;
   const int tiles_j = (p.Nj + 255) >> 8;
-  const int split_id = blockIdx.x % p.splits, tile_id = blockIdx.x / p.splits;
+  // XCD-aware mapping (round 5): the workgroups of one SPLIT (same contraction rows, different output tiles) re-use each other's operand
+  // panels - the At panel of a tile row is read by tiles_j of them, the Bt panel of a tile column by tiles_i - so they should share an L2.
+  // Workgroups are dealt round-robin over the 8 XCDs; xcd_remap hands every XCD a CONTIGUOUS range of the split-major sequence
+  // (split, tile), so a split's tiles sit on one XCD (or straddle two) WHATEVER the split count.  The round-1 mapping
+  // (split = blockIdx.x % splits) did that only for split counts that are multiples of 8: with 21 splits (the 1536 x 512 qkv weight
+  // gradient: 12 tiles) or 7 (the 512 x 4608 convolution weight gradients: 36 tiles) every XCD fetched every panel - 807 TFLOP/s
+  // against 1079 for the 16-split 2048 x 512 shape with the same 256 workgroups (profiles/r05_tn_gather_cost.txt).
+  const int ntiles_ = (int)gridDim.x / p.splits;
+  const int seq = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int split_id = seq / ntiles_, tile_id = seq - split_id * ntiles_;
   const int i0 = (tile_id / tiles_j) << 8, j0 = (tile_id % tiles_j) << 8;
   const int nst_all = (p.Mk + BMK - 1) / BMK;
   const int per = (nst_all + p.splits - 1) / p.splits;
