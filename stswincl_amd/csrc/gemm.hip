@@ -85,6 +85,7 @@ struct GemmNT {
   int f8_rows, f8_cols;
   // ring kernels: start-time stagger of the first round of workgroups (see stagger_wait): 100 MHz ticks per phase, 0 = off
   int stagger_ticks;
+  int persist;                   // ring kernels: > 0 = persistent form, the grid's workgroups walk the tiles (experiment, STSWIN_NT_PERSIST)
 };
 
 // Column sum `v` of output rows [128*blk, 128*blk + 128*nblk) of column gn.  Default: one fp32 atomic per (tile, column) -
@@ -463,7 +464,7 @@ DEVI int swz64(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 // BM x BN x 32 tile, 8 waves as WM x WN, NST-stage ring (prefetch distance NST-1), epilogue in EH row slabs.
 //   <256,256,2,4,4>: 128 KB LDS, 1 workgroup / CU (128 FLOP per L2 byte)
 //   <256,128,4,2,3>:  72 KB LDS, 2 workgroups / CU (87 FLOP per L2 byte; the neighbour's main loop hides the epilogue)
-template <int BM, int BN, int WM, int WN, int NST, int MINW, int PIPE, bool SWAP = false>   // PIPE: 0 plain, 1 ping-pong (8 waves), 2 register-pipelined (4 waves)
+template <int BM, int BN, int WM, int WN, int NST, int MINW, int PIPE, bool SWAP = false, bool PERSIST = false>   // PIPE: 0 plain, 1 ping-pong (8 waves), 2 register-pipelined (4 waves)
 __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT p) {
   using T = bf16;
   constexpr int BK = 32, ROWB = 64;
@@ -482,10 +483,20 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
   static_assert(SWAP || (EROWS >= TM && BM % EROWS == 0), "epilogue slab");
   static_assert(!SWAP || BM * BN * 2 <= NST * STAGE, "register epilogue image");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, l = tid & 63, w = wave_id();
-  const int wr = w / WN, wc = w % WN;
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  // Persistent form (p.persist, round-5 experiment: STSWIN_NT_PERSIST=1): a grid of <= 256 workgroups, workgroup b walks the tiles b,
+  // b + grid, ... one after the other (no cross-tile overlap: epilogue, barrier, next prologue) - what a launch gains when the
+  // per-tile workgroup dispatch disappears.  Default: one tile per workgroup (the loop runs once).
+  // (a TEMPLATE switch, tuning builds only: as a run-time loop in the product kernel the back edge cost it 26 registers and 280 bytes of
+  //  scratch - the per-tile constants become loop-carried)
+  const int ntot_ = tiles_m * tiles_n;
+  int tix_ = blockIdx.x;
+  do {
+  int tid_ = threadIdx.x;
+  if constexpr (PERSIST) asm volatile("" : "+v"(tid_));   // (lane constants are re-derived per tile, not carried across the tile loop)
+  const int tid = tid_, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w / WN, wc = w % WN;
+  const int t = xcd_remap(tix_, ntot_);
   int tm = t / tiles_n, tn = t % tiles_n;
   // Wide outputs (>= 24 column tiles; none in the training step): row-major order hands the 32 CUs of an XCD one tile row at a
   // time = 1 A panel + 32 B panels through a 4 MB L2 (8192^3: all of B re-streamed per tile row, 4.3 GB, HBM-bound at 1.25
@@ -1731,6 +1742,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
     if constexpr (SWAP) epilogue_reg();
     else epilogue();
   }
+  if constexpr (PERSIST) {
+    tix_ += (int)gridDim.x;
+    if (tix_ < ntot_) __syncthreads();               // every wave has read its pieces of the image before the next tile's copies land
+  }
+  } while (PERSIST && tix_ < ntot_);
 }
 
 
@@ -3083,6 +3099,19 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
       }
     }
     g_last_variant[0] = regepi ? STSWIN_VAR_NT_RING256_REGEPI : STSWIN_VAR_NT_RING256_LDSEPI;
+#ifdef STSWIN_TUNING
+    {
+      const char* ep = getenv("STSWIN_NT_PERSIST");       // experiment (read per call): walk the tiles with a grid of 256 workgroups
+      if (regepi && ep && atoi(ep) > 0 && big_tiles > 256 && S == 1) {
+        static int once_ps = (int)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)once_ps;
+        p.persist = 1;
+        hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, 1, true, true>), dim3(256), dim3(512), 131072, (hipStream_t)stream, p);
+        STSWIN_CHECK_LAUNCH();
+        return 0;
+      }
+    }
+#endif
     if (regepi) hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, true>), dim3((unsigned)big_tiles), dim3(512), 131072, (hipStream_t)stream, p);
     STSWIN_CHECK_LAUNCH();
