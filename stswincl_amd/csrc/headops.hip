@@ -3,6 +3,7 @@
 // statistics (G = 1 for the head; G = frames lets the per-frame ResNet calls of base18.py:86-89 be batched without
 // changing the per-frame statistics the reference computes).
 #include "common.h"
+#include <cstdlib>
 
 // ----------------------------------------------------------------------------------------- column statistics
 // sum[g][c] += sum_rows (x - pivot), sumsq[g][c] += sum_rows (x - pivot)^2, pivot = x[first row of group][c]
@@ -20,8 +21,12 @@ static int reduce_rows_per_chunk(int group_rows, int other_blocks, int nrl) {
 // 33 MB maps, 32 for layer5's 67 MB, 64 for the stem's 134 MB; with 8 rows everywhere the per-thread prologue - 40 channel
 // constants - and, in pass 1, 512 atomics per workgroup on 2 x groups x C addresses cost as much as the rows themselves).
 static int bn_bwd_rows(long rows_all_groups, int col_blocks, int nrl, int max_rows) {
+  // (workgroup target: STSWIN_BN_RED_WGS for the reduce pass [max_rows 64], STSWIN_BN_DX_WGS for the dx pass [max_rows 32]; tuning knobs, read once)
+  static const int tgt_red = getenv("STSWIN_BN_RED_WGS") ? atoi(getenv("STSWIN_BN_RED_WGS")) : 512;
+  static const int tgt_dx = getenv("STSWIN_BN_DX_WGS") ? atoi(getenv("STSWIN_BN_DX_WGS")) : 512;
+  const int tgt = max_rows > 32 ? tgt_red : tgt_dx;
   int rows = 8;
-  while (rows < max_rows && (long)col_blocks * (rows_all_groups / ((long)2 * rows * nrl)) >= 512) rows *= 2;
+  while (rows < max_rows && (long)col_blocks * (rows_all_groups / ((long)2 * rows * nrl)) >= tgt) rows *= 2;
   return rows;
 }
 
@@ -156,7 +161,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, long ldx, con
 // ReLU mask: from the stored output y, or - when there is no residual, y == NULL - recomputed from x with bn_apply's own
 // expression x * (rstd*gamma) + (beta - mean*rstd*gamma) > 0 (the same operations in the same order: the same sign): one
 // tensor less to read in both passes.
+#ifndef BN_BWD_U
 #define BN_BWD_U 4
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, long lddy, const T* x, long ldx, const T* y, long ldy,
                                                              const float* mean, const float* rstd, float* spart,
