@@ -39,7 +39,7 @@ def test_the_hot_kernels_are_in_the_report_and_within_their_register_budget(usag
         assert hits, f"no kernel named like {sub!r} in the report"
         return hits
 
-    for sub in ("gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, 1, true>", "gemm_tn_ring_kernel<0, true>", "gemm_tn_ring_kernel<3, true>",
+    for sub in ("gemm_nt_ring_kernel<256, 256, 2, 4, 4, 2, 1, true, false>", "gemm_tn_ring_kernel<0, true>", "gemm_tn_ring_kernel<3, true>",
                 "attn_bwd8_kernel<64, true, false>", "attn_bwd8_kernel<64, true, true>", "attn_qkv_fwd_kernel<64, 512>"):
         for r in find(sub):
             assert r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 256, (sub, r)
