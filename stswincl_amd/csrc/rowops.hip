@@ -1,6 +1,7 @@
 // HBM-bound row kernels: window gather / scatter (bit-exact indexing), row-map builders, LayerNorm, column sums.
 // Every kernel moves whole 16-byte pieces per lane (8 bf16 / 4 f32), one wave per token row.
 #include "common.h"
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------------
 // Source token of row `r` of the pair-regrouped window layout  (B*nW, T, ws*ws)  <-  (B, T, H*W).
@@ -541,53 +542,83 @@ int stswin_fold_launch(const float* ws, long slab_stride, long ws_batch_stride, 
 
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma += sum dy*xhat ; dbeta += sum dy.
 // Each wave walks `rows_per_wave` consecutive rows keeping its dgamma/dbeta columns in registers, the block
-// folds its 4 waves through LDS and stores one partial row per workgroup (summed by slab_fold_kernel).
-template <typename T, int NP>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, const T* x, long ldx, const int* rows,
-                                                      int S, int Cseg, const float* gamma, const float* mean,
-                                                      const float* rstd, T* dx, long lddx, float* dgamma,
-                                                      float* dbeta, int M, int rows_per_wave, int accumulate_dx,
-                                                      float* dxsum, float* ws) {
+// folds its NW waves through LDS and stores one partial row per workgroup (summed by slab_fold_kernel).
+// Round 5 (profiles/r05_layernorm_kernels.txt): ALL pieces of a row - x, dy, the old dx when accumulating, mean, rstd - are
+// requested before the first one is used (inside the per-piece `if (c < C)` bodies hipcc kept each piece's loads behind the
+// previous piece's arithmetic: one round trip per piece), gamma is read from LDS (as global loads its pieces were re-requested for
+// every row), "accumulate" and "column sums of dx" are template switches (C = 2048 had spilled), and workgroups are 8 waves where
+// four would leave the grid at <= 512 workgroups.  C = 1024: 35.5 -> 30.9 us, C = 2048 gathered: 113 -> 70 us; C = 512 unchanged
+// (one piece per row; ~200 VALU instructions per row and wave make that launch as much VALU- as HBM-bound).  Measured and NOT
+// kept: the next row prefetched behind the current one, 2 or 4 rows of a wave in flight together (138-186 registers, C = 512
+// 50 -> 68 us), g / xhat forcibly re-derived in the second pass (more VALU work), fused multiply-adds (no change).
+template <typename T, int NP, int NW, bool ACC, bool DXS>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* dy, long lddy, const T* x, long ldx, const int* rows,
+                                                          int S, int Cseg, const float* gamma, const float* mean,
+                                                          const float* rstd, T* dx, long lddx, float* dgamma,
+                                                          float* dbeta, int M, int rows_per_wave, float* ws) {
   constexpr int PACK = TT<T>::PACK;
+  typedef decltype(Vec16<T>().v) vec_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int C = S * Cseg;
-  float dg[NP][PACK], db[NP][PACK], ds[NP][PACK];
+  float dg[NP][PACK], db[NP][PACK], ds[DXS ? NP : 1][PACK];
 #pragma unroll
   for (int p = 0; p < NP; ++p)
 #pragma unroll
-    for (int e = 0; e < PACK; ++e) { dg[p][e] = 0.f; db[p][e] = 0.f; ds[p][e] = 0.f; }
+    for (int e = 0; e < PACK; ++e) { dg[p][e] = 0.f; db[p][e] = 0.f; if (DXS) ds[p][e] = 0.f; }
+  float* sgam = (float*)smem + NW * C;
+  for (int c = threadIdx.x; c < C; c += NW * 64) sgam[c] = gamma[c];
+  __syncthreads();
   // workgroups walk row groups blockIdx.x, blockIdx.x + gridDim.x, ... (the launcher caps the grid at 1024: the parameter-gradient
   // partial sums stay in registers across a workgroup's groups, so there is one slab per workgroup to fold afterwards)
-  for (int rg = blockIdx.x; rg * 4 * rows_per_wave < M; rg += gridDim.x) {
-  const int r_begin = (rg * 4 + w) * rows_per_wave;
+  typedef f32x4 raw_t;                 // 16 bytes of a row as a register quad
+  constexpr bool EARLY = ACC && NP <= 4;      // (NP = 8: the row's own pieces fill the register file)
+  struct Row { raw_t xi[NP], di[NP], old[EARLY ? NP : 1]; float mu, rs; };
+  for (int rg = blockIdx.x; rg * NW * rows_per_wave < M; rg += gridDim.x) {
+  const int r_begin = (rg * NW + w) * rows_per_wave;
   for (int r = r_begin; r < min(M, r_begin + rows_per_wave); ++r) {
-    const float mu = mean[r], rs = rstd[r];
-    float g[NP][PACK], xh[NP][PACK];
-    float s1 = 0.f, s2 = 0.f;
+    // every piece of the row is requested up front - the old dx, too, when accumulating (requested where it is used it cost a
+    // second round trip per row)
+    Row cur;
+    cur.mu = mean[r]; cur.rs = rstd[r];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int c = (p * 64 + l) * PACK;
       if (c < C) {
         const int s = c / Cseg, cc = c - s * Cseg;
         const long row = rows ? (long)rows[(long)s * M + r] : (long)r;
+        cur.xi[p] = *(const raw_t*)(x + row * ldx + cc);
+        cur.di[p] = *(const raw_t*)(dy + (long)r * lddy + c);
+        if constexpr (EARLY) cur.old[p] = *(const raw_t*)(dx + row * lddx + cc);
+      }
+    }
+    const float mu = cur.mu, rs = cur.rs;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int c = (p * 64 + l) * PACK;
+      if (c < C) {
         Vec16<T> xi, di;
-        xi.v = *(const decltype(xi.v)*)(x + row * ldx + cc);
-        di.v = *(const decltype(di.v)*)(dy + (long)r * lddy + c);
+        xi.v = __builtin_bit_cast(vec_t, cur.xi[p]); di.v = __builtin_bit_cast(vec_t, cur.di[p]);
+        float gm[PACK];
+#pragma unroll
+        for (int e = 0; e < PACK; e += 4) *(f32x4*)(gm + e) = *(const f32x4*)(sgam + c + e);
 #pragma unroll
         for (int e = 0; e < PACK; ++e) {
           const float d = di.get(e);
-          xh[p][e] = (xi.get(e) - mu) * rs;
-          g[p][e] = d * gamma[c + e];
-          s1 += g[p][e];
-          s2 += g[p][e] * xh[p][e];
-          dg[p][e] += d * xh[p][e];
+          const float xh = (xi.get(e) - mu) * rs;
+          const float g = d * gm[e];
+          s1 += g;
+          s2 += g * xh;
+          dg[p][e] += d * xh;
           db[p][e] += d;
         }
       }
     }
     s1 = wave_sum(s1) / C;
     s2 = wave_sum(s2) / C;
+    // (g and xhat are written out again from the row's pieces; hipcc decides per instantiation whether to keep the first pass's
+    // floats or to re-derive them)
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int c = (p * 64 + l) * PACK;
@@ -595,52 +626,53 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, con
         const int s = c / Cseg, cc = c - s * Cseg;
         const long row = rows ? (long)rows[(long)s * M + r] : (long)r;
         T* dst = dx + row * lddx + cc;
-        Vec16<T> o;
-        if (accumulate_dx) o.v = *(const decltype(o.v)*)dst;
+        Vec16<T> xi, di, o;
+        xi.v = __builtin_bit_cast(vec_t, cur.xi[p]); di.v = __builtin_bit_cast(vec_t, cur.di[p]);
+        if constexpr (EARLY) o.v = __builtin_bit_cast(vec_t, cur.old[p]);
+        else if constexpr (ACC) o.v = *(const vec_t*)dst;
+        float gm[PACK];
+#pragma unroll
+        for (int e = 0; e < PACK; e += 4) *(f32x4*)(gm + e) = *(const f32x4*)(sgam + c + e);
 #pragma unroll
         for (int e = 0; e < PACK; ++e) {
-          const float val = rs * (g[p][e] - s1 - xh[p][e] * s2);
-          const float fin = accumulate_dx ? o.get(e) + val : val;
+          const float xh = (xi.get(e) - mu) * rs;
+          const float g = di.get(e) * gm[e];
+          const float val = rs * (g - s1 - xh * s2);
+          const float fin = ACC ? o.get(e) + val : val;
           o.set(e, fin);
-          ds[p][e] += fin;
+          if constexpr (DXS) ds[p][e] += fin;
         }
-        *(decltype(o.v)*)dst = o.v;
+        *(vec_t*)dst = o.v;
       }
     }
   }
   }
-  // fold the 4 waves: smem[w][C] x 2
+  // fold the NW waves through ONE [NW][C] LDS table, a vector at a time; slab `blockIdx.x` of the caller's scratch:
+  // [3][C] = dgamma | dbeta | dxsum partial sums of this workgroup's rows (plain stores; slab_fold_kernel adds the slabs in order
+  // afterwards: deterministic, and no same-address atomics)
   float* sg = (float*)smem;
-  float* sb = sg + 4 * C;
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const int c = (p * 64 + l) * PACK;
-    if (c < C) {
-#pragma unroll
-      for (int e = 0; e < PACK; ++e) { sg[w * C + c + e] = dg[p][e]; sb[w * C + c + e] = db[p][e]; }
-    }
-  }
-  __syncthreads();
-  // slab `blockIdx.x` of the caller's scratch: [3][C] = dgamma | dbeta | dxsum partial sums of this workgroup's rows (plain
-  // stores; slab_fold_kernel adds the slabs in order afterwards: deterministic, and no same-address atomics)
   float* rep = ws + (long)blockIdx.x * 3 * C;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    rep[c] = sg[c] + sg[C + c] + sg[2 * C + c] + sg[3 * C + c];
-    rep[C + c] = sb[c] + sb[C + c] + sb[2 * C + c] + sb[3 * C + c];
-  }
-  if (dxsum) {                       // column sums of the written dx (= the bias gradient of the Linear that produced x)
-    __syncthreads();
+  auto fold = [&](const float (&acc)[NP][PACK], float* out) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int c = (p * 64 + l) * PACK;
       if (c < C) {
 #pragma unroll
-        for (int e = 0; e < PACK; ++e) sg[w * C + c + e] = ds[p][e];
+        for (int e = 0; e < PACK; ++e) sg[w * C + c + e] = acc[p][e];
       }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) rep[2 * C + c] = sg[c] + sg[C + c] + sg[2 * C + c] + sg[3 * C + c];
-  }
+    for (int c = threadIdx.x; c < C; c += NW * 64) {
+      float t = sg[c];
+#pragma unroll
+      for (int k = 1; k < NW; ++k) t += sg[k * C + c];
+      out[c] = t;
+    }
+    __syncthreads();
+  };
+  fold(dg, rep);
+  fold(db, rep + C);
+  if constexpr (DXS) fold(ds, rep + 2 * C);     // column sums of the written dx (= the bias gradient of the Linear that produced x)
 }
 
 // part[blockIdx.y][n] = sum of rows [blockIdx.y * rows_per_block, ...) of Y[:, n]   (bias gradients; slab_fold_kernel adds the
@@ -885,12 +917,24 @@ extern "C" int stswin_layernorm_fwd(int dtype, const void* x, long ldx, const in
   return 0;
 }
 
+// Geometry: 8 rows per wave (M >= 16384); workgroups of 8 waves when four would leave the grid at <= 512 workgroups (C >= 1024 in
+// the step: M = 16384), so that 4 waves per SIMD are resident without more slabs to fold; grid capped at 1024.
 static int ln_bwd_rows_per_wave(int M) { return M >= 16384 ? 8 : (M >= 4096 ? 4 : 2); }
-static int ln_bwd_grid(int M) {
-  const int rpw = ln_bwd_rows_per_wave(M), groups = (M + 4 * rpw - 1) / (4 * rpw);
+static int ln_bwd_waves(int M, int C, int pack) {
+  const int np = (C / pack + 63) / 64;
+  static const char* e = getenv("STSWIN_LN_BWD_WAVES");     // A/B switch (tools/bench_ln.py): 4 or 8
+  if (e && (atoi(e) == 4 || atoi(e) == 8)) return np <= 2 ? atoi(e) : 4;
+  const int rpw = ln_bwd_rows_per_wave(M);
+  return (M + 4 * rpw - 1) / (4 * rpw) <= 512 && M >= 8 * rpw * 128 && np <= 2 ? 8 : 4;
+}
+static int ln_bwd_grid(int M, int C, int pack) {
+  const int rpw = ln_bwd_rows_per_wave(M), nw = ln_bwd_waves(M, C, pack), groups = (M + nw * rpw - 1) / (nw * rpw);
   return groups < 1024 ? groups : 1024;
 }
-extern "C" long stswin_layernorm_bwd_scratch(int M, int C) { return (long)ln_bwd_grid(M) * 3 * C; }
+extern "C" long stswin_layernorm_bwd_scratch(int M, int C) {      // (sized for the 4-wave geometry: the larger of the two)
+  const int rpw = ln_bwd_rows_per_wave(M), groups = (M + 4 * rpw - 1) / (4 * rpw);
+  return (long)(groups < 1024 ? groups : 1024) * 3 * C;
+}
 
 template <typename T>
 static int ln_bwd_launch(const void* dy, long lddy, const void* x, long ldx, const int* rows, int S, int Cseg,
@@ -898,21 +942,26 @@ static int ln_bwd_launch(const void* dy, long lddy, const void* x, long ldx, con
                          int M, int acc, float* dxsum, float* ws, hipStream_t st) {
   constexpr int PACK = TT<T>::PACK;
   const int C = S * Cseg, np = (C / PACK + 63) / 64;
-  // 8 rows per wave: >= 4 waves per SIMD at M = 32768 (the serial row loop with two wave reductions per row is
-  // latency-bound)
-  const int rpw = ln_bwd_rows_per_wave(M);
-  dim3 grid((unsigned)ln_bwd_grid(M)), blk(256);
-  const size_t lds = (size_t)8 * C * sizeof(float);
+  const int rpw = ln_bwd_rows_per_wave(M), nw = ln_bwd_waves(M, C, PACK);
+  dim3 grid((unsigned)ln_bwd_grid(M, C, PACK)), blk(nw * 64);
+  const size_t lds = (size_t)(nw + 1) * C * sizeof(float);
   if (!ws) return -1111;
-#define LN_B(NP) hipLaunchKernelGGL((ln_bwd_kernel<T, NP>), grid, blk, lds, st, (const T*)dy, lddy, (const T*)x, ldx, rows, S, Cseg, g, mean, rstd, (T*)dx, lddx, dg, db, M, rpw, acc, dxsum, ws)
+#define LN_B4(NP, NW, A, D) hipLaunchKernelGGL((ln_bwd_kernel<T, NP, NW, A, D>), grid, blk, lds, st, (const T*)dy, lddy, (const T*)x, ldx, rows, S, Cseg, g, mean, rstd, (T*)dx, lddx, dg, db, M, rpw, ws)
+#define LN_B2(NP, NW) do { if (acc) { if (dxsum) LN_B4(NP, NW, true, true); else LN_B4(NP, NW, true, false); } \
+                           else { if (dxsum) LN_B4(NP, NW, false, true); else LN_B4(NP, NW, false, false); } } while (0)
+#define LN_B(NP) do { if (nw == 8) LN_B2(NP, 8); else LN_B2(NP, 4); } while (0)
+#define LN_BW4(NP) LN_B2(NP, 4)
   switch (np) {
     case 1: LN_B(1); break;
     case 2: LN_B(2); break;
-    case 3: case 4: LN_B(4); break;
-    case 5: case 6: case 7: case 8: LN_B(8); break;
+    case 3: case 4: LN_BW4(4); break;
+    case 5: case 6: case 7: case 8: LN_BW4(8); break;
     default: return -1104;
   }
 #undef LN_B
+#undef LN_BW4
+#undef LN_B2
+#undef LN_B4
   return stswin_fold_launch(ws, 3L * C, 0, (int)grid.x, C, dxsum ? 3 : 2, dg, db, dxsum, 0, 1, 1, st);
 }
 
@@ -922,7 +971,7 @@ extern "C" int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const 
                                     float* workspace, void* stream) {
   const int pack = dtype == 0 ? 8 : 4;
   if (Cseg % pack || ldx % pack || lddy % pack || lddx % pack) return -1105;
-  if ((long)S * Cseg * 8 * 4 > 65536) return -1106;
+  if ((long)S * Cseg * 5 * 4 > 65536) return -1106;
   int rc = dtype == 0 ? ln_bwd_launch<bf16>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, accumulate_dx, dxsum, workspace, (hipStream_t)stream)
                       : ln_bwd_launch<float>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, accumulate_dx, dxsum, workspace, (hipStream_t)stream);
   if (rc) return rc;
