@@ -17,13 +17,16 @@ static int reduce_rows_per_chunk(int group_rows, int other_blocks, int nrl) {
   while (rpc < 64 * nrl && (long)other_blocks * ((group_rows + 2 * rpc - 1) / (2 * rpc)) >= 1024) rpc *= 2;
   return rpc;
 }
-// Rows per thread of the BatchNorm backward passes: as many as leave about 512 workgroups (tools/bench_bn.py: 16 rows for the
-// 33 MB maps, 32 for layer5's 67 MB, 64 for the stem's 134 MB; with 8 rows everywhere the per-thread prologue - 40 channel
-// constants - and, in pass 1, 512 atomics per workgroup on 2 x groups x C addresses cost as much as the rows themselves).
+// Rows per thread of the BatchNorm backward passes: as many as leave about 512 (reduce pass: the LDS fold and the slab are per
+// workgroup) or 2048 (dx pass) workgroups.  Until round 5 the dx pass ran 512, too: every thread loaded its 8 channels' constants
+// from six arrays (48 loads + the arithmetic in front of the first row - a quarter of the pass, and the reason why smaller
+// workgroups were slower); now one thread per channel computes them and LDS hands them out, and the dx pass is 25-30 % faster at
+// 2048 workgroups (layer5: 63 -> 43 us, stem: 96 -> 79 us on cold operands; profiles/r05_bn_dx_prologue_experiment.txt,
+// r05_bn_bwd_lds_constants_sweep.txt; step +1.1 % same box).
 static int bn_bwd_rows(long rows_all_groups, int col_blocks, int nrl, int max_rows) {
   // (workgroup target: STSWIN_BN_RED_WGS for the reduce pass [max_rows 64], STSWIN_BN_DX_WGS for the dx pass [max_rows 32]; tuning knobs, read once)
   static const int tgt_red = getenv("STSWIN_BN_RED_WGS") ? atoi(getenv("STSWIN_BN_RED_WGS")) : 512;
-  static const int tgt_dx = getenv("STSWIN_BN_DX_WGS") ? atoi(getenv("STSWIN_BN_DX_WGS")) : 512;
+  static const int tgt_dx = getenv("STSWIN_BN_DX_WGS") ? atoi(getenv("STSWIN_BN_DX_WGS")) : 2048;
   const int tgt = max_rows > 32 ? tgt_red : tgt_dx;
   int rows = 8;
   while (rows < max_rows && (long)col_blocks * (rows_all_groups / ((long)2 * rows * nrl)) >= tgt) rows *= 2;
@@ -127,17 +130,26 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, long ldx, con
                                                         T* y, long ldy, int C, int group_rows, int chunks_per_group,
                                                         int rows_per_chunk, int relu, int cpb, int unit) {
   constexpr int PACK = TT<T>::PACK;
+  __shared__ __attribute__((aligned(16))) float coef[2][256];
   const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
   const int c = (blockIdx.x * cpb + cp) * PACK;
-  if (c >= C) return;
   const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
   const long gr0 = group_row0(g, ch, rows_per_chunk, group_rows, unit, gridDim.y / chunks_per_group);
+  {   // scale / shift of the workgroup's cpb * PACK <= 256 channels: one thread per channel, handed out through LDS (bn_bwd_dx_kernel)
+    const int t = threadIdx.x, cc = blockIdx.x * cpb * PACK + t;
+    if (t < cpb * PACK && cc < C) {
+      const float rs = rstd[(long)g * C + cc] * gamma[cc];
+      coef[0][t] = rs;
+      coef[1][t] = beta[cc] - mean[(long)g * C + cc] * rs;
+    }
+  }
+  __syncthreads();
+  if (c >= C) return;
   float sc[8], sh[8];
 #pragma unroll
-  for (int e = 0; e < PACK; ++e) {
-    const float rs = rstd[(long)g * C + c + e] * gamma[c + e];
-    sc[e] = rs;
-    sh[e] = beta[c + e] - mean[(long)g * C + c + e] * rs;
+  for (int e = 0; e < PACK; e += 4) {
+    *(f32x4*)(sc + e) = *(const f32x4*)&coef[0][cp * PACK + e];
+    *(f32x4*)(sh + e) = *(const f32x4*)&coef[1][cp * PACK + e];
   }
   const int r_end = min(group_rows, (ch + 1) * rows_per_chunk);
   for (int r = ch * rows_per_chunk + rl; r < r_end; r += nrl) {
@@ -171,21 +183,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, long ld
                                                              int relu, int cpb, const float* gamma, const float* beta, int unit) {
   constexpr int PACK = TT<T>::PACK;
   constexpr int U = BN_BWD_U;
-  __shared__ float part[2][256 * 8];
+  __shared__ __attribute__((aligned(16))) float part[2][256 * 8];
   const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
   const int c = (blockIdx.x * cpb + cp) * PACK;
   const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
   const long gr0 = group_row0(g, ch, rows_per_chunk, group_rows, unit, gridDim.y / chunks_per_group);
   float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (c < C) {
-    const bool remask = relu && y == nullptr, ymask = relu && y != nullptr;
-    float mu[8], rs[8], pm[8], qm[8];
-#pragma unroll
-    for (int e = 0; e < PACK; ++e) {
-      mu[e] = mean[(long)g * C + c + e]; rs[e] = rstd[(long)g * C + c + e];
-      pm[e] = remask ? rs[e] * gamma[c + e] : 0.f;
-      qm[e] = remask ? beta[c + e] - mu[e] * pm[e] : 0.f;
+  const bool remask = relu && y == nullptr, ymask = relu && y != nullptr;
+  {   // channel constants: one thread per channel, handed out through LDS (see bn_bwd_dx_kernel); `part` is free until the fold
+    const int t = threadIdx.x, cc = blockIdx.x * cpb * PACK + t;
+    if (t < cpb * PACK && cc < C) {
+      const float m = mean[(long)g * C + cc], r = rstd[(long)g * C + cc];
+      const float pmv = remask ? r * gamma[cc] : 0.f;
+      part[0][t] = m; part[0][256 + t] = r; part[0][512 + t] = pmv; part[0][768 + t] = remask ? beta[cc] - m * pmv : 0.f;
     }
+  }
+  __syncthreads();
+  float mu[8], rs[8], pm[8], qm[8];
+  if (c < C) {
+#pragma unroll
+    for (int e = 0; e < PACK; e += 4) {
+      *(f32x4*)(mu + e) = *(const f32x4*)&part[0][cp * PACK + e];
+      *(f32x4*)(rs + e) = *(const f32x4*)&part[0][256 + cp * PACK + e];
+      *(f32x4*)(pm + e) = *(const f32x4*)&part[0][512 + cp * PACK + e];
+      *(f32x4*)(qm + e) = *(const f32x4*)&part[0][768 + cp * PACK + e];
+    }
+  }
+  __syncthreads();
+  if (c < C) {
     const int r_end = min(group_rows, (ch + 1) * rows_per_chunk);
     for (int r = ch * rows_per_chunk + rl; r < r_end; r += U * nrl) {
       Vec16<T> d[U], xi[U], yo[U];
@@ -238,11 +263,33 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* dy, long lddy, 
                                                          const float* beta, int unit, float* gsum) {
   constexpr int PACK = TT<T>::PACK;
   constexpr int U = BN_BWD_U;
+  __shared__ __attribute__((aligned(16))) float coef[5][256];
   const int cp = threadIdx.x % cpb, rl = threadIdx.x / cpb, nrl = 256 / cpb;
   const int c = (blockIdx.x * cpb + cp) * PACK;
-  if (c >= C) return;
   const int g = blockIdx.y / chunks_per_group, ch = blockIdx.y % chunks_per_group;
   const long gr0 = group_row0(g, ch, rows_per_chunk, group_rows, unit, gridDim.y / chunks_per_group);
+  const bool remask = relu && y == nullptr, ymask = relu && y != nullptr;
+  // dx = A*dyr + B*x + D  with  A = gamma*rstd, B = -A*rstd*s2/n, D = -A*s1/n - B*mean      (training)
+  // The workgroup's cpb * PACK <= 256 channels get their five constants from ONE thread each (coalesced loads) and LDS hands every
+  // thread its 8: as 48 per-thread loads + the arithmetic in front of the first row the prologue was a quarter of the pass and
+  // made more, smaller workgroups slower (profiles/r05_bn_dx_prologue_experiment.txt).
+  {
+    const int t = threadIdx.x, cc = blockIdx.x * cpb * PACK + t;
+    if (t < cpb * PACK && cc < C) {
+      const long gc = (long)g * C + cc;
+      const float rsd = rstd[gc], mu = mean[gc], ga = gamma[cc];
+      const float A = ga * rsd;
+      const float kbv = training ? -A * rsd * s2[gc] * inv_n : 0.f;
+      const float pmv = remask ? rsd * ga : 0.f;
+      coef[0][t] = A;
+      coef[1][t] = kbv;
+      coef[2][t] = training ? -A * s1[gc] * inv_n - kbv * mu : 0.f;
+      coef[3][t] = pmv;
+      coef[4][t] = remask ? beta[cc] - mu * pmv : 0.f;
+    }
+  }
+  __syncthreads();
+  if (c >= C) return;
   if (gsum && blockIdx.y == 0 && rl == 0) {              // parameter gradients: dbeta | dgamma = s1 | s2 summed over the groups
     const int G = gridDim.y / chunks_per_group;
 #pragma unroll
@@ -253,19 +300,14 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* dy, long lddy, 
       gsum[C + c + e] = b;
     }
   }
-  // dx = A*dyr + B*x + D  with  A = gamma*rstd, B = -A*rstd*s2/n, D = -A*s1/n - B*mean      (training)
-  const bool remask = relu && y == nullptr, ymask = relu && y != nullptr;
   float ka[8], kb[8], kd[8], pm[8], qm[8];
 #pragma unroll
-  for (int e = 0; e < PACK; ++e) {
-    const long gc = (long)g * C + c + e;
-    const float rsd = rstd[gc], mu = mean[gc], ga = gamma[c + e];
-    const float A = ga * rsd;
-    ka[e] = A;
-    kb[e] = training ? -A * rsd * s2[gc] * inv_n : 0.f;
-    kd[e] = training ? -A * s1[gc] * inv_n - kb[e] * mu : 0.f;
-    pm[e] = remask ? rsd * ga : 0.f;
-    qm[e] = remask ? beta[c + e] - mu * pm[e] : 0.f;
+  for (int e = 0; e < PACK; e += 4) {
+    *(f32x4*)(ka + e) = *(const f32x4*)&coef[0][cp * PACK + e];
+    *(f32x4*)(kb + e) = *(const f32x4*)&coef[1][cp * PACK + e];
+    *(f32x4*)(kd + e) = *(const f32x4*)&coef[2][cp * PACK + e];
+    *(f32x4*)(pm + e) = *(const f32x4*)&coef[3][cp * PACK + e];
+    *(f32x4*)(qm + e) = *(const f32x4*)&coef[4][cp * PACK + e];
   }
   const int r_end = min(group_rows, (ch + 1) * rows_per_chunk);
   for (int r = ch * rows_per_chunk + rl; r < r_end; r += U * nrl) {
