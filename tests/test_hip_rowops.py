@@ -82,6 +82,37 @@ def test_layernorm_fwd_bwd(dtype, m, c):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("m,c", [(16384, 1024), (4100, 1536), (8192, 512), (300, 2048), (16390, 256)])
+@pytest.mark.parametrize("acc,dxs", [(False, True), (True, True), (True, False)])
+def test_layernorm_bwd_accumulate_and_column_sums(dtype, m, c, acc, dxs):
+    """The template switches of the backward (dx += / column sums of the written dx = the bias gradient of the Linear that produced x)
+    in both workgroup geometries (8 waves where four would leave <= 512 workgroups, e.g. 16384 x 1024 and 8192 x 512) and with a
+    ragged last piece (C = 1536: three of four 16-byte pieces per lane) - against torch on the GPU in fp32."""
+    torch.manual_seed(m + c)
+    x = (torch.randn(m, c, device="cuda") * 2 + 0.5).to(dtype)
+    g = (1 + 0.1 * torch.randn(c, device="cuda"))
+    b = 0.1 * torch.randn(c, device="cuda")
+    dy = torch.randn(m, c, device="cuda").to(dtype)
+    old = torch.randn(m, c, device="cuda").to(dtype)
+    xr = x.float().requires_grad_(True)
+    gr = g.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    (F.layer_norm(xr, (c,), gr, br) * dy.float()).sum().backward()
+    _, mean, rstd = hip.layernorm_fwd(x, g, b, M=m)
+    dg, db = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+    cs = torch.zeros(c, device="cuda") if dxs else None
+    dx = old.clone() if acc else torch.empty_like(x)
+    hip.layernorm_bwd(dy, x, g, mean, rstd, dg, db, M=m, dx=dx, accumulate=acc, dxsum=cs)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    want = xr.grad + (old.float() if acc else 0)
+    assert torch.allclose(dx.float(), want, atol=tol * 8, rtol=tol * 2)
+    lim = 2e-4 * m if dtype == torch.float32 else 0.05 * m ** 0.5
+    assert torch.allclose(dg, gr.grad, atol=lim, rtol=1e-3) and torch.allclose(db, br.grad, atol=lim, rtol=1e-3)
+    if dxs:
+        assert torch.allclose(cs, dx.float().sum(0), atol=lim, rtol=2e-3)      # sums of the values as written (rounded to the output type)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_layernorm_with_patch_merge_gather(dtype):
     torch.manual_seed(2)
     frames, h, w, c = 4, 8, 8, 64
