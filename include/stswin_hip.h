@@ -182,6 +182,29 @@ int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, cons
                    float* C, long ldc, int Mk, int Ni, int Nj, int splits, int bseg,
                    float* workspace /* optional caller-owned scratch: split-K partials are stored there and combined by a
                                        second kernel instead of fp32 atomics */, long workspace_floats, void* stream);
+/* Up to 4 bf16 weight-gradient problems of ONE backward step in one launch (round 5).  The reference's autograd computes the weight
+ * gradients of a Swin block one by one (swin_512.py:115-141,18-21 through torch.autograd: qkv, proj, fc1, fc2); each of those GEMMs has
+ * few 256x256 output tiles (4-16 at stage 1), so alone it needs 16-64 contraction splits to fill the device and pays its own ramp,
+ * partial-tile round trip and combine.  Launched together, the three that are ready at the end of a block's backward (fc1, proj, qkv)
+ * are 32 tiles x 8 splits = 256 workgroups.  Every problem is one stswin_gemm_tn would give to the 256x256 ring kernel with the fused
+ * combine (both output dims >= 256, at most one row map, bf16 partials, ldc >= 0); split counts are chosen so that every workgroup
+ * gets about the same number of 32-row stages and the grid is at most one workgroup per compute unit (stswin_set_cu_budget).
+ * Returns 0 when launched; STSWIN_TN_GROUP_DECLINED when the set is not eligible (a hold of stswin_tn_fused_hold is outstanding,
+ * STSWIN_TN_FUSED=0 / STSWIN_TN_F32_SLABS=1 / STSWIN_TN_GROUP=0 in the environment, a shape outside the ring kernel's range, less than
+ * 7/8 of the device filled, workspace too small) - nothing has been written and the caller launches the problems one by one with
+ * stswin_gemm_tn; other negative codes: malformed arguments.  splits_out (optional, [count]): the split counts used.  The result of a
+ * problem is a deterministic function of its operands and its split count (partials rounded to bf16 once, added in split order). */
+#define STSWIN_TN_GROUP_DECLINED (-1050)
+typedef struct stswin_tn_problem {
+  const void* At; long lda; const int* at_rows;     /* [Mk (gathered by at_rows)][Ni] */
+  const void* Bt; long ldb; const int* bt_rows;     /* [Mk (gathered by bt_rows; with bseg > 0: per-tap maps [Nj / bseg][Mk])][Nj or bseg] */
+  float* C; long ldc;                               /* [Ni][Nj] fp32 */
+  int Mk, Ni, Nj, bseg;
+  int overwrite;                                    /* 1: C = result, 0: C += result */
+  int tapminor;                                     /* with bseg > 0: store [row][channel][tap] (STSWIN_TN_OUT_TAPMINOR) */
+} stswin_tn_problem;
+int stswin_gemm_tn_group(int dtype, int count, const stswin_tn_problem* problems, float* workspace, long workspace_floats, int* splits_out,
+                         void* stream);
 /* The combine pass of a stswin_gemm_tn launched with STSWIN_TN_NO_COMBINE, for callers that run it on a second stream (it then
  * overlaps the input-gradient GEMM that follows every weight-gradient GEMM of a backward pass instead of standing between two
  * launches; ordering between the two streams is the caller's: events).  splits / slab_bf16 as stswin_last_variant(1) reported

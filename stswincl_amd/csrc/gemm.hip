@@ -2279,8 +2279,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(GemmTN p) {
 // leaves (see the hand-over below) - no workgroup needs another one to be resident, so a busy second stream, a second process or an
 // RCCL kernel holding compute units costs time, never correctness; the launcher still fuses only grids of <= one workgroup per CU,
 // because that is where the distributed combine is faster than the separate pass.
-template <int MODE, bool FUSE = false>
-__global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
+// The kernel body as a device function of (problem, position `seq` in the problem's split-major (split, tile) sequence, workgroups of
+// the problem, stamp row): gemm_tn_ring_kernel runs one problem per launch, gemm_tn_ring_group_kernel (round 5) several.
+template <int MODE, bool FUSE>
+DEVI void gemm_tn_ring_body(const GemmTN& p, const int seq, const int nwg, const int stamp_row) {
   constexpr bool MAPS = MODE != 0, MAP_A = MODE == 1, MAP_B = MODE >= 2, TAPS = MODE == 3;
   using T = bf16;
   constexpr int BMK = 32, ROWB = 512, NST = 4, OP_BYTES = BMK * ROWB, STAGE = 2 * OP_BYTES, PER_STAGE = 4;
@@ -2296,8 +2298,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
   // (split = blockIdx.x % splits) did that only for split counts that are multiples of 8: with 21 splits (the 1536 x 512 qkv weight
   // gradient: 12 tiles) or 7 (the 512 x 4608 convolution weight gradients: 36 tiles) every XCD fetched every panel - 807 TFLOP/s
   // against 1079 for the 16-split 2048 x 512 shape with the same 256 workgroups (profiles/r05_tn_gather_cost.txt).
-  const int ntiles_ = (int)gridDim.x / p.splits;
-  const int seq = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int ntiles_ = nwg / p.splits;
   const int split_id = seq / ntiles_, tile_id = seq - split_id * ntiles_;
   const int i0 = (tile_id / tiles_j) << 8, j0 = (tile_id % tiles_j) << 8;
   const int nst_all = (p.Mk + BMK - 1) / BMK;
@@ -2306,7 +2307,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
   const int nt = max(0, s_end - s_begin);
   const bool dbg_ts = p.ldc == -1;                       // DBG (tools/gemm_timeline.py tn): C is a u64 [workgroups][8] timestamp buffer
   auto stamp = [&](int slot) {
-    if (dbg_ts && threadIdx.x == 0) ((unsigned long long*)p.C)[(long)blockIdx.x * 8 + slot] = wall_clock64();
+    if (dbg_ts && threadIdx.x == 0) ((unsigned long long*)p.C)[(long)stamp_row * 8 + slot] = wall_clock64();
   };
   stamp(0);
 
@@ -2526,7 +2527,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores ...
     __syncthreads();                                   // ... before the one lane that signals for all of them (the image is dead now)
     typedef __attribute__((address_space(1))) unsigned gu32;
-    const int ntiles = gridDim.x / p.splits;
+    const int ntiles = nwg / p.splits;
     gu32* arrive = (gu32*)p.tile_cnt + tile_id;
     gu32* depart = (gu32*)p.tile_cnt + ntiles + tile_id;
     gu32* ticket = (gu32*)p.tile_cnt + 2 * ntiles + tile_id;
@@ -2636,6 +2637,34 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
           else atomicAdd(p.C + (long)gi * p.ldc + gj, acc[i][j][r]);
         }
       }
+}
+
+template <int MODE, bool FUSE = false>
+__global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
+  gemm_tn_ring_body<MODE, FUSE>(p, xcd_remap((int)blockIdx.x, (int)gridDim.x), (int)gridDim.x, (int)blockIdx.x);
+}
+
+// Several weight-gradient problems in ONE launch (round 5, stswin_gemm_tn_group): the three late weight gradients of a Swin block
+// (fc1, proj, qkv) are 16 + 4 + 12 output tiles at stage 1 - launched one by one each needs 16 / 64 / 21 splits to fill the chip and pays
+// its own ramp, prologue, partial-tile round trip and combine (~30 us of a 58-129 us launch); together they are 32 tiles x 7-9 splits =
+// 256 workgroups with twice to eight times the contraction rows per workgroup.  Measured (profiles/r05_tn_group_probe.txt,
+// r05_tn_group_in_step_ab.txt): three PLAIN problems of these shapes 229 us grouped against 291 one by one; with the step's row maps
+// (proj gathers A, qkv gathers B) 282 against 314 - the gathered workgroups are the slow ones -, step +0.7 %.  The problems' (split, tile) sequences are laid end
+// to end and xcd_remap hands every XCD a contiguous range of the whole; a workgroup finds its problem by its position and runs the
+// body instantiated for that problem's gather mode (resolved per workgroup, not per stage).  Fused combine only.
+#define TN_GROUP_MAX 4
+struct GemmTNGroup { GemmTN q[TN_GROUP_MAX]; int first[TN_GROUP_MAX + 1]; int mode[TN_GROUP_MAX]; int count; };
+__global__ __launch_bounds__(512, 2) void gemm_tn_ring_group_kernel(GemmTNGroup g) {
+  const int seq = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  int i = 0;
+  while (i + 1 < g.count && seq >= g.first[i + 1]) ++i;
+  const int local = seq - g.first[i], nwg = g.first[i + 1] - g.first[i];
+  switch (g.mode[i]) {
+    case 0: gemm_tn_ring_body<0, true>(g.q[i], local, nwg, (int)blockIdx.x); break;
+    case 1: gemm_tn_ring_body<1, true>(g.q[i], local, nwg, (int)blockIdx.x); break;
+    case 2: gemm_tn_ring_body<2, true>(g.q[i], local, nwg, (int)blockIdx.x); break;
+    default: gemm_tn_ring_body<3, true>(g.q[i], local, nwg, (int)blockIdx.x); break;
+  }
 }
 
 // C[i][j] += sum_s slabs[s][i][j]   (the split-K combine: plain stores + this pass cost ~half of 32 MB of fp32 atomics).
@@ -3269,6 +3298,100 @@ extern "C" int stswin_tn_fused_hold(int delta) {
     return cur > 0 ? cur - 1 : 0;
   }
   return g_tn_fused_holds.load();
+}
+
+// Several bf16 weight-gradient problems in one launch of gemm_tn_ring_group_kernel (see there).  Every problem must be one the ring
+// kernel with the fused combine takes on its own (both output dims >= 256, at most one gather map, 32-bit operand offsets, bf16
+// partials); the split counts are chosen so that every workgroup of the launch gets about the same number of 32-row stages and the
+// whole grid is at most one workgroup per compute unit.  Returns 0 when launched, STSWIN_TN_GROUP_DECLINED (-1050) when the set is not
+// eligible or would fill less than 7/8 of the device (the caller then launches the problems one by one - nothing has been written),
+// another negative code for malformed arguments.  `splits_out` (optional, [count]): the split counts used.
+typedef stswin_tn_problem StswinTnProblem;       // include/stswin_hip.h
+extern "C" int stswin_gemm_tn_group(int dtype, int count, const StswinTnProblem* pr, float* workspace, long workspace_floats,
+                                    int* splits_out, void* stream) {
+  if (count <= 0) return 0;
+  if (count > TN_GROUP_MAX || !pr) return -1052;
+  const int declined = -1050;
+  if (dtype != 0 || !workspace) return declined;
+  { const char* f32_env = getenv("STSWIN_TN_F32_SLABS"); if (f32_env && atoi(f32_env)) return declined; }
+  { const char* ef = getenv("STSWIN_TN_FUSED"); if (ef ? atoi(ef) == 0 : g_tn_fused_holds.load() != 0) return declined; }
+  { const char* eg = getenv("STSWIN_TN_GROUP"); if (eg && atoi(eg) == 0) return declined; }          // A/B switch, read per call
+  int tiles[TN_GROUP_MAX], nst[TN_GROUP_MAX], rs[TN_GROUP_MAX];
+  long tile_stages = 0, total_tiles = 0;
+  for (int i = 0; i < count; ++i) {
+    const StswinTnProblem& q = pr[i];
+    if (q.Mk <= 0 || q.Ni <= 0 || q.Nj <= 0) return -1052;
+    if (q.Ni % 8 || q.Nj % 8 || q.lda % 8 || q.ldb % 8) return -1003;
+    if (q.bseg < 0 || (q.bseg > 0 && (q.bseg % 8 || !q.bt_rows || q.Nj % q.bseg))) return -1004;
+    if (q.Ni < 256 || q.Nj < 256 || q.ldc < 0 || (q.at_rows && q.bt_rows) || ((q.at_rows || q.bt_rows) && q.Mk % 32 != 0)) return declined;
+    if ((!q.at_rows && (long)q.Mk * q.lda * 2 > 0xFFFF0000L) || (!q.bt_rows && (long)q.Mk * q.ldb * 2 > 0xFFFF0000L)) return declined;
+    if (q.bseg > 0)
+      for (int j0 = 0; j0 < q.Nj; j0 += 256)
+        if ((j0 + 255 < q.Nj ? j0 + 255 : q.Nj - 1) / q.bseg - j0 / q.bseg > 1) return declined;
+    if (q.tapminor && q.bseg <= 0) return -1052;
+    tiles[i] = ((q.Ni + 255) / 256) * ((q.Nj + 255) / 256);
+    nst[i] = (q.Mk + 31) / 32;
+    tile_stages += (long)tiles[i] * nst[i];
+    total_tiles += tiles[i];
+  }
+  if (total_tiles > 1024) return declined;
+  const int cus = stswin_cu_budget();
+  if (cus > tn_resident_workgroups()) return declined;
+  // stages per workgroup: the smallest count with which the grid fits the budget (>= 16: below that the ring never reaches steady state)
+  // A workgroup of a problem with a row map runs its stages slower than a plain one (the scalar index loads and the per-row copies:
+  // ~1.1x alone, 1.2-1.3x beside plain workgroups) and the launch ends with its slowest workgroup: such a problem's stage count is
+  // weighted by 1.2 (STSWIN_TN_GROUP_W, percent, tuning; profiles/r05_tn_group_weight_sweep.txt: fc1 + proj + qkv at stage 1 then
+  // split 7 / 9 / 9 instead of 8 / 8 / 8, 282 against 302 us, and 314 one by one)
+  long target = (tile_stages + cus - 1) / cus;
+  if (target < 16) target = 16;
+  const char* ew = getenv("STSWIN_TN_GROUP_W");
+  const long wmap = ew && atoi(ew) >= 100 && atoi(ew) <= 300 ? atoi(ew) : 120;
+  long total = 0;
+  for (int guard = 0; guard < 4096; ++guard, ++target) {
+    total = 0;
+    for (int i = 0; i < count; ++i) {
+      const long wi = (pr[i].at_rows || pr[i].bt_rows) ? wmap : 100;
+      int r = (int)((nst[i] * wi + target * 100 - 1) / (target * 100));
+      if (r < 1) r = 1;
+      const int per = (nst[i] + r - 1) / r;
+      rs[i] = (nst[i] + per - 1) / per;              // no empty split (its slab would never be written)
+      total += (long)tiles[i] * rs[i];
+    }
+    if (total <= cus) break;
+  }
+  if (total > cus || total * 8 < (long)cus * 7) return declined;
+  long ws_need = 0;
+  for (int i = 0; i < count; ++i) {
+    if ((long)rs[i] * pr[i].Ni * pr[i].Nj * 2 >= 0x7FFFFFF0L) return declined;
+    ws_need += ((long)rs[i] * pr[i].Ni * pr[i].Nj + 1) / 2 + 64;       // bf16 partials, in floats, each problem's block 256-byte aligned
+    ws_need = (ws_need + 63) / 64 * 64;
+  }
+  if (ws_need > workspace_floats) return declined;
+  unsigned* cnt = tn_tile_counters((int)total_tiles, (hipStream_t)stream);
+  if (!cnt) return declined;
+  GemmTNGroup g;
+  g.count = count;
+  g.first[0] = 0;
+  long wo = 0, to = 0;
+  for (int i = 0; i < count; ++i) {
+    const StswinTnProblem& q = pr[i];
+    const int perm = (q.tapminor && q.bseg > 0) ? q.bseg : 0;
+    g.q[i] = GemmTN{q.At, q.lda, q.at_rows, q.Bt, q.ldb, q.bt_rows, q.C, q.ldc, q.Mk, q.Ni, q.Nj, rs[i], q.bseg, workspace + wo, 1,
+                    cnt + 3 * to, q.overwrite ? 1 : 0, perm};
+    g.mode[i] = q.at_rows ? 1 : (q.bt_rows ? (q.bseg > 0 ? 3 : 2) : 0);
+    g.first[i + 1] = g.first[i] + tiles[i] * rs[i];
+    wo += ((long)rs[i] * q.Ni * q.Nj + 1) / 2 + 64;
+    wo = (wo + 63) / 64 * 64;
+    to += tiles[i];
+    if (splits_out) splits_out[i] = rs[i];
+  }
+  for (int i = count; i < TN_GROUP_MAX; ++i) { g.q[i] = g.q[0]; g.mode[i] = 0; g.first[i + 1] = g.first[count]; }
+  static int once_g = (int)hipFuncSetAttribute((const void*)gemm_tn_ring_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  (void)once_g;
+  g_last_variant[1] = STSWIN_VAR_TN_RING_PLAIN | STSWIN_VAR_TN_SLABS_BF16 | STSWIN_VAR_TN_FUSED | (rs[0] << 16);
+  hipLaunchKernelGGL(gemm_tn_ring_group_kernel, dim3((unsigned)total), dim3(512), 131072, (hipStream_t)stream, g);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at_rows, const void* Bt, long ldb,

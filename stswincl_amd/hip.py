@@ -316,6 +316,9 @@ class _Span:
                 self.a.record()
         return self
 
+    def cancel(self):                # nothing was launched inside the span (a declined grouped launch): no sample
+        self.a = None
+
     def __exit__(self, *exc):
         if self.a is not None:
             b = torch.cuda.Event(enable_timing=True)
@@ -722,6 +725,56 @@ def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: in
             _TN_PENDING = torch.cuda.Event()
             _TN_PENDING.record(side)
     return out_f32
+
+
+class _TnProblem(ctypes.Structure):
+    """stswin_tn_problem (include/stswin_hip.h)"""
+    _fields_ = [("At", ctypes.c_void_p), ("lda", ctypes.c_long), ("at_rows", ctypes.c_void_p),
+                ("Bt", ctypes.c_void_p), ("ldb", ctypes.c_long), ("bt_rows", ctypes.c_void_p),
+                ("C", ctypes.c_void_p), ("ldc", ctypes.c_long),
+                ("Mk", ctypes.c_int), ("Ni", ctypes.c_int), ("Nj", ctypes.c_int), ("bseg", ctypes.c_int),
+                ("overwrite", ctypes.c_int), ("tapminor", ctypes.c_int)]
+
+
+TN_GROUP_DECLINED = -1050
+LAST_TN_GROUP_SPLITS: list = []      # split counts of the last grouped launch (tests, tools)
+
+
+def gemm_tn_group(problems) -> bool:
+    """problems: [dict(At=, Bt=, out=, Mk=, at_rows=None, bt_rows=None, bseg=0, overwrite=True, tapminor=False)] - up to 4 bf16 weight
+    gradients of one backward step in ONE launch (stswin_gemm_tn_group).  Returns False when the library declines the set (nothing has
+    been written: call gemm_tn for each), True when it was launched."""
+    n = len(problems)
+    if n == 0:
+        return True
+    first = problems[0]["At"]
+    if n > 4 or first.dtype != torch.bfloat16 or torch.cuda.is_current_stream_capturing() and first.device not in _TN_WS:
+        return False
+    arr = (_TnProblem * n)()
+    flops = 0.0
+    for i, q in enumerate(problems):
+        At, Bt, out = q["At"], q["Bt"], q["out"]
+        assert out.dtype == torch.float32 and At.dtype == Bt.dtype == torch.bfloat16
+        ar, br = q.get("at_rows"), q.get("bt_rows")
+        arr[i] = _TnProblem(At.data_ptr(), _ld(At), ar.data_ptr() if ar is not None else None, Bt.data_ptr(), _ld(Bt),
+                            br.data_ptr() if br is not None else None, out.data_ptr(), _ld(out), q["Mk"], out.shape[0], out.shape[1],
+                            q.get("bseg", 0), 1 if q.get("overwrite", True) else 0, 1 if q.get("tapminor", False) else 0)
+        flops += 2.0 * q["Mk"] * out.shape[0] * out.shape[1]
+    ws = _tn_workspace(first.device)
+    tn_join()
+    sp = (_c_int * n)()
+    name = "gemm_tn_bf16"
+    if _SHAPE_NAMES:
+        name += " group " + " + ".join(f"{q['out'].shape[0]}x{q['out'].shape[1]}" for q in problems) + f" Mk={problems[0]['Mk']}"
+    with _Span(name, flops) as span:
+        rc = load().stswin_gemm_tn_group(0, n, arr, _p(ws), _c_long(ws.numel()), sp, _stream())
+        if rc == TN_GROUP_DECLINED:
+            span.cancel()
+    if rc == TN_GROUP_DECLINED:
+        return False
+    _check(rc, "gemm_tn_group")
+    LAST_TN_GROUP_SPLITS[:] = list(sp)
+    return True
 
 
 # kernel-variant codes of stswin_last_variant (include/stswin_hip.h)

@@ -207,6 +207,9 @@ def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 _UNIQ_MASKS: Dict[int, tuple] = {}
 
 
+_TN_GROUP = os.environ.get("STSWIN_NO_TN_GROUP") != "1"      # (A/B switch)
+
+
 def _duo(site: str, M: int, N: int, K: int) -> int:
     """GF_DUO (the two-workgroups-per-CU gemm_nt of STSWIN_TUNING builds) for the named call sites: STSWIN_DUO=fc1,fc2d,...  (read per
     call: the in-step A/B of profiles/r05_duo_in_step_ab.txt - it measured 0.3-1.3 % slower than the 256x256 ring kernel inside the
@@ -505,8 +508,8 @@ class SwinBlockFn(torch.autograd.Function):
             dh_pre = torch.empty(M, hid, dtype=dt, device=dev)
             hip.gemm_nt(dy2, wcast(fc2_w, dt, True), dh_pre, M=M, resid=h_pre,
                         flags=(hip.GF_MUL_DGELU if ctx.gelu_bwd else hip.GF_MUL_R) | _duo("fc2d", M, hid, C), colsum_out=dfc1_b)
-            # fc1
-            hip.gemm_tn(dh_pre, n2, dfc1_w, Mk=M, overwrite=True)
+            # fc1 (its weight gradient waits for the grouped launch below: dh_pre stays alive until then)
+            late = [dict(At=dh_pre, Bt=n2, out=dfc1_w, Mk=M)]
             dn2 = torch.empty(M, C, dtype=dt, device=dev)
             hip.gemm_nt(dh_pre, wcast(fc1_w, dt, True), dn2, M=M)
             del dh_pre
@@ -514,7 +517,7 @@ class SwinBlockFn(torch.autograd.Function):
             dx1 = hip.layernorm_bwd(dn2, x1, _f32(n2_w), mean2, rstd2, dn2_w, dn2_b, M=M, dx=dy2, accumulate=True,
                                     dxsum=dproj_b)
             # proj (window order on the attention side)
-            hip.gemm_tn(dx1, o, dproj_w, Mk=M, at_rows=rmap, overwrite=True)
+            late.append(dict(At=dx1, Bt=o, out=dproj_w, Mk=M, at_rows=rmap))
             do = dn2  # reuse
             # (dv third of the qkv bias gradient = column sums of dO: softmax rows sum to one; the dk third is exactly zero)
             hip.gemm_nt(dx1, wcast(proj_w, dt, True), do, M=M, a_rows=rmap, colsum_out=dqkv_b[2 * C:])
@@ -530,8 +533,13 @@ class SwinBlockFn(torch.autograd.Function):
             raise
         folds.__exit__(None, None, None)
         hip.bias_scatter(dbiasT, index.reshape(-1).contiguous(), dtable, N, heads, lists=_scatter_lists_for(index, ws, tsz))
-        # qkv
-        hip.gemm_tn(dqkv, X2, dqkv_w, Mk=M, bt_rows=rmap if ctx.src is None else ctx.src.compose(rmap), overwrite=True)
+        # qkv - and with it the fc1 and proj weight gradients: ONE launch of three problems (32 tiles x 8 splits at stage 1 instead of
+        # 16 x 16, 4 x 64 and 12 x 21 one after the other: hip.gemm_tn_group); one by one when the library declines the set
+        late.append(dict(At=dqkv, Bt=X2, out=dqkv_w, Mk=M, bt_rows=rmap if ctx.src is None else ctx.src.compose(rmap)))
+        if not (_TN_GROUP and hip.gemm_tn_group(late)):
+            for q in late:
+                hip.gemm_tn(q["At"], q["Bt"], q["out"], Mk=M, at_rows=q.get("at_rows"), bt_rows=q.get("bt_rows"), overwrite=True)
+        del late
         src = ctx.src
         if src is None:
             dx = torch.empty(M, C, dtype=dt, device=dev)

@@ -579,3 +579,75 @@ def test_gemm_nt_duo_kernel_is_bitwise_the_ring_kernel(m, n, k, s_):
             assert torch.equal(res[0][1], res[1][1]), f"C2 differs: {sorted(kw)}"
         if res[0][2] is not None:                      # column sums: per-128-row blocks in both kernels, same fold order
             assert torch.allclose(res[0][2], res[1][2], rtol=1e-5, atol=1e-3), f"colsum differs: {sorted(kw)}"
+
+
+@pytest.mark.parametrize("mk,c,hid", [(65536, 512, 2048), (16384, 1024, 4096), (32768, 512, 2048), (8192, 1024, 4096)])
+def test_gemm_tn_group_is_bitwise_the_single_launches_at_the_same_split_counts(mk, c, hid):
+    """stswin_gemm_tn_group: the three late weight gradients of a Swin block (fc1: plain, proj: gathered A rows, qkv: gathered B rows) in ONE
+    launch.  A problem's result is a function of its operands and its split count alone: bit for bit what stswin_gemm_tn gives when it is
+    forced to the same split count (ring kernel, fused combine) - for overwrite and accumulate, twice (the counters re-arm), and within
+    bf16-partial rounding of the fp32 product."""
+    torch.manual_seed(mk // 64 + c)
+    dev = "cuda"
+    dh = torch.randn(mk, hid, device=dev).bfloat16()
+    n2 = (torch.randn(mk, c, device=dev) / 8).bfloat16()
+    dx1 = torch.randn(mk, c, device=dev).bfloat16()
+    o = (torch.randn(mk, c, device=dev) / 8).bfloat16()
+    dqkv = torch.randn(mk, 3 * c, device=dev).bfloat16()
+    x2 = (torch.randn(mk, c, device=dev) / 8).bfloat16()
+    rmap = torch.randperm(mk, device=dev).to(torch.int32)
+
+    def outs(ow):
+        mk_ = (lambda *s: torch.empty(*s, device=dev)) if ow else (lambda *s: torch.full(s, 0.25, device=dev))
+        return mk_(hid, c), mk_(c, c), mk_(3 * c, c)
+
+    def problems(bufs, ow):
+        return [dict(At=dh, Bt=n2, out=bufs[0], Mk=mk, overwrite=ow), dict(At=dx1, Bt=o, out=bufs[1], Mk=mk, at_rows=rmap, overwrite=ow),
+                dict(At=dqkv, Bt=x2, out=bufs[2], Mk=mk, bt_rows=rmap, overwrite=ow)]
+    for ow in (True, False):
+        g = outs(ow)
+        assert hip.gemm_tn_group(problems(g, ow)), "the library declined a set the training step relies on"
+        sp = list(hip.LAST_TN_GROUP_SPLITS)
+        assert len(sp) == 3 and min(sp) >= 1
+        tiles = [(hid // 256) * (c // 256), (c // 256) ** 2, (3 * c // 256) * (c // 256)]
+        wgs = sum(t * s_ for t, s_ in zip(tiles, sp))
+        assert 224 <= wgs <= 256, f"{wgs} workgroups for {tiles} tiles x {sp} splits"
+        g2 = outs(ow)
+        assert hip.gemm_tn_group(problems(g2, ow))
+        single = outs(ow)
+        for q, s_, dst in zip(problems(single, ow), sp, single):
+            hip.gemm_tn(q["At"], q["Bt"], dst, Mk=mk, at_rows=q.get("at_rows"), bt_rows=q.get("bt_rows"), overwrite=ow, splits=s_ | (1 << 29))
+            assert hip.load().stswin_last_variant(1) & hip.VAR_TN_FUSED
+        for a, a2, b in zip(g, g2, single):
+            assert torch.equal(a, a2), "two grouped launches differ"
+            assert torch.equal(a, b), "grouped launch and single launch at the same split count differ"
+        ref = dh.float().t() @ n2.float() + (0.0 if ow else 0.25)
+        assert float((g[0] - ref).abs().max()) < 1e-2 * float(ref.abs().max())
+        refp = dx1.float()[rmap.long()].t() @ o.float() + (0.0 if ow else 0.25)
+        assert float((g[1] - refp).abs().max()) < 1e-2 * float(refp.abs().max())
+        refq = dqkv.float().t() @ x2.float()[rmap.long()] + (0.0 if ow else 0.25)
+        assert float((g[2] - refq).abs().max()) < 1e-2 * float(refq.abs().max())
+
+
+def test_gemm_tn_group_declines_what_the_ring_kernel_does_not_take(monkeypatch):
+    """Sets the grouped launch must hand back untouched (the caller then launches one by one): a narrow output, a fused-combine hold, the
+    A/B switch, too little work to fill 7/8 of the device."""
+    dev = "cuda"
+    a = torch.randn(8192, 512, device=dev).bfloat16()
+    b = torch.randn(8192, 128, device=dev).bfloat16()
+    sentinel = torch.full((512, 128), 7.0, device=dev)
+    assert not hip.gemm_tn_group([dict(At=a, Bt=b, out=sentinel, Mk=8192)])
+    assert bool((sentinel == 7.0).all())
+    big = torch.randn(65536, 512, device=dev).bfloat16()
+    out = torch.full((512, 512), 7.0, device=dev)
+    ok = [dict(At=big, Bt=big, out=out, Mk=65536)]
+    hold = hip.TnFusedHold()
+    assert not hip.gemm_tn_group(ok)
+    hold.release()
+    monkeypatch.setenv("STSWIN_TN_GROUP", "0")
+    assert not hip.gemm_tn_group(ok)
+    monkeypatch.delenv("STSWIN_TN_GROUP")
+    assert bool((out == 7.0).all())
+    assert hip.gemm_tn_group(ok) and list(hip.LAST_TN_GROUP_SPLITS) == [64]        # 4 tiles x 64 splits: what the single launch picks, too
+    small = torch.randn(1024, 512, device=dev).bfloat16()
+    assert not hip.gemm_tn_group([dict(At=small, Bt=small, out=torch.empty(512, 512, device=dev), Mk=1024)])     # 4 tiles x 2 splits of 16 stages
