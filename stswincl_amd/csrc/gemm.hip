@@ -2279,6 +2279,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(GemmTN p) {
 // leaves (see the hand-over below) - no workgroup needs another one to be resident, so a busy second stream, a second process or an
 // RCCL kernel holding compute units costs time, never correctness; the launcher still fuses only grids of <= one workgroup per CU,
 // because that is where the distributed combine is faster than the separate pass.
+#ifdef STSWIN_TUNING
+// tuning builds: stamps of a NORMAL run (results written, combine included) into a caller-set buffer [workgroups][8] u64
+// (stswin_debug_set_tn_stamps; tools/tn_group_timeline.py): 0 start, 1 prologue issued, 2 first stage landed, 3 main loop done,
+// 4 the tile's partials complete, 5 combine done, 6 Ni of the problem, 7 split * 1000 + tile
+__device__ unsigned long long* g_tn_stamp_buf = nullptr;
+extern "C" int stswin_debug_set_tn_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tn_stamp_buf), &buf, sizeof(buf)); }
+#endif
 // The kernel body as a device function of (problem, position `seq` in the problem's split-major (split, tile) sequence, workgroups of
 // the problem, stamp row): gemm_tn_ring_kernel runs one problem per launch, gemm_tn_ring_group_kernel (round 5) several.
 template <int MODE, bool FUSE>
@@ -2308,6 +2315,12 @@ DEVI void gemm_tn_ring_body(const GemmTN& p, const int seq, const int nwg, const
   const bool dbg_ts = p.ldc == -1;                       // DBG (tools/gemm_timeline.py tn): C is a u64 [workgroups][8] timestamp buffer
   auto stamp = [&](int slot) {
     if (dbg_ts && threadIdx.x == 0) ((unsigned long long*)p.C)[(long)stamp_row * 8 + slot] = wall_clock64();
+#ifdef STSWIN_TUNING
+    else if (g_tn_stamp_buf && threadIdx.x == 0) {
+      g_tn_stamp_buf[(long)stamp_row * 8 + slot] = wall_clock64();
+      if (slot == 0) { g_tn_stamp_buf[(long)stamp_row * 8 + 6] = (unsigned long long)p.Ni; g_tn_stamp_buf[(long)stamp_row * 8 + 7] = (unsigned long long)(split_id * 1000 + tile_id); }
+    }
+#endif
   };
   stamp(0);
 
@@ -2647,13 +2660,28 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTN p) {
 // Several weight-gradient problems in ONE launch (round 5, stswin_gemm_tn_group): the three late weight gradients of a Swin block
 // (fc1, proj, qkv) are 16 + 4 + 12 output tiles at stage 1 - launched one by one each needs 16 / 64 / 21 splits to fill the chip and pays
 // its own ramp, prologue, partial-tile round trip and combine (~30 us of a 58-129 us launch); together they are 32 tiles x 7-9 splits =
-// 256 workgroups with twice to eight times the contraction rows per workgroup.  Measured (profiles/r05_tn_group_probe.txt,
-// r05_tn_group_in_step_ab.txt): three PLAIN problems of these shapes 229 us grouped against 291 one by one; with the step's row maps
-// (proj gathers A, qkv gathers B) 282 against 314 - the gathered workgroups are the slow ones -, step +0.7 %.  The problems' (split, tile) sequences are laid end
-// to end and xcd_remap hands every XCD a contiguous range of the whole; a workgroup finds its problem by its position and runs the
-// body instantiated for that problem's gather mode (resolved per workgroup, not per stage).  Fused combine only.
+// 256 workgroups with twice to eight times the contraction rows per workgroup.  Measured (profiles/r05_tn_group_timeline_static.txt,
+// r05_tn_group_static_in_step_ab.txt): 237 us for the three of stage 1 against 134 + 54 + 116 one by one; step +1.9 %.
 #define TN_GROUP_MAX 4
 struct GemmTNGroup { GemmTN q[TN_GROUP_MAX]; int first[TN_GROUP_MAX + 1]; int mode[TN_GROUP_MAX]; int count; };
+// The same with the problems' slots and gather modes fixed at compile time (M0..M3, -1 = no such slot): every field of a problem then
+// sits at a constant kernel-argument offset like the single-problem kernel's.  Indexed dynamically (the generic kernel below) the
+// selected problem's fields are held in SGPRs for the whole body and the row-map bodies - six index sets = 48 SGPRs - spill 19 of
+// them into VGPR lanes: 1.07 us per stage against 0.78 us of the plain workgroups beside them (profiles/r05_tn_group_timeline.txt).
+template <int M0, int M1, int M2, int M3>
+__global__ __launch_bounds__(512, 2) void gemm_tn_ring_group_static_kernel(GemmTNGroup g) {
+  const int seq = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  if constexpr (M3 >= 0) {
+    if (seq >= g.first[3]) { gemm_tn_ring_body<M3 < 0 ? 0 : M3, true>(g.q[3], seq - g.first[3], g.first[4] - g.first[3], (int)blockIdx.x); return; }
+  }
+  if constexpr (M2 >= 0) {
+    if (seq >= g.first[2]) { gemm_tn_ring_body<M2 < 0 ? 0 : M2, true>(g.q[2], seq - g.first[2], g.first[3] - g.first[2], (int)blockIdx.x); return; }
+  }
+  if constexpr (M1 >= 0) {
+    if (seq >= g.first[1]) { gemm_tn_ring_body<M1 < 0 ? 0 : M1, true>(g.q[1], seq - g.first[1], g.first[2] - g.first[1], (int)blockIdx.x); return; }
+  }
+  gemm_tn_ring_body<M0, true>(g.q[0], seq, g.first[1], (int)blockIdx.x);
+}
 __global__ __launch_bounds__(512, 2) void gemm_tn_ring_group_kernel(GemmTNGroup g) {
   const int seq = xcd_remap((int)blockIdx.x, (int)gridDim.x);
   int i = 0;
@@ -3338,14 +3366,13 @@ extern "C" int stswin_gemm_tn_group(int dtype, int count, const StswinTnProblem*
   const int cus = stswin_cu_budget();
   if (cus > tn_resident_workgroups()) return declined;
   // stages per workgroup: the smallest count with which the grid fits the budget (>= 16: below that the ring never reaches steady state)
-  // A workgroup of a problem with a row map runs its stages slower than a plain one (the scalar index loads and the per-row copies:
-  // ~1.1x alone, 1.2-1.3x beside plain workgroups) and the launch ends with its slowest workgroup: such a problem's stage count is
-  // weighted by 1.2 (STSWIN_TN_GROUP_W, percent, tuning; profiles/r05_tn_group_weight_sweep.txt: fc1 + proj + qkv at stage 1 then
-  // split 7 / 9 / 9 instead of 8 / 8 / 8, 282 against 302 us, and 314 one by one)
+  // A workgroup of a problem with a row map runs its stages ~8 % slower than a plain one beside it (0.83 against 0.77 us;
+  // profiles/r05_tn_group_timeline_static.txt) and the launch ends with its slowest workgroup: such a problem's stage count is weighted
+  // by 1.05 in the split choice (STSWIN_TN_GROUP_W, percent, tuning; 100-110 measure the same in the step, 120 is slower)
   long target = (tile_stages + cus - 1) / cus;
   if (target < 16) target = 16;
   const char* ew = getenv("STSWIN_TN_GROUP_W");
-  const long wmap = ew && atoi(ew) >= 100 && atoi(ew) <= 300 ? atoi(ew) : 120;
+  const long wmap = ew && atoi(ew) >= 100 && atoi(ew) <= 300 ? atoi(ew) : 105;
   long total = 0;
   for (int guard = 0; guard < 4096; ++guard, ++target) {
     total = 0;
@@ -3386,9 +3413,19 @@ extern "C" int stswin_gemm_tn_group(int dtype, int count, const StswinTnProblem*
     if (splits_out) splits_out[i] = rs[i];
   }
   for (int i = count; i < TN_GROUP_MAX; ++i) { g.q[i] = g.q[0]; g.mode[i] = 0; g.first[i + 1] = g.first[count]; }
-  static int once_g = (int)hipFuncSetAttribute((const void*)gemm_tn_ring_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  static int once_g = (int)hipFuncSetAttribute((const void*)gemm_tn_ring_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
+                      (int)hipFuncSetAttribute((const void*)gemm_tn_ring_group_static_kernel<0, 1, 2, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
+                      (int)hipFuncSetAttribute((const void*)gemm_tn_ring_group_static_kernel<0, 0, -1, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   (void)once_g;
   g_last_variant[1] = STSWIN_VAR_TN_RING_PLAIN | STSWIN_VAR_TN_SLABS_BF16 | STSWIN_VAR_TN_FUSED | (rs[0] << 16);
+  // slot / mode combinations of the training step get the kernel with constant argument offsets (the problems keep their order:
+  // the caller lists them plain, A-gathered, B-gathered)
+  const bool m012 = count == 3 && g.mode[0] == 0 && g.mode[1] == 1 && g.mode[2] == 2;
+  const bool m00 = count == 2 && g.mode[0] == 0 && g.mode[1] == 0;
+  static const char* egd = getenv("STSWIN_TN_GROUP_DYNAMIC");          // A/B switch: the dynamically indexed kernel for every set
+  if (m012 && !(egd && atoi(egd))) hipLaunchKernelGGL((gemm_tn_ring_group_static_kernel<0, 1, 2, -1>), dim3((unsigned)total), dim3(512), 131072, (hipStream_t)stream, g);
+  else if (m00 && !(egd && atoi(egd))) hipLaunchKernelGGL((gemm_tn_ring_group_static_kernel<0, 0, -1, -1>), dim3((unsigned)total), dim3(512), 131072, (hipStream_t)stream, g);
+  else
   hipLaunchKernelGGL(gemm_tn_ring_group_kernel, dim3((unsigned)total), dim3(512), 131072, (hipStream_t)stream, g);
   STSWIN_CHECK_LAUNCH();
   return 0;

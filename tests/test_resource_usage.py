@@ -43,3 +43,10 @@ def test_the_hot_kernels_are_in_the_report_and_within_their_register_budget(usag
                 "attn_bwd8_kernel<64, true, false>", "attn_bwd8_kernel<64, true, true>", "attn_qkv_fwd_kernel<64, 512>"):
         for r in find(sub):
             assert r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 256, (sub, r)
+    # The grouped weight-gradient kernels of the training step (problem slots and gather modes fixed at compile time) must not spill
+    # SGPRs: the row-map bodies hold six index sets (48 SGPRs), and in the dynamically indexed kernel 19 spilled SGPRs made their
+    # stages 38 % slower than the plain workgroups beside them (profiles/r05_tn_group_timeline.txt against ..._static.txt).
+    for sub in ("gemm_tn_ring_group_static_kernel<0, 1, 2, -1>", "gemm_tn_ring_group_static_kernel<0, 0, -1, -1>",
+                "gemm_tn_ring_kernel<0, true>", "gemm_tn_ring_kernel<1, true>", "gemm_tn_ring_kernel<2, true>"):
+        for r in find(sub):
+            assert r["scratch"] == 0 and r["sgpr_spill"] == 0, (sub, r)

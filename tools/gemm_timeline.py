@@ -66,10 +66,10 @@ def tn_timeline(Mk=65536, Ni=2048, Nj=512, mapped=False):
     Bt = torch.randn(Mk, Nj, device="cuda").bfloat16()
     side = int((Mk // 16) ** 0.5)
     rmap = hip.win_rowmap(4, 4, side, side, 8, 4) if mapped else None
-    nblk = 256
+    nblk = 512
     for _ in range(3):
         ts = torch.zeros(Ni, Nj, dtype=torch.float32, device="cuda")
-        hip.gemm_tn(At, Bt, ts, Mk=Mk, bt_rows=rmap, atomics=True, debug_ts=True)
+        hip.gemm_tn(At, Bt, ts, Mk=Mk, bt_rows=rmap, atomics=True, debug_ts=True, splits=(int(os.environ['STSWIN_TL_SPLITS']) | (1 << 29)) if os.environ.get('STSWIN_TL_SPLITS') else 0)
     torch.cuda.synchronize()
     raw = ts.view(torch.int64).view(-1)[: nblk * 8].view(nblk, 8).cpu().double()
     raw = raw[raw[:, 3] > 0]

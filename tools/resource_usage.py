@@ -63,7 +63,8 @@ def _unit(unit: str, extra=()):
             m = re.search(key + r": (\d+)", blk)
             return int(m.group(1)) if m else -1
         rows.append(dict(unit=unit, mangled=blk.split()[0], scratch=g(r"ScratchSize \[bytes/lane\]"), vgpr=g("VGPRs"), agpr=g("AGPRs"),
-                         sgpr=g("SGPRs"), occupancy=g(r"Occupancy \[waves/SIMD\]"), lds=g(r"LDS Size \[bytes/block\]")))
+                         sgpr=g("SGPRs"), occupancy=g(r"Occupancy \[waves/SIMD\]"), lds=g(r"LDS Size \[bytes/block\]"),
+                         sgpr_spill=g("SGPRs Spill")))
     return rows
 
 
@@ -90,7 +91,7 @@ def allowed_reason(kernel: str):
 def main():
     rows = collect(extra=("-DSTSWIN_TUNING",) if "--tuning" in sys.argv else ())
     only = "--scratch-only" in sys.argv
-    print(f"{'unit':10s} {'scratch':>7s} {'VGPR':>4s} {'AGPR':>4s} {'SGPR':>4s} {'occ':>3s} {'LDS':>7s}  kernel")
+    print(f"{'unit':10s} {'scratch':>7s} {'VGPR':>4s} {'AGPR':>4s} {'SGPR':>4s} {'sspl':>4s} {'occ':>3s} {'LDS':>7s}  kernel   (sspl = SGPRs spilled into VGPR lanes)")
     bad = 0
     for r in sorted(rows, key=lambda r: (r["unit"], r["kernel"])):
         if only and r["scratch"] <= 0:
@@ -98,7 +99,7 @@ def main():
         why = allowed_reason(r["kernel"]) if r["scratch"] > 0 else None
         mark = "" if r["scratch"] <= 0 else (f"   [allowed: {why}]" if why else "   <-- PRODUCT KERNEL WITH SCRATCH")
         bad += r["scratch"] > 0 and not why
-        print(f"{r['unit']:10s} {r['scratch']:7d} {r['vgpr']:4d} {r['agpr']:4d} {r['sgpr']:4d} {r['occupancy']:3d} {r['lds']:7d}  {r['kernel'][:150]}{mark}")
+        print(f"{r['unit']:10s} {r['scratch']:7d} {r['vgpr']:4d} {r['agpr']:4d} {r['sgpr']:4d} {r['sgpr_spill']:4d} {r['occupancy']:3d} {r['lds']:7d}  {r['kernel'][:150]}{mark}")
     print(f"{len(rows)} kernels, {sum(r['scratch'] > 0 for r in rows)} with scratch, {bad} of them product kernels")
     return 1 if bad else 0
 
