@@ -298,6 +298,12 @@ int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, lo
                          float* scratch /* >= stswin_layernorm_bwd_scratch(M, S*Cseg) floats: one [3][S*Cseg] slab (dgamma | dbeta |
                                            dxsum partial sums) per workgroup; folded into dgamma / dbeta / dxsum (+=) in slab order */,
                          void* stream);
+/* The same with the accumulated-into tensor as a separate, read-only operand: dx = add + LN'(dy).  The backward of a pre-norm block
+ * (swin_512.py:228-234: x = shortcut + attn; x = x + mlp(norm2(x))) then leaves the incoming gradient `add` intact for the weight-gradient
+ * GEMM that reads it later (stswin_gemm_tn_group). */
+int stswin_layernorm_bwd_add(int dtype, const void* dy, long lddy, const void* x, long ldx, const int* rows, int S, int Cseg,
+                             const float* gamma, const float* mean, const float* rstd, const void* add, long ldadd, void* dx, long lddx,
+                             float* dgamma, float* dbeta, int M, float* dxsum, float* scratch, void* stream);
 long stswin_layernorm_bwd_scratch(int M, int C);
 
 /* out[i] = map[i] >= 0 ? v[map[i]] : fill, i < n: padding of per-channel parameter vectors (BatchNorm weight / bias / running

@@ -3387,6 +3387,18 @@ extern "C" int stswin_gemm_tn_group(int dtype, int count, const StswinTnProblem*
     if (total <= cus) break;
   }
   if (total > cus || total * 8 < (long)cus * 7) return declined;
+  {   // balance: the launch ends with its longest workgroup - decline a plan whose longest (weighted) stage count is more than 15 %
+      // above the mean over the device (stage 2 of the Swin stack, all four weight gradients: 192 tiles -> splits 1 / 1 / 2 / 2,
+      // 389 us against 117 + 230 for fc2 alone + the other three; profiles/r05_tn_group4_in_step_ab.txt)
+    long wsum = 0, wmax = 0;
+    for (int i = 0; i < count; ++i) {
+      const long wi = (pr[i].at_rows || pr[i].bt_rows) ? wmap : 100;
+      const long per = (nst[i] + rs[i] - 1) / rs[i];
+      wsum += (long)tiles[i] * nst[i] * wi;
+      if (per * wi > wmax) wmax = per * wi;
+    }
+    if (wmax * cus * 100 > wsum * 115) return declined;
+  }
   long ws_need = 0;
   for (int i = 0; i < count; ++i) {
     if ((long)rs[i] * pr[i].Ni * pr[i].Nj * 2 >= 0x7FFFFFF0L) return declined;
@@ -3415,16 +3427,19 @@ extern "C" int stswin_gemm_tn_group(int dtype, int count, const StswinTnProblem*
   for (int i = count; i < TN_GROUP_MAX; ++i) { g.q[i] = g.q[0]; g.mode[i] = 0; g.first[i + 1] = g.first[count]; }
   static int once_g = (int)hipFuncSetAttribute((const void*)gemm_tn_ring_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
                       (int)hipFuncSetAttribute((const void*)gemm_tn_ring_group_static_kernel<0, 1, 2, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
-                      (int)hipFuncSetAttribute((const void*)gemm_tn_ring_group_static_kernel<0, 0, -1, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                      (int)hipFuncSetAttribute((const void*)gemm_tn_ring_group_static_kernel<0, 0, -1, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) |
+                      (int)hipFuncSetAttribute((const void*)gemm_tn_ring_group_static_kernel<0, 0, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   (void)once_g;
   g_last_variant[1] = STSWIN_VAR_TN_RING_PLAIN | STSWIN_VAR_TN_SLABS_BF16 | STSWIN_VAR_TN_FUSED | (rs[0] << 16);
   // slot / mode combinations of the training step get the kernel with constant argument offsets (the problems keep their order:
   // the caller lists them plain, A-gathered, B-gathered)
   const bool m012 = count == 3 && g.mode[0] == 0 && g.mode[1] == 1 && g.mode[2] == 2;
   const bool m00 = count == 2 && g.mode[0] == 0 && g.mode[1] == 0;
+  const bool m0012 = count == 4 && g.mode[0] == 0 && g.mode[1] == 0 && g.mode[2] == 1 && g.mode[3] == 2;
   static const char* egd = getenv("STSWIN_TN_GROUP_DYNAMIC");          // A/B switch: the dynamically indexed kernel for every set
   if (m012 && !(egd && atoi(egd))) hipLaunchKernelGGL((gemm_tn_ring_group_static_kernel<0, 1, 2, -1>), dim3((unsigned)total), dim3(512), 131072, (hipStream_t)stream, g);
   else if (m00 && !(egd && atoi(egd))) hipLaunchKernelGGL((gemm_tn_ring_group_static_kernel<0, 0, -1, -1>), dim3((unsigned)total), dim3(512), 131072, (hipStream_t)stream, g);
+  else if (m0012 && !(egd && atoi(egd))) hipLaunchKernelGGL((gemm_tn_ring_group_static_kernel<0, 0, 1, 2>), dim3((unsigned)total), dim3(512), 131072, (hipStream_t)stream, g);
   else
   hipLaunchKernelGGL(gemm_tn_ring_group_kernel, dim3((unsigned)total), dim3(512), 131072, (hipStream_t)stream, g);
   STSWIN_CHECK_LAUNCH();

@@ -555,7 +555,8 @@ template <typename T, int NP, int NW, bool ACC, bool DXS>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* dy, long lddy, const T* x, long ldx, const int* rows,
                                                           int S, int Cseg, const float* gamma, const float* mean,
                                                           const float* rstd, T* dx, long lddx, float* dgamma,
-                                                          float* dbeta, int M, int rows_per_wave, float* ws) {
+                                                          float* dbeta, int M, int rows_per_wave, float* ws,
+                                                          const T* add, long ldadd) {      // ACC: dx = add + LN'(dy) (add may be dx itself)
   constexpr int PACK = TT<T>::PACK;
   typedef decltype(Vec16<T>().v) vec_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* dy, long lddy,
         const long row = rows ? (long)rows[(long)s * M + r] : (long)r;
         cur.xi[p] = *(const raw_t*)(x + row * ldx + cc);
         cur.di[p] = *(const raw_t*)(dy + (long)r * lddy + c);
-        if constexpr (EARLY) cur.old[p] = *(const raw_t*)(dx + row * lddx + cc);
+        if constexpr (EARLY) cur.old[p] = *(const raw_t*)(add + row * ldadd + cc);
       }
     }
     const float mu = cur.mu, rs = cur.rs;
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* dy, long lddy,
         Vec16<T> xi, di, o;
         xi.v = __builtin_bit_cast(vec_t, cur.xi[p]); di.v = __builtin_bit_cast(vec_t, cur.di[p]);
         if constexpr (EARLY) o.v = __builtin_bit_cast(vec_t, cur.old[p]);
-        else if constexpr (ACC) o.v = *(const vec_t*)dst;
+        else if constexpr (ACC) o.v = *(const vec_t*)(add + row * ldadd + cc);
         float gm[PACK];
 #pragma unroll
         for (int e = 0; e < PACK; e += 4) *(f32x4*)(gm + e) = *(const f32x4*)(sgam + c + e);
@@ -939,14 +940,15 @@ extern "C" long stswin_layernorm_bwd_scratch(int M, int C) {      // (sized for 
 template <typename T>
 static int ln_bwd_launch(const void* dy, long lddy, const void* x, long ldx, const int* rows, int S, int Cseg,
                          const float* g, const float* mean, const float* rstd, void* dx, long lddx, float* dg, float* db,
-                         int M, int acc, float* dxsum, float* ws, hipStream_t st) {
+                         int M, int acc, float* dxsum, float* ws, hipStream_t st, const void* add = nullptr, long ldadd = 0) {
+  if (acc && !add) { add = dx; ldadd = lddx; }
   constexpr int PACK = TT<T>::PACK;
   const int C = S * Cseg, np = (C / PACK + 63) / 64;
   const int rpw = ln_bwd_rows_per_wave(M), nw = ln_bwd_waves(M, C, PACK);
   dim3 grid((unsigned)ln_bwd_grid(M, C, PACK)), blk(nw * 64);
   const size_t lds = (size_t)(nw + 1) * C * sizeof(float);
   if (!ws) return -1111;
-#define LN_B4(NP, NW, A, D) hipLaunchKernelGGL((ln_bwd_kernel<T, NP, NW, A, D>), grid, blk, lds, st, (const T*)dy, lddy, (const T*)x, ldx, rows, S, Cseg, g, mean, rstd, (T*)dx, lddx, dg, db, M, rpw, ws)
+#define LN_B4(NP, NW, A, D) hipLaunchKernelGGL((ln_bwd_kernel<T, NP, NW, A, D>), grid, blk, lds, st, (const T*)dy, lddy, (const T*)x, ldx, rows, S, Cseg, g, mean, rstd, (T*)dx, lddx, dg, db, M, rpw, ws, (const T*)add, ldadd)
 #define LN_B2(NP, NW) do { if (acc) { if (dxsum) LN_B4(NP, NW, true, true); else LN_B4(NP, NW, true, false); } \
                            else { if (dxsum) LN_B4(NP, NW, false, true); else LN_B4(NP, NW, false, false); } } while (0)
 #define LN_B(NP) do { if (nw == 8) LN_B2(NP, 8); else LN_B2(NP, 4); } while (0)
@@ -974,6 +976,22 @@ extern "C" int stswin_layernorm_bwd(int dtype, const void* dy, long lddy, const 
   if ((long)S * Cseg * 5 * 4 > 65536) return -1106;
   int rc = dtype == 0 ? ln_bwd_launch<bf16>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, accumulate_dx, dxsum, workspace, (hipStream_t)stream)
                       : ln_bwd_launch<float>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, accumulate_dx, dxsum, workspace, (hipStream_t)stream);
+  if (rc) return rc;
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
+/* dx = add + LN'(dy): the residual sum of a pre-norm block's backward written to a NEW buffer, so that `add` (the gradient of the block's
+ * output branch, an operand of a weight-gradient GEMM that is launched later: stswin_gemm_tn_group) stays intact */
+extern "C" int stswin_layernorm_bwd_add(int dtype, const void* dy, long lddy, const void* x, long ldx, const int* rows, int S,
+                                        int Cseg, const float* gamma, const float* mean, const float* rstd, const void* add, long ldadd,
+                                        void* dx, long lddx, float* dgamma, float* dbeta, int M, float* dxsum, float* workspace,
+                                        void* stream) {
+  const int pack = dtype == 0 ? 8 : 4;
+  if (!add || Cseg % pack || ldx % pack || lddy % pack || lddx % pack || ldadd % pack) return -1105;
+  if ((long)S * Cseg * 5 * 4 > 65536) return -1106;
+  int rc = dtype == 0 ? ln_bwd_launch<bf16>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, 1, dxsum, workspace, (hipStream_t)stream, add, ldadd)
+                      : ln_bwd_launch<float>(dy, lddy, x, ldx, rows, S, Cseg, gamma, mean, rstd, dx, lddx, dgamma, dbeta, M, 1, dxsum, workspace, (hipStream_t)stream, add, ldadd);
   if (rc) return rc;
   STSWIN_CHECK_LAUNCH();
   return 0;

@@ -849,12 +849,20 @@ def layernorm_fwd(x, gamma, beta, *, M, rows=None, S=1, Cseg=None, eps=1e-5, sav
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, *, M, rows=None, S=1, Cseg=None, dx=None, accumulate=False,
-                  dxsum=None):
+                  dxsum=None, add=None):
+    """add (optional): dx = add + LN'(dy) into a fresh (or the given) dx, `add` left intact."""
     Cseg = x.shape[1] if Cseg is None else Cseg
     if dx is None:
         dx = torch.empty_like(x)
         accumulate = False
     ws = scratch(x.device, load().stswin_layernorm_bwd_scratch(M, S * Cseg))
+    if add is not None:
+        assert not accumulate and add.dtype == x.dtype
+        rc = load().stswin_layernorm_bwd_add(_dt(x), _p(dy), _c_long(_ld(dy)), _p(x), _c_long(_ld(x)), _p(rows), S, Cseg,
+                                             _p(gamma), _p(mean), _p(rstd), _p(add), _c_long(_ld(add)), _p(dx), _c_long(_ld(dx)),
+                                             _p(dgamma), _p(dbeta), M, _p(dxsum), _p(ws), _stream())
+        _check(rc, "layernorm_bwd_add")
+        return dx
     rc = load().stswin_layernorm_bwd(_dt(x), _p(dy), _c_long(_ld(dy)), _p(x), _c_long(_ld(x)), _p(rows), S, Cseg,
                                      _p(gamma), _p(mean), _p(rstd), _p(dx), _c_long(_ld(dx)), _p(dgamma), _p(dbeta), M,
                                      1 if accumulate else 0, _p(dxsum), _p(ws), _stream())

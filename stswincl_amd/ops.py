@@ -208,6 +208,7 @@ _UNIQ_MASKS: Dict[int, tuple] = {}
 
 
 _TN_GROUP = os.environ.get("STSWIN_NO_TN_GROUP") != "1"      # (A/B switch)
+_TN_GROUP4 = os.environ.get("STSWIN_NO_TN_GROUP4") != "1"    # (A/B switch: fc2 joins the group)
 
 
 def _duo(site: str, M: int, N: int, K: int) -> int:
@@ -503,19 +504,26 @@ class SwinBlockFn(torch.autograd.Function):
         try:
             # norm1 (its dx column sums are fc2's bias gradient)
             dy2 = hip.layernorm_bwd(g, y2, _f32(n1_w), mean1, rstd1, dn1_w, dn1_b, M=M, dxsum=dfc2_b)
-            # fc2 (+ GELU', + fc1's bias gradient from the epilogue)
-            hip.gemm_tn(dy2, h, dfc2_w, Mk=M, overwrite=True)
+            # fc2 (+ GELU', + fc1's bias gradient from the epilogue); the four weight gradients of the block wait for the grouped
+            # launch at the end (see there): dy2, dh_pre stay alive until then and norm2's backward writes dx1 into a new buffer
+            late = [dict(At=dy2, Bt=h, out=dfc2_w, Mk=M)]
             dh_pre = torch.empty(M, hid, dtype=dt, device=dev)
             hip.gemm_nt(dy2, wcast(fc2_w, dt, True), dh_pre, M=M, resid=h_pre,
                         flags=(hip.GF_MUL_DGELU if ctx.gelu_bwd else hip.GF_MUL_R) | _duo("fc2d", M, hid, C), colsum_out=dfc1_b)
-            # fc1 (its weight gradient waits for the grouped launch below: dh_pre stays alive until then)
-            late = [dict(At=dh_pre, Bt=n2, out=dfc1_w, Mk=M)]
+            # fc1
+            late.append(dict(At=dh_pre, Bt=n2, out=dfc1_w, Mk=M))
             dn2 = torch.empty(M, C, dtype=dt, device=dev)
             hip.gemm_nt(dh_pre, wcast(fc1_w, dt, True), dn2, M=M)
             del dh_pre
-            # norm2 ; dx1 = dy2 + LN'(dn2) accumulated in place into dy2; its column sums are proj's bias gradient
-            dx1 = hip.layernorm_bwd(dn2, x1, _f32(n2_w), mean2, rstd2, dn2_w, dn2_b, M=M, dx=dy2, accumulate=True,
-                                    dxsum=dproj_b)
+            # norm2 ; dx1 = dy2 + LN'(dn2); its column sums are proj's bias gradient.  In place over dy2 when fc2's weight gradient
+            # has already been launched (no grouping), else into a new buffer (dy2 is an operand of the grouped launch)
+            if _TN_GROUP:
+                dx1 = hip.layernorm_bwd(dn2, x1, _f32(n2_w), mean2, rstd2, dn2_w, dn2_b, M=M, add=dy2, dxsum=dproj_b)
+            else:
+                hip.gemm_tn(dy2, h, dfc2_w, Mk=M, overwrite=True)
+                late.pop(0)
+                dx1 = hip.layernorm_bwd(dn2, x1, _f32(n2_w), mean2, rstd2, dn2_w, dn2_b, M=M, dx=dy2, accumulate=True,
+                                        dxsum=dproj_b)
             # proj (window order on the attention side)
             late.append(dict(At=dx1, Bt=o, out=dproj_w, Mk=M, at_rows=rmap))
             do = dn2  # reuse
@@ -533,12 +541,19 @@ class SwinBlockFn(torch.autograd.Function):
             raise
         folds.__exit__(None, None, None)
         hip.bias_scatter(dbiasT, index.reshape(-1).contiguous(), dtable, N, heads, lists=_scatter_lists_for(index, ws, tsz))
-        # qkv - and with it the fc1 and proj weight gradients: ONE launch of three problems (32 tiles x 8 splits at stage 1 instead of
-        # 16 x 16, 4 x 64 and 12 x 21 one after the other: hip.gemm_tn_group); one by one when the library declines the set
+        # qkv - and with it the block's other weight gradients in ONE launch (hip.gemm_tn_group): fc2, fc1, proj, qkv = 48 tiles x 5-6
+        # splits at stage 1 instead of 16 x 16, 16 x 16, 4 x 64 and 12 x 21 one after the other; where the four do not fill the device
+        # (stage 2: 192 tiles) fc2 goes alone and the other three together (128 tiles x 2); one by one when the library declines
         late.append(dict(At=dqkv, Bt=X2, out=dqkv_w, Mk=M, bt_rows=rmap if ctx.src is None else ctx.src.compose(rmap)))
-        if not (_TN_GROUP and hip.gemm_tn_group(late)):
-            for q in late:
-                hip.gemm_tn(q["At"], q["Bt"], q["out"], Mk=M, at_rows=q.get("at_rows"), bt_rows=q.get("bt_rows"), overwrite=True)
+
+        def single(q):
+            hip.gemm_tn(q["At"], q["Bt"], q["out"], Mk=M, at_rows=q.get("at_rows"), bt_rows=q.get("bt_rows"), overwrite=True)
+        if not (_TN_GROUP and len(late) == 4 and _TN_GROUP4 and hip.gemm_tn_group(late)):
+            if len(late) == 4:
+                single(late.pop(0))
+            if not (_TN_GROUP and hip.gemm_tn_group(late)):
+                for q in late:
+                    single(q)
         del late
         src = ctx.src
         if src is None:

@@ -110,6 +110,13 @@ def test_layernorm_bwd_accumulate_and_column_sums(dtype, m, c, acc, dxs):
     assert torch.allclose(dg, gr.grad, atol=lim, rtol=1e-3) and torch.allclose(db, br.grad, atol=lim, rtol=1e-3)
     if dxs:
         assert torch.allclose(cs, dx.float().sum(0), atol=lim, rtol=2e-3)      # sums of the values as written (rounded to the output type)
+    if acc:      # the same sum with the accumulated-into tensor as a separate read-only operand (stswin_layernorm_bwd_add): same bits
+        dg2, db2 = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+        cs2 = torch.zeros(c, device="cuda") if dxs else None
+        keep = old.clone()
+        dx2 = hip.layernorm_bwd(dy, x, g, mean, rstd, dg2, db2, M=m, add=keep, dxsum=cs2)
+        assert torch.equal(dx2, dx) and torch.equal(keep, old) and torch.equal(dg2, dg) and torch.equal(db2, db)
+        assert cs2 is None or torch.equal(cs2, cs)
 
 
 @pytest.mark.parametrize("dtype", DT)
