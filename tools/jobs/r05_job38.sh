@@ -1,0 +1,6 @@
+#!/bin/bash
+set -u
+OUT=gpurun_out/r05q
+mkdir -p $OUT
+export TMPDIR=/tmp
+python3 tools/ragged_rounds.py 2>&1 | grep -v amdgpu.ids | tee $OUT/r05_ragged_rounds.txt
