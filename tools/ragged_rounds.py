@@ -37,4 +37,8 @@ for M, N, K, note in shapes:
     vd = hip.load().stswin_last_variant(0)
     tb = timeit(lambda i: hip.gemm_nt(A[i], W[i], O[i], M=M, flags=hip.GF_BIG), nset)
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    print(f"{M:6d} {N:5d} {K:5d} {tiles:5d} | {td:10.1f} {fl / td * 1e-6:6.0f} {vd:8x} | {tb:8.1f} {fl / tb * 1e-6:6.0f} | {note}", flush=True)
+    duo = ""
+    if hip.tuning_build():          # the 128x256-tile, two-workgroups-per-CU variant of tuning builds (GF_DUO)
+        tdu = timeit(lambda i: hip.gemm_nt(A[i], W[i], O[i], M=M, flags=hip.GF_DUO | hip.GF_BIG), nset)
+        duo = f" | duo {tdu:7.1f} us {fl / tdu * 1e-6:6.0f} TF/s"
+    print(f"{M:6d} {N:5d} {K:5d} {tiles:5d} | {td:10.1f} {fl / td * 1e-6:6.0f} {vd:8x} | {tb:8.1f} {fl / tb * 1e-6:6.0f}{duo} | {note}", flush=True)
