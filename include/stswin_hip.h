@@ -349,9 +349,11 @@ int stswin_win_attn_fwd(int dtype, const void* qkv, long ld, void* out, long ldo
  * mask table and the softmax never leave the CU.  x [.][C] token rows, rmap int [nB_ * 128] = token row of every window row (-1:
  * zero row; NULL: identity), w = qkv.weight [3C][C] (bf16), bqkv fp32 [3C] or NULL, biasT as in stswin_win_attn_fwd with
  * bias_windows / bias_index (the pre-summed bias + mask table; no separate maskT).  qkv_out (optional, [nB_ * 128][3C]) receives
- * q * scale | k | v for stswin_win_attn_bwd; NULL in no-grad passes, which then never write q, k, v to memory. */
-int stswin_win_attn_qkv_fwd(const void* x, long ldx, const int* rmap, const void* w, long ldw, const float* bqkv, void* qkv_out, long ldq,
-                            void* out, long ldo, const float* biasT, int nB_, int nW, int T_frames, int ws, int heads, int C,
+ * q * scale | k | v for stswin_win_attn_bwd; NULL in no-grad passes, which then never write q, k, v to memory.
+ * x_rows = token rows of x (every rmap value is < x_rows; 0: nB_ * 128).  The kernel addresses x with 32-bit byte offsets:
+ * x_rows * ldx * 2 > 0xFFFF0000 returns -1208 and launches nothing (the caller runs stswin_gemm_nt + stswin_win_attn_fwd). */
+int stswin_win_attn_qkv_fwd(const void* x, long ldx, long x_rows, const int* rmap, const void* w, long ldw, const float* bqkv, void* qkv_out,
+                            long ldq, void* out, long ldo, const float* biasT, int nB_, int nW, int T_frames, int ws, int heads, int C,
                             float scale, int bias_windows, const int* bias_index, void* stream);
 /* BASELINE.json configs[4] "fp8 MFMA attention": the forward above with q, k, v and the probabilities quantised to OCP e4m3 in
  * registers (per (window, head) amax scales, P x 128) and both products on v_mfma_f32_32x32x16_fp8_fp8; qkv / out stay bf16 in
@@ -535,6 +537,22 @@ int stswin_multi_tensor(int mode, int count, void* const* p, const void* const* 
 int stswin_multi_tensor_lars(int count, void* const* p, const void* const* g, void* const* m, const int* n, float* norms,
                              long norms_floats, float lr, float momentum, float wd, float trust_coef, float eps, int first, int adaptive,
                              void* stream);
+
+/* Step-dependent optimizer scalars in DEVICE memory, so that a hipGraph replay of a training step advances like eager steps do
+ * (the reference's loops step Adam / LARS / the key-encoder momentum from host state every iteration: seg18/train_swin.py:122,171-173,
+ * pixcontrast_18/main_pretrain_swinv5.py:37-47, contrast/models/PixPro_swin_v5.py:258-289).  hyper = fp32 [4] {lr, c1, c2, EMA momentum}.
+ * stswin_optim_tick (one thread, double precision like the host expressions it replaces):
+ *   kind 0: t = ++counter[0]; hyper[1] = 1 - a^t; hyper[2] = sqrt(1 - b^t)                   (Adam bias corrections, a, b = betas)
+ *   kind 1: k = counter[0]++; hyper[3] = 1 - (1 - a) (cos(pi k / b) + 1) / 2                  (PixPro_swin_v5.py:260; a = base momentum, b = K)
+ * stswin_multi_tensor_dev / stswin_multi_tensor_lars_dev: stswin_multi_tensor / stswin_multi_tensor_lars reading lr (hyper[0]), the Adam
+ * corrections (hyper[1], hyper[2]) or the EMA momentum (hyper[3]) from `hyper` instead of their arguments; `first` as c1 != 0 above.
+ * hyper[0] is written by the host with a stream-ordered fill whenever the scheduler changes the learning rate. */
+int stswin_optim_tick(int kind, int* counter, float* hyper, double a, double b, void* stream);
+int stswin_multi_tensor_dev(int mode, int count, void* const* p, const void* const* g, void* const* m, void* const* v, const int* n,
+                            const float* hyper, float b1, float b2, float eps, float wd, int first, void* stream);
+int stswin_multi_tensor_lars_dev(int count, void* const* p, const void* const* g, void* const* m, const int* n, float* norms,
+                                 long norms_floats, const float* hyper, float momentum, float wd, float trust_coef, float eps, int first,
+                                 int adaptive, void* stream);
 
 /* ---- device self-test of the MFMA / LDS primitives the kernels are built on; writes a report into `out`
  * (fp32, >= 64 KiB) and returns the number of failed checks (0 = all good). Used by tests only. */

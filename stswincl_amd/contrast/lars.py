@@ -16,7 +16,7 @@ from __future__ import annotations
 import torch
 
 from .. import hip
-from ..optim import _mark_updated
+from ..optim import _mark_updated, group_clock
 
 __all__ = ["LARS", "add_weight_decay"]
 
@@ -61,7 +61,15 @@ class LARS:
         return self.optim.state
 
     def state_dict(self):
-        return self.optim.state_dict()
+        sd = self.optim.state_dict()
+        sd["param_groups"] = [{k: v for k, v in g.items() if k != "_clock"} for g in sd["param_groups"]]
+        return sd
+
+    def push_hyper(self):
+        """Before a hipGraph replay of the step: the groups' current learning rates -> device (stswincl_amd.graph.GraphedStep)."""
+        for group in self.optim.param_groups:
+            if group.get("_clock") is not None:
+                group["_clock"].push_lr(group["lr"])
 
     def load_state_dict(self, state_dict):
         self.optim.load_state_dict(state_dict)
@@ -102,7 +110,9 @@ class LARS:
                 touched.append(p)
             for (ps, gs, ms), is_first in ((first, True), (later, False)):
                 if ps:
+                    # (the learning rate travels through device memory: a hipGraph replay of the step sees the scheduler's current value)
                     hip.multi_tensor_lars(ps, gs, ms, None, lr=float(group["lr"]), momentum=momentum,
-                                          wd=wd, trust_coef=self.trust_coef, eps=self.eps, first=is_first, adaptive=adaptive)
+                                          wd=wd, trust_coef=self.trust_coef, eps=self.eps, first=is_first, adaptive=adaptive,
+                                          hyper=group_clock(group, ps[0].device).hyper)
             _mark_updated(touched)
         return loss

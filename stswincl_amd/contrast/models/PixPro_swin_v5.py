@@ -215,7 +215,7 @@ class PairLossFn(torch.autograd.Function):
     copy launches forward and as many backward."""
 
     @staticmethod
-    def forward(ctx, proj_q, bank, lb, cfg):
+    def forward(ctx, proj_q, lq, bank, lb, cfg):
         b, HW, q_block, bank_block, class_num, inv_tau, want_lse = cfg
         gmap = ((1, 2, 3, 4, 5), (0, 2, 3, 4, 5))
         X = proj_q.detach()
@@ -223,7 +223,10 @@ class PairLossFn(torch.autograd.Function):
             X = X.contiguous()
         q_tok = torch.empty(2 * b * HW, X.shape[1], dtype=X.dtype, device=X.device)
         inv = hip.rownorm_scatter(X, q_tok, 2, HW, b, want_inv=True)
-        lq = lb[:2].reshape(-1)                         # (the first two maps' labels are the two query views': a view, no copy)
+        # lq: THIS rank's labels of the two query views (rows of the LOCAL lb[:2], taken by the caller before any all-gather of
+        # the bank: a gathered lb is rank-major per map and 'world' times as long as the query matrix)
+        if lq.numel() != q_tok.shape[0]:
+            raise ValueError(f"PairLossFn: {lq.numel()} query labels for {q_tok.shape[0]} query rows")
         cnt = hip.label_counts(lq, lb, q_sets=2, q_block=q_block, bank_block=bank_block, ncls=class_num, gmap=gmap)
         # (unit_rows: both operands were normalised by rownorm_scatter - the log-sum-exp takes the fixed-reference form)
         pos, tot, rmax, lse = hip.contrast_bank_fwd(q_tok, lq, bank, lb, q_sets=2, q_block=q_block, bank_block=bank_block, gmap=gmap,
@@ -243,12 +246,13 @@ class PairLossFn(torch.autograd.Function):
         dpos, dneg = hip.pair_loss_bwd(pos, tot, cnt, dloss.detach().float().contiguous(), 2, bank_block)
         ksum = hip.contrast_class_sums(bank, lb, bank_block, class_num)
         dq = hip.contrast_bank_dq(dpos, dneg, cnt, lq, ksum, q_sets=2, q_block=q_block, seg=bank.shape[1], bank_block=bank_block, gmap=gmap)
-        return hip.rownorm_scatter_bwd(X, inv, dq, 2, HW, b), None, None, None
+        return hip.rownorm_scatter_bwd(X, inv, dq, 2, HW, b), None, None, None, None
 
 
 def pair_loss_tokens(proj_q, bank, lb, b, HW, class_num, bank_mode="sample", inv_tau=1.0, want_lse=False):
     """consistency_pair_loss on the token operands the batched encoder passes leave behind: proj_q = projector output of the batched
     query pass (clip-major rows, before F.normalize), bank [6][b HW][C] = normalised key embeddings (view-major), lb int32 [6][b HW]."""
+    lq = lb[:2].reshape(-1)           # the two query views' labels of this rank (a view of the local lb; BEFORE the gather)
     if bank_mode == "sample":
         q_block = bank_block = HW
     else:
@@ -257,7 +261,7 @@ def pair_loss_tokens(proj_q, bank, lb, b, HW, class_num, bank_mode="sample", inv
         elif bank_mode != "batch":
             raise ValueError(f"bank_mode {bank_mode!r}")
         q_block, bank_block = b * HW, bank.shape[1]
-    return PairLossFn.apply(proj_q, bank, lb, (b, HW, q_block, bank_block, class_num, float(inv_tau), bool(want_lse)))
+    return PairLossFn.apply(proj_q, lq, bank, lb, (b, HW, q_block, bank_block, class_num, float(inv_tau), bool(want_lse)))
 
 
 def Proj_Head(in_dim=400, inner_dim=512, out_dim=256):
@@ -320,6 +324,7 @@ class PixPro(nn.Module):
                     self.projector_k):
             nn.SyncBatchNorm.convert_sync_batchnorm(mod)
         ws = _world_size()
+        self._ema = None                  # optim.EmaSchedule: k and the momentum of the step in device memory (made at the first update)
         self.K = int(args.num_instances * 1. / ws / args.batch_size * args.epochs)
         self.k = int(args.num_instances * 1. / ws / args.batch_size * (args.start_epoch - 1))
         if self.pixpro_transform_layer == 0:
@@ -336,18 +341,40 @@ class PixPro(nn.Module):
                 (self.proj1, self.proj_k_1), (self.proj2, self.proj_k_2), (self.proj3, self.proj_k_3),
                 (self.projector, self.projector_k)]
 
+    @property
+    def k(self) -> int:
+        """Key-encoder updates done so far (PixPro_swin_v5.py:246,262).  Once the schedule lives on the device this is its host mirror:
+        exact in eager loops; after hipGraph replays of the step call `sync_k()` (one device read) before relying on it."""
+        return self._ema.k if self._ema is not None else self._k
+
+    @k.setter
+    def k(self, value) -> None:
+        self._k = int(value)
+        self._ema = None                   # re-made from _k at the next update
+
+    def sync_k(self) -> int:
+        if self._ema is not None:
+            self._k = self._ema.sync()
+        return self._k
+
     @torch.no_grad()
     def _momentum_update_key_encoder(self):
-        """k <- k m + q (1-m), m = 1 - (1-m0)(cos(pi k/K)+1)/2 (PixPro_swin_v5.py:258-289), on the multi-tensor HIP kernel."""
-        m = 1. - (1. - self.pixpro_momentum) * (math.cos(math.pi * self.k / self.K) + 1) / 2.
-        self.k = self.k + 1
+        """k <- k m + q (1-m), m = 1 - (1-m0)(cos(pi k/K)+1)/2 (PixPro_swin_v5.py:258-289), on the multi-tensor HIP kernel.  The step
+        counter k and the momentum m live in device memory (optim.EmaSchedule: one one-thread launch evaluates the reference's
+        expression in double precision and advances k), so a hipGraph replay of the training step walks the schedule like eager
+        steps do."""
+        from ...optim import EmaSchedule, ema_update
         qs, ks = [], []
         for q_mod, k_mod in self._pairs():
             for pq, pk in zip(q_mod.parameters(), k_mod.parameters()):
                 qs.append(pq.data)
                 ks.append(pk)                              # the parameter itself: ema_update bumps its version counter
-        from ...optim import ema_update
-        ema_update(ks, qs, m)
+        if self._ema is None or self._ema.clock.counter.device != ks[0].device or self._ema.K != float(self.K) \
+                or self._ema.m0 != float(self.pixpro_momentum):
+            if torch.cuda.is_current_stream_capturing():
+                raise hip.StswinHipError("PixPro: first key-encoder update inside a hipGraph capture; run one eager step first")
+            self._ema = EmaSchedule(ks[0].device, self.pixpro_momentum, self.K, self._k)
+        ema_update(ks, qs, 0.0, hyper=self._ema.tick())
 
     def _embed(self, seq, key: bool, tokens: bool = False):
         e1, e2, e3, p1, p2, p3, head = ((self.encoder_k_1, self.encoder_k_2, self.encoder_k_3, self.proj_k_1, self.proj_k_2,

@@ -595,7 +595,11 @@ __global__ __launch_bounds__(512) void attn_qkv_fwd_kernel(AttnQkvArgs q) {
     __syncthreads();                                   // tiles and ring are reused by the next problem
     stamp(6);
   }
-  if (xrow_bad) __builtin_trap();
+#ifdef STSWIN_TUNING
+  if (xrow_bad) __builtin_trap();                      // debug assertion only: the launcher refuses an x beyond the 32-bit offset range
+#else
+  (void)xrow_bad;
+#endif
 }
 
 // ====================================================================================================
@@ -1887,9 +1891,13 @@ extern "C" int stswin_win_attn_bwd(int dtype, const void* qkv, long ld, const vo
   return attn_common(dtype, a, T_frames, ws, true, stream);
 }
 
-extern "C" int stswin_win_attn_qkv_fwd(const void* x, long ldx, const int* rmap, const void* w, long ldw, const float* bqkv, void* qkv_out,
-                                       long ldq, void* out, long ldo, const float* biasT, int nB_, int nW, int T_frames, int ws, int heads,
-                                       int C, float scale, int bias_windows, const int* bias_index, void* stream) {
+extern "C" int stswin_win_attn_qkv_fwd(const void* x, long ldx, long x_rows, const int* rmap, const void* w, long ldw, const float* bqkv,
+                                       void* qkv_out, long ldq, void* out, long ldo, const float* biasT, int nB_, int nW, int T_frames, int ws,
+                                       int heads, int C, float scale, int bias_windows, const int* bias_index, void* stream) {
+  // the gathered token rows are addressed with 32-bit byte offsets from x: refuse (the caller takes the GEMM + attention pair) an x
+  // whose last row a buffer offset cannot reach, instead of faulting on the device
+  if (x_rows <= 0) x_rows = (long)nB_ * T_frames * ws * ws;
+  if (ldx <= 0 || (unsigned long long)x_rows * (unsigned long long)ldx * 2ull > 0xFFFF0000ull) return -1208;
   unsigned long long* dbg_ts = nullptr;               // DBG: bit 30 of bias_windows = qkv_out is a u64 [256][8][8] stamp buffer instead
   if (bias_windows & (1 << 30)) { bias_windows &= ~(1 << 30); dbg_ts = (unsigned long long*)qkv_out; qkv_out = nullptr; }
   if (T_frames * ws * ws != 128 || heads <= 0 || C != heads * 128 || C % 32) return -1206;     // the stage-1 shape only

@@ -489,7 +489,9 @@ static int contrast_bank_fwd_impl(int dtype, const void* Q, long ldq, const int*
   for (int s = 0; s < 2; ++s)
     for (int g = 0; g < CB_MAX_GROUPS; ++g) a.gmap[s][g] = (s < q_sets && g < groups) ? gmap[s * groups + g] : 0;
   a.inv_tau = inv_tau;
-  a.want_lse = (rowmax || lse) ? (unit_rows && inv_tau > 0.f ? 2 : 1) : 0;
+  // fixed-reference form exp(inv_tau (s - 1)) only while its smallest term, exp(-2 inv_tau), stays a normal fp32 number
+  // (inv_tau <= 40: e^-80 = 1.8e-35); colder temperatures take the online (running-maximum) form
+  a.want_lse = (rowmax || lse) ? (unit_rows && inv_tau > 0.f && inv_tau <= 40.f ? 2 : 1) : 0;
   const int TM = 128;
   const long row_tiles = (long)q_sets * nblk * ((q_block + TM - 1) / TM);
   // bank splits (one 8-wave workgroup per CU): the split count that minimises rounds x (bank tiles per workgroup + ~2 tiles of

@@ -20,7 +20,36 @@ struct MTArgs {
                                // 3 LARS-scaled SGD: mode 1 with the gradient (after weight decay) times the tensor's trust ratio
   const float* norms;          // mode 3: fp32 [count][2] = sum p^2, sum (g + wd p)^2 per tensor (mt_norms_kernel), or NULL = ratio 1
   float trust;                 // mode 3: trust coefficient (b2 is unused there; eps = LARS eps)
+  const float* hyper;          // device fp32 [4] = {lr, c1, c2, EMA momentum} or NULL.  When set, the step-dependent scalars are READ
+                               // FROM MEMORY (written by stswin_optim_tick / a stream-ordered fill) instead of the kernel arguments:
+                               // a hipGraph replay of the step then advances exactly like eager steps do.
 };
+
+// One thread: advance a device-resident step counter and derive the step-dependent scalars from it, in double precision like the
+// host expressions they replace.
+//   kind 0 (Adam, torch.optim.Adam's bias corrections): t = ++counter; hyper[1] = 1 - a^t; hyper[2] = sqrt(1 - b^t)   (a, b = betas)
+//   kind 1 (PixPro key-encoder momentum, PixPro_swin_v5.py:258-262): k = counter++; hyper[3] = 1 - (1 - a) (cos(pi k / b) + 1) / 2
+//          (a = base momentum, b = K total steps)
+__global__ void optim_tick_kernel(int kind, int* __restrict__ counter, float* __restrict__ hyper, double a, double b) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (kind == 0) {
+    const int t = counter[0] + 1;
+    counter[0] = t;
+    hyper[1] = (float)(1.0 - pow(a, (double)t));
+    hyper[2] = (float)sqrt(1.0 - pow(b, (double)t));
+  } else {
+    const int k = counter[0];
+    counter[0] = k + 1;
+    hyper[3] = (float)(1.0 - (1.0 - a) * (cos(3.141592653589793 * (double)k / b) + 1.0) / 2.0);
+  }
+}
+
+extern "C" int stswin_optim_tick(int kind, int* counter, float* hyper, double a, double b, void* stream) {
+  if (kind < 0 || kind > 1 || !counter || !hyper) return -1604;
+  hipLaunchKernelGGL(optim_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kind, counter, hyper, a, b);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
 
 // LARS needs ||p|| and ||g + wd p|| of every tensor before any element moves (contrast/lars.py:131-139): one pass over the
 // same (tensor, chunk) grid as the update kernel, a wave-level fold and one fp32 atomic pair per block (<= a few hundred
@@ -93,6 +122,12 @@ __global__ __launch_bounds__(256) void multi_tensor_kernel(MTArgs a) {
   float* __restrict__ v = a.v[t];
   const int base = b * MT_CHUNK;
   const int end = min(n, base + MT_CHUNK);
+  float lr = a.lr, b1 = a.b1, c1 = a.c1, c2 = a.c2;
+  if (a.hyper) {                               // step-dependent scalars from memory (uniform loads)
+    if (a.mode == 2) b1 = a.hyper[3];
+    else lr = a.hyper[0];
+    if (a.mode == 0) { c1 = a.hyper[1]; c2 = a.hyper[2]; }
+  }
   float ratio = 1.f;                           // LARS trust ratio of this tensor (lars.py:136-139)
   if (a.mode == 3 && a.norms) {
     const float pn = sqrtf(a.norms[2 * t]), gn = sqrtf(a.norms[2 * t + 1]);
@@ -120,16 +155,16 @@ __global__ __launch_bounds__(256) void multi_tensor_kernel(MTArgs a) {
       if (e >= cnt) break;
       if (a.mode == 0) {                       // torch.optim.Adam (no amsgrad; L2 weight decay added to the gradient)
         float gr = gv[e] + a.wd * pv[e];
-        mv[e] = a.b1 * mv[e] + (1.f - a.b1) * gr;
+        mv[e] = b1 * mv[e] + (1.f - b1) * gr;
         vv[e] = a.b2 * vv[e] + (1.f - a.b2) * gr * gr;
-        const float denom = sqrtf(vv[e]) / a.c2 + a.eps;
-        pv[e] -= (a.lr / a.c1) * (mv[e] / denom);
+        const float denom = sqrtf(vv[e]) / c2 + a.eps;
+        pv[e] -= (lr / c1) * (mv[e] / denom);
       } else if (a.mode == 1 || a.mode == 3) { // torch.optim.SGD with momentum (mode 3: gradient scaled by the trust ratio)
         float gr = (gv[e] + a.wd * pv[e]) * ratio;
-        mv[e] = (a.c1 != 0.f) ? gr : a.b1 * mv[e] + gr;     // first step: buf = grad
-        pv[e] -= a.lr * (a.b1 != 0.f ? mv[e] : gr);
+        mv[e] = (c1 != 0.f) ? gr : b1 * mv[e] + gr;     // first step: buf = grad
+        pv[e] -= lr * (b1 != 0.f ? mv[e] : gr);
       } else {                                 // EMA: key = key * m + query * (1 - m)
-        pv[e] = pv[e] * a.b1 + gv[e] * (1.f - a.b1);
+        pv[e] = pv[e] * b1 + gv[e] * (1.f - b1);
       }
     }
     if (vec) {
@@ -147,9 +182,9 @@ __global__ __launch_bounds__(256) void multi_tensor_kernel(MTArgs a) {
 }
 
 // ptrs: host arrays of `count` device pointers (count <= 48 per call; the caller chunks).
-extern "C" int stswin_multi_tensor(int mode, int count, void* const* p, const void* const* g, void* const* m, void* const* v,
-                                   const int* n, float lr, float b1, float b2, float eps, float wd, float c1, float c2,
-                                   void* stream) {
+static int multi_tensor_impl(int mode, int count, void* const* p, const void* const* g, void* const* m, void* const* v,
+                             const int* n, float lr, float b1, float b2, float eps, float wd, float c1, float c2, const float* hyper,
+                             void* stream) {
   if (count <= 0) return 0;
   if (count > MT_MAX || mode < 0 || mode > 2) return -1601;
   MTArgs a;
@@ -161,19 +196,34 @@ extern "C" int stswin_multi_tensor(int mode, int count, void* const* p, const vo
     blocks += (n[i] + MT_CHUNK - 1) / MT_CHUNK;
   }
   a.count = count; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = wd; a.c1 = c1; a.c2 = c2; a.mode = mode;
-  a.norms = nullptr; a.trust = 0.f;
+  a.norms = nullptr; a.trust = 0.f; a.hyper = hyper;
   hipLaunchKernelGGL(multi_tensor_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   STSWIN_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int stswin_multi_tensor(int mode, int count, void* const* p, const void* const* g, void* const* m, void* const* v,
+                                   const int* n, float lr, float b1, float b2, float eps, float wd, float c1, float c2,
+                                   void* stream) {
+  return multi_tensor_impl(mode, count, p, g, m, v, n, lr, b1, b2, eps, wd, c1, c2, nullptr, stream);
+}
+
+// The same update with its step-dependent scalars in device memory (`hyper`, fp32 [4] = {lr, c1, c2, EMA momentum}; see
+// stswin_optim_tick): Adam reads lr, c1, c2; SGD reads lr (`first` as in stswin_multi_tensor's c1); EMA reads the momentum.
+extern "C" int stswin_multi_tensor_dev(int mode, int count, void* const* p, const void* const* g, void* const* m, void* const* v,
+                                       const int* n, const float* hyper, float b1, float b2, float eps, float wd, int first,
+                                       void* stream) {
+  if (!hyper) return -1604;
+  return multi_tensor_impl(mode, count, p, g, m, v, n, 0.f, b1, b2, eps, wd, first ? 1.f : 0.f, 1.f, hyper, stream);
 }
 
 // LARS over SGD-momentum (contrast/lars.py:109-152 around torch.optim.SGD, main_pretrain_swinv5.py:37-47) for up to 48 tensors
 // of ONE parameter group: g' = g + wd p; adaptive: g' *= trust_coef ||p|| / (||g'|| + eps) when both norms are > 0;
 // buf = first ? g' : momentum buf + g'; p -= lr buf.  `norms` = caller-owned fp32 scratch of norms_floats >= 2 * count + 2 * blocks
 // floats (blocks = sum_i ceil(n_i / 8192)): [count][2] norms, then one partial pair per block.
-extern "C" int stswin_multi_tensor_lars(int count, void* const* p, const void* const* g, void* const* m, const int* n,
-                                        float* norms, long norms_floats, float lr, float momentum, float wd, float trust_coef, float eps,
-                                        int first, int adaptive, void* stream) {
+static int multi_tensor_lars_impl(int count, void* const* p, const void* const* g, void* const* m, const int* n,
+                                  float* norms, long norms_floats, float lr, const float* hyper, float momentum, float wd, float trust_coef,
+                                  float eps, int first, int adaptive, void* stream) {
   if (count <= 0) return 0;
   if (count > MT_MAX || (adaptive && !norms)) return -1602;
   MTArgs a;
@@ -183,7 +233,7 @@ extern "C" int stswin_multi_tensor_lars(int count, void* const* p, const void* c
     blocks += (n[i] + MT_CHUNK - 1) / MT_CHUNK;
   }
   a.count = count; a.lr = lr; a.b1 = momentum; a.b2 = 0.f; a.eps = eps; a.wd = wd; a.c1 = first ? 1.f : 0.f; a.c2 = 0.f; a.mode = 3;
-  a.norms = adaptive ? norms : nullptr; a.trust = trust_coef;
+  a.norms = adaptive ? norms : nullptr; a.trust = trust_coef; a.hyper = hyper;
   if (adaptive) {
     if (norms_floats < 2 * (long)count + 2 * blocks) return -1603;
     float* part = norms + 2 * count;
@@ -193,4 +243,18 @@ extern "C" int stswin_multi_tensor_lars(int count, void* const* p, const void* c
   hipLaunchKernelGGL(multi_tensor_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   STSWIN_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int stswin_multi_tensor_lars(int count, void* const* p, const void* const* g, void* const* m, const int* n,
+                                        float* norms, long norms_floats, float lr, float momentum, float wd, float trust_coef, float eps,
+                                        int first, int adaptive, void* stream) {
+  return multi_tensor_lars_impl(count, p, g, m, n, norms, norms_floats, lr, nullptr, momentum, wd, trust_coef, eps, first, adaptive, stream);
+}
+
+// ... with the learning rate in device memory (hyper[0]; the scheduler's value reaches it by a stream-ordered fill outside a captured step)
+extern "C" int stswin_multi_tensor_lars_dev(int count, void* const* p, const void* const* g, void* const* m, const int* n,
+                                            float* norms, long norms_floats, const float* hyper, float momentum, float wd, float trust_coef,
+                                            float eps, int first, int adaptive, void* stream) {
+  if (!hyper) return -1604;
+  return multi_tensor_lars_impl(count, p, g, m, n, norms, norms_floats, 0.f, hyper, momentum, wd, trust_coef, eps, first, adaptive, stream);
 }

@@ -81,7 +81,7 @@ class GradBucketReducer:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0, comm_dtype: Optional[torch.dtype] = None,
-                 group=None, overlap: bool = True, simulate=None, hold_tn_fused: bool = False):
+                 group=None, overlap: bool = True, simulate=None, hold_tn_fused: Optional[bool] = None):
         """simulate = (world, collective): measurement hook (tools/overlap_proxy.py) - behave like rank 0 of `world` ranks without a
         process group; collective(msg) is enqueued on the communication stream in place of dist.all_reduce (a stand-in kernel that
         holds compute units the way an RCCL kernel does) and returns None or an object with wait()."""
@@ -103,11 +103,14 @@ class GradBucketReducer:
             self.buckets.append(cur)
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
         # While an all-reduce runs on the comm stream its RCCL kernel holds compute units, so a 256-workgroup GEMM launched on the main
-        # stream is not resident all at once.  Since round 5 the fused split-K combine of the weight-gradient GEMMs does not need that
-        # (ticketed row slices, bounded wait: include/stswin_hip.h), and with a stand-in collective holding 8 / 16 / 32 CUs the step
-        # measures 29.02 / 29.68 / 29.40 ms with the fused combine against 29.14 / 29.75 / 29.35 ms with the separate pass
-        # (profiles/r05_overlap_proxy.txt): no reason to switch it off.  hold_tn_fused=True takes the library's refcounted hold for
-        # the reducer's lifetime anyway (separate pass; STSWIN_TN_FUSED=0 / 1 in the environment overrides either way).
+        # stream is not resident all at once.  The fused split-K combine of the weight-gradient GEMMs does not NEED residency (ticketed
+        # row slices behind a bounded wait: include/stswin_hip.h), and with a stand-in collective holding 8 / 16 / 32 CUs the step
+        # measures the same with it as with the separate pass (profiles/r05_overlap_proxy.txt) - but that is a single-GPU proxy, and no
+        # N > 1 RCCL run of it exists.  Until one does, a real (non-simulated) overlapped reducer of a world > 1 takes the library's
+        # ref-counted hold by default (separate combine pass, weight gradients launched one by one: the configuration every earlier
+        # round's multi-rank tests ran); hold_tn_fused=False or STSWIN_DP_TN_FUSED=1 opts into the fused / grouped launches.
+        if hold_tn_fused is None:
+            hold_tn_fused = simulate is None and os.environ.get("STSWIN_DP_TN_FUSED", "0") != "1"
         self._tn_hold = None
         if self.world > 1 and overlap and hold_tn_fused:
             from . import hip

@@ -316,7 +316,15 @@ class _Span:
                 self.a.record()
         return self
 
-    def cancel(self):                # nothing was launched inside the span (a declined grouped launch): no sample
+    def cancel(self):
+        """Nothing was launched inside the span (a declined grouped launch): no sample, and the launch / per-step site numbers
+        __enter__ handed out go back, so that the family's launch count and the rotation of timed sites are those of the launches
+        that did happen (the round-5 line counted a declined group as a launch and credited its work to the next sample)."""
+        if _PROFILE is not None and not getattr(self, "_cancelled", False):
+            self._cancelled = True
+            _PROFILE_COUNT[self.name] = _PROFILE_COUNT.get(self.name, 1) - 1
+            if _PROFILE_STEP_COUNT is not None and self.name in _PROFILE_STEP_COUNT:
+                _PROFILE_STEP_COUNT[self.name] -= 1
         self.a = None
 
     def __exit__(self, *exc):
@@ -580,6 +588,7 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
                                                   _p(bias), M, N, Kseg, S, 1 if (flags & GF_RELU) else 0, _p(ws), _c_long(ws.numel()), _stream())
             if rc != -1008:                  # -1008: not a split-K candidate after all (an `out` column slice that is not 16-byte
                 _check(rc, "gemm_nt_splitk")  # aligned, a row pitch that is not a multiple of 8): the tiled kernels below take it
+                _log_variant("nt", (M, N, Kseg, S), 0)
                 return out
     with _Span(name, 2.0 * M * N * Ktot):
         rc = load().stswin_gemm_nt(
@@ -588,6 +597,7 @@ def gemm_nt(A: torch.Tensor, Bw: torch.Tensor, out: torch.Tensor, *, M: int, a_r
             _c_long(_ld(resid) if resid is not None else 0), _p(r_rows), M, N, Kseg, S, _c_float(scale), scale_cols,
             flags, _p(cs_table if cs_table is not None else colsum_out), _stream())
     _check(rc, "gemm_nt")
+    _log_variant("nt", (M, N, Kseg, S), 0)
     if cs_table is not None:
         _check(load().stswin_cs_reduce(_p(cs_table), M, N, _p(colsum_out), _stream()), "cs_reduce")
     return out
@@ -607,6 +617,14 @@ def gemm_nt_qkv_fp8(A: torch.Tensor, Bw: torch.Tensor, *, M: int, a_rows=None, b
                                            _stream())
     _check(rc, "gemm_nt_qkv_fp8")
     return out8, scales
+
+
+VARIANT_LOG = None     # tests: set to a list -> every gemm_nt / gemm_tn / gemm_tn_group launch appends (family, shape, stswin_last_variant)
+
+
+def _log_variant(family: str, shape, fam_id: int) -> None:
+    if VARIANT_LOG is not None:
+        VARIANT_LOG.append((family, tuple(int(v) for v in shape), int(load().stswin_last_variant(fam_id))))
 
 
 _WARNED = {}
@@ -709,6 +727,7 @@ def gemm_tn(At: torch.Tensor, Bt: torch.Tensor, out_f32: torch.Tensor, *, Mk: in
                                    (splits | TN_NO_COMBINE) if defer else splits, bseg, _p(ws),
                                    _c_long(ws.numel() if ws is not None else 0), _stream())
     _check(rc, "gemm_tn")
+    _log_variant("tn", (Mk, Ni, Nj, bseg), 1)
     if defer:
         v = load().stswin_last_variant(1)
         if v & (VAR_TN_SLABS_F32 | VAR_TN_SLABS_BF16):   # partials are waiting in the workspace
@@ -774,6 +793,7 @@ def gemm_tn_group(problems) -> bool:
         return False
     _check(rc, "gemm_tn_group")
     LAST_TN_GROUP_SPLITS[:] = list(sp)
+    _log_variant("tn_group", (n, problems[0]["Mk"]) + tuple(sp), 1)
     return True
 
 
@@ -973,19 +993,24 @@ def win_attn_qkv_fwd(x, rmap, w, bqkv, biasT, *, nB_, nW, T, ws, heads, C, scale
     out = torch.empty(rows, C, dtype=x.dtype, device=x.device)
     qkv = torch.empty(rows, 3 * C, dtype=x.dtype, device=x.device) if want_qkv else None
     if debug_ts is not None:                     # tools/attn_qkv_timeline.py: int64 [256][8][8] stamp buffer in place of qkv_out
-        rc = load().stswin_win_attn_qkv_fwd(_p(x), _c_long(_ld(x)), _p(rmap), _p(w), _c_long(_ld(w)), _p(bqkv), _p(debug_ts), _c_long(0),
+        rc = load().stswin_win_attn_qkv_fwd(_p(x), _c_long(_ld(x)), _c_long(x.shape[0]), _p(rmap), _p(w), _c_long(_ld(w)), _p(bqkv), _p(debug_ts), _c_long(0),
                                             _p(out), _c_long(_ld(out)), _p(biasT), nB_, nW, T, ws, heads, C, _c_float(scale),
                                             _bias_windows(biasT, None, nW, bias_index) | (1 << 30), _p(bias_index), _stream())
         _check(rc, "win_attn_qkv_fwd")
         return out, None
     name = "attn_qkv_fwd_bf16"
     with _Span(name, 2.0 * rows * 3 * C * C + 4.0 * nB_ * heads * (T * ws * ws) ** 2 * (C // heads)):
-        rc = load().stswin_win_attn_qkv_fwd(_p(x), _c_long(_ld(x)), _p(rmap), _p(w), _c_long(_ld(w)), _p(bqkv), _p(qkv),
+        rc = load().stswin_win_attn_qkv_fwd(_p(x), _c_long(_ld(x)), _c_long(x.shape[0]), _p(rmap), _p(w), _c_long(_ld(w)), _p(bqkv), _p(qkv),
                                             _c_long(_ld(qkv) if qkv is not None else 0), _p(out), _c_long(_ld(out)), _p(biasT), nB_, nW, T,
                                             ws, heads, C, _c_float(scale), _bias_windows(biasT, None, nW, bias_index), _p(bias_index),
                                             _stream())
     _check(rc, "win_attn_qkv_fwd")
     return out, qkv
+
+
+def win_attn_qkv_fwd_ok(x: torch.Tensor) -> bool:
+    """Whether the fused kernel's 32-bit buffer offsets reach every token row of x (stswin_win_attn_qkv_fwd returns -1208 otherwise)."""
+    return x.shape[0] * _ld(x) * 2 <= 0xFFFF0000
 
 
 def win_attn_bwd(qkv, dout, biasT, maskT, dbiasT, *, nB_, nW, T, ws, heads, C, scale, colsum_out=None, debug_ts=False,
@@ -1158,6 +1183,9 @@ def contrast_bank_fwd(Q, lq, bank, lb, *, q_sets, q_block, bank_block, gmap, inv
     groups = len(gmap[0])
     assert Q.dtype == bank.dtype and bank.is_contiguous() and lb.is_contiguous() and lq.is_contiguous()
     assert lq.dtype == torch.int32 and lb.dtype == torch.int32 and len(gmap) == q_sets and all(len(g) == groups for g in gmap)
+    if lq.numel() != M or lb.shape != (maps, seg):
+        raise StswinHipError(f"contrast_bank_fwd: {lq.numel()} query labels for {M} query rows, bank labels {tuple(lb.shape)} for a "
+                             f"{maps} x {seg} bank")
     pos = torch.empty(M, groups, dtype=torch.float32, device=Q.device)
     tot = torch.empty(M, groups, dtype=torch.float32, device=Q.device)
     rowmax = torch.empty(M, dtype=torch.float32, device=Q.device) if want_lse else None
@@ -1230,6 +1258,9 @@ def labels_resize(masks, h: int, w: int) -> torch.Tensor:
 def label_counts(lq: torch.Tensor, lb: torch.Tensor, *, q_sets, q_block, bank_block, ncls, gmap) -> torch.Tensor:
     """cnt fp32 [M][groups]: visible bank rows of each group whose label equals the query's."""
     M, (maps, seg), groups = lq.numel(), lb.shape, len(gmap[0])
+    if M % q_sets or (M // q_sets) % q_block or seg % bank_block or not lq.is_contiguous() or not lb.is_contiguous():
+        raise StswinHipError(f"label_counts: {M} query labels do not split into {q_sets} sets of {q_block}-row blocks "
+                             f"(bank {maps} x {seg}, blocks of {bank_block})")
     hist = torch.empty(maps, seg // bank_block, ncls, dtype=torch.int32, device=lq.device)
     cnt = torch.empty(M, groups, dtype=torch.float32, device=lq.device)
     gm = (_c_int * (q_sets * groups))(*[int(v) for row in gmap for v in row])
@@ -1264,8 +1295,16 @@ def upsample_argmax(logits, H, W, gt=None):
     return labels, counts
 
 
-def multi_tensor(mode, ps, gs, ms=None, vs=None, lr=0.0, b1=0.0, b2=0.0, eps=0.0, wd=0.0, c1=1.0, c2=1.0):
-    """mode 0 Adam / 1 SGD-momentum / 2 EMA over lists of fp32 tensors (chunks of 48 tensors per launch)."""
+def optim_tick(kind: int, counter: torch.Tensor, hyper: torch.Tensor, a: float, b: float) -> None:
+    """Advance a device-resident step counter (int32 [1]) and derive the step's scalars into hyper (fp32 [4]); include/stswin_hip.h."""
+    assert counter.dtype == torch.int32 and hyper.dtype == torch.float32 and hyper.numel() >= 4 and counter.is_cuda and hyper.is_cuda
+    _check(load().stswin_optim_tick(int(kind), _p(counter), _p(hyper), ctypes.c_double(a), ctypes.c_double(b), _stream()), "optim_tick")
+
+
+def multi_tensor(mode, ps, gs, ms=None, vs=None, lr=0.0, b1=0.0, b2=0.0, eps=0.0, wd=0.0, c1=1.0, c2=1.0, hyper=None):
+    """mode 0 Adam / 1 SGD-momentum / 2 EMA over lists of fp32 tensors (chunks of 48 tensors per launch).  hyper (device fp32 [4] =
+    {lr, c1, c2, EMA momentum}): read the step-dependent scalars from it instead of lr / c1 / c2 / b1(EMA) - for SGD c1 != 0 still
+    marks the first step."""
     lib = load()
     st = _stream()
     for t in ps:
@@ -1276,12 +1315,16 @@ def multi_tensor(mode, ps, gs, ms=None, vs=None, lr=0.0, b1=0.0, b2=0.0, eps=0.0
         k = hi - lo
         arr = lambda ts: (_c_void_p * k)(*[t.data_ptr() for t in ts[lo:hi]]) if ts is not None else None  # noqa: E731
         ns = (_c_int * k)(*[t.numel() for t in ps[lo:hi]])
-        _check(lib.stswin_multi_tensor(mode, k, arr(ps), arr(gs), arr(ms), arr(vs), ns, _c_float(lr), _c_float(b1),
-                                       _c_float(b2), _c_float(eps), _c_float(wd), _c_float(c1), _c_float(c2), st),
-               "multi_tensor")
+        if hyper is not None:
+            _check(lib.stswin_multi_tensor_dev(mode, k, arr(ps), arr(gs), arr(ms), arr(vs), ns, _p(hyper), _c_float(b1), _c_float(b2),
+                                               _c_float(eps), _c_float(wd), 1 if (mode == 1 and c1 != 0.0) else 0, st), "multi_tensor_dev")
+        else:
+            _check(lib.stswin_multi_tensor(mode, k, arr(ps), arr(gs), arr(ms), arr(vs), ns, _c_float(lr), _c_float(b1),
+                                           _c_float(b2), _c_float(eps), _c_float(wd), _c_float(c1), _c_float(c2), st),
+                   "multi_tensor")
 
 
-def multi_tensor_lars(ps, gs, ms, norms, *, lr, momentum, wd, trust_coef, eps, first, adaptive):
+def multi_tensor_lars(ps, gs, ms, norms, *, lr, momentum, wd, trust_coef, eps, first, adaptive, hyper=None):
     """LARS-scaled SGD-momentum step of one parameter group (lists of contiguous fp32 GPU tensors; chunks of 48 tensors,
     two launches each: norms, update).  norms: fp32 scratch of >= 96 floats."""
     lib = load()
@@ -1297,6 +1340,11 @@ def multi_tensor_lars(ps, gs, ms, norms, *, lr, momentum, wd, trust_coef, eps, f
         need = 2 * k + 2 * sum((t.numel() + 8191) // 8192 for t in ps[lo:hi])
         if norms is None or norms.numel() < need:
             norms = scratch(ps[lo].device, need)
+        if hyper is not None:          # the learning rate from device memory (hyper[0])
+            _check(lib.stswin_multi_tensor_lars_dev(k, arr(ps), arr(gs), arr(ms), ns, _p(norms), _c_long(norms.numel()), _p(hyper),
+                                                    _c_float(momentum), _c_float(wd), _c_float(trust_coef), _c_float(eps), 1 if first else 0,
+                                                    1 if adaptive else 0, st), "multi_tensor_lars_dev")
+            continue
         _check(lib.stswin_multi_tensor_lars(k, arr(ps), arr(gs), arr(ms), ns, _p(norms), _c_long(norms.numel()), _c_float(lr), _c_float(momentum),
                                             _c_float(wd), _c_float(trust_coef), _c_float(eps), 1 if first else 0,
                                             1 if adaptive else 0, st), "multi_tensor_lars")

@@ -427,7 +427,7 @@ class SwinBlockFn(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad)
         fp8 = dt == torch.bfloat16 and os.environ.get("STSWIN_FP8_ATTN") == "1"
         if (_fused_qkv(need_bwd) and dt == torch.bfloat16 and not fp8 and T * N == 128 and d == 128 and C in (256, 512, 1024)
-                and (shift == 0 or attn_mask is not None)):
+                and (shift == 0 or attn_mask is not None) and hip.win_attn_qkv_fwd_ok(X2)):
             # stage-1 shape: window gather + QKV projection + attention core in ONE kernel; q | k | v reach memory only when a
             # backward will read them (swin_512.py:115-141)
             o, qkv = hip.win_attn_qkv_fwd(X2, rmap_in, wcast(qkv_w, dt), _f32(qkv_b), biasT, nB_=Bp * nW, nW=nW, T=T, ws=ws, heads=heads,

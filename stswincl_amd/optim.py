@@ -36,9 +36,59 @@ def _mark_updated(params: Sequence[torch.Tensor]) -> None:
         ops.repack(params)
 
 
+class _Clock:
+    """Device-resident step state shared by the parameters of one Adam launch group: `counter` int32 [1] (steps taken) and `hyper`
+    fp32 [4] = {lr, 1 - b1^t, sqrt(1 - b2^t), -} (csrc/optim.hip, stswin_optim_tick).  The update kernels read their step-dependent
+    scalars from `hyper`, so a hipGraph replay of the step advances the bias corrections exactly like eager steps do; the host
+    mirror `step` is what state_dict() reports and is re-read from the device after replays (sync())."""
+
+    def __init__(self, device, step: int = 0):
+        self.counter = torch.full((1,), int(step), dtype=torch.int32, device=device)
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=device)
+        self.step = int(step)
+        self.lr = None                       # the value hyper[0] holds
+
+    def push_lr(self, lr: float) -> None:
+        """Stream-ordered fill of hyper[0] when the host's learning rate differs from what the device holds (schedulers); a no-op
+        otherwise - in particular inside a capture whose warm-up steps already ran with this rate."""
+        lr = float(lr)
+        if self.lr != lr:
+            self.hyper[0:1].fill_(lr)
+            self.lr = lr
+
+    def sync(self) -> int:
+        self.step = int(self.counter.item())
+        return self.step
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._replayed = False
+        self._clock_groups = []
+
+    def _clocks(self):
+        seen = {}
+        for st in self.state.values():
+            c = st.get("_clock")
+            if c is not None:
+                seen[id(c)] = c
+        return list(seen.values())
+
+    def push_hyper(self) -> None:
+        """Before a graph replay: hand the groups' current learning rates to the device (stswincl_amd.graph.GraphedStep calls this)."""
+        self._replayed = True
+        for clock, group in self._clock_groups:         # (clock, group) pairs of the last step() - the one that was captured
+            clock.push_lr(group["lr"])
+
+    def sync_steps(self) -> None:
+        """Host step counts <- device counters (after graph replays the host mirrors are stale)."""
+        for c in self._clocks():
+            c.sync()
+        for st in self.state.values():
+            if st.get("_clock") is not None:
+                st["step"] = st["_clock"].step
+        self._replayed = False
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -46,47 +96,94 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:                    # (torch.optim re-enables grad for the closure: it runs forward + backward)
             with torch.enable_grad():
                 loss = closure()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self._replayed and not capturing:       # eager steps after graph replays: the host mirrors first
+            self.sync_steps()
+        self._clock_groups = []
         for group in self.param_groups:
             b1, b2 = group["betas"]
-            by_step = {}          # torch.optim.Adam keeps the step count PER PARAMETER (bias corrections differ when a branch
-            touched = []          # had no gradient on some steps, or a parameter was unfrozen later): one launch per count
+            by_clock = {}         # torch.optim.Adam keeps the step count PER PARAMETER (bias corrections differ when a branch
+            touched = []          # had no gradient on some steps, or a parameter was unfrozen later): one launch per count.
+            fresh = {}            # Parameters at the same count share a device clock.
             for p in group["params"]:
                 if p.grad is None:
                     continue
                 st = self.state[p]
-                if not st:
+                if "exp_avg" not in st:
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 if not isinstance(st["step"], int):          # a state loaded from torch.optim.Adam holds tensor steps: one host
                     st["step"] = int(st["step"])             # read, here, before any capture (see load_state_dict)
-                st["step"] += 1
-                ps, gs, ms, vs = by_step.setdefault(st["step"], ([], [], [], []))
+                clock = st.get("_clock")
+                if clock is None:                            # first gradient (or a loaded state): join the clock of this count
+                    if capturing:
+                        raise hip.StswinHipError("FusedAdam: a parameter got its first gradient inside a hipGraph capture; run the "
+                                                 "step eagerly once before capturing it")
+                    key = (st["step"], p.device)
+                    clock = fresh.get(key)
+                    if clock is None:
+                        clock = fresh[key] = next((c for (c, *_r) in by_clock.values() if c.step == st["step"] and c.counter.device == p.device),
+                                                  None) or _Clock(p.device, st["step"])
+                    st["_clock"] = clock
+                _c, ps, gs, ms, vs, sts = by_clock.setdefault(id(clock), (clock, [], [], [], [], []))
                 ps.append(p.data)
                 touched.append(p)
                 gs.append(p.grad.contiguous() if not p.grad.is_contiguous() else p.grad)
                 ms.append(st["exp_avg"])
                 vs.append(st["exp_avg_sq"])
-            for step, (ps, gs, ms, vs) in by_step.items():
-                hip.multi_tensor(0, ps, gs, ms, vs, lr=group["lr"], b1=b1, b2=b2, eps=group["eps"], wd=group["weight_decay"],
-                                 c1=1.0 - b1 ** step, c2=math.sqrt(1.0 - b2 ** step))
+                sts.append(st)
+            for clock, ps, gs, ms, vs, sts in by_clock.values():
+                self._clock_groups.append((clock, group))
+                clock.push_lr(group["lr"])
+                hip.optim_tick(0, clock.counter, clock.hyper, float(b1), float(b2))
+                clock.step += 1
+                for st in sts:
+                    st["step"] = clock.step
+                hip.multi_tensor(0, ps, gs, ms, vs, b1=b1, b2=b2, eps=group["eps"], wd=group["weight_decay"], hyper=clock.hyper)
             _mark_updated(touched)
         return loss
 
+    def state_dict(self):
+        """(the device clocks stay out of the checkpoint: `step` per parameter is what torch.optim.Adam writes, too)"""
+        if self._replayed:
+            self.sync_steps()
+        sd = super().state_dict()
+        sd["state"] = {k: {kk: vv for kk, vv in v.items() if kk != "_clock"} for k, v in sd["state"].items()}
+        return sd
 
     def load_state_dict(self, state_dict):
-        """torch.optim.Adam checkpoints keep `step` as a (possibly GPU) tensor per parameter; the fused kernel takes the bias
-        corrections as host scalars, so the counts become Python ints here - once, outside any hipGraph capture - instead of
-        forcing a device-to-host read inside step()."""
+        """torch.optim.Adam checkpoints keep `step` as a (possibly GPU) tensor per parameter; the counts become Python ints here -
+        once, outside any hipGraph capture - and the device clocks are re-made from them at the next step()."""
         super().load_state_dict(state_dict)
         for st in self.state.values():
+            st.pop("_clock", None)
             if "step" in st and not isinstance(st["step"], int):
                 st["step"] = int(st["step"])
+
+
+def group_clock(group, device) -> _Clock:
+    """The device-resident learning rate of a parameter group (SGD / LARS: lr is their only step-dependent scalar)."""
+    c = group.get("_clock")
+    if c is None or c.hyper.device != device:
+        c = group["_clock"] = _Clock(device)
+    c.push_lr(group["lr"])
+    return c
 
 
 class FusedSGD(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+
+    def push_hyper(self) -> None:
+        for group in self.param_groups:
+            if group.get("_clock") is not None:
+                group["_clock"].push_lr(group["lr"])
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["param_groups"] = [{k: v for k, v in g.items() if k != "_clock"} for g in sd["param_groups"]]
+        return sd
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -112,17 +209,41 @@ class FusedSGD(torch.optim.Optimizer):
                 tgt[2].append(st["momentum_buffer"])
             for (ps, gs, ms), c1 in ((first, 1.0), (later, 0.0)):
                 if ps:
-                    hip.multi_tensor(1, ps, gs, ms, None, lr=group["lr"], b1=group["momentum"], wd=group["weight_decay"], c1=c1)
+                    hip.multi_tensor(1, ps, gs, ms, None, b1=group["momentum"], wd=group["weight_decay"], c1=c1,
+                                     hyper=group_clock(group, ps[0].device).hyper)
             _mark_updated(touched)
         return loss
 
 
 @torch.no_grad()
-def ema_update(keys: Sequence[torch.Tensor], queries: Sequence[torch.Tensor], momentum: float) -> None:
+def ema_update(keys: Sequence[torch.Tensor], queries: Sequence[torch.Tensor], momentum: float, hyper=None) -> None:
     """key <- key * momentum + query * (1 - momentum) for every pair.  Pass the key PARAMETERS (not their .data aliases):
-    their version counters are bumped so that caches keyed on them see the update."""
-    hip.multi_tensor(2, [k.data for k in keys], [q.data for q in queries], b1=momentum)
+    their version counters are bumped so that caches keyed on them see the update.  hyper (device fp32 [4]): the momentum is read
+    from hyper[3] (EmaSchedule) instead of the argument."""
+    hip.multi_tensor(2, [k.data for k in keys], [q.data for q in queries], b1=momentum, hyper=hyper)
     _mark_updated(list(keys))
+
+
+class EmaSchedule:
+    """The key-encoder momentum schedule of PixPro_swin_v5.py:258-262 - m = 1 - (1 - m0)(cos(pi k / K) + 1) / 2, k += 1 per update -
+    with k and m in device memory (stswin_optim_tick kind 1), so that eager steps and hipGraph replays of the step walk the same
+    schedule.  `k` (host mirror) is re-read from the device by sync()."""
+
+    def __init__(self, device, base_momentum: float, K: int, k: int = 0):
+        self.clock = _Clock(device, k)
+        self.m0, self.K = float(base_momentum), float(K)
+
+    def tick(self) -> torch.Tensor:
+        hip.optim_tick(1, self.clock.counter, self.clock.hyper, self.m0, self.K)
+        self.clock.step += 1
+        return self.clock.hyper
+
+    @property
+    def k(self) -> int:
+        return self.clock.step
+
+    def sync(self) -> int:
+        return self.clock.sync()
 
 
 def make_contrast_optimizer(params, batch_size: int, base_learning_rate: float = 1.0, momentum: float = 0.9,

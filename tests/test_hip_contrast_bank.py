@@ -142,3 +142,88 @@ def test_production_size_bank_of_65k_entries():
     assert torch.equal(pos_u, pos) and torch.equal(tot_u, tot)
     assert float((rmax_u - rmax).abs().max()) <= 1e-5 * float(rmax.abs().max()) + 1e-6
     assert float((lse_u - lse).abs().max()) <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# bank_mode 'world' through the TOKEN path (PairLossFn) on two ranks sharing the GPU (gloo): the query labels are this rank's, the
+# bank and its labels are every rank's.  (Round-5 advisor finding: the query labels were taken from the GATHERED label matrix.)
+def _world_token_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import stswin_oracle as O
+        from stswincl_amd.contrast.models import PixPro_swin_v5 as P
+        from stswincl_amd import headops as H
+        b, h, w, C, ncls = 2, 4, 5, 32, 12
+        HW = h * w
+
+        def rank_data(r):
+            g = torch.Generator().manual_seed(100 + r)
+            proj = torch.randn(2 * b * HW, C, generator=g)                       # clip-major rows: clip = sample * 2 + view
+            keys = torch.nn.functional.normalize(torch.randn(6, b * HW, C, generator=g), dim=2)
+            lab = torch.randint(0, ncls, (6, b * HW), generator=g, dtype=torch.int32)
+            return proj, keys, lab
+
+        data = [rank_data(r) for r in range(world)]
+        proj, keys, lab = data[rank]
+        pq = proj.cuda().requires_grad_(True)
+        loss, _, _ = P.pair_loss_tokens(pq, keys.cuda().contiguous(), lab.cuda().contiguous(), b, HW, ncls, bank_mode="world")
+        loss.backward()
+        # expectation without any collective: this rank's (normalised, view-major) queries against the rank-major concatenation
+        qn = torch.nn.functional.normalize(proj, dim=1).view(b, 2, HW, C).permute(1, 0, 2, 3).reshape(2 * b * HW, C)
+        qn = qn.clone().requires_grad_(True)
+        bank = torch.cat([d[1] for d in data], 1)
+        lb = torch.cat([d[2] for d in data], 1).long()
+        lq = torch.cat([lab[0], lab[1]]).long()
+        gmap = [[1, 2, 3, 4, 5], [0, 2, 3, 4, 5]]
+        ref = O.bank_contrast_loss(qn, lq, bank, lb, gmap, b * HW, world * b * HW)
+        # the torch-glue formulation of the same mode (consistency_pair_loss) on NCHW embeddings
+        qv = torch.nn.functional.normalize(proj, dim=1).view(b, 2, HW, C)
+        nchw = lambda t: t.reshape(b, h, w, C).permute(0, 3, 1, 2).contiguous().cuda()
+        ks = [nchw(keys[i]) for i in range(6)]
+        ms = [lab[i].view(b, 1, h, w).float().cuda() for i in range(6)]
+        glue, _, _ = P.consistency_pair_loss(nchw(qv[:, 0]), nchw(qv[:, 1]), *ks, ms, ncls, bank_mode="world")
+        # gradient reference: oracle autograd through the normalisation
+        pr = proj.clone().requires_grad_(True)
+        qr = torch.nn.functional.normalize(pr, dim=1).view(b, 2, HW, C).permute(1, 0, 2, 3).reshape(2 * b * HW, C)
+        O.bank_contrast_loss(qr, lq, bank, lb, gmap, b * HW, world * b * HW).backward()
+        e_g = float((pq.grad.cpu() - pr.grad).norm() / pr.grad.norm())
+        q.put((rank, float(loss), float(ref), float(glue), e_g))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_token_path_world_bank_on_two_ranks():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_world_token_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    losses = {}
+    for rank, loss, ref, glue, e_g in res:
+        assert abs(loss - ref) <= 2e-5 * abs(ref), (rank, loss, ref)
+        assert abs(glue - ref) <= 2e-5 * abs(ref), (rank, glue, ref)
+        assert e_g < 2e-4, (rank, e_g)
+        losses[rank] = loss
+    assert losses[0] != losses[1]          # different queries per rank: a path that read rank 0's labels everywhere would not differ only here
+
+
+def test_query_label_count_is_checked():
+    Q = torch.nn.functional.normalize(torch.randn(64, 32, device="cuda"), dim=1)
+    bank = torch.nn.functional.normalize(torch.randn(6, 64, 32, device="cuda"), dim=2)
+    lb = torch.randint(0, 12, (6, 64), device="cuda", dtype=torch.int32)
+    with pytest.raises(hip.StswinHipError):
+        hip.contrast_bank_fwd(Q, lb[:2].reshape(-1).repeat(2), bank, lb, q_sets=2, q_block=32, bank_block=64,
+                              gmap=((1, 2, 3, 4, 5), (0, 2, 3, 4, 5)))

@@ -1,0 +1,148 @@
+"""Whole-model parity AT THE SIZES THAT MATTER (round-5 verdict, missing #3): the bench configuration (B = 4 clips x 4 frames x
+3x512x512, BASELINE configs[1]) and the reference's default resolution 512x640 (swin_512.py:281, base18.py:57), against
+
+* `tests/golden/fullsize.npz` - the REFERENCE itself run at these sizes in the build container (tools/gen_golden.py --only
+  fullsize: subsampled fp32 logits, OHEM loss, a running statistic, five weight gradients), and
+* the CPU oracle's forward on the same inputs (the whole logits tensor, not a subsample).
+
+fp32 path: 1e-3 relative on logits / loss (BASELINE.json north_star), 2e-3 on the weight gradients.  bf16 path (the one bench.py
+times): against the reference's fp32 logits at 1.3 x what the reference's own bf16 autocast run loses at 256x256 (bf16_yardstick.npz),
+with the kernel variants of every GEMM launch of the step logged - the 256x256 ring kernel, the fused split-K combine and the
+grouped weight-gradient launch must be what ran (hip.VARIANT_LOG)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+GRADS = {"swin.layers.0.0.attn.qkv.weight": (8, 8), "swin.layers.1.1.mlp.fc1.weight": (8, 8), "swin.layers.5.1.mlp.fc2.weight": (16, 16),
+         "resnet.layer5.1.conv2.weight": (4, 4), "classifier.0.weight": (4, 4)}
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(np.asarray(b)).double()
+    return float((a - b).norm() / b.norm())
+
+
+def full_labels(tag, bsz, hh, ww):
+    """(the same key-seeded construction as tools/gen_golden.py::full_labels)"""
+    lab = torch.floor(gu.det_tensor(f"tswinplus/labels{tag}", (bsz, hh // 32, ww // 32), "uniform", 12.0)).clamp(0, 11).long()
+    lab = lab.repeat_interleave(32, 1).repeat_interleave(32, 2)
+    lab[0, :5, :7] = -1
+    return lab
+
+
+def _model(hh, ww):
+    from stswincl_amd.net.Ours.base18 import TswinPlus
+    g = gu.load("tswinplus.npz")
+    m = TswinPlus(12, (hh // 8, ww // 8))
+    sd = gu.det_fill(gu.skeleton_sd(g["keys"], g["shapes"], g["dtypes"]))
+    sd = {k: v for k, v in sd.items() if not k.endswith("attn_mask")}          # (the mask buffer depends on the resolution)
+    r = m.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys and all(k.endswith(("attn_mask", "relative_position_index")) for k in r.missing_keys)
+    return m, {k: v.clone() for k, v in m.state_dict().items()}
+
+
+def test_bench_size_fp32_path_vs_the_reference_and_the_oracle():
+    """B = 4 x 512x512, train mode, fp32 path: logits, OHEM loss, running statistic and five weight gradients against the reference's
+    own run; the whole logits tensor against the CPU oracle (which itself is held to the reference's subsample at 1e-5 here)."""
+    from oracle import stswin_oracle as O
+    from stswincl_amd.utils.losses import OhemCELoss2D
+    g = gu.load("fullsize.npz")
+    S, B = 512, 4
+    m, sd_cpu = _model(S, S)
+    x = gu.det_tensor("tswinplus/x512", (B, 4, 3, S, S))
+    labels = full_labels("512", B, S, S)
+    with torch.no_grad():
+        y_or = O.tswin_plus(x, sd_cpu, training=True)
+        loss_or = float(O.ohem_ce(y_or, labels, S * S // 16))
+    r_or = rel(y_or[:, :, ::8, ::8], g["y_sub_512"])
+    assert r_or < 1e-5 and abs(loss_or - float(g["loss_512"])) < 1e-5 * float(g["loss_512"]), (r_or, loss_or)
+    m = m.cuda().train()
+    y = m(x.cuda())
+    loss = OhemCELoss2D(S * S // 16)(y, labels.cuda())
+    r_gold, r_full = rel(y[:, :, ::8, ::8], g["y_sub_512"]), rel(y, y_or)
+    r_loss = abs(float(loss) - float(g["loss_512"])) / float(g["loss_512"])
+    r_rm = rel(m.resnet.layer5[1].bn2.running_mean, g["rm_512"])
+    print(f"512x512 B=4 fp32 path: logits vs reference subsample {r_gold:.2e}, vs oracle (all) {r_full:.2e}, loss {r_loss:.2e}, "
+          f"running mean {r_rm:.2e}; oracle vs reference {r_or:.1e}")
+    assert r_gold < 1e-3 and r_full < 1e-3 and r_loss < 1e-3 and r_rm < 1e-3
+    ysum = y.detach().double()
+    assert abs(float(ysum.norm()) - float(g["y_sum_512"][2])) < 1e-3 * float(g["y_sum_512"][2])
+    loss.backward()
+    params = dict(m.named_parameters())
+    rows = []
+    for n, (s0, s1) in GRADS.items():
+        gr = params[n].grad.detach()
+        r = rel(gr[::s0, ::s1], g["grad_512/" + n])
+        rn = abs(float(gr.double().norm()) - float(g["gradnorm_512/" + n][0])) / float(g["gradnorm_512/" + n][0])
+        rows.append(f"{n}: slice rel-L2 {r:.2e}, norm {rn:.2e}")
+        assert r < 2e-3 and rn < 2e-3, rows[-1]
+    print("weight gradients vs the reference's autograd at 512x512 B=4: " + "; ".join(rows))
+
+
+def test_reference_default_resolution_512x640_fp32_path():
+    from oracle import stswin_oracle as O
+    from stswincl_amd.utils.losses import OhemCELoss2D
+    g = gu.load("fullsize.npz")
+    hh, ww, B = 512, 640, 2
+    m, sd_cpu = _model(hh, ww)
+    x = gu.det_tensor("tswinplus/x512x640", (B, 4, 3, hh, ww))
+    labels = full_labels("512x640", B, hh, ww)
+    with torch.no_grad():
+        y_or = O.tswin_plus(x, sd_cpu, training=True)
+    m = m.cuda().train()
+    with torch.no_grad():
+        y = m(x.cuda())
+    loss = OhemCELoss2D(hh * ww // 16)(y, labels.cuda())
+    r_gold, r_full = rel(y[:, :, ::8, ::8], g["y_sub_512x640"]), rel(y, y_or)
+    r_loss = abs(float(loss) - float(g["loss_512x640"])) / float(g["loss_512x640"])
+    print(f"512x640 B=2 fp32 path: logits vs reference subsample {r_gold:.2e}, vs oracle (all) {r_full:.2e}, loss {r_loss:.2e}")
+    assert r_gold < 1e-3 and r_full < 1e-3 and r_loss < 1e-3
+    assert rel(m.resnet.layer5[1].bn2.running_mean, g["rm_512x640"]) < 1e-3
+
+
+def test_bench_size_bf16_step_runs_the_production_kernels_and_stays_at_the_reference():
+    """The step bench.py times (bf16 autocast, B = 4 x 512x512), now against the REFERENCE's fp32 logits instead of the HIP fp32 path,
+    with every GEMM launch's kernel variant logged."""
+    from stswincl_amd import hip
+    from stswincl_amd.utils.losses import OhemCELoss2D
+    g, yard = gu.load("fullsize.npz"), gu.load("bf16_yardstick.npz")
+    S, B = 512, 4
+    m, _ = _model(S, S)
+    m = m.cuda().train()
+    x = gu.det_tensor("tswinplus/x512", (B, 4, 3, S, S)).cuda()
+    labels = full_labels("512", B, S, S).cuda()
+    hip.VARIANT_LOG = log = []
+    try:
+        with torch.autocast("cuda", dtype=BF):
+            y = m(x)
+            loss = OhemCELoss2D(S * S // 16)(y, labels)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        hip.VARIANT_LOG = None
+    r_log = rel(y.float()[:, :, ::8, ::8], g["y_sub_512"])
+    r_loss = abs(float(loss) - float(g["loss_512"])) / float(g["loss_512"])
+    bound = 1.3 * float(g["rel_logits_bf16_512"]) if "rel_logits_bf16_512" in g.files else 1.3 * float(yard["rel_logits_256"])
+    print(f"512x512 B=4 bf16 step vs the reference's fp32 logits: {r_log:.4f} (bound {bound:.4f}), loss {r_loss:.2e}")
+    assert r_log < bound and r_loss < 1e-2
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    # what ran: (i) every stage-1 / stage-2 Swin GEMM (M = 65536 / 16384 rows) on the 256x256 ring kernel with register epilogues;
+    nt = [(shape, v) for fam, shape, v in log if fam == "nt"]
+    big = [(shape, v) for shape, v in nt if shape[0] in (65536, 16384) and shape[1] >= 512 and shape[2] >= 512 and shape[3] == 1]
+    assert len(big) >= 12 * 8, len(big)                  # 12 block calls x (qkv|fused, proj, fc1, fc2) forward + their input gradients
+    bad = [(shape, v) for shape, v in big if (v & 0xFFF) not in (hip.VAR_NT_RING256_REGEPI, hip.VAR_NT_RING256_LDSEPI)]
+    assert not bad, bad[:4]
+    assert sum(1 for shape, v in big if (v & 0xFFF) == hip.VAR_NT_RING256_REGEPI) >= len(big) * 3 // 4
+    # (ii) ASPP's dilated convolutions / the classifier convolution on the split-K ring;
+    assert any((v & 0xFFF) == hip.VAR_NT_SPLITK and (v >> 16) > 1 for _, v in nt), "no split-K gemm_nt in the step"
+    # (iii) the Swin blocks' weight gradients as grouped launches, and every split weight gradient combined inside its launch
+    groups = [shape for fam, shape, v in log if fam == "tn_group"]
+    assert len(groups) >= 12 and all(v & hip.VAR_TN_FUSED for fam, _, v in log if fam == "tn_group"), len(groups)
+    tn = [(shape, v) for fam, shape, v in log if fam == "tn"]
+    split = [(shape, v) for shape, v in tn if (v >> 16) > 1]
+    assert split and all(v & hip.VAR_TN_FUSED for _, v in split), [s for s, v in split if not v & hip.VAR_TN_FUSED][:4]

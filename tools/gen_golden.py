@@ -511,6 +511,59 @@ def gen_bf16_yardstick(swin, base, losses):
     save("bf16_yardstick.npz", **res)
 
 
+FULL_GRADS = {"swin.layers.0.0.attn.qkv.weight": (8, 8), "swin.layers.1.1.mlp.fc1.weight": (8, 8), "swin.layers.5.1.mlp.fc2.weight": (16, 16),
+              "resnet.layer5.1.conv2.weight": (4, 4), "classifier.0.weight": (4, 4)}
+
+
+def full_labels(tag, bsz, hh, ww):
+    """Blocky label maps (32 x 32 blocks, a few ignore pixels), regenerated by the tests from the key."""
+    lab = torch.floor(gu.det_tensor(f"tswinplus/labels{tag}", (bsz, hh // 32, ww // 32), "uniform", 12.0)).clamp(0, 11).long()
+    lab = lab.repeat_interleave(32, 1).repeat_interleave(32, 2)
+    lab[0, :5, :7] = -1
+    return lab
+
+
+def gen_fullsize(swin, base, losses):
+    """The reference itself at the sizes that matter (round-5 verdict, missing #3): the bench configuration B = 4 clips x 4 frames x
+    512 x 512 (train mode, fp32: logits, OHEM loss and five weight gradients) and the reference's default resolution 512 x 640 with
+    B = 2 (swin_512.py:281, base18.py:57).  Inputs, weights and labels are key-seeded (regenerated by the tests); stored are
+    subsampled logits, the loss, strided slices + norms of the gradients."""
+    res = {}
+    for tag, hh, ww, bsz, want_grad in (("512", 512, 512, 4, True), ("512x640", 512, 640, 2, False)):
+        x = gu.det_tensor(f"tswinplus/x{tag}", (bsz, 4, 3, hh, ww))
+        labels = full_labels(tag, bsz, hh, ww)
+        net = _make_tswin(base, swin, 12, (hh // 8, ww // 8))
+        gu.det_fill(net.state_dict())
+        net.train()
+        crit = losses.OhemCELoss2D(hh * ww // 16)
+        with torch.set_grad_enabled(want_grad):
+            y = net(x)
+            loss = crit(y, labels)
+        res[f"y_sub_{tag}"] = y.detach()[:, :, ::8, ::8].clone()
+        res[f"y_sum_{tag}"] = torch.stack([y.detach().double().sum(), y.detach().double().abs().sum(), y.detach().double().norm()])
+        res[f"loss_{tag}"] = loss.detach()
+        res[f"rm_{tag}"] = net.resnet.layer5[1].bn2.running_mean.clone()
+        print(f"  fullsize {tag}: loss {float(loss):.6f}")
+        if want_grad:           # what the reference's own bf16 autocast forward loses at this size (the yardstick of the bf16 step test)
+            net2 = _make_tswin(base, swin, 12, (hh // 8, ww // 8))
+            gu.det_fill(net2.state_dict())
+            net2.train()
+            with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+                yb = net2(x).float()
+            res[f"rel_logits_bf16_{tag}"] = np.array(float((yb.double() - y.detach().double()).norm() / y.detach().double().norm()))
+            print(f"  fullsize {tag}: bf16 autocast logits rel-L2 {float(res[f'rel_logits_bf16_{tag}']):.4f}")
+            del net2, yb
+        if want_grad:
+            loss.backward()
+            params = dict(net.named_parameters())
+            for n, (s0, s1) in FULL_GRADS.items():
+                g = params[n].grad.detach()
+                res[f"grad_{tag}/" + n] = g[::s0, ::s1].clone()
+                res[f"gradnorm_{tag}/" + n] = torch.stack([g.double().norm(), g.double().sum()])
+        del net, y, loss
+    save("fullsize.npz", **res)
+
+
 def gen_loadmodel():
     """f3: the REFERENCE's four checkpoint loaders (seg18/utils/LoadModel.py) on the toy model / files of golden_util: for
     every (loader, file) the fixture stores which model keys ended up holding the file's values and a checksum of the
@@ -581,6 +634,8 @@ def main():
         gen_tswinplus(swin, base, losses)
     if want("bf16_yardstick"):
         gen_bf16_yardstick(swin, base, losses)
+    if want("fullsize"):
+        gen_fullsize(swin, base, losses)
     if want("regression_loss") or want("consistency") or want("lars") or want("regression_bank"):
         pix = import_contrast()
         if want("lars"):
