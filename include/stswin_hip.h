@@ -557,6 +557,11 @@ int stswin_multi_tensor_lars_dev(int count, void* const* p, const void* const* g
 /* ---- device self-test of the MFMA / LDS primitives the kernels are built on; writes a report into `out`
  * (fp32, >= 64 KiB) and returns the number of failed checks (0 = all good). Used by tests only. */
 int stswin_selftest(float* out, int which, void* stream);
+/* In-run calibration probes of bench.py (measurement infrastructure, never on the product path): stswin_calib_mfma launches 256
+ * workgroups of `waves_per_cu` waves, each running `iters` rounds of 8 independent v_mfma_f32_16x16x32_bf16, and returns the MFMA
+ * instructions per round of the whole launch (flops = that x iters x 16384); stswin_calib_copy copies `bytes` with 16-byte lanes. */
+long stswin_calib_mfma(int waves_per_cu, int iters, float* sink, void* stream);
+int stswin_calib_copy(const void* src, void* dst, long bytes, void* stream);
 /* Measurement stand-in for an RCCL all-reduce of one gradient bucket as the main stream sees it (tools/overlap_proxy.py): `workgroups`
  * workgroups of 256 threads copy src -> dst (`bytes`, 16-byte pieces) `passes` times, i.e. hold that many compute units for that long.
  * No peer traffic; never on the product path. */

@@ -77,6 +77,40 @@ extern "C" int stswin_proxy_collective(const void* src, void* dst, long bytes, i
   return 0;
 }
 
+// In-run calibration of bench.py (round 6): two fixed probes that tell one box of the pool from another, so that throughput lines
+// measured on different boxes can be compared.  (i) MFMA: `waves` waves per CU on 256 workgroups, each running `iters` rounds of 8
+// independent v_mfma_f32_16x16x32_bf16 (2 * 16 * 16 * 32 flops each) - the sustained matrix-core rate at the clock the box settles on;
+// (ii) copy: a 16-byte-per-lane grid-stride copy of `bytes` (choose > the 256 MB infinity cache) - the sustained HBM read + write rate.
+// Measurement infrastructure only - never on the product path.
+__global__ __launch_bounds__(512) void calib_mfma_kernel(int iters, float* sink) {
+  f32x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = (bf16)((threadIdx.x & 63) * 0.001f + i); b[i] = (bf16)(1.f + i * 0.01f); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 123.456f) sink[0] = s;
+}
+extern "C" long stswin_calib_mfma(int waves_per_cu, int iters, float* sink, void* stream) {
+  if (waves_per_cu < 1 || waves_per_cu > 8 || iters < 1 || !sink) return -1303;
+  hipLaunchKernelGGL(calib_mfma_kernel, dim3(256), dim3(64 * waves_per_cu), 0, (hipStream_t)stream, iters, sink);
+  STSWIN_CHECK_LAUNCH();
+  return 256L * waves_per_cu * 8;              // MFMA instructions per iteration of the whole launch (x iters x 16384 flops)
+}
+extern "C" int stswin_calib_copy(const void* src, void* dst, long bytes, void* stream) {
+  if (!src || !dst || bytes < 16) return -1303;
+  hipLaunchKernelGGL(proxy_collective_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, bytes / 16, 1);
+  STSWIN_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int stswin_abi_version(void) { return 1; }
 
 extern "C" int stswin_selftest(float* out, int which, void* stream) {

@@ -1363,6 +1363,37 @@ def set_cu_budget(cus: int) -> int:
     return int(load().stswin_set_cu_budget(int(cus)))
 
 
+def calibrate(device=None, seconds: float = 0.1) -> dict:
+    """Box calibration for bench lines (include/stswin_hip.h: stswin_calib_mfma / stswin_calib_copy): sustained bf16 MFMA TFLOP/s of a
+    register-only loop (4 waves per CU) and sustained copy TB/s (read + write) over 2 x 512 MB, each the best of three timed launches
+    of ~`seconds`/3 after a warm-up launch.  HIP events on the current stream."""
+    lib = load()
+    dev = torch.device(device if device is not None else "cuda")
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    st = _stream()
+
+    def timed(fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b) * 1e-3
+
+    iters = int(300000 * max(seconds, 0.01) / 0.1)
+    per = int(lib.stswin_calib_mfma(4, 20000, _p(sink), st))                      # warm-up
+    t = min(timed(lambda: lib.stswin_calib_mfma(4, iters, _p(sink), st)) for _ in range(3))
+    tflops = per * iters * 16384.0 / t / 1e12
+    n = 512 << 20
+    src = torch.empty(n, dtype=torch.uint8, device=dev)
+    dst = torch.empty(n, dtype=torch.uint8, device=dev)
+    src.zero_()
+    _check(lib.stswin_calib_copy(_p(src), _p(dst), _c_long(n), st), "calib_copy")
+    tc = min(timed(lambda: lib.stswin_calib_copy(_p(src), _p(dst), _c_long(n), st)) for _ in range(3))
+    del src, dst
+    return {"mfma_bf16_tflops": tflops, "mfma_probe_ms": t * 1e3, "copy_tbps": 2.0 * n / tc / 1e12, "copy_probe_ms": tc * 1e3}
+
+
 def selftest(which: int) -> torch.Tensor:
     out = torch.zeros(16384, dtype=torch.float32, device="cuda")
     if which == 5:
