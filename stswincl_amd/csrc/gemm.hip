@@ -1076,527 +1076,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
 #pragma unroll
       for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  if constexpr (PIPE == 0) {
-    for (int kt = 0; kt < nt; ++kt) {
-      const int newer = min(NST - 2, nt - 1 - kt);     // later tiles that may stay in flight
-      if (newer >= 2) wait_vmcnt<2 * PER_STAGE>();
-      else if (newer == 1) wait_vmcnt<PER_STAGE>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      if (kt + NST - 1 < nt) issue(kt + NST - 1);
-      const char* Ab = smem + (kt % NST) * STAGE;
-      const char* Bb = Ab + A_BYTES;
-      bf16x8 a[FI], b[FJ];
-#pragma unroll
-      for (int j = 0; j < FJ; ++j) b[j] = *(const bf16x8*)(Bb + (wc * TN + j * 16) * ROWB + rd_off);
-#pragma unroll
-      for (int i = 0; i < FI; ++i) a[i] = *(const bf16x8*)(Ab + (wr * TM + i * 16) * ROWB + rd_off);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < FI; ++i)
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) {
-          if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-      __builtin_amdgcn_s_setprio(0);
-    }
-    if constexpr (SWAP) epilogue_reg();
-    else epilogue();
-  } else if constexpr (PIPE == 2) {
-    // Register-pipelined main loop, ONE wave per SIMD (4 waves of 128x128: 8x8 fragments, 256 accumulator registers): nothing else
-    // runs on the SIMD, so the wave overlaps its own work - while the 64 MFMAs of stage kt run on fragment set kt & 1, the 16
-    // ds_read_b128 of stage kt+1 fill the other set and the 8 LDS-DMA copies of stage kt+3 are requested, one read per four MFMAs
-    // and one copy per eight (sched_barrier keeps the groups apart).  16 fragment reads per 64 MFMAs (the 8-wave ping-pong
-    // kernel: 12 per 32 - its LDS read traffic is what tools/probes/half_reads.sh priced at 5-8 % of the loop), one barrier per
-    // stage and no second wave row to hand the matrix pipe to.
-    // Ring safety: slot (kt+3) % 4 held stage kt-1, whose fragments every wave read during step kt-2 and consumed in step kt-1,
-    // i.e. before it arrived at the barrier on top of step kt.  Stage kt+1 (read in step kt) was requested in step kt-2: each wave
-    // waits for its own copies of it (one newer stage may stay in flight) before that barrier.
-    static_assert(NST == 4 && SWAP && NWV == 4 && FI == 4 && FJ == 16 && PER_STAGE == 8, "4-wave register-pipelined variant");
-    constexpr int NT = FJ / 4;                         // 32-column accumulator tiles per wave (4)
-    bf16x8 fa[2][2 * FI], fb[2][2 * NT];               // [set][tile * 2 + k half]
-    int is_koff = 0, is_qoff = 0;
-    auto issue_prep = [&](int q) {
-      const int Q = q + qbase;
-      int sg = 0, kt = Q;
-      if (p.S > 1) { sg = Q / kps; kt = Q - sg * kps; }
-      if (sg != seg) { seg = sg; load_a_bases(sg); }
-      is_koff = kt * (BK * (int)sizeof(T));
-      is_qoff = Q * (BK * (int)sizeof(T));
-    };
-    auto issue_one = [&](int slot, int part) __attribute__((always_inline)) {
-      char* Ab = smem + slot * STAGE;
-      if (part < NIA) glds16_buf(p.A, aoff[part], is_koff, Ab + (w * NIA + part) * 1024);
-      else glds16_buf(p.B, boff[part - NIA], is_qoff, Ab + A_BYTES + (w * NIB + part - NIA) * 1024);
-    };
-    auto read_frag = [&](int set, int slot, int g) __attribute__((always_inline)) {   // g: 0..7 weight tiles x k halves, 8..15 activation tiles
-      const char* Ab = smem + slot * STAGE;
-      const int t = (g & 7) >> 1, off = (g & 1) ? rd_off1 : rd_off;
-      if (g < 2 * NT) fb[set][g] = *(const bf16x8*)(Ab + A_BYTES + (wc * TN + t * 32) * ROWB + off);
-      else fa[set][g - 2 * NT] = *(const bf16x8*)(Ab + (wr * TM + t * 32) * ROWB + off);
-    };
-    auto step = [&](auto setc, auto slotc, int kt, bool do_issue, bool do_read) __attribute__((always_inline)) {
-      constexpr int SET = decltype(setc)::value, SLOT = decltype(slotc)::value;
-      if (do_issue) issue_prep(kt + 3);
-#ifndef STSWIN_W4X_SCHED
-#define STSWIN_W4X_SCHED 0
-#endif
-#if STSWIN_W4X_SCHED == 0
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-#ifndef STSWIN_W4X_NO_READ                             // (diagnosis builds, tools/probes/w4_variants.sh: what does each stream cost?)
-        if (do_read) read_frag(SET ^ 1, (SLOT + 1) % NST, g);
-#endif
-#ifndef STSWIN_W4X_NO_DMA
-        if (do_issue && (g & 1) == 0) issue_one((SLOT + 3) % NST, g >> 1);
-#endif
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {                    // k half 0 of all 16 tiles, then k half 1: 16 MFMAs between two uses of a tile
-          const int idx = g * 2 + u, kh = idx / 16, tt = idx % 16, i = tt / NT, j = tt % NT;
-          acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[SET][j * 2 + kh], fa[SET][i * 2 + kh], acc32[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+#ifdef STSWIN_TUNING
+#include "gemm_nt_ring_tuning.inc"   // `if constexpr (PIPE == 0) {..} else if constexpr (PIPE == 2) {..} .. else`: the measured losers, A/B builds only
 #else
-      // the two streams apart: SCHED 1 / 2 = fragment reads behind MFMAs 0..15, copies behind MFMAs 16, 18, .. 30 (2: after an explicit
-      // lgkmcnt(0)); SCHED 3 = copies first (MFMAs 0, 2, .. 14), reads behind MFMAs 16..31
-#pragma unroll
-      for (int idx = 0; idx < 32; ++idx) {
-        constexpr bool RF = STSWIN_W4X_SCHED != 3;       // reads in the first half
-        const bool rd_slot = RF ? idx < 16 : idx >= 16, cp_slot = (RF ? idx >= 16 : idx < 16) && (idx & 1) == 0;
-        if (do_read && rd_slot) read_frag(SET ^ 1, (SLOT + 1) % NST, idx & 15);
-#if STSWIN_W4X_SCHED == 2
-        if (idx == 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  static_assert(PIPE == 1 && !PERSIST, "the product library instantiates the ping-pong loop only (other loops: STSWIN_TUNING builds)");
 #endif
-        if (do_issue && cp_slot) issue_one((SLOT + 3) % NST, (idx & 15) >> 1);
-        const int kh = idx / 16, tt = idx % 16, i = tt / NT, j = tt % NT;
-        acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[SET][j * 2 + kh], fa[SET][i * 2 + kh], acc32[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#endif
-    };
-    using std::integral_constant;
-    stamp(1);
-    // stage 0 landed (the prologue requested min(3, nt) stages): its fragments into set 0
-    if (nt >= 3) wait_vmcnt<2 * PER_STAGE>();
-    else if (nt == 2) wait_vmcnt<PER_STAGE>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    stamp(2);
-#pragma unroll
-    for (int g = 0; g < 16; ++g) read_frag(0, 0, g);
-    auto stage_sync = [&]() __attribute__((always_inline)) {   // this wave's copies of the next stage have landed; so have everybody's behind the barrier
-#ifndef STSWIN_W4X_NO_WAIT
-      wait_vmcnt<PER_STAGE>();
-#endif
-#ifndef STSWIN_W4X_NO_BARRIER
-      __builtin_amdgcn_s_barrier();
-#endif
-    };
-    int kt = 0;
-    for (; kt + 6 < nt; kt += 4) {                       // steady state: every step requests a stage and reads one
-      stage_sync();
-      step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt, true, true);
-      stage_sync();
-      step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1, true, true);
-      stage_sync();
-      step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2, true, true);
-      stage_sync();
-      step(integral_constant<int, 1>{}, integral_constant<int, 3>{}, kt + 3, true, true);
-    }
-    auto tail_step = [&](auto setc, auto slotc, int k) __attribute__((always_inline)) {
-      if (k >= nt) return;
-      if (k + 2 < nt) wait_vmcnt<PER_STAGE>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      step(setc, slotc, k, k + 3 < nt, k + 1 < nt);
-    };
-    // the last 1..6 steps (kt is a multiple of 4 here): runtime tests of what is left to request / read
-    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt);
-    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1);
-    tail_step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2);
-    tail_step(integral_constant<int, 1>{}, integral_constant<int, 3>{}, kt + 3);
-    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt + 4);
-    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 5);
-    if (arow_bad) __builtin_trap();
-    epilogue_reg();
-  } else if constexpr (PIPE == 4) {
-    // The 4-wave kernel once more, register-STAGED: a stage travels global -> VGPR (buffer_load_dwordx4, requested in step kt for
-    // stage kt+3) -> LDS (ds_write_b128 in step kt+1, the same linear piece layout the LDS-DMA copies produce) -> fragments (read in
-    // step kt+2) -> MFMAs (step kt+3).  No LDS-DMA piece (each holds a lone wave ~57 cycles, profiles/r04_gemm_w4_experiment.txt);
-    // two register sets of 8 x 16 bytes per lane carry the stages in flight.  hipcc tracks the loads itself (no counted vmcnt waits).
-    static_assert(NST == 4 && SWAP && NWV == 4 && FI == 4 && FJ == 16 && PER_STAGE == 8, "4-wave register-staged variant");
-    constexpr int NT = FJ / 4;
-    typedef int v4i32r __attribute__((ext_vector_type(4)));
-    bf16x8 fa[2][2 * FI], fb[2][2 * NT];
-    v4i32r rs[2][PER_STAGE];
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, (short)0, (int)0xFFFFFFFE, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, (short)0, (int)0xFFFFFFFE, 0x00020000);
-    int is_koff = 0, is_qoff = 0;
-    auto issue_prep = [&](int q) {
-      const int Q = q + qbase;
-      int sg = 0, kt = Q;
-      if (p.S > 1) { sg = Q / kps; kt = Q - sg * kps; }
-      if (sg != seg) { seg = sg; load_a_bases(sg); }
-      is_koff = kt * (BK * (int)sizeof(T));
-      is_qoff = Q * (BK * (int)sizeof(T));
-    };
-    auto load_one = [&](int set, int part) __attribute__((always_inline)) {
-      if (part < NIA) rs[set][part] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)aoff[part], is_koff, 0);
-      else rs[set][part] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)boff[part - NIA], is_qoff, 0);
-    };
-    auto write_one = [&](int set, int slot, int part) __attribute__((always_inline)) {
-      char* Ab = smem + slot * STAGE;
-      char* dst = (part < NIA ? Ab + (w * NIA + part) * 1024 : Ab + A_BYTES + (w * NIB + part - NIA) * 1024) + l * 16;
-      *(v4i32r*)dst = rs[set][part];
-    };
-    auto read_frag = [&](int set, int slot, int g) __attribute__((always_inline)) {
-      const char* Ab = smem + slot * STAGE;
-      const int t = (g & 7) >> 1, off = (g & 1) ? rd_off1 : rd_off;
-      if (g < 2 * NT) fb[set][g] = *(const bf16x8*)(Ab + A_BYTES + (wc * TN + t * 32) * ROWB + off);
-      else fa[set][g - 2 * NT] = *(const bf16x8*)(Ab + (wr * TM + t * 32) * ROWB + off);
-    };
-    auto step = [&](auto setc, auto slotc, int kt, bool do_load, bool do_write, bool do_read) __attribute__((always_inline)) {
-      constexpr int SET = decltype(setc)::value, SLOT = decltype(slotc)::value;
-      if (do_load) issue_prep(kt + 3);
-#pragma unroll
-      for (int idx = 0; idx < 32; ++idx) {
-        if (do_read && idx < 16) read_frag(SET ^ 1, (SLOT + 1) % NST, idx);                       // stage kt+1 -> the other fragment set
-        if (do_load && idx >= 16 && (idx & 1) == 0) load_one(SET, (idx - 16) >> 1);              // stage kt+3 -> this step's register set
-        if (do_write && idx >= 16 && (idx & 1) == 1) write_one(SET ^ 1, (SLOT + 2) % NST, (idx - 16) >> 1);   // stage kt+2 (requested a step ago)
-        const int kh = idx / 16, tt = idx % 16, i = tt / NT, j = tt % NT;
-        acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[SET][j * 2 + kh], fa[SET][i * 2 + kh], acc32[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    using std::integral_constant;
-    auto stage_sync = [&]() __attribute__((always_inline)) {   // this wave's LDS writes (and reads) are done; behind the barrier so are everybody's
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    };
-    stamp(1);
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      if (q < nt) {
-        issue_prep(q);
-#pragma unroll
-        for (int part = 0; part < PER_STAGE; ++part) load_one(0, part);
-#pragma unroll
-        for (int part = 0; part < PER_STAGE; ++part) write_one(0, q, part);
-      }
-    if (2 < nt) {
-      issue_prep(2);
-#pragma unroll
-      for (int part = 0; part < PER_STAGE; ++part) load_one(1, part);
-    }
-    stage_sync();
-    stamp(2);
-#pragma unroll
-    for (int g = 0; g < 16; ++g) read_frag(0, 0, g);
-    int kt = 0;
-    for (; kt + 6 < nt; kt += 4) {
-      stage_sync();
-      step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt, true, true, true);
-      stage_sync();
-      step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1, true, true, true);
-      stage_sync();
-      step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2, true, true, true);
-      stage_sync();
-      step(integral_constant<int, 1>{}, integral_constant<int, 3>{}, kt + 3, true, true, true);
-    }
-    auto tail_step = [&](auto setc, auto slotc, int k) __attribute__((always_inline)) {
-      if (k >= nt) return;
-      stage_sync();
-      step(setc, slotc, k, k + 3 < nt, k + 2 < nt, k + 1 < nt);
-    };
-    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt);
-    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1);
-    tail_step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2);
-    tail_step(integral_constant<int, 1>{}, integral_constant<int, 3>{}, kt + 3);
-    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt + 4);
-    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 5);
-    if (arow_bad) __builtin_trap();
-    epilogue_reg();
-  } else if constexpr (PIPE == 6) {
-    // 8 waves WITHOUT phases: every wave software-pipelines its own 128x64 tile - fragment sets kt & 1, the 12 ds_read_b128 of stage kt+1
-    // and its 4 LDS-DMA pieces of stage kt+3 spread between the 32 MFMAs of stage kt, ONE barrier per stage - and which of the two waves of
-    // a SIMD issues next is left to the hardware.  The ping-pong loop makes one wave read while the other multiplies and hands over at a
-    // barrier twice per stage; its bare structure costs 1220 cycles per stage, this one 1153 (tools/probes/pp_rows_probe.hip: bursts
-    // of reads or of pieces, or MFMAs under s_setprio, are all worse than the even spread).  48 more fragment registers per lane.
-    // Ring safety / data arrival as in the 4-wave loop above: slot (kt+3) % 4 held stage kt-1, read by every wave during step kt-2;
-    // each wave waits for its own pieces of stage kt+1 (one newer stage may be in flight) before the barrier on top of step kt.
-    static_assert(NST == 4 && SWAP && !M32 && NWV == 8 && PER_STAGE == 4, "8-wave software-pipelined variant");
-    constexpr int NG = FI + FJ;                        // fragment reads per stage (12)
-    bf16x8 fa[2][FI], fb[2][FJ];
-    int is_koff = 0, is_qoff = 0;
-    auto issue_prep = [&](int q) {
-      const int Q = q + qbase;
-      int sg = 0, kt = Q;
-      if (p.S > 1) { sg = Q / kps; kt = Q - sg * kps; }
-      if (sg != seg) { seg = sg; load_a_bases(sg); }
-      is_koff = kt * (BK * (int)sizeof(T));
-      is_qoff = Q * (BK * (int)sizeof(T));
-    };
-    auto issue_one = [&](int slot, int part) __attribute__((always_inline)) {
-      char* Ab = smem + slot * STAGE;
-      if (part < NIA) glds16_buf(p.A, aoff[part], is_koff, Ab + (w * NIA + part) * 1024);
-      else glds16_buf(p.B, boff[part - NIA], is_qoff, Ab + A_BYTES + (w * NIB + part - NIA) * 1024);
-    };
-    auto read_frag = [&](int set, int slot, int g) __attribute__((always_inline)) {
-      const char* Ab = smem + slot * STAGE;
-      if (g < FI) fa[set][g] = *(const bf16x8*)(Ab + (wr * TM + g * 16) * ROWB + rd_off);
-      else fb[set][g - FI] = *(const bf16x8*)(Ab + A_BYTES + (wc * TN + (g - FI) * 16) * ROWB + rd_off);
-    };
-    auto step = [&](auto setc, auto slotc, int kt, bool do_issue, bool do_read) __attribute__((always_inline)) {
-      constexpr int SET = decltype(setc)::value, SLOT = decltype(slotc)::value;
-      if (do_issue) issue_prep(kt + 3);
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        if (do_read) read_frag(SET ^ 1, (SLOT + 1) % NST, g);
-        if (do_issue && g % (NG / PER_STAGE) == 0) issue_one((SLOT + 3) % NST, g / (NG / PER_STAGE));
-#pragma unroll
-        for (int m = g * (FI * FJ) / NG; m < (g + 1) * (FI * FJ) / NG; ++m) {
-          const int i = m / FJ, j = m % FJ;
-          // (as inline assembly with the destination TIED to the accumulator: left to hipcc, with 224 of 256 registers live it picks the
-          //  untied form of the instruction, rotates the accumulators through fresh registers and spills ~100 of them)
-          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fb[SET][j]), "v"(fa[SET][i]));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    using std::integral_constant;
-    auto stage_sync = [&]() __attribute__((always_inline)) {
-      wait_vmcnt<PER_STAGE>();
-      __builtin_amdgcn_s_barrier();
-    };
-    stamp(1);
-    if (nt >= 3) wait_vmcnt<2 * PER_STAGE>();
-    else if (nt == 2) wait_vmcnt<PER_STAGE>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    stamp(2);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) read_frag(0, 0, g);
-    int kt = 0;
-    for (; kt + 6 < nt; kt += 4) {
-      stage_sync();
-      step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt, true, true);
-      stage_sync();
-      step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1, true, true);
-      stage_sync();
-      step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2, true, true);
-      stage_sync();
-      step(integral_constant<int, 1>{}, integral_constant<int, 3>{}, kt + 3, true, true);
-    }
-    auto tail_step = [&](auto setc, auto slotc, int k) __attribute__((always_inline)) {
-      if (k >= nt) return;
-      if (k + 2 < nt) wait_vmcnt<PER_STAGE>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      step(setc, slotc, k, k + 3 < nt, k + 1 < nt);
-    };
-    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt);
-    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1);
-    tail_step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2);
-    tail_step(integral_constant<int, 1>{}, integral_constant<int, 3>{}, kt + 3);
-    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt + 4);
-    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 5);
-    if (arow_bad) __builtin_trap();
-    epilogue_reg();
-  } else if constexpr (PIPE == 7) {
-    // "Duo" (round 5): 128x256 tile, FOUR waves (one per SIMD) of 128x64, three 24 KB ring slots = 72 KB, so TWO independent workgroups
-    // share a CU (2 x 72 KB LDS, 2 x 4 waves of <= 256 registers) - while one of them is in its epilogue (activation polynomials on
-    // the VALU, LDS image, stores), waits for its first stages or is being replaced by its successor, the other one owns the matrix
-    // pipe.  The 8-wave 256x256 kernel cannot do that: its two wave rows share every barrier, so the whole CU goes through the
-    // epilogue together with the matrix pipe idle (fc1 + GELU + GELU': 12.7 us of main loop in a 27 us tile,
-    // profiles/r05_gemm_tile_timeline.txt).  Round 2's duo kernel (PIPE 0: read 12 fragments, then 32 MFMAs, per stage) lost in the
-    // main loop what it gained in the epilogue, because a lone wave that reads and then multiplies leaves its SIMD idle half the
-    // time and two un-coordinated workgroups do not interleave reliably.  Here every wave software-pipelines ITSELF (the structure
-    // of PIPE 6): fragment sets kt & 1, the 12 ds_read_b128 of stage kt+1 and its 6 LDS-DMA pieces of stage kt+3 spread between the
-    // 32 MFMAs of stage kt, one barrier per stage - a wave alone on its SIMD keeps the pipe busy, two of them (the other
-    // workgroup's) share it.
-    // Ring safety with THREE slots: stage kt's fragments were read during step kt-1; every wave drains its LDS reads (lgkmcnt(0))
-    // before the barrier on top of step kt, after which slot kt % 3 takes stage kt+3.  Data arrival: before that barrier each wave
-    // waits for its own pieces of stage kt+1 (stage kt+2's may stay in flight).
-    static_assert(NST == 3 && SWAP && !M32 && NWV == 4 && WM == 1, "4-wave self-pipelined variant");
-    constexpr int NG = FI + FJ;                        // fragment reads per stage (8 + 4)
-    static_assert(NG % PER_STAGE == 0, "copy pieces spread evenly over the read groups");
-    bf16x8 fa[2][FI], fb[2][FJ];
-    int is_koff = 0, is_qoff = 0;
-    auto issue_prep = [&](int q) {
-      const int Q = q + qbase;
-      int sg = 0, kt = Q;
-      if (p.S > 1) { sg = Q / kps; kt = Q - sg * kps; }
-      if (sg != seg) { seg = sg; load_a_bases(sg); }
-      is_koff = kt * (BK * (int)sizeof(T));
-      is_qoff = Q * (BK * (int)sizeof(T));
-    };
-    auto issue_one = [&](int slot, int part) __attribute__((always_inline)) {
-      char* Ab = smem + slot * STAGE;
-      if (part < NIA) glds16_buf(p.A, aoff[part], is_koff, Ab + (w * NIA + part) * 1024);
-      else glds16_buf(p.B, boff[part - NIA], is_qoff, Ab + A_BYTES + (w * NIB + part - NIA) * 1024);
-    };
-    auto read_frag = [&](int set, int slot, int g) __attribute__((always_inline)) {
-      const char* Ab = smem + slot * STAGE;
-      if (g < FJ) fb[set][g] = *(const bf16x8*)(Ab + A_BYTES + (wc * TN + g * 16) * ROWB + rd_off);
-      else fa[set][g - FJ] = *(const bf16x8*)(Ab + (wr * TM + (g - FJ) * 16) * ROWB + rd_off);
-    };
-    auto step = [&](auto setc, auto slotc, int kt, bool do_issue, bool do_read) __attribute__((always_inline)) {
-      constexpr int SET = decltype(setc)::value, SLOT = decltype(slotc)::value;
-      if (do_issue) issue_prep(kt + NST);
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        if (do_read) read_frag(SET ^ 1, (SLOT + 1) % NST, g);
-        if (do_issue && g % (NG / PER_STAGE) == 0) issue_one(SLOT, g / (NG / PER_STAGE));
-#pragma unroll
-        for (int m = g * (FI * FJ) / NG; m < (g + 1) * (FI * FJ) / NG; ++m) {
-          // row-major over the fragment rows: row i needs fa[i] (read group FJ + i of the PREVIOUS step) and all four fb
-          const int i = m / FJ, j = m % FJ;
-          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fb[SET][j]), "v"(fa[SET][i]));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    using std::integral_constant;
-    auto stage_sync = [&]() __attribute__((always_inline)) {
-      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-      static_assert(PER_STAGE == 6, "literal wait count");
-      __builtin_amdgcn_s_barrier();
-    };
-    stamp(1);
-    if (nt >= 3) wait_vmcnt<2 * PER_STAGE>();
-    else if (nt == 2) wait_vmcnt<PER_STAGE>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    stamp(2);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) read_frag(0, 0, g);
-    int kt = 0;
-    for (; kt + 8 < nt; kt += 6) {                       // steady state (period 6 = fragment sets x ring slots): every step requests a stage and reads one
-      stage_sync();
-      step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt, true, true);
-      stage_sync();
-      step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1, true, true);
-      stage_sync();
-      step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2, true, true);
-      stage_sync();
-      step(integral_constant<int, 1>{}, integral_constant<int, 0>{}, kt + 3, true, true);
-      stage_sync();
-      step(integral_constant<int, 0>{}, integral_constant<int, 1>{}, kt + 4, true, true);
-      stage_sync();
-      step(integral_constant<int, 1>{}, integral_constant<int, 2>{}, kt + 5, true, true);
-    }
-    auto tail_step = [&](auto setc, auto slotc, int k) __attribute__((always_inline)) {
-      if (k >= nt) return;
-      if (k + 2 < nt) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      step(setc, slotc, k, k + NST < nt, k + 1 < nt);
-    };
-    // the last 1..8 steps (kt is a multiple of 6 here): runtime tests of what is left to request / read
-    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt);
-    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1);
-    tail_step(integral_constant<int, 0>{}, integral_constant<int, 2>{}, kt + 2);
-    tail_step(integral_constant<int, 1>{}, integral_constant<int, 0>{}, kt + 3);
-    tail_step(integral_constant<int, 0>{}, integral_constant<int, 1>{}, kt + 4);
-    tail_step(integral_constant<int, 1>{}, integral_constant<int, 2>{}, kt + 5);
-    tail_step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt + 6);
-    tail_step(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 7);
-    if (arow_bad) __builtin_trap();
-    epilogue_reg();
-  } else if constexpr (PIPE == 5) {
-    // Rotated ping-pong, ONE barrier per stage.  The two waves of a SIMD (wave rows 0 / 1) no longer hand the matrix pipe over at a
-    // second barrier in mid-stage (each hand-over leaves it idle for the barrier's release latency: the loop above spends ~1224
-    // cycles per stage against the pipe's 1024, tools/probes/gemm_clock.py): the lag row runs its stage ROTATED - after barrier kt
-    // it first issues the MFMAs of fragment rows [R, FI) of stage kt-1 (operands still in its registers), then requests stage kt+3,
-    // reads the fragments of stage kt and issues rows [0, R) of it - while the lead row requests / reads and then issues all FI rows.
-    // The lag row's first burst covers the lead row's copy requests and reads, the lead row's MFMAs cover the lag row's; which
-    // wave gets the pipe inside an interval is the hardware's choice.  Every accumulator still adds the stages in order: same bits.
-    // Ring safety and data arrival as in the two-barrier loop: stage kt-1 was read by both rows before barrier kt (the request of
-    // stage kt+3 into its slot comes after it), and every wave has waited for its own pieces of stage kt before barrier kt.
-    static_assert(NST >= 4 && WM == 2 && !M32 && SWAP, "rotated ping-pong variant");
-    constexpr int R = 2;
-    const bool lag = (wr == 1);
-    bf16x8 a[FI], b[FJ];
-    auto read_frags = [&](int q) __attribute__((always_inline)) {
-      const char* Ab = smem + (q % NST) * STAGE;
-      const char* Bb = Ab + A_BYTES;
-#pragma unroll
-      for (int j = 0; j < FJ; ++j) b[j] = *(const bf16x8*)(Bb + (wc * TN + j * 16) * ROWB + rd_off);
-#pragma unroll
-      for (int i = 0; i < FI; ++i) a[i] = *(const bf16x8*)(Ab + (wr * TM + i * 16) * ROWB + rd_off);
-    };
-    auto mma_rows = [&](auto i0c, auto i1c) __attribute__((always_inline)) {
-      constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = I0; i < I1; ++i)
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    };
-    auto wait_tile = [&](int kt) {
-      const int newer = min(NST - 2, nt - 1 - kt);
-      if (newer >= 2) wait_vmcnt<2 * PER_STAGE>();
-      else if (newer == 1) wait_vmcnt<PER_STAGE>();
-      else wait_vmcnt<0>();
-    };
-    using IC0 = std::integral_constant<int, 0>;
-    using ICR = std::integral_constant<int, R>;
-    using ICF = std::integral_constant<int, FI>;
-    stamp(1);
-    wait_tile(0);
-    stamp(2);
-    if (!lag) {
-      int kt = 0;
-      if (p.S == 1)
-        for (; kt + NST - 1 < nt; ++kt) {                // steady state: constant wait, no data-dependent branch
-          __builtin_amdgcn_s_barrier();
-          issue(kt + NST - 1);
-          read_frags(kt);
-          wait_vmcnt<2 * PER_STAGE>();
-          mma_rows(IC0{}, ICF{});
-        }
-      for (; kt < nt; ++kt) {
-        __builtin_amdgcn_s_barrier();
-        if (kt + NST - 1 < nt) issue(kt + NST - 1);
-        read_frags(kt);
-        if (kt + 1 < nt) wait_tile(kt + 1);
-        mma_rows(IC0{}, ICF{});
-      }
-    } else {
-      int kt = 0;
-      if (nt > 0) {                                      // stage 0: nothing of a previous stage to finish
-        __builtin_amdgcn_s_barrier();
-        if (NST - 1 < nt) issue(NST - 1);
-        read_frags(0);
-        if (1 < nt) wait_tile(1);
-        mma_rows(IC0{}, ICR{});
-        kt = 1;
-      }
-      if (p.S == 1)
-        for (; kt + NST - 1 < nt; ++kt) {
-          __builtin_amdgcn_s_barrier();
-          mma_rows(ICR{}, ICF{});
-          issue(kt + NST - 1);
-          read_frags(kt);
-          wait_vmcnt<2 * PER_STAGE>();
-          mma_rows(IC0{}, ICR{});
-        }
-      for (; kt < nt; ++kt) {
-        __builtin_amdgcn_s_barrier();
-        mma_rows(ICR{}, ICF{});
-        if (kt + NST - 1 < nt) issue(kt + NST - 1);
-        read_frags(kt);
-        if (kt + 1 < nt) wait_tile(kt + 1);
-        mma_rows(IC0{}, ICR{});
-      }
-      if (nt > 0) mma_rows(ICR{}, ICF{});
-    }
-    if (arow_bad) __builtin_trap();
-    epilogue_reg();
-  } else {
+  {
     // Ping-pong: waves w and w+4 share a SIMD (wave rows wr = 0 / 1).  With ONE barrier per stage both read their
     // fragments at the same time (matrix pipe idle) and then serialise their MFMAs.  Here every stage has two barriers
     // and the two wave rows run half a stage apart: while row 0 reads the fragments of tile kt, row 1 issues the MFMAs
@@ -1751,307 +1236,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_ring_kernel(GemmNT
 
 
 #ifdef STSWIN_TUNING   // measured losers kept for A/B runs only: not compiled into the product library (build with STSWIN_TUNING=1)
-// =====================================================================================================
-// gemm_nt "stream" (bf16, S = 1, no A gather): the 256x256 ping-pong ring kernel made PERSISTENT.  A workgroup owns tiles
-// blockIdx.x, blockIdx.x + gridDim.x, ... and the 4-stage LDS ring streams straight across tile boundaries: the first
-// three K stages of the next tile are requested while the last stages of the current one are multiplied, so no tile
-// pays the ~2 us prologue, the workgroup relaunch gap, or a drained pipeline.  Between its last MFMA of a tile and its
-// first fragment read of the next, each wave row runs the register epilogue (operand-swapped MFMA: 4 consecutive output
-// columns per lane) through a WAVE-PRIVATE 8 KB image in a fifth 32 KB LDS region - no workgroup barrier, the other
-// wave row keeps multiplying - and its global stores drain while the next tile's stages are consumed.
-// Measured on the non-persistent kernel at K = 512: 12 us of main loop + 14 us of prologue / epilogue / store drain /
-// relaunch per tile (tools/epi_ksweep.py).
-// vmcnt: epilogue loads/stores share the counter with the LDS-DMA stream.  Before its first epilogue memory operation a
-// wave waits for ALL its outstanding stage copies (they are 1-3 stages old), then skips the next two counted waits (those
-// stages are known to have landed); every later counted wait is conservative with stores in flight, never wrong.
-// =====================================================================================================
-__global__ __launch_bounds__(512, 2) void gemm_nt_stream_kernel(GemmNT p) {
-  using T = bf16;
-  constexpr int BM = 256, BN = 256, BK = 32, ROWB = 64, NST = 4;
-  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-  constexpr int TM = 128, TN = 64, FI = 8, FJ = 4, NIA = 2, NIB = 2, PER_STAGE = NIA + NIB;
-  constexpr int IMG = NST * STAGE;                   // byte offset of the epilogue image region (4 x 8 KB, one wave row at a time)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, l = tid & 63, w = wave_id();
-  const int wr = w >> 2, wc = w & 3;
-  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
-  const int nt = p.Kseg / BK;
-  const int nk = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1)
-  const int TS = nk * nt;                            // stages of this workgroup's stream
-
-  // buffer-addressed copies (see gemm_nt_ring_kernel): per lane and copy one 32-bit offset, rebuilt at every tile switch
-  // of the ISSUE cursor (which runs NST-1 stages ahead of the multiplying cursor)
-  unsigned aoff[NIA], boff[NIB];
-  auto set_issue_tile = [&](int k) {
-    const int t = xcd_remap((int)blockIdx.x + k * (int)gridDim.x, ntiles);
-    const int mi = (t / tiles_n) * BM, ni = (t % tiles_n) * BN;
-    int lane = l;                                    // lane constants re-derived here (opaque): kept live they get spilled
-    asm volatile("" : "+v"(lane));
-    const int rsub = lane >> 2, cphys = lane & 3, csrc = cphys ^ swz64(rsub);
-#pragma unroll
-    for (int i = 0; i < NIB; ++i) {
-      const int gn = ni + (w * NIB + i) * 16 + rsub;
-      boff[i] = gn < p.N ? (unsigned)gn * (unsigned)(p.ldb * sizeof(T)) + csrc * 16 : 0xFFFFFFFFu;
-    }
-#pragma unroll
-    for (int i = 0; i < NIA; ++i) {
-      const int gm = mi + (w * NIA + i) * 16 + rsub;
-      aoff[i] = gm < p.M ? (unsigned)gm * (unsigned)(p.lda * sizeof(T)) + csrc * 16 : 0xFFFFFFFFu;
-    }
-  };
-  int ik = 0, is = 0;                                // issue cursor: tile number of this workgroup, stage within it
-  set_issue_tile(0);
-  auto issue_next = [&](int g) {                     // stage g of the stream -> ring slot g & 3
-    char* Ab = smem + (g & (NST - 1)) * STAGE;
-    char* Bb = Ab + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < NIA; ++i) glds16_buf(p.A, aoff[i], is * (BK * (int)sizeof(T)), Ab + (w * NIA + i) * 1024);
-#pragma unroll
-    for (int i = 0; i < NIB; ++i) glds16_buf(p.B, boff[i], is * (BK * (int)sizeof(T)), Bb + (w * NIB + i) * 1024);
-    if (++is == nt) {
-      is = 0;
-      if (++ik < nk) set_issue_tile(ik);
-    }
-  };
-
-  f32x4 acc[FI][FJ];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int i = 0; i < FI; ++i)
-#pragma unroll
-      for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  };
-  zero_acc();
-  const bool lag = (wr == 1);                        // wave-uniform
-  bf16x8 a[FI], b[FJ];
-  auto read_frags = [&](int g) {
-    const int fr = l & 15, fq = l >> 4;
-    const int rd_off = fr * ROWB + ((fq ^ swz64(fr)) << 4);
-    const char* Ab = smem + (g & (NST - 1)) * STAGE;
-    const char* Bb = Ab + A_BYTES;
-#pragma unroll
-    for (int j = 0; j < FJ; ++j) b[j] = *(const bf16x8*)(Bb + (wc * TN + j * 16) * ROWB + rd_off);
-#pragma unroll
-    for (int i = 0; i < FI; ++i) a[i] = *(const bf16x8*)(Ab + (wr * TM + i * 16) * ROWB + rd_off);
-  };
-  auto mma_all = [&]() {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < FI; ++i)
-#pragma unroll
-      for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
-
-  // ---------------- per-tile register epilogue of this wave (its 128 x 64 sub-tile), wave-private LDS image ----------------
-  enum { E_BIAS = 1, E_SCALE = 2, E_GELU = 4, E_C2 = 8, E_RESID = 16, E_DGELU = 32, E_COLSUM = 64, E_RELU = 128, E_MULR = 256, E_C2D = 512 };
-  auto epilogue_body = [&](auto tag, int m0, int n0) {
-    constexpr int MD = decltype(tag)::value;
-#define EPI_HAS(bit, rt) (MD >= 0 ? ((MD & (bit)) != 0) : (rt))
-    const bool has_bias = EPI_HAS(E_BIAS, p.bias != nullptr), has_scale = EPI_HAS(E_SCALE, p.scale_cols > 0);
-    const bool do_gelu = EPI_HAS(E_GELU, (p.flags & GF_GELU) != 0), has_c2 = EPI_HAS(E_C2, p.C2 != nullptr);
-    const bool do_resid = EPI_HAS(E_RESID, (p.flags & GF_RESID) != 0), do_dgelu = EPI_HAS(E_DGELU, (p.flags & GF_MUL_DGELU) != 0);
-    const bool do_cs = EPI_HAS(E_COLSUM, p.colsum != nullptr), do_relu = EPI_HAS(E_RELU, (p.flags & GF_RELU) != 0);
-    const bool do_mulr = EPI_HAS(E_MULR, (p.flags & GF_MUL_R) != 0), c2_dgelu = EPI_HAS(E_C2D, (p.flags & GF_C2_DGELU) != 0);
-    const bool has_r = do_resid || do_dgelu || do_mulr;
-    int lane = l;                                    // epilogue lane constants: derived here, not kept live (and spilled)
-    asm volatile("" : "+v"(lane));                   // across the stream loop
-    const int fr = lane & 15, fq = lane >> 4;
-    char* img = smem + IMG + wc * 8192;              // [64 rows][128 B], 16-byte chunk ^= row & 7
-    const int colb = n0 + wc * TN + 4 * fq;          // + j*16: first of this lane's 4 columns
-    f32x4 bj[FJ];
-    if (has_bias) {
-#pragma unroll
-      for (int j = 0; j < FJ; ++j) bj[j] = *(const f32x4*)(p.bias + min(colb + j * 16, p.N - 4));   // columns >= N are never stored
-    }
-    auto pre_act = [&](int i, int j) -> f32x4 {
-      f32x4 v = acc[i][j];
-      if (has_bias) v += bj[j];
-      if (has_scale) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (colb + j * 16 + e < p.scale_cols) v[e] *= p.scale;
-      }
-      return v;
-    };
-    auto put = [&](int ih, int j, f32x4 v) {          // ih = fragment row within the half (0..3)
-      const int row = ih * 16 + fr;
-      const int chunk = 2 * j + (fq >> 1);
-      bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-      *(bf16x4*)(img + row * 128 + ((chunk ^ (fr & 7)) << 4) + (fq & 1) * 8) = o;
-    };
-    const int rb_row = lane >> 3, rb_chunk = lane & 7;
-    const bool rb_col_ok = n0 + wc * TN + rb_chunk * 8 < p.N;
-    auto readback = [&](int h2, void* Cout, long ldo) { // rows of half h2: m0 + wr*128 + h2*64 + 0..63
-      int orow32[8];
-#pragma unroll
-      for (int ps = 0; ps < 8; ++ps) {
-        const int gm = m0 + wr * TM + h2 * 64 + ps * 8 + rb_row;
-        orow32[ps] = p.c_rows ? p.c_rows[min(gm, p.M - 1)] : gm;      // unpredicated on purpose (a predicated load stays
-      }                                                               // "pending" for hipcc across the loop back edge)
-#pragma unroll
-      for (int ps = 0; ps < 8; ++ps) {
-        const int row = ps * 8 + rb_row;
-        const int gm = m0 + wr * TM + h2 * 64 + row;
-        if (gm < p.M && rb_col_ok) {
-          const bf16x8 val = *(const bf16x8*)(img + row * 128 + ((rb_chunk ^ (row & 7)) << 4));
-          __builtin_nontemporal_store(val, (bf16x8*)((T*)Cout + (long)orow32[ps] * ldo + n0 + wc * TN + rb_chunk * 8));
-        }
-      }
-    };
-    if (has_c2) {                                     // second output: pre-activation, or gelu'(pre) for the backward multiply
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-        for (int ih = 0; ih < 4; ++ih)
-#pragma unroll
-          for (int j = 0; j < FJ; ++j) {
-            f32x4 v = pre_act(h2 * 4 + ih, j);
-            if (c2_dgelu) {
-              const f32x2 lo = dgelu_fast2((f32x2){v[0], v[1]}), hi = dgelu_fast2((f32x2){v[2], v[3]});
-              v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
-            }
-            put(ih, j, v);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        readback(h2, p.C2, p.ldc2);
-      }
-      if (has_bias) {                                 // launder: keep hipcc from holding 128 bias-added values for the pass below
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) asm volatile("" : "+v"(bj[j]));
-      }
-    }
-    f32x4 cs[FJ];
-#pragma unroll
-    for (int j = 0; j < FJ; ++j) cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x4 rcur[FJ], rnext[FJ];
-    auto load_r = [&](int i, bf16x4 (&dst)[FJ]) {
-      const int gm = min(m0 + wr * TM + i * 16 + fr, p.M - 1);      // rows >= M / columns >= N: clamped, never stored
-      const long rrow = p.r_rows ? (long)p.r_rows[gm] : (long)gm;
-#pragma unroll
-      for (int j = 0; j < FJ; ++j) dst[j] = *(const bf16x4*)((const T*)p.R + rrow * p.ldr + min(colb + j * 16, p.N - 4));
-    };
-    if (has_r) load_r(0, rcur);
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-      for (int ih = 0; ih < 4; ++ih) {
-        const int i = h2 * 4 + ih;
-        if (has_r && i + 1 < FI) load_r(i + 1, rnext);
-        const bool row_ok = m0 + wr * TM + i * 16 + fr < p.M;
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) {
-          f32x4 v = pre_act(i, j);
-          if (do_gelu) {
-            const f32x2 lo = gelu_fast2((f32x2){v[0], v[1]}), hi = gelu_fast2((f32x2){v[2], v[3]});
-            v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
-          }
-          if (has_r) {
-            const f32x4 r = {(float)rcur[j][0], (float)rcur[j][1], (float)rcur[j][2], (float)rcur[j][3]};
-            if (do_resid) v += r;
-            else if (do_mulr) v *= r;
-            else {
-              const f32x2 lo = dgelu_fast2((f32x2){r[0], r[1]}), hi = dgelu_fast2((f32x2){r[2], r[3]});
-              v *= (f32x4){lo[0], lo[1], hi[0], hi[1]};
-            }
-          }
-          if (do_relu) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
-          if (do_cs) { if (row_ok) cs[j] += v; }
-          put(ih, j, v);
-          if (do_gelu || do_dgelu) __builtin_amdgcn_sched_barrier(0);
-        }
-        if (has_r && i + 1 < FI) {
-#pragma unroll
-          for (int j = 0; j < FJ; ++j) rcur[j] = rnext[j];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      readback(h2, p.C, p.ldc);
-    }
-    if (do_cs) {                                      // fold the 16 rows (fr) of each lane group, then one atomic per column
-#pragma unroll
-      for (int j = 0; j < FJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float tsum = cs[j][e];
-          tsum = sum16(tsum);
-          const int gn = colb + j * 16 + e;
-          if (fr == 0 && gn < p.N) {
-            if (TM % 128 == 0) cs_emit(p, (m0 + wr * TM) / 128, TM / 128, gn, tsum);
-            else atomicAdd(p.colsum + gn, tsum);
-          }
-        }
-    }
-#undef EPI_HAS
-  };
-  const int epi_mode = (p.bias ? E_BIAS : 0) | (p.scale_cols > 0 ? E_SCALE : 0) | ((p.flags & GF_GELU) ? E_GELU : 0) |
-                       (p.C2 ? E_C2 : 0) | ((p.flags & GF_RESID) ? E_RESID : 0) | ((p.flags & GF_MUL_DGELU) ? E_DGELU : 0) |
-                       (p.colsum ? E_COLSUM : 0) | ((p.flags & GF_RELU) ? E_RELU : 0) | ((p.flags & GF_MUL_R) ? E_MULR : 0) |
-                       ((p.flags & GF_C2_DGELU) ? E_C2D : 0);
-  int skip = 0;                                      // counted waits to skip (stages verified by the epilogue's vmcnt(0))
-  auto epilogue = [&](int k) {
-    const int t = xcd_remap((int)blockIdx.x + k * (int)gridDim.x, ntiles);
-    const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
-    wait_vmcnt<0>();                                 // every stage copy of this wave has landed; epilogue memory ops may follow
-    skip = 2;
-    switch (epi_mode) {
-      case 0: epilogue_body(std::integral_constant<int, 0>{}, m0, n0); break;
-      case E_BIAS: epilogue_body(std::integral_constant<int, E_BIAS>{}, m0, n0); break;
-      case E_BIAS | E_GELU | E_C2 | E_C2D: epilogue_body(std::integral_constant<int, E_BIAS | E_GELU | E_C2 | E_C2D>{}, m0, n0); break;
-      case E_BIAS | E_RESID: epilogue_body(std::integral_constant<int, E_BIAS | E_RESID>{}, m0, n0); break;
-      case E_RESID: epilogue_body(std::integral_constant<int, E_RESID>{}, m0, n0); break;
-      case E_MULR | E_COLSUM: epilogue_body(std::integral_constant<int, E_MULR | E_COLSUM>{}, m0, n0); break;
-      default: epilogue_body(std::integral_constant<int, -1>{}, m0, n0); break;
-    }
-    zero_acc();
-  };
-
-  // ---------------- the stream ----------------
-  auto wait_stage = [&](int g1) {                    // stage g1 of the stream has landed (this wave's share)
-    if (g1 >= TS) return;
-    if (skip > 0) { --skip; return; }
-    const int newer = min(NST - 2, TS - 1 - g1);
-    if (newer >= 2) wait_vmcnt<2 * PER_STAGE>();
-    else if (newer == 1) wait_vmcnt<PER_STAGE>();
-    else wait_vmcnt<0>();
-  };
-  for (int q = 0; q < NST - 1 && q < TS; ++q) issue_next(q);
-  wait_stage(0);
-  if (lag) __builtin_amdgcn_s_barrier();
-  int g = 0;
-  for (int ck = 0; ck < nk; ++ck) {                  // one tile of this workgroup per trip
-    const int gend = g + nt;
-    // stages 0 and 1 of a tile: the waits may be the "known landed" ones after an epilogue
-    for (int r = 0; r < 2 && g < gend; ++r, ++g) {
-      __builtin_amdgcn_s_barrier();
-      if (g + NST - 1 < TS) issue_next(g + NST - 1);
-      read_frags(g);
-      wait_stage(g + 1);
-      __builtin_amdgcn_s_barrier();
-      mma_all();
-    }
-    // branch-free steady state of the tile (every iteration requests a stage, constant wait count)
-    const int gsteady = min(gend, TS - (NST - 1));
-    for (; g < gsteady; ++g) {
-      __builtin_amdgcn_s_barrier();
-      issue_next(g + NST - 1);
-      read_frags(g);
-      wait_vmcnt<2 * PER_STAGE>();
-      __builtin_amdgcn_s_barrier();
-      mma_all();
-    }
-    for (; g < gend; ++g) {                           // the stream's last stages (nothing left to request)
-      __builtin_amdgcn_s_barrier();
-      read_frags(g);
-      wait_stage(g + 1);
-      __builtin_amdgcn_s_barrier();
-      mma_all();
-    }
-    epilogue(ck);
-  }
-  if (!lag) __builtin_amdgcn_s_barrier();
-}
-
+#include "gemm_nt_tuning_kernels.inc"
 #endif  // STSWIN_TUNING
 
 // =====================================================================================================

@@ -249,12 +249,14 @@ def test_config4_full_size_fp8_finetune_step_vs_the_oracle(tmp_path):
     assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
     # fp8-step gradients against the bf16 step's (same weights, same clips, same loss scale): e4m3 q | k | v carry 2^-4 relative
     # rounding per element into every attention product; behind the decode head that is a few 1e-2 on the gradients, in front of the
-    # 12 Swin blocks (ResNet) it accumulates.  Bounds per family, stated (measured on MI355X in brackets): classifier 0.1 (0.056),
-    # projections 0.2 (0.08-0.11), ASPP 0.25 (0.15: it sits directly behind the stage-2 blocks), Swin 0.35 (0.23), ResNet 0.5 (0.22)
+    # 12 Swin blocks (ResNet) it accumulates.  Bounds per family = 1.3 x measured (measured on MI355X in brackets): classifier 0.075 (0.056),
+    # projections 0.14 (0.08-0.11), ASPP 0.315 (0.24: it sits directly behind the stage-2 blocks), Swin 0.305 (0.23), ResNet 0.29 (0.22)
     # rel-L2, and every parameter's gradient keeps its direction (cosine > 0.85, measured >= 0.97) - a wrong scale factor (sq, sk, sv on
     # the wrong accumulator) or a missing straight-through term is O(1) and flips directions.  (The biases of the ASPP convolutions in
     # front of a train-mode BatchNorm have an exactly-zero true gradient - both runs hold rounding noise there - and are skipped.)
-    fam_bound = {"classifier": 0.1, "aspp": 0.25, "project1": 0.2, "project2": 0.2, "project3": 0.2, "swin": 0.35, "resnet": 0.5}
+    # (round 6: the bounds are 1.3 x the values measured on the final tree - classifier 0.056, ASPP 0.241 (aspp.conv_1x1_2), projections
+    #  0.078-0.107, Swin 0.234, ResNet 0.224; the kernels are deterministic, the printed line below shows the current values)
+    fam_bound = {"classifier": 0.075, "aspp": 0.315, "project1": 0.14, "project2": 0.14, "project3": 0.14, "swin": 0.305, "resnet": 0.29}
     worst, worst_cos, bad = {}, {}, []
     for k in g16:
         if k.startswith("aspp.conv_") and k.endswith(".bias") and "conv_1x1_4" not in k:
