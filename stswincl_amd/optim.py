@@ -47,6 +47,7 @@ class _Clock:
         self.hyper = torch.zeros(4, dtype=torch.float32, device=device)
         self.step = int(step)
         self.lr = None                       # the value hyper[0] holds
+        self.members = []                    # optimizer state dicts of the parameters that took the last step on this clock
 
     def push_lr(self, lr: float) -> None:
         """Stream-ordered fill of hyper[0] when the host's learning rate differs from what the device holds (schedulers); a no-op
@@ -85,9 +86,8 @@ class FusedAdam(torch.optim.Optimizer):
         """Host step counts <- device counters (after graph replays the host mirrors are stale)."""
         for c in self._clocks():
             c.sync()
-        for st in self.state.values():
-            if st.get("_clock") is not None:
-                st["step"] = st["_clock"].step
+            for st in c.members:            # (a parameter that shares the clock but sat the captured step out keeps its own count)
+                st["step"] = c.step
         self._replayed = False
 
     @torch.no_grad()
@@ -116,6 +116,8 @@ class FusedAdam(torch.optim.Optimizer):
                 if not isinstance(st["step"], int):          # a state loaded from torch.optim.Adam holds tensor steps: one host
                     st["step"] = int(st["step"])             # read, here, before any capture (see load_state_dict)
                 clock = st.get("_clock")
+                if clock is not None and clock.step != st["step"]:
+                    clock = None                             # it sat out steps the clock's other parameters took: its own count, its own clock
                 if clock is None:                            # first gradient (or a loaded state): join the clock of this count
                     if capturing:
                         raise hip.StswinHipError("FusedAdam: a parameter got its first gradient inside a hipGraph capture; run the "
@@ -138,6 +140,7 @@ class FusedAdam(torch.optim.Optimizer):
                 clock.push_lr(group["lr"])
                 hip.optim_tick(0, clock.counter, clock.hyper, float(b1), float(b2))
                 clock.step += 1
+                clock.members = sts
                 for st in sts:
                     st["step"] = clock.step
                 hip.multi_tensor(0, ps, gs, ms, vs, b1=b1, b2=b2, eps=group["eps"], wd=group["weight_decay"], hyper=clock.hyper)

@@ -156,7 +156,7 @@ def _world_token_worker(rank, world, port, q):
         from oracle import stswin_oracle as O
         from stswincl_amd.contrast.models import PixPro_swin_v5 as P
         from stswincl_amd import headops as H
-        b, h, w, C, ncls = 2, 4, 5, 32, 12
+        b, h, w, C, ncls = 2, 4, 5, 64, 12          # (C: a multiple of 64, rownorm_scatter's row layout)
         HW = h * w
 
         def rank_data(r):
@@ -207,10 +207,10 @@ def test_token_path_world_bank_on_two_ranks():
     procs = [ctx.Process(target=_world_token_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+        p.join(240)
+        assert p.exitcode == 0, "a rank failed (its traceback is in the captured stderr)"
+    res = [q.get(timeout=10) for _ in procs]
     losses = {}
     for rank, loss, ref, glue, e_g in res:
         assert abs(loss - ref) <= 2e-5 * abs(ref), (rank, loss, ref)
@@ -221,8 +221,8 @@ def test_token_path_world_bank_on_two_ranks():
 
 
 def test_query_label_count_is_checked():
-    Q = torch.nn.functional.normalize(torch.randn(64, 32, device="cuda"), dim=1)
-    bank = torch.nn.functional.normalize(torch.randn(6, 64, 32, device="cuda"), dim=2)
+    Q = torch.nn.functional.normalize(torch.randn(64, 64, device="cuda"), dim=1)
+    bank = torch.nn.functional.normalize(torch.randn(6, 64, 64, device="cuda"), dim=2)
     lb = torch.randint(0, 12, (6, 64), device="cuda", dtype=torch.int32)
     with pytest.raises(hip.StswinHipError):
         hip.contrast_bank_fwd(Q, lb[:2].reshape(-1).repeat(2), bank, lb, q_sets=2, q_block=32, bank_block=64,

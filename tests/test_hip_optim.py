@@ -163,3 +163,27 @@ def test_batched_repack_after_optimizer_step_matches_lazy_packing():
         hip.linear_pack, hip.conv_pack = real_lin, real_conv
     # the (12, 256) weight has n % 4 == 0 too; nothing may have been re-packed lazily after the batched pass
     assert calls == {"lin": 0, "conv": 0}, calls
+
+
+def test_fused_adam_parameters_that_sit_steps_out_leave_their_shared_device_clock():
+    """Parameters that stepped together share a device clock (stswincl_amd.optim._Clock); one that later sits a step out (grad None)
+    must continue with ITS count, not the clock's (round 6: found by tests/fuzz/fuzz_ops.py::fuzz_optim_groups)."""
+    a = [p.clone().requires_grad_(True) for p in _params(6)[:8]]
+    b = [p.clone().requires_grad_(True) for p in _params(6)[:8]]
+    oa = torch.optim.Adam([{"params": a[:3], "lr": 1e-2}, {"params": a[3:]}], 3e-3)
+    ob = FusedAdam([{"params": b[:3], "lr": 1e-2}, {"params": b[3:]}], 3e-3)
+    torch.manual_seed(7)
+    for step in range(6):
+        for i, (x, y) in enumerate(zip(a, b)):
+            if (step + i) % 4 == 1 or (step == 2 and i < 5):       # different parameters sit out different (later) steps
+                x.grad = y.grad = None
+                continue
+            g = torch.randn_like(x)
+            x.grad, y.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, atol=1e-6, rtol=1e-5)
+    steps_a = [int(oa.state[p]["step"]) for p in a]
+    steps_b = [ob.state_dict()["state"][i]["step"] for i in range(len(b))]
+    assert steps_a == steps_b, (steps_a, steps_b)
