@@ -146,5 +146,6 @@ def test_bench_size_bf16_step_runs_the_production_kernels_and_stays_at_the_refer
     groups = [shape for fam, shape, v in log if fam == "tn_group"]
     assert len(groups) >= 12 and all(v & hip.VAR_TN_FUSED for fam, _, v in log if fam == "tn_group"), len(groups)
     tn = [(shape, v) for fam, shape, v in log if fam == "tn"]
-    split = [(shape, v) for shape, v in tn if (v >> 16) > 1]
-    assert split and all(v & hip.VAR_TN_FUSED for _, v in split), [s for s, v in split if not v & hip.VAR_TN_FUSED][:4]
+    ring = (hip.VAR_TN_RING_PLAIN, hip.VAR_TN_RING_ATROWS, hip.VAR_TN_RING_BTROWS, hip.VAR_TN_RING_BSEG)
+    split = [(shape, v) for shape, v in tn if (v >> 16) > 1 and (v & 0xFFF) in ring]          # (the 128 x 128 kernel of the narrow outputs - 48 /
+    assert split and all(v & hip.VAR_TN_FUSED for _, v in split), [s for s, v in split if not v & hip.VAR_TN_FUSED][:4]   # 64 columns - keeps tn_reduce)
