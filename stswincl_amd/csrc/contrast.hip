@@ -352,46 +352,57 @@ __global__ __launch_bounds__(512, 2) void contrast_bank_kernel(BankArgs p) {
         }
       }
       if (sk == KST - 1) {                          // bank tile finished: fold the 16 FI x 64 scores of this wave
-        int lcol[4]; bool cok[4];
+        // The fold is VALU work beside the MFMAs of the next tile (~8 instructions per score against a budget of 4-5 at C = 256).  A tile
+        // that lies wholly inside the split's range - all but the last one - needs no per-column validity selects: FULL drops 8 of the
+        // ~35 instructions per 4 scores of the log-sum-exp path (round 6).
+        auto fold = [&](auto fullc) __attribute__((always_inline)) {
+          constexpr bool FULL = decltype(fullc)::value;
+          int lcol[4]; bool cok[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int c = wc * 64 + jj * 16 + fr;
-          cok[jj] = k_lo + kt * 128 + c < k_hi;
-          const int lab = *(const int*)(Bb + 16384 + w * 256 + (jj * 16 + fr) * 4);
-          lcol[jj] = cok[jj] ? lab : -2147483646;
-        }
-#pragma unroll
-        for (int i = 0; i < FI; ++i) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int e = i * 4 + r;
-            float v0 = acc[i][0][r], v1 = acc[i][1][r], v2 = acc[i][2][r], v3 = acc[i][3][r];
-            pall[e] += (v0 + v1) + (v2 + v3);
-            ppos[e] += ((lrow[e] == lcol[0] ? v0 : 0.f) + (lrow[e] == lcol[1] ? v1 : 0.f)) +
-                       ((lrow[e] == lcol[2] ? v2 : 0.f) + (lrow[e] == lcol[3] ? v3 : 0.f));
-            if (p.want_lse == 2) {
-              // unit-norm rows (stswin_contrast_bank_fwd_unit): |score| <= 1, so inv_tau is an upper bound of every scaled score and
-              // serves as the FIXED reference point of the sum of exponentials - no running maximum inside the sum, no rescaling
-              // of the partial sum per tile: one fma + one v_exp_f32 per score (the online form: 35 VALU per 4 scores, after the
-              // MFMAs of the tile and as long as them - 795 -> 609 TFLOP/s; profiles/r04_contrast_kernels.txt).  The row maximum
-              // (an output of its own) is two v_max3.
-              const float c2 = p.inv_tau * 1.4426950408889634f;
-              const float e0 = cok[0] ? __builtin_amdgcn_exp2f(__builtin_fmaf(v0, c2, -c2)) : 0.f, e1 = cok[1] ? __builtin_amdgcn_exp2f(__builtin_fmaf(v1, c2, -c2)) : 0.f;
-              const float e2 = cok[2] ? __builtin_amdgcn_exp2f(__builtin_fmaf(v2, c2, -c2)) : 0.f, e3 = cok[3] ? __builtin_amdgcn_exp2f(__builtin_fmaf(v3, c2, -c2)) : 0.f;
-              pse[e] += (e0 + e1) + (e2 + e3);
-              v0 = cok[0] ? v0 : -3.0e38f; v1 = cok[1] ? v1 : -3.0e38f; v2 = cok[2] ? v2 : -3.0e38f; v3 = cok[3] ? v3 : -3.0e38f;
-              pmax[e] = fmaxf(fmaxf(pmax[e], fmaxf(v0, v1)), fmaxf(v2, v3));        // (unscaled: x inv_tau at the end)
-            } else if (p.want_lse) {
-              v0 = cok[0] ? v0 * p.inv_tau : -3.0e38f; v1 = cok[1] ? v1 * p.inv_tau : -3.0e38f;
-              v2 = cok[2] ? v2 * p.inv_tau : -3.0e38f; v3 = cok[3] ? v3 * p.inv_tau : -3.0e38f;
-              const float mx = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), pmax[e]);
-              pse[e] = pse[e] * __expf(pmax[e] - mx) + ((__expf(v0 - mx) + __expf(v1 - mx)) + (__expf(v2 - mx) + __expf(v3 - mx)));
-              pmax[e] = mx;
-            }
+          for (int jj = 0; jj < 4; ++jj) {
+            const int c = wc * 64 + jj * 16 + fr;
+            cok[jj] = FULL || k_lo + kt * 128 + c < k_hi;
+            const int lab = *(const int*)(Bb + 16384 + w * 256 + (jj * 16 + fr) * 4);
+            lcol[jj] = cok[jj] ? lab : -2147483646;
           }
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+          for (int i = 0; i < FI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int e = i * 4 + r;
+              float v0 = acc[i][0][r], v1 = acc[i][1][r], v2 = acc[i][2][r], v3 = acc[i][3][r];
+              pall[e] += (v0 + v1) + (v2 + v3);
+              ppos[e] += ((lrow[e] == lcol[0] ? v0 : 0.f) + (lrow[e] == lcol[1] ? v1 : 0.f)) +
+                         ((lrow[e] == lcol[2] ? v2 : 0.f) + (lrow[e] == lcol[3] ? v3 : 0.f));
+              if (p.want_lse == 2) {
+                // unit-norm rows (stswin_contrast_bank_fwd_unit): |score| <= 1, so inv_tau is an upper bound of every scaled score and
+                // serves as the FIXED reference point of the sum of exponentials - no running maximum inside the sum, no rescaling
+                // of the partial sum per tile: one fma + one v_exp_f32 per score (the online form: 35 VALU per 4 scores, after the
+                // MFMAs of the tile and as long as them - 795 -> 609 TFLOP/s; profiles/r04_contrast_kernels.txt).  The row maximum
+                // (an output of its own) is two v_max3.
+                const float c2 = p.inv_tau * 1.4426950408889634f;
+                float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(v0, c2, -c2)), e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(v1, c2, -c2));
+                float e2 = __builtin_amdgcn_exp2f(__builtin_fmaf(v2, c2, -c2)), e3 = __builtin_amdgcn_exp2f(__builtin_fmaf(v3, c2, -c2));
+                if constexpr (!FULL) {
+                  e0 = cok[0] ? e0 : 0.f; e1 = cok[1] ? e1 : 0.f; e2 = cok[2] ? e2 : 0.f; e3 = cok[3] ? e3 : 0.f;
+                  v0 = cok[0] ? v0 : -3.0e38f; v1 = cok[1] ? v1 : -3.0e38f; v2 = cok[2] ? v2 : -3.0e38f; v3 = cok[3] ? v3 : -3.0e38f;
+                }
+                pse[e] += (e0 + e1) + (e2 + e3);
+                pmax[e] = fmaxf(fmaxf(pmax[e], fmaxf(v0, v1)), fmaxf(v2, v3));        // (unscaled: x inv_tau at the end)
+              } else if (p.want_lse) {
+                v0 = cok[0] ? v0 * p.inv_tau : -3.0e38f; v1 = cok[1] ? v1 * p.inv_tau : -3.0e38f;
+                v2 = cok[2] ? v2 * p.inv_tau : -3.0e38f; v3 = cok[3] ? v3 * p.inv_tau : -3.0e38f;
+                const float mx = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), pmax[e]);
+                pse[e] = pse[e] * __expf(pmax[e] - mx) + ((__expf(v0 - mx) + __expf(v1 - mx)) + (__expf(v2 - mx) + __expf(v3 - mx)));
+                pmax[e] = mx;
+              }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        };
+        if (k_lo + kt * 128 + 128 <= k_hi) fold(std::true_type{});
+        else fold(std::false_type{});
       }
     }
   }

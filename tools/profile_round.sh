@@ -18,11 +18,13 @@ run_prof() {  # name, rocprof flags..., -- cmd
 }
 # 1. kernel trace + stats
 rm -rf /tmp/prof_kt
-rocprofv3 --output-format csv --kernel-trace --stats -d /tmp/prof_kt -o kt -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.log 2>&1
+# (round 6: the timed steps are hipGraph replays; no bracketed pass and no calibration probes inside the trace, so that the last 150 ms are replayed steps only)
+rocprofv3 --output-format csv --kernel-trace --stats -d /tmp/prof_kt -o kt -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-secondary --no-profile --no-calibration > $OUT/bench_under_rocprof.log 2>&1
 KT=$(find /tmp/prof_kt -name "*kernel_trace.csv" | head -1)
 ST=$(find /tmp/prof_kt -name "*kernel_stats.csv" | head -1)
 [ -n "$ST" ] && head -60 "$ST" > $OUT/${TAG}_rocprofv3_kernel_stats.csv
 [ -n "$KT" ] && python3 tools/prof_summary.py "$KT" --last-ms 150 --top 60 --gaps 25 > $OUT/${TAG}_bench_steady_state_kernels.txt 2>&1
+[ -n "$KT" ] && python3 tools/step_sequence.py "$KT" --no-list > $OUT/${TAG}_step_sequence_graph.txt 2>&1
 grep '^{"metric"' $OUT/bench_under_rocprof.log | tail -1 > $OUT/${TAG}_bench_line_under_rocprof.json
 # 2. clean bench line + per-shape table
 python3 bench.py --steps 20 --warmup 3 > $OUT/bench_clean.log 2>&1
@@ -31,7 +33,7 @@ STSWIN_SHAPE_PROFILE=1 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline -
 # 3. PMC passes (each its own run)
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/prof_pmc_$C
-  rocprofv3 --output-format csv --pmc $C --kernel-trace -d /tmp/prof_pmc_$C -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-secondary --graph 0 > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --output-format csv --pmc $C --kernel-trace -d /tmp/prof_pmc_$C -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-calibration --no-secondary --graph 0 > $OUT/pmc_$C.log 2>&1
   CC=$(find /tmp/prof_pmc_$C -name "*counter_collection.csv" | head -1)
   [ -n "$CC" ] && python3 tools/pmc_summary.py "$CC" $C 0.34 > $OUT/${TAG}_pmc_$(echo $C | tr A-Z a-z).txt 2>&1
   [ -n "$CC" ] && cp "$CC" /tmp/pmc_$C.csv
