@@ -79,19 +79,31 @@ extern "C" int stswin_proxy_collective(const void* src, void* dst, long bytes, i
 
 // In-run calibration of bench.py (round 6): two fixed probes that tell one box of the pool from another, so that throughput lines
 // measured on different boxes can be compared.  (i) MFMA: `waves` waves per CU on 256 workgroups, each running `iters` rounds of 8
-// independent v_mfma_f32_16x16x32_bf16 (2 * 16 * 16 * 32 flops each) - the sustained matrix-core rate at the clock the box settles on;
+// independent v_mfma_f32_16x16x32_bf16 (2 * 16 * 16 * 32 flops each) on pseudo-random operands - the sustained matrix-core rate at the
+// clock the box settles on under that load;
 // (ii) copy: a 16-byte-per-lane grid-stride copy of `bytes` (choose > the 256 MB infinity cache) - the sustained HBM read + write rate.
 // Measurement infrastructure only - never on the product path.
 __global__ __launch_bounds__(512) void calib_mfma_kernel(int iters, float* sink) {
+  // Eight chains with their own pseudo-random operands in [-1, 1): consecutive MFMAs see different bits on both inputs, like the
+  // fragments of a GEMM on real data - on constant operands the matrix pipe draws little power and the probe reads the same
+  // ~2.33 PFLOP/s on every box, while the step (power-limited at 1.65-1.85 GHz) differs by 4 % between them.
   f32x4 acc[8];
+  bf16x8 a[8], b[8];
+  unsigned h = (threadIdx.x + 1u) * 2654435761u ^ (blockIdx.x * 40503u);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) {
+    acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { a[i] = (bf16)((threadIdx.x & 63) * 0.001f + i); b[i] = (bf16)(1.f + i * 0.01f); }
+    for (int e = 0; e < 8; ++e) {
+      h = h * 1664525u + 1013904223u;
+      a[i][e] = (bf16)((float)(int)(h >> 8 & 0xFFFF) * (1.0f / 32768.0f) - 1.0f);
+      h = h * 1664525u + 1013904223u;
+      b[i][e] = (bf16)((float)(int)(h >> 8 & 0xFFFF) * (1.0f / 32768.0f) - 1.0f);
+    }
+  }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[i], acc[i], 0, 0, 0);
   }
   float s = 0.f;
 #pragma unroll

@@ -38,8 +38,8 @@ class GraphedStep:
         self.before_step = before_step
         self.steps_run = 0
         self.warmup_losses = []
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
+        side = self.stream = torch.cuda.Stream()         # (eager steps run later should use it too: the parameters' AccumulateGrad nodes
+        side.wait_stream(torch.cuda.current_stream())     #  are bound to the stream of their first backward)
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):           # (at least one: optimizer state and device clocks must exist before the capture)
                 if before_step is not None:
