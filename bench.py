@@ -404,7 +404,7 @@ def seg_run(a, ctx):
     if profile_stride:
         prof_steps = 2 * profile_stride if profile_stride > 1 else 4
         # (the graph and its private memory pool are dropped first: eager steps beside a live capture of the same step run 6-7 % slower on
-        #  the DEVICE - 28.05 against 26.30 ms, back to 26.7 once the pool is released; tools/_eager_after_graph.py - so the kernels would be
+        #  the DEVICE - 28.05 against 26.30 ms, back to 26.7 once the pool is released; tools/eager_after_graph.py - so the kernels would be
         #  timed in a memory layout the headline never sees)
         if use_graph:
             import gc
