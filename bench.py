@@ -12,9 +12,13 @@ N > 1 without WORLD_SIZE in the environment: this process starts N ranks itself 
 --nproc-per-node N ... bench.py <same flags>`, BEFORE anything here touches the GPU) and exits with the child's code;
 under torch.distributed.run (WORLD_SIZE set) it is one rank of the job.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, live HIP
-events), `secondary` (BASELINE's second metric, contrastive pairs/s, from a short run of the configs[3] step) and
-`cpu_baseline` (the CPU oracle timed on this host, N = 1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement).  Order of a run (round 6): W warm-up steps -> `calibration`
+probes (0.1 s: an MFMA loop on pseudo-random operands, a 1 GB copy) -> 2 more untimed steps -> EXACTLY K timed steps between barrier +
+synchronize, with NO event brackets inside (`value`; a hipGraph replay of the whole step at N = 1 - a training mode, stswincl_amd/graph.py -,
+eager launches at N > 1) -> the graph is released -> a separate eager pass of 2 x stride steps in which one launch in `stride` of every
+kernel family is bracketed by HIP events on the launch stream (`roofline`, `profile_pass`; not part of `value`) -> `secondary` (BASELINE's
+second metric, contrastive pairs/s, from a short run of the configs[3] step, and its inter-video bank mode) -> `cpu_baseline` (the CPU
+oracle timed on this host, N = 1 only).  `value_normalised` = `value` referred to a box whose MFMA probe reads bench.py's CAL_REF.
 """
 from __future__ import annotations
 
