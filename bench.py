@@ -238,12 +238,13 @@ def capture(step_fn, zero_grad, optimizers=()):
 
 
 # Calibration reference of `value_normalised` (see calibration_block).  From the round-6 development boxes
-# (profiles/r06_calibration_boxes.txt): two kinds of box showed up, MFMA probe 1870-1876 TFLOP/s <-> 597.8-598.9 frames/s and
-# 1944 <-> 610.2: the step follows the probe with weight 0.5 ((610.2 / 598.6 - 1) / (1944 / 1872.5 - 1) = 0.51) - the other half of the
-# step (HBM-bound passes, output-bound K = 512 GEMMs) does not move with it.  The copy probe is reported but NOT used: it reads
-# 4.93-5.11 TB/s on boxes whose step times agree to 0.2 %.
+# (profiles/r06_calibration_boxes.txt): MFMA probe 1870-1876 TFLOP/s <-> 597.8-598.9 frames/s, 1944 <-> 610.2, 1975 <-> 610.3,
+# 2010 <-> 632.9.  Least squares of (value / 603) against (probe / 1900) over the four kinds of box gives a slope of 0.70: about 70 % of the
+# step (the MFMA-bound GEMM families) moves with the probe, the HBM-bound passes and the output-bound K = 512 GEMMs do not.  The probe
+# itself repeats to +-1.5 %, which is the residual spread of the normalised values (594-609 against 598-633 raw).  The copy probe is
+# reported but NOT used: it reads 4.85-5.11 TB/s without ordering the boxes.
 CAL_REF = {"mfma_bf16_tflops": 1900.0, "copy_tbps": 5.0}
-CAL_WEIGHT_MFMA = 0.5
+CAL_WEIGHT_MFMA = 0.7
 
 
 def calibration_block(cal, value):

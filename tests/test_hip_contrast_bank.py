@@ -144,6 +144,26 @@ def test_production_size_bank_of_65k_entries():
     assert float((lse_u - lse).abs().max()) <= 1e-4
 
 
+def test_unit_rows_lse_at_cold_temperatures_takes_the_online_form():
+    """The fixed-reference log-sum-exp of unit-norm rows sums exp(inv_tau (s - 1)): at inv_tau > 40 scores near -1 flush to zero in fp32
+    (round-5 advisor), so the launcher falls back to the online (running-maximum) form there - same numbers as unit_rows=False."""
+    M, C, maps, seg = 256, 64, 2, 512
+    torch.manual_seed(11)
+    q = F.normalize(torch.randn(M, C), dim=1)
+    bank = -q[torch.randint(0, M, (maps, seg))] + 1e-3 * torch.randn(maps, seg, C)          # every key is (almost) the negative of a query
+    bank = F.normalize(bank, dim=2)
+    lq = torch.randint(0, 12, (M,), dtype=torch.int32)
+    lb = torch.randint(0, 12, (maps, seg), dtype=torch.int32)
+    out = {}
+    for unit in (False, True):
+        out[unit] = hip.contrast_bank_fwd(q.cuda(), lq.cuda(), bank.cuda(), lb.cuda(), q_sets=1, q_block=M, bank_block=seg, gmap=[[0, 1]],
+                                          inv_tau=200.0, want_lse=True, unit_rows=unit)
+    assert torch.isfinite(out[True][3]).all()
+    assert torch.equal(out[True][3], out[False][3]) and torch.equal(out[True][2], out[False][2])
+    ref = torch.logsumexp(200.0 * torch.cat([bank[0] @ q.T, bank[1] @ q.T], 0).T, 1)
+    assert float((out[True][3].cpu() - ref).abs().max()) < 1e-2
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # bank_mode 'world' through the TOKEN path (PairLossFn) on two ranks sharing the GPU (gloo): the query labels are this rank's, the
 # bank and its labels are every rank's.  (Round-5 advisor finding: the query labels were taken from the GATHERED label matrix.)
