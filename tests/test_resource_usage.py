@@ -3,7 +3,7 @@ report of a gfx950 cross-compile, tools/resource_usage.py).
 
 Why it is a test and not a tuning note: on this path a scratch reload is followed by `s_waitcnt vmcnt(0)`, i.e. by a wait for the
 kernel's own output stores and for every LDS-DMA prefetch in flight - round 4 found 223 spilled registers in the dominant GEMM's
-column-sum epilogues and a scratch-resident offset table in the attention backward that way, and the round-4
+column-sum epilogues and a scratch-resident offset table in the attention backward that way (profiles/HISTORY.md §6 round 4), and the round-4
 verdict found three more kernels that had grown spills unnoticed.  The allow-list (fp32 parity instantiations, test-only geometries)
 lives in tools/resource_usage.py with a reason per entry."""
 import os
