@@ -36,6 +36,21 @@ int stswin_cu_budget();
 // 256 B of zeros in device memory: the source of every padded / out-of-range 16-byte chunk.
 static __device__ uint4 g_stswin_zero[16];  // per-TU copy (no -fgpu-rdc); zero-initialised
 
+// Zero fill of a 4-byte-aligned region as a KERNEL on the launch stream.  The library does not use hipMemsetAsync / hipMemset2DAsync on its
+// launch streams (round 6): inside a hipGraph (ROCm 7.0 / 7.2) a captured memset node did not reproduce the eager call - a 2-D fill left
+// parts of a weight-gradient buffer on garbage, and the OHEM histogram block was not cleared between replays - so that a graph-replayed
+// training run went to NaN where the eager run did not (tools/probes/tn_graph_repro.py, tools/probes/graph_vs_eager.py).
+static __global__ __launch_bounds__(256) void stswin_zero_words_kernel(unsigned* __restrict__ p, long words) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < words; i += (long)gridDim.x * 256) p[i] = 0u;
+}
+static inline void stswin_zero_bytes(void* p, size_t bytes, hipStream_t stream) {
+  const long words = (long)((bytes + 3) / 4);
+  if (words <= 0) return;
+  long blocks = (words + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(stswin_zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned*)p, words);
+}
+
 DEVI int lane_id() { return threadIdx.x & 63; }
 DEVI int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 

@@ -2164,9 +2164,9 @@ extern "C" int stswin_gemm_nt(int dtype, const void* A, long lda, const int* a_r
   if ((flags & GF_CS_SQ) && (!(flags & GF_CS_PARTIAL) || !colsum || (flags & (GF_MID | GF_HALF | GF_DUO | GF_STREAM | GF_NOREGEPI))))
     return -1006;                                            // squares need the per-block table and a kernel that writes them
   if ((flags & GF_CS_PARTIAL) && colsum && ((M + 127) / 128) % 2) { // 128-row tiles never touch the last row of the [2*ceil(M/256)][N] table
-    (void)hipMemsetAsync(colsum + (long)(2 * ((M + 255) / 256) - 1) * N, 0, sizeof(float) * N, (hipStream_t)stream);
+    stswin_zero_bytes(colsum + (long)(2 * ((M + 255) / 256) - 1) * N, sizeof(float) * N, (hipStream_t)stream);   // (a kernel: see common.h)
     if (flags & GF_CS_SQ)
-      (void)hipMemsetAsync(colsum + (long)(4 * ((M + 255) / 256) - 1) * N, 0, sizeof(float) * N, (hipStream_t)stream);
+      stswin_zero_bytes(colsum + (long)(4 * ((M + 255) / 256) - 1) * N, sizeof(float) * N, (hipStream_t)stream);
   }
   GemmNT p{A, lda, a_rows, B, ldb, C, ldc, c_rows, C2, ldc2, bias, R, ldr, r_rows, M, N, Kseg, S, scale, scale_cols, flags, colsum};
   if (dtype == 0 && M <= 8 && S == 1 && !a_rows && !c_rows && !C2 && !R && !colsum && !(flags & ~GF_RELU) && scale_cols == 0 && Kseg % 8 == 0 &&
@@ -2458,6 +2458,30 @@ static long tn_resident_workgroups() {
 // per device, outside any stream capture (the first fused launch of a process is a warm-up launch; if it is not, the unfused path
 // is taken).  A captured hipGraph node keeps the region of the stream it was captured on: replay it on that stream.
 #include <atomic>
+// Zero fill of an [Ni][Nj] fp32 result with row pitch ldc, as a KERNEL.  Round 6: this used to be hipMemset2DAsync; inside a hipGraph
+// (ROCm 7.0 / 7.2) the captured 2-D memset node does not reproduce what the eager call does - replays of a weight-gradient GEMM that
+// accumulates into the filled buffer (overwrite without split-K slabs: ASPP's dilated convolutions at 16x16 / 32x32 maps) left a quarter
+// to most of the result on stale or garbage values (tools/probes/tn_graph_repro.py: 78 of 120 replayed launches differed from the eager
+// ones, by up to 1e25), which is what sent a graph-replayed training run to NaN after ~130 steps while 20-step comparisons passed.
+__global__ __launch_bounds__(256) void tn_zero_fill_kernel(float* __restrict__ C, long ldc, int Ni, int Nj) {
+  const long n4 = (long)Ni * ((Nj + 3) / 4);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long r = i / ((Nj + 3) / 4);
+    const int c = (int)(i - r * ((Nj + 3) / 4)) * 4;
+    float* q = C + r * ldc + c;
+    if (c + 3 < Nj && ((((uintptr_t)q) & 15) == 0)) *(f32x4*)q = (f32x4){0.f, 0.f, 0.f, 0.f};
+    else
+      for (int e = 0; e < 4 && c + e < Nj; ++e) q[e] = 0.f;
+  }
+}
+static void tn_zero_fill(float* C, long ldc, int Ni, int Nj, hipStream_t stream) {
+  const long n4 = (long)Ni * ((Nj + 3) / 4);
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(tn_zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, C, ldc, Ni, Nj);
+}
+
 #include <mutex>
 static std::mutex g_tn_mutex;
 static std::atomic<int> g_tn_fused_holds{0};
@@ -2699,7 +2723,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
     { const int per = (nst + rs - 1) / rs; rs = (nst + per - 1) / per; }   // no empty split (its slab would never be written)
     if (ring) {
       const bool slabs = workspace && rs > 1 && (long)rs * Ni * Nj <= workspace_floats;
-      if (overwrite && !slabs) (void)hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)Nj * sizeof(float), (size_t)Ni, (hipStream_t)stream);
+      if (overwrite && !slabs) tn_zero_fill(C, ldc, Ni, Nj, (hipStream_t)stream);
       // Fused split-K combine (gemm_tn_ring_kernel<MODE, true>): bf16 partials, a grid of at most one workgroup per CU (where the
       // distributed combine beats the separate pass; residency is NOT needed for correctness any more), byte offsets of the partials
       // within 31 bits.  Off while stswin_tn_fused_hold() holds are outstanding; STSWIN_TN_FUSED=0 / 1 overrides (read per call).
@@ -2764,7 +2788,7 @@ extern "C" int stswin_gemm_tn(int dtype, const void* At, long lda, const int* at
   // empty): such a workgroup returns before it writes its slab and the combine would add whatever the workspace held
   { const int per = (ntile + splits - 1) / splits; splits = (ntile + per - 1) / per; }
   const bool use_slabs = workspace && splits > 1 && (long)splits * Ni * Nj <= workspace_floats;
-  if (overwrite && !use_slabs) (void)hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)Nj * sizeof(float), (size_t)Ni, (hipStream_t)stream);
+  if (overwrite && !use_slabs) tn_zero_fill(C, ldc, Ni, Nj, (hipStream_t)stream);
   GemmTN p{At, lda, at_rows, Bt, ldb, bt_rows, C, ldc, Mk, Ni, Nj, splits, bseg, use_slabs ? workspace : nullptr, slab_bf16, nullptr, 0, 0};
   dim3 grid(((Ni + 127) / 128) * ((Nj + 127) / 128) * splits);
   static int once = set_lds_once((const void*)gemm_tn_kernel<bf16, 4>) | set_lds_once((const void*)gemm_tn_kernel<float, 4>) |

@@ -957,7 +957,7 @@ extern "C" int stswin_ohem_select(const float* loss, long n, long n_min, float t
   if (n <= 0 || n_min <= 0 || n_min > n) return -1301;
   if (work_bytes < (long)sizeof(OhemWork)) return -1302;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(work, 0, sizeof(OhemWork), st) != hipSuccess) return -1303;
+  stswin_zero_bytes(work, sizeof(OhemWork), st);         // (a kernel, not hipMemsetAsync: see common.h)
   const unsigned grid = (unsigned)max(1L, min(512L, (n + 4095) / 4096));
   for (int level = 0; level < 3; ++level)
     hipLaunchKernelGGL(ohem_hist_kernel, dim3(grid), dim3(256), 0, st, loss, n, n_min, stats, (OhemWork*)work, level);

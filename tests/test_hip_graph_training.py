@@ -182,3 +182,60 @@ def test_adam_bias_corrections_from_the_device_clock_match_the_host_expressions(
         want = 1.0 - (1.0 - 0.99) * (math.cos(math.pi * k / 167625) + 1) / 2.0
         assert abs(float(h[3]) - want) <= 1.2e-7, (k, float(h[3]), want)
     assert e.sync() == 1010
+
+
+def test_weight_gradient_zero_fill_and_ohem_histograms_inside_a_graph():
+    """Two launcher-side fills used to be runtime memsets (hipMemset2DAsync of a weight-gradient buffer that a direct-store gemm_tn adds
+    into; hipMemsetAsync of the OHEM radix-select histograms).  Captured into a hipGraph they did not reproduce the eager calls (ROCm 7.x):
+    replays left parts of the gradient on stale / garbage values and the histograms uncleared, and a replayed training run went to NaN
+    after ~130 steps while 20-step comparisons passed (tools/probes/tn_graph_repro.py, graph_vs_eager.py).  They are kernels now; this
+    replays both against eager launches on fresh operands."""
+    from stswincl_amd import hip
+    from stswincl_amd.utils.losses import OhemCELoss2D
+    dev = "cuda"
+    frames, Hh, Ni, Cin = 4, 16, 512, 1024
+    Mk = frames * Hh * Hh
+    dils = (18, 12, 6)
+    maps = [hip.conv_rowmap(frames, Hh, Hh, Hh, Hh, 3, 1, d, d, False, dev) for d in dils]
+    g = [torch.randn(Mk, Ni, device=dev).bfloat16() for _ in dils]
+    X = torch.randn(Mk, Cin, device=dev).bfloat16()
+    outs = [torch.empty(Ni, 9 * Cin, dtype=torch.float32, device=dev) for _ in dils]
+    crit = OhemCELoss2D(64 * 64 // 16)
+    logits = torch.randn(2, 12, 64, 64, device=dev)
+    labels = torch.randint(0, 12, (2, 64, 64), device=dev)
+    loss_out = torch.zeros((), device=dev)
+
+    def launches():
+        hip.arena_reset(dev)               # (as a model forward does: the step's zero-initialised accumulators come from a block filled inside the step)
+        for i in range(len(dils)):
+            hip.gemm_tn(g[i], X, outs[i], Mk=Mk, bt_rows=maps[i], bseg=Cin, overwrite=True, tapminor=True)
+        loss_out.copy_(crit(logits, labels))
+
+    launches()
+    v = hip.last_variant(1)
+    assert v["slabs"] == "" and v["splits"] == 1, v          # the direct-store launch that needs the zero fill
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        launches()
+    torch.cuda.synchronize()
+    hip.note_capture()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        launches()
+    for it in range(12):
+        torch.manual_seed(100 + it)
+        for t in g:
+            t.copy_(torch.randn(Mk, Ni, device=dev).bfloat16())
+        X.copy_(torch.randn(Mk, Cin, device=dev).bfloat16())
+        # alternate between the two OHEM branches: confident logits (few hard pixels -> the n_min largest by radix select) and random ones
+        lg = torch.randn(2, 12, 64, 64, device=dev)
+        if it % 2:
+            lg = lg + 12.0 * torch.nn.functional.one_hot(labels, 12).permute(0, 3, 1, 2)
+        logits.copy_(lg)
+        graph.replay()
+        torch.cuda.synchronize()
+        got, got_loss = [o.clone() for o in outs], float(loss_out)
+        launches()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(got, outs)), it
+        assert got_loss == float(loss_out) and got_loss == got_loss, (it, got_loss, float(loss_out))
