@@ -150,7 +150,10 @@ def arena_reset(device=None) -> None:
     if device is None:
         _ARENAS.clear()
     else:
-        _ARENAS.pop(torch.device(device), None)
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:      # ("cuda" means the current device, as in zeros())
+            device = torch.device("cuda", torch.cuda.current_device())
+        _ARENAS.pop(device, None)
 
 
 def zeros(*shape, device) -> torch.Tensor:
