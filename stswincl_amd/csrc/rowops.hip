@@ -256,7 +256,7 @@ DEVI void linear_pack_tile(float (&tile)[64][65], const float* w, T* fwd, T* tr,
     const int row = ps * 16 + r, gn = n0 + row, gk = k0 + g * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (gn < n && gk < k) {                                        // (k % 4 == 0: whole pieces)
-      v = *(const f32x4*)(w + (long)gn * k + gk);
+      v = __builtin_nontemporal_load((const f32x4*)(w + (long)gn * k + gk));   // (the fp32 master weights stream through once: repack 0.275 -> 0.263 ms)
       typedef T tx4 __attribute__((ext_vector_type(4)));
       *(tx4*)(fwd + (long)gn * k + gk) = (tx4){from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
     }
