@@ -247,6 +247,29 @@ CAL_REF = {"mfma_bf16_tflops": 1900.0, "copy_tbps": 5.0}
 CAL_WEIGHT_MFMA = 0.7
 
 
+def matmul_probe(dev):
+    """A third, code-independent probe: the vendor library's bf16 GEMM (torch.matmul, 8192^3, random operands), best of three timings of ten
+    launches.  Measurement only - the library is not on the product path - but it loads the chip like the step's GEMMs do (MFMA under real
+    operand traffic, power-limited), which the register-only loop does not fully capture."""
+    A = torch.randn(8192, 8192, device=dev).bfloat16()
+    B = torch.randn(8192, 8192, device=dev).bfloat16()
+    C = torch.empty(8192, 8192, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        torch.matmul(A, B.t(), out=C)
+    best = None
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            torch.matmul(A, B.t(), out=C)
+        b.record()
+        b.synchronize()
+        t = a.elapsed_time(b) * 1e-3 / 10
+        best = t if best is None or t < best else best
+    del A, B, C
+    return 2.0 * 8192.0 ** 3 / best / 1e12
+
+
 def calibration_block(cal, value):
     """`cal` = hip.calibrate() readings taken after the warm-up steps (~0.1 s of fixed probes: a register-only MFMA loop on pseudo-random
     operands - power-limited like the step's GEMMs - and a 1 GB copy), so that lines from different boxes can be compared:
@@ -256,7 +279,7 @@ def calibration_block(cal, value):
     rm, rc = cal["mfma_bf16_tflops"] / CAL_REF["mfma_bf16_tflops"], cal["copy_tbps"] / CAL_REF["copy_tbps"]
     scale = CAL_WEIGHT_MFMA / rm + (1.0 - CAL_WEIGHT_MFMA)
     cal.update({"reference": dict(CAL_REF), "mfma_weight": CAL_WEIGHT_MFMA, "relative_mfma": rm, "relative_copy": rc,
-                "normalisation": "value x (w / relative_mfma + 1 - w); the copy probe is informational",
+                "normalisation": "value x (w / relative_mfma + 1 - w); the copy probe and the vendor-matmul probe (torch.matmul 8192^3 bf16) are informational",
                 "probe": "256 workgroups x 4 waves x 8 independent v_mfma_f32_16x16x32_bf16 chains on pseudo-random operands (~20 ms, best "
                          "of 3); 16-byte-lane copy 512 MB -> 512 MB (best of 3); HIP events; after the warm-up steps, before the timed region"})
     return cal, value * scale
@@ -401,6 +424,8 @@ def seg_run(a, ctx):
         step()
     ctx.barrier()
     cal = hip.calibrate(dev) if not a.no_calibration else None      # every rank probes its own GPU at the same time; rank 0 reports
+    if cal is not None:
+        cal["matmul_bf16_tflops"] = matmul_probe(dev)
     # headline: exactly K steps, NO event brackets, graph replay when N == 1 (two more untimed steps re-warm the caches behind the probes)
     dt, _, loss = timed_steps(ctx, step, a.steps, 2 if cal is not None else 0, 0)
     # roofline pass: the same step, eager, rank 0's launches bracketed by HIP events (one launch in `stride` per family, rotating, so that
