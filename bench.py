@@ -425,7 +425,11 @@ def seg_run(a, ctx):
     ctx.barrier()
     cal = hip.calibrate(dev) if not a.no_calibration else None      # every rank probes its own GPU at the same time; rank 0 reports
     if cal is not None:
-        cal["matmul_bf16_tflops"] = matmul_probe(dev)
+        try:
+            cal["matmul_bf16_tflops"] = matmul_probe(dev)
+        except Exception as e:     # noqa: BLE001   (informational: a missing / failing vendor library must not cost the line)
+            cal["matmul_bf16_tflops"] = None
+            cal["matmul_probe_error"] = f"{type(e).__name__}: {e}"[:200]
     # headline: exactly K steps, NO event brackets, graph replay when N == 1 (two more untimed steps re-warm the caches behind the probes)
     dt, _, loss = timed_steps(ctx, step, a.steps, 2 if cal is not None else 0, 0)
     # roofline pass: the same step, eager, rank 0's launches bracketed by HIP events (one launch in `stride` per family, rotating, so that
