@@ -439,3 +439,30 @@ def test_bench_two_ranks_sharing_the_gpu_runs_the_data_parallel_path():
         assert d["config"]["launch"].startswith("eager launches (hipGraph capture needs the RCCL backend"), d["config"]["launch"]
         losses[comm] = d["config"]["loss"]
     assert abs(losses["bf16"] - losses["fp32"]) < 2e-2 * abs(losses["fp32"]), losses      # bf16 on the wire: same training, rounded gradients
+
+
+def test_bench_line_carries_the_round6_blocks():
+    """bench.py's N = 1 line (small clips, few steps): graph-replayed headline, calibration block with the normalised value, a separate
+    bracketed pass for the roofline figures, and gemm_tn's sampled work close to its launches' (the cancelled-span accounting of round 6)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "3", "--batch", "2", "--size", "256",
+                          "--no-cpu-baseline", "--no-secondary", "--profile-stride", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                      # ONE JSON line on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 3 and d["value"] > 0 and d["dtype"] == "bf16"
+    assert d["config"]["launch"].startswith("hipGraph replay of the whole step") and "no event brackets" in d["config"]["launch"]
+    cal = d["calibration"]
+    assert cal["mfma_bf16_tflops"] > 500 and cal["copy_tbps"] > 1 and cal["reference"]["mfma_bf16_tflops"] > 0
+    assert abs(d["value_normalised"] / d["value"] - (cal["mfma_weight"] / cal["relative_mfma"] + 1 - cal["mfma_weight"])) < 1e-9
+    assert d["profile_pass"]["steps"] == 4 and d["profile_pass"]["ms_per_step"] > 0
+    r = d["roofline"]
+    assert r["kernel"] == "gemm_nt_bf16" and r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "gemm_tn_bf16" in r["other_kernels"]
+    assert d["config"]["loss"] == d["config"]["loss"]
